@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py — SimRank iterations/sec on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload pl32768] [--mode auto]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one loop body of the reference's ``fit`` (SimRank.py:138-140): both legs of
+S <- C.W.S.W^T with the fused diagonal/convergence epilogue, plus the read-back of the
+convergence count (the reference tests convergence every iteration, SimRank.py:130).
+Inputs (the CSR graph and S) are resident in HBM when the timed region starts.  Default
+workload = BASELINE.json configs[3]: synthetic power-law directed graph, N = 32768, average
+degree 32, fp32 (the configuration the metric is quoted on; it fits one GPU: 3 x 4 GiB).
+With N > 1 ranks S is column-sharded and each update does one RCCL all-to-all (strong
+scaling: total work fixed).
+
+One JSON line is printed by rank 0.  ``roofline`` is for the dominant kernel (the slower
+of the two gather legs), achieved = algorithmic bytes per launch / mean launch duration
+measured with HIP events on the engine's stream inside the timed region.
+``cpu_baseline`` (rank 0, N = 1 only) times the oracle's dense float64 update on a bounded
+row slab of the same workload and scales it to a full iteration.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
+
+
+def leg_bytes(n_rows, n_cols_in, n_cols_x, nnz, leg2, has_evidence=False):
+    """Algorithmic HBM bytes of one gather-leg launch:
+    read X once, write Y once, CSR (col + rowptr) once per launch; leg 2 also reads the
+    previous iterate for the convergence count (and 1 B/elt of evidence counts)."""
+    b = 4 * n_cols_in * n_cols_x + 4 * n_rows * n_cols_x + 8 * nnz + 4 * (n_rows + 1)
+    if leg2:
+        b += 4 * n_rows * n_cols_x
+        if has_evidence:
+            b += n_rows * n_cols_x
+    return b
+
+
+def cpu_baseline(csr, S_host, coef, budget_s=20.0):
+    """Oracle (dense float64 NumPy, the reference's arithmetic) on a row slab of one
+    iteration; value = iterations/s of a full iteration extrapolated from the slab."""
+    from oracle import simrank_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count()
+    n = csr.n_rows
+    G = csr.dense()                                        # what the reference keeps as `Graph`
+    probe = slice(0, 32)
+    t0 = time.perf_counter()
+    O.update_rows(G, S_host, coef, probe)
+    t_probe = time.perf_counter() - t0
+    rows = int(min(n, max(64, 32 * budget_s / max(t_probe, 1e-3))))
+    rows = min(rows, 4096)
+    slab = slice(0, rows)
+    t0 = time.perf_counter()
+    new = O.update_rows(G, S_host, coef, slab)
+    t_update = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    old = S_host[slab].copy()                              # copy.deepcopy, SimRank.py:138
+    O.converged(old, new, 1e-4)                            # SimRank.py:130
+    t_rest = time.perf_counter() - t0
+    per_iter = (t_update + t_rest) * n / rows
+    return {"value": 1.0 / per_iter, "unit": "iterations/s", "cores": int(threads),
+            "kind": "port",
+            "sample": f"oracle dense f64 update (2 dgemm + copy + convergence test) of rows "
+                      f"0..{rows - 1} of one N={n} iteration: {t_update + t_rest:.2f} s, "
+                      f"scaled x{n / rows:.1f} to a full iteration ({per_iter:.1f} s); "
+                      f"host cpu_count={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="pl32768")
+    ap.add_argument("--mode", default="auto")
+    ap.add_argument("--panel", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world_size:
+        if world_size == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs: python -m torch.distributed.run --nnodes=1 "
+                     f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus}")
+        args.gpus = world_size
+
+    import torch
+    import torch.distributed as dist
+    from simrank_amd import ingest, synth
+    from simrank_amd.driver import LocalWorld, SideSpec, Solver, TorchWorld
+    from simrank_amd.engine import HipOps
+
+    torch.cuda.set_device(local_rank)
+    if world_size > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        world = TorchWorld()
+    else:
+        world = LocalWorld(1)
+
+    ops = HipOps(local_rank)
+    if args.panel is not None:
+        ops.set_tuning(panel=args.panel)
+    factory, kind = synth.WORKLOADS[args.workload]
+    assert kind == "directed", "bench workloads are the directed SimRank configurations"
+    df = factory()
+    _, csr = ingest.directed(df, False, "from", "to", "weight")
+    n, nnz = csr.n_rows, csr.nnz
+    coef = 0.8
+    solver = Solver(lambda r: ops, world, [SideSpec(csr, csr.rowscale, coef)], args.mode)
+    solver.reset()
+
+    def barrier():
+        ops.synchronize()
+        torch.cuda.synchronize()
+        if world_size > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        solver.step(0.0)
+    solver.enable_timing()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.step(0.0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world_size > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    legs = solver.leg_times()                 # mean ms per launch, measured by HIP events
+    solver.events = None
+    side = solver.sides[0][rank if world_size > 1 else 0]
+    out = {
+        "metric": "simrank_iterations_per_sec", "value": args.steps / elapsed,
+        "unit": "iterations/s", "n_gpus": world_size, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: synthetic directed graph N={n} nnz={nnz} "
+                               f"SimRank C=0.8 fp32, eps test every iteration",
+                   "N": n, "nnz": nnz, "mode": solver.mode,
+                   "sharding": f"S column-sharded over {world_size} rank(s), all-to-all per update"},
+    }
+    if solver.mode == "sparse":
+        l1 = legs["leg1.0"][0]
+        l2 = legs["leg2.0"][0]
+        b1 = leg_bytes(side.M, side.K, side.Lk, nnz, leg2=False)
+        b2 = leg_bytes(side.M, side.K, side.Lm, nnz, leg2=True)
+        rl = []
+        for name, ms, b in (("spmm_gather leg 1 (transposed store)", l1, b1),
+                            ("spmm_gather leg 2 (fused epilogue)", l2, b2)):
+            gbs = b / (ms * 1e-3) / 1e9
+            rl.append({"kernel": name, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                       "ms": ms, "algorithmic_bytes": b,
+                       "gathered_bytes": 4 * nnz * (side.Lk if "leg 1" in name else side.Lm)})
+        rl.sort(key=lambda r: -r["ms"])
+        out["roofline"], out["roofline_other"] = rl[0], rl[1]
+    else:
+        flops = 2.0 * side.M * side.M * side.K
+        ms = legs["leg2.0"][0]
+        tf = flops / (ms * 1e-3) / 1e12
+        out["roofline"] = {"kernel": "gemm_nt_mfma (leg 2, fused epilogue)", "bound": "mfma",
+                           "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                           "frac": tf / MFMA_F32_PEAK_TF, "traffic": None, "ms": ms}
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc) and "roofline" in out:
+        try:
+            rec = json.load(open(pmc)).get(f"{args.workload}:{world_size}", {})
+            for r in (out["roofline"], out.get("roofline_other", {})):
+                key = "leg1" if "leg 1" in r.get("kernel", "") else "leg2"
+                if key in rec:
+                    r["traffic"] = rec[key]
+        except Exception:
+            pass
+
+    if not args.no_extras:
+        # wall-clock to converge with the reference's defaults (eps = 1e-4)
+        barrier()
+        t0 = time.perf_counter()
+        k = solver.run(100, 1e-4)
+        barrier()
+        out["converge"] = {"eps": 1e-4, "iterations": k, "seconds": time.perf_counter() - t0}
+
+    if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
+        try:
+            import psutil
+            avail = psutil.virtual_memory().available
+        except Exception:
+            avail = 0
+        need = 3 * 8 * n * n
+        if avail and avail < need * 1.2:
+            out["cpu_baseline"] = None
+            out["cpu_baseline_note"] = f"skipped: needs {need / 2**30:.0f} GiB host RAM"
+        else:
+            S_host = solver.result(0)
+            solver.release()
+            out["cpu_baseline"] = cpu_baseline(csr, S_host, coef)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+/*
+ * simrank_hip.h — C ABI of the MI355X (gfx950) SimRank / SimRank++ iteration engine.
+ *
+ * The reference (ysong1231/SimRank) has no FFI: its hot path is inline NumPy inside the
+ * `fit` methods of SimRank/SimRank.py.  This header is what a binding for that path
+ * binds instead; each entry point names the reference lines it replaces.  The Python
+ * host (simrank_amd/engine.py, ctypes) is the only caller in this repository, and
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every function returns 0 on success or a negative simrank_status; the message of
+ *     the last failure on the calling thread is simrank_last_error().
+ *   - "device pointer" = HIP device memory of the current device (from simrank_malloc or
+ *     from any other allocator, e.g. torch.Tensor.data_ptr()).  Host buffers are caller
+ *     owned; device buffers passed in are caller owned; a simrank_graph owns its CSR copy.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All work is
+ *     asynchronous on that stream unless a function says it synchronises.
+ *   - matrices are row-major float32 with an explicit leading dimension `ld` (elements).
+ *     The fast (16-byte vector) kernels run when pointers are 16-byte aligned and every
+ *     ld is a multiple of 4; otherwise a scalar variant runs (same results).
+ *
+ * Data model
+ *   W = diag(rowscale) . A, A the 0/1 pattern of a CSR matrix with n_rows x n_cols.
+ *   Every normalised adjacency the reference builds has this form (SimRank.py:45-52,
+ *   :191-200: each stored value is 1/in-degree or 1/sum-of-weights of its ROW node; the
+ *   SimRank++ "spread" factor of :326-333 is again per row).
+ *   One similarity update  S' = coef . W . S . W^T (.*E) (+ lbd.A), diag <- 1  is two calls
+ *   of simrank_spmm:   Tt = (W . S)^T      (transpose_out = 1, no epilogue)
+ *                      S' = W . Tt          (epilogue)            [S symmetric]
+ *   or, for dense graphs, simrank_spmm / simrank_gemm_nt on a densified W (MFMA).
+ */
+#ifndef SIMRANK_HIP_H
+#define SIMRANK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIMRANK_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define SIMRANK_API __attribute__((visibility("default")))
+#else
+#define SIMRANK_API
+#endif
+
+typedef enum simrank_status {
+    SIMRANK_OK = 0,
+    SIMRANK_ERR_INVALID = -1,   /* bad argument (shape, NULL, alignment the call requires) */
+    SIMRANK_ERR_HIP = -2,       /* a HIP runtime call failed; see simrank_last_error()      */
+    SIMRANK_ERR_NO_DEVICE = -3, /* no gfx950 device visible                                 */
+    SIMRANK_ERR_ALLOC = -4
+} simrank_status;
+
+SIMRANK_API int simrank_abi_version(void);
+SIMRANK_API const char* simrank_last_error(void);
+
+/* ---- device, memory, stream, event plumbing (thin HIP wrappers) ------------------- */
+SIMRANK_API int simrank_device_count(int* count);
+SIMRANK_API int simrank_set_device(int device);
+SIMRANK_API int simrank_device_info(int device, char* name, int name_len, int64_t* total_bytes,
+                        int* compute_units, char* arch, int arch_len);
+SIMRANK_API int simrank_malloc(void** dptr, size_t bytes);
+SIMRANK_API int simrank_free(void* dptr);
+SIMRANK_API int simrank_memset(void* dptr, int byte_value, size_t bytes, void* stream);
+/* copies are enqueued on `stream` and the call returns after they completed */
+SIMRANK_API int simrank_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes, void* stream);
+SIMRANK_API int simrank_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes, void* stream);
+SIMRANK_API int simrank_memcpy_d2d(void* dst_device, const void* src_device, size_t bytes, void* stream);
+/* 2-D device->host copy of a row-major block, converting float32 -> float64 on the host
+ * side (replaces the DataFrame hand-back of SimRank.py:141, :303). */
+SIMRANK_API int simrank_download_f64(double* dst_host, int64_t ld_dst, const float* src_device,
+                         int64_t ld_src, int64_t n_rows, int64_t n_cols, void* stream);
+SIMRANK_API int simrank_stream_create(void** stream);
+SIMRANK_API int simrank_stream_destroy(void* stream);
+SIMRANK_API int simrank_stream_synchronize(void* stream);
+SIMRANK_API int simrank_event_create(void** event);
+SIMRANK_API int simrank_event_destroy(void* event);
+SIMRANK_API int simrank_event_record(void* event, void* stream);
+/* waits for `stop`, then returns the time between the two records in milliseconds */
+SIMRANK_API int simrank_event_elapsed_ms(void* start, void* stop, float* ms);
+
+/* ---- graph: normalised adjacency in CSR (replaces the dense `Graph` DataFrame built at
+ *      SimRank.py:43-52 and the pivots at :199-200 / :390-391) ---------------------- */
+typedef struct simrank_graph simrank_graph;
+
+/* rowptr[n_rows+1], col[nnz] (column indices ascending within a row, < n_cols),
+ * rowscale[n_rows]: host arrays, copied.  Builds the transposed pattern (CSC) too. */
+SIMRANK_API int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr,
+                         const int32_t* col, const float* rowscale, simrank_graph** out);
+SIMRANK_API int simrank_graph_destroy(simrank_graph* g);
+SIMRANK_API int simrank_graph_shape(const simrank_graph* g, int64_t* n_rows, int64_t* n_cols, int64_t* nnz);
+
+/* ---- K0: S[:, block] <- columns [col0, col0+n_cols) of the identity
+ *      (SimRank.py:124-126, :280-285, :346-348, :402-407) --------------------------- */
+SIMRANK_API int simrank_fill_identity(float* S, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t col0,
+                          void* stream);
+
+/* ---- fused epilogue of an update: scale, evidence, prior, diagonal, convergence count
+ *      (SimRank.py:139-140, :361-362, :453-454 and `_converged` :74) ---------------- */
+typedef struct simrank_epilogue {
+    float coef;                      /* C (C1/C2)                                         */
+    float lbd;                       /* prior blend, used only when apriori != NULL       */
+    const uint8_t* evidence;         /* device, common-in-neighbour counts (saturated at
+                                        255) of this column block, or NULL: value is
+                                        multiplied by 1 - 2^-count  (SimRank.py:315-316)  */
+    int64_t ld_evidence;
+    const float* apriori;            /* device, prior block or NULL:
+                                        v <- (1-lbd).v + lbd.apriori  (SimRank.py:453)    */
+    int64_t ld_apriori;
+    const float* previous;           /* device, previous iterate block or NULL            */
+    int64_t ld_previous;
+    double eps;                      /* strict |new - previous| > eps, every element      */
+    unsigned long long* n_changed;   /* device counter; zeroed by the call, then += count */
+    int64_t diag_col0;               /* global column index of local column 0             */
+    int32_t set_diag;                /* 1: element (a, a - diag_col0) <- 1                */
+    int32_t reserved;
+} simrank_epilogue;
+
+/* ---- K2 (+K3 sparse form, K4, K5): Y = diag(rowscale).A.X with optional transposed
+ *      store and fused epilogue.  X: n_cols(g) x n_cols_x, Y: n_rows(g) x n_cols_x.
+ *      transpose_out = 0: Y[a*ldy + c]
+ *      transpose_out = 1: rows are grouped in blocks of t_block rows (t_block <= 0 or
+ *        >= n_rows(g): one block); block h holds Y^T of its rows, contiguous:
+ *        Y[h*n_cols_x*t_block + c*rows_in_block(h) + (a - h*t_block)]
+ *        (ldy is ignored, except that with a single block and ldy >= n_rows(g) it is the
+ *        row stride of Y^T: Y[c*ldy + a])
+ *      This is the layout an all-to-all between column-sharded ranks needs.
+ *      (first `.dot` of SimRank.py:139/:298/:301/:361/:420/:423; with the epilogue also
+ *      the second, using S' = W.(W.S)^T for symmetric S.) */
+SIMRANK_API int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_cols_x,
+                 float* Y, int64_t ldy, int32_t transpose_out, int64_t t_block,
+                 const simrank_epilogue* epilogue, void* stream);
+
+/* ---- K7: counts of common in-neighbours, saturated at 255, for columns
+ *      [col0, col0+n_cols) of the n_rows x n_rows evidence matrix; only rows with
+ *      rowscale > 0 take part (pattern G > 0).  Replaces the int64 matmul of
+ *      SimRank.py:315; E = 1 - 2^-count is applied in the epilogue (:316). */
+SIMRANK_API int simrank_evidence_counts(const simrank_graph* g, int64_t col0, int64_t n_cols,
+                            uint8_t* counts, int64_t ld, void* stream);
+
+/* ---- dense MFMA path (second `.dot(G.T)` of SimRank.py:139 when W really is dense) -- */
+/* Wd[a*ld + i] = rowscale[a] where (a,i) is stored, 0 elsewhere */
+SIMRANK_API int simrank_graph_densify(const simrank_graph* g, float* Wd, int64_t ld, void* stream);
+/* C[M x N] = epilogue(A[M x K] . B[N x K]^T) on v_mfma_f32_32x32x2_f32 (exact f32).
+ * epilogue may be NULL (plain product).  Requires 16-byte aligned pointers and
+ * lda, ldb, ldc multiples of 4. */
+SIMRANK_API int simrank_gemm_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                    const float* B, int64_t ldb, float* C, int64_t ldc,
+                    const simrank_epilogue* epilogue, void* stream);
+
+/* ---- tuning knobs (measurement harness): "panel" = columns per gather panel
+ *      (16, 32, 64, 128, 256; 0 = automatic), "xcd_map" = 0/1 ---------------------- */
+SIMRANK_API int simrank_set_tuning(const char* key, int64_t value);
+SIMRANK_API int simrank_get_tuning(const char* key, int64_t* value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMRANK_HIP_H */

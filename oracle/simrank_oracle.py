@@ -177,6 +177,15 @@ def update(W: np.ndarray, S: np.ndarray, coef: float, E=None, apriori=None, lbd=
     return new
 
 
+def update_rows(W: np.ndarray, S: np.ndarray, coef: float, rows: slice):
+    """Rows ``rows`` of ``update(W, S, coef)`` — the same expression restricted to a slab of
+    output rows (used by bench.py to time a bounded sample of one CPU iteration)."""
+    new = coef * W[rows].dot(S).dot(W.T)
+    idx = np.arange(rows.start, rows.stop)
+    new[idx - rows.start, idx] = 1
+    return new
+
+
 def iterate_directed(W, C=0.8, iterations=100, eps=1e-4, E=None, apriori=None, lbd=None,
                      out: io.StringIO | None = None):
     """Loop of SimRank.py:124-140 (PP :346-362, Apriori :438-454).

@@ -1,0 +1,113 @@
+"""ctypes binding of libsimrank_hip.so (the C ABI declared in include/simrank_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or no gfx950 device is
+visible when a device call is made, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsimrank_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "simrank_hip.h")
+
+
+class SimRankHipError(RuntimeError):
+    """A call into libsimrank_hip.so failed."""
+
+
+class Epilogue(C.Structure):
+    """struct simrank_epilogue (include/simrank_hip.h)."""
+    _fields_ = [
+        ("coef", C.c_float),
+        ("lbd", C.c_float),
+        ("evidence", C.c_void_p),
+        ("ld_evidence", C.c_int64),
+        ("apriori", C.c_void_p),
+        ("ld_apriori", C.c_int64),
+        ("previous", C.c_void_p),
+        ("ld_previous", C.c_int64),
+        ("eps", C.c_double),
+        ("n_changed", C.c_void_p),
+        ("diag_col0", C.c_int64),
+        ("set_diag", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+_vp, _i64, _i32, _int = C.c_void_p, C.c_int64, C.c_int32, C.c_int
+_pvp = C.POINTER(C.c_void_p)
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+PROTOTYPES = {
+    "simrank_abi_version": [],
+    "simrank_last_error": [],
+    "simrank_device_count": [C.POINTER(_int)],
+    "simrank_set_device": [_int],
+    "simrank_device_info": [_int, C.c_char_p, _int, C.POINTER(_i64), C.POINTER(_int),
+                            C.c_char_p, _int],
+    "simrank_malloc": [_pvp, C.c_size_t],
+    "simrank_free": [_vp],
+    "simrank_memset": [_vp, _int, C.c_size_t, _vp],
+    "simrank_memcpy_h2d": [_vp, _vp, C.c_size_t, _vp],
+    "simrank_memcpy_d2h": [_vp, _vp, C.c_size_t, _vp],
+    "simrank_memcpy_d2d": [_vp, _vp, C.c_size_t, _vp],
+    "simrank_download_f64": [_vp, _i64, _vp, _i64, _i64, _i64, _vp],
+    "simrank_stream_create": [_pvp],
+    "simrank_stream_destroy": [_vp],
+    "simrank_stream_synchronize": [_vp],
+    "simrank_event_create": [_pvp],
+    "simrank_event_destroy": [_vp],
+    "simrank_event_record": [_vp, _vp],
+    "simrank_event_elapsed_ms": [_vp, _vp, C.POINTER(C.c_float)],
+    "simrank_graph_create": [_i64, _i64, _i64, _vp, _vp, _vp, _pvp],
+    "simrank_graph_destroy": [_vp],
+    "simrank_graph_shape": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
+    "simrank_fill_identity": [_vp, _i64, _i64, _i64, _i64, _vp],
+    "simrank_spmm": [_vp, _vp, _i64, _i64, _vp, _i64, _i32, _i64, C.POINTER(Epilogue), _vp],
+    "simrank_evidence_counts": [_vp, _i64, _i64, _vp, _i64, _vp],
+    "simrank_graph_densify": [_vp, _vp, _i64, _vp],
+    "simrank_gemm_nt": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64,
+                        C.POINTER(Epilogue), _vp],
+    "simrank_set_tuning": [C.c_char_p, _i64],
+    "simrank_get_tuning": [C.c_char_p, C.POINTER(_i64)],
+}
+_RESTYPES = {"simrank_last_error": C.c_char_p}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the library once; raise ImportError with build instructions if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP engine is not built.  Build it with "
+            "`make -C simrank_amd/csrc` (or `python -c 'import __graft_entry__ as g; "
+            "g.build()'`).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError = symbol missing from the .so
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    if lib.simrank_abi_version() != 1:
+        raise ImportError("libsimrank_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().simrank_last_error()
+        raise SimRankHipError(f"{what or 'simrank call'} failed ({rc}): "
+                              f"{msg.decode() if msg else '?'}")
+
+
+def device_count() -> int:
+    """Number of visible HIP devices (0 when there is none; never raises)."""
+    n = C.c_int(0)
+    load().simrank_device_count(C.byref(n))
+    return n.value

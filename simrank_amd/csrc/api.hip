@@ -1,0 +1,307 @@
+// Plumbing half of the C ABI: errors, device/memory/stream/event wrappers, graph upload,
+// tuning knobs.  Kernels live in spmm.hip (sparse legs, evidence, identity) and dense.hip
+// (densify + f32 MFMA GEMM).
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace simrank {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+Tuning& tuning() {
+    static Tuning t;
+    return t;
+}
+
+}  // namespace simrank
+
+using namespace simrank;
+
+extern "C" {
+
+int simrank_abi_version(void) { return SIMRANK_ABI_VERSION; }
+const char* simrank_last_error(void) { return g_err; }
+
+int simrank_device_count(int* count) {
+    SR_REQUIRE(count, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return SIMRANK_ERR_NO_DEVICE;
+    }
+    *count = n;
+    return SIMRANK_OK;
+}
+
+int simrank_set_device(int device) {
+    SR_HIP(hipSetDevice(device));
+    return SIMRANK_OK;
+}
+
+int simrank_device_info(int device, char* name, int name_len, int64_t* total_bytes,
+                        int* compute_units, char* arch, int arch_len) {
+    hipDeviceProp_t p;
+    SR_HIP(hipGetDeviceProperties(&p, device));
+    if (name && name_len > 0) snprintf(name, name_len, "%s", p.name);
+    if (arch && arch_len > 0) snprintf(arch, arch_len, "%s", p.gcnArchName);
+    if (total_bytes) *total_bytes = (int64_t)p.totalGlobalMem;
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    return SIMRANK_OK;
+}
+
+int simrank_malloc(void** dptr, size_t bytes) {
+    SR_REQUIRE(dptr, "dptr is NULL");
+    *dptr = nullptr;
+    if (bytes == 0) return SIMRANK_OK;
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+        (void)hipGetLastError();
+        return e == hipErrorOutOfMemory ? SIMRANK_ERR_ALLOC : SIMRANK_ERR_HIP;
+    }
+    return SIMRANK_OK;
+}
+
+int simrank_free(void* dptr) {
+    if (dptr) SR_HIP(hipFree(dptr));
+    return SIMRANK_OK;
+}
+
+int simrank_memset(void* dptr, int v, size_t bytes, void* stream) {
+    if (bytes) SR_HIP(hipMemsetAsync(dptr, v, bytes, as_stream(stream)));
+    return SIMRANK_OK;
+}
+
+static int copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, void* stream) {
+    if (bytes == 0) return SIMRANK_OK;
+    SR_REQUIRE(dst && src, "NULL pointer in copy of %zu bytes", bytes);
+    SR_HIP(hipMemcpyAsync(dst, src, bytes, kind, as_stream(stream)));
+    SR_HIP(hipStreamSynchronize(as_stream(stream)));
+    return SIMRANK_OK;
+}
+
+int simrank_memcpy_h2d(void* d, const void* s, size_t b, void* st) {
+    return copy_sync(d, s, b, hipMemcpyHostToDevice, st);
+}
+int simrank_memcpy_d2h(void* d, const void* s, size_t b, void* st) {
+    return copy_sync(d, s, b, hipMemcpyDeviceToHost, st);
+}
+int simrank_memcpy_d2d(void* d, const void* s, size_t b, void* st) {
+    return copy_sync(d, s, b, hipMemcpyDeviceToDevice, st);
+}
+
+int simrank_download_f64(double* dst, int64_t ld_dst, const float* src, int64_t ld_src,
+                         int64_t n_rows, int64_t n_cols, void* stream) {
+    SR_REQUIRE(n_rows >= 0 && n_cols >= 0 && ld_dst >= n_cols && ld_src >= n_cols, "bad shape");
+    if (n_rows == 0 || n_cols == 0) return SIMRANK_OK;
+    SR_REQUIRE(dst && src, "NULL pointer");
+    // staged through pinned slabs so the PCIe copy of slab k+1 overlaps the f32->f64
+    // widening of slab k on the host
+    const int64_t slab_rows = std::max<int64_t>(1, (int64_t(32) << 20) / (n_cols * 4));
+    float* pin[2] = {nullptr, nullptr};
+    hipEvent_t done[2];
+    for (int i = 0; i < 2; ++i) {
+        SR_HIP(hipHostMalloc((void**)&pin[i], size_t(slab_rows) * n_cols * 4, hipHostMallocDefault));
+        SR_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    }
+    hipStream_t st = as_stream(stream);
+    auto issue = [&](int64_t r0, int buf) -> hipError_t {
+        int64_t nr = std::min(slab_rows, n_rows - r0);
+        hipError_t e = hipMemcpy2DAsync(pin[buf], n_cols * 4, src + r0 * ld_src, ld_src * 4,
+                                        n_cols * 4, nr, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return e;
+        return hipEventRecord(done[buf], st);
+    };
+    int rc = SIMRANK_OK;
+    hipError_t e = issue(0, 0);
+    int buf = 0;
+    for (int64_t r0 = 0; r0 < n_rows && e == hipSuccess; r0 += slab_rows, buf ^= 1) {
+        if (r0 + slab_rows < n_rows) e = issue(r0 + slab_rows, buf ^ 1);
+        if (e != hipSuccess) break;
+        e = hipEventSynchronize(done[buf]);
+        if (e != hipSuccess) break;
+        int64_t nr = std::min(slab_rows, n_rows - r0);
+        for (int64_t r = 0; r < nr; ++r) {
+            const float* s = pin[buf] + r * n_cols;
+            double* d = dst + (r0 + r) * ld_dst;
+            for (int64_t c = 0; c < n_cols; ++c) d[c] = (double)s[c];
+        }
+    }
+    if (e != hipSuccess) {
+        set_error("simrank_download_f64: %s", hipGetErrorString(e));
+        rc = SIMRANK_ERR_HIP;
+    }
+    (void)hipStreamSynchronize(st);
+    for (int i = 0; i < 2; ++i) {
+        (void)hipHostFree(pin[i]);
+        (void)hipEventDestroy(done[i]);
+    }
+    return rc;
+}
+
+int simrank_stream_create(void** stream) {
+    SR_REQUIRE(stream, "stream is NULL");
+    hipStream_t s;
+    SR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return SIMRANK_OK;
+}
+int simrank_stream_destroy(void* stream) {
+    if (stream) SR_HIP(hipStreamDestroy(as_stream(stream)));
+    return SIMRANK_OK;
+}
+int simrank_stream_synchronize(void* stream) {
+    SR_HIP(hipStreamSynchronize(as_stream(stream)));
+    return SIMRANK_OK;
+}
+int simrank_event_create(void** event) {
+    SR_REQUIRE(event, "event is NULL");
+    hipEvent_t e;
+    SR_HIP(hipEventCreate(&e));
+    *event = e;
+    return SIMRANK_OK;
+}
+int simrank_event_destroy(void* event) {
+    if (event) SR_HIP(hipEventDestroy((hipEvent_t)event));
+    return SIMRANK_OK;
+}
+int simrank_event_record(void* event, void* stream) {
+    SR_HIP(hipEventRecord((hipEvent_t)event, as_stream(stream)));
+    return SIMRANK_OK;
+}
+int simrank_event_elapsed_ms(void* start, void* stop, float* ms) {
+    SR_REQUIRE(ms, "ms is NULL");
+    SR_HIP(hipEventSynchronize((hipEvent_t)stop));
+    SR_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return SIMRANK_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// graph
+// ---------------------------------------------------------------------------------------
+int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr,
+                         const int32_t* col, const float* rowscale, simrank_graph** out) {
+    SR_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    SR_REQUIRE(n_rows > 0 && n_cols > 0 && nnz >= 0, "bad graph shape %lld x %lld, nnz %lld",
+               (long long)n_rows, (long long)n_cols, (long long)nnz);
+    SR_REQUIRE(n_rows < (int64_t(1) << 31) && n_cols < (int64_t(1) << 31) &&
+                   nnz < (int64_t(1) << 31),
+               "graph too large for 32-bit indices");
+    SR_REQUIRE(rowptr && rowscale && (col || nnz == 0), "NULL CSR array");
+    SR_REQUIRE(rowptr[0] == 0 && rowptr[n_rows] == nnz, "rowptr does not span [0, nnz]");
+    int32_t max_row = 0;
+    std::vector<int32_t> t_rowptr(size_t(n_cols) + 1, 0);
+    for (int64_t a = 0; a < n_rows; ++a) {
+        SR_REQUIRE(rowptr[a + 1] >= rowptr[a], "rowptr not monotone at row %lld", (long long)a);
+        max_row = std::max(max_row, rowptr[a + 1] - rowptr[a]);
+        for (int32_t j = rowptr[a]; j < rowptr[a + 1]; ++j) {
+            SR_REQUIRE(col[j] >= 0 && col[j] < n_cols, "column index %d out of range at row %lld",
+                       col[j], (long long)a);
+            SR_REQUIRE(j == rowptr[a] || col[j] > col[j - 1],
+                       "columns of row %lld not strictly ascending", (long long)a);
+            t_rowptr[size_t(col[j]) + 1]++;
+        }
+    }
+    for (int64_t i = 0; i < n_cols; ++i) t_rowptr[i + 1] += t_rowptr[i];
+    std::vector<int32_t> t_col(std::max<size_t>(1, size_t(nnz)));
+    {
+        std::vector<int32_t> cur(t_rowptr.begin(), t_rowptr.end() - 1);
+        for (int64_t a = 0; a < n_rows; ++a)
+            for (int32_t j = rowptr[a]; j < rowptr[a + 1]; ++j) t_col[cur[col[j]]++] = (int32_t)a;
+    }
+    simrank_graph* g = new simrank_graph;
+    g->n_rows = n_rows;
+    g->n_cols = n_cols;
+    g->nnz = nnz;
+    g->max_row_nnz = max_row;
+    auto up = [&](void** d, const void* h, size_t bytes) -> int {
+        size_t alloc = std::max<size_t>(bytes, 16);
+        hipError_t e = hipMalloc(d, alloc);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error("graph upload: %s", hipGetErrorString(e));
+            (void)hipGetLastError();
+            return SIMRANK_ERR_HIP;
+        }
+        return SIMRANK_OK;
+    };
+    int rc = up((void**)&g->rowptr, rowptr, size_t(n_rows + 1) * 4);
+    if (!rc) rc = up((void**)&g->col, col, size_t(nnz) * 4);
+    if (!rc) rc = up((void**)&g->rowscale, rowscale, size_t(n_rows) * 4);
+    if (!rc) rc = up((void**)&g->t_rowptr, t_rowptr.data(), size_t(n_cols + 1) * 4);
+    if (!rc) rc = up((void**)&g->t_col, t_col.data(), size_t(nnz) * 4);
+    if (rc) {
+        simrank_graph_destroy(g);
+        return rc;
+    }
+    *out = g;
+    return SIMRANK_OK;
+}
+
+int simrank_graph_destroy(simrank_graph* g) {
+    if (!g) return SIMRANK_OK;
+    (void)hipFree(g->rowptr);
+    (void)hipFree(g->col);
+    (void)hipFree(g->rowscale);
+    (void)hipFree(g->t_rowptr);
+    (void)hipFree(g->t_col);
+    delete g;
+    return SIMRANK_OK;
+}
+
+int simrank_graph_shape(const simrank_graph* g, int64_t* n_rows, int64_t* n_cols, int64_t* nnz) {
+    SR_REQUIRE(g, "graph is NULL");
+    if (n_rows) *n_rows = g->n_rows;
+    if (n_cols) *n_cols = g->n_cols;
+    if (nnz) *nnz = g->nnz;
+    return SIMRANK_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// tuning
+// ---------------------------------------------------------------------------------------
+int simrank_set_tuning(const char* key, int64_t value) {
+    SR_REQUIRE(key, "key is NULL");
+    Tuning& t = tuning();
+    if (!strcmp(key, "panel")) {
+        SR_REQUIRE(value == 0 || value == 16 || value == 32 || value == 64 || value == 128 ||
+                       value == 256,
+                   "panel must be 0, 16, 32, 64, 128 or 256");
+        t.panel = value;
+    } else if (!strcmp(key, "xcd_map")) {
+        t.xcd_map = value ? 1 : 0;
+    } else if (!strcmp(key, "unroll")) {
+        SR_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, "unroll must be 1,2,4,8");
+        t.unroll = value;
+    } else {
+        SR_REQUIRE(false, "unknown tuning key '%s'", key);
+    }
+    return SIMRANK_OK;
+}
+
+int simrank_get_tuning(const char* key, int64_t* value) {
+    SR_REQUIRE(key && value, "NULL argument");
+    const Tuning& t = tuning();
+    if (!strcmp(key, "panel")) *value = t.panel;
+    else if (!strcmp(key, "xcd_map")) *value = t.xcd_map;
+    else if (!strcmp(key, "unroll")) *value = t.unroll;
+    else SR_REQUIRE(false, "unknown tuning key '%s'", key);
+    return SIMRANK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// Internal declarations shared by the translation units of libsimrank_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "simrank_hip.h"
+
+namespace simrank {
+
+void set_error(const char* fmt, ...);
+
+#define SR_HIP(call)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            ::simrank::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                                 __FILE__, __LINE__);                                  \
+            return SIMRANK_ERR_HIP;                                                    \
+        }                                                                              \
+    } while (0)
+
+#define SR_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            ::simrank::set_error(__VA_ARGS__); \
+            return SIMRANK_ERR_INVALID;       \
+        }                                     \
+    } while (0)
+
+struct Tuning {
+    int64_t panel = 0;    // 0 = automatic
+    int64_t xcd_map = 1;  // panel -> XCD affinity (blockIdx % 8 shares an L2)
+    int64_t unroll = 4;
+};
+Tuning& tuning();
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace simrank
+
+// The graph object: device CSR of the 0/1 pattern + per-row scale, and the transposed
+// pattern (CSC) used by the evidence kernel.
+struct simrank_graph {
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    int32_t* rowptr = nullptr;    // [n_rows+1]
+    int32_t* col = nullptr;       // [nnz]
+    float* rowscale = nullptr;    // [n_rows]
+    int32_t* t_rowptr = nullptr;  // [n_cols+1]  transposed pattern
+    int32_t* t_col = nullptr;     // [nnz]       row ids, ascending per column
+    int32_t max_row_nnz = 0;
+};

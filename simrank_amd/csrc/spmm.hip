@@ -1,0 +1,412 @@
+// Sparse legs of the SimRank update for gfx950 (MI355X), plus identity init and the
+// SimRank++ evidence counts.
+//
+//   Y = diag(rowscale) . A . X          A = 0/1 CSR pattern, X dense row-major
+//
+// Row-gather form: output row a is rowscale[a] times the sum of the rows of X listed in
+// CSR row a.  The kernel is HBM/L2-bandwidth work, not arithmetic:
+//   * a launch is tiled into column PANELS of PW = VEC*LPR floats; inside a panel one
+//     64-lane wave owns RT consecutive output rows.  LPR lanes cover one neighbour row
+//     segment (16 B per lane when VEC = 4), so a wave gathers G = 64/LPR different
+//     neighbour rows per load instruction and keeps UNROLL of those in flight;
+//   * the G partial sums are combined with cross-lane shuffles in a fixed order (the
+//     result is bitwise reproducible; no float atomics anywhere);
+//   * all workgroups whose blockIdx is congruent mod 8 share an XCD and therefore an L2:
+//     panel p is given to the blocks with blockIdx % 8 == p % 8, in row-tile order, so
+//     the N x PW slice of X a panel re-reads (deg times on average) stays in that L2;
+//   * leg 1 stores its tile TRANSPOSED (through a per-wave LDS tile, RT consecutive
+//     floats per output row segment) so that leg 2 is the same row gather;
+//   * leg 2 fuses the whole reference epilogue: coef, evidence 1-2^-count, prior blend,
+//     diag <- 1, and the |new-old| > eps count of `_converged` (SimRank.py:74,139-140).
+#include <algorithm>
+
+#include "common.h"
+
+namespace simrank {
+
+__device__ __forceinline__ int64_t imin(int64_t a, int64_t b) { return a < b ? a : b; }
+
+struct SpmmArgs {
+    const int32_t* rowptr;
+    const int32_t* col;
+    const float* rowscale;
+    const float* X;
+    int64_t ldx;
+    int64_t L;  // columns of X and of Y
+    float* Y;
+    int64_t ldy;
+    int64_t M;       // rows of the graph = rows of Y
+    int64_t tblock;  // rows per transposed block (TRANS only)
+    int64_t tstride; // TRANS, single block: row stride of Y^T (0 = rows in block)
+    int32_t n_panels;
+    int32_t row_tiles;
+    int32_t xcd_map;
+    int32_t has_ep;
+    // epilogue (has_ep)
+    float coef;
+    float lbd;
+    const uint8_t* ev;
+    int64_t ld_ev;
+    const float* ap;
+    int64_t ld_ap;
+    const float* prev;
+    int64_t ld_prev;
+    double eps;
+    unsigned long long* n_changed;
+    int64_t diag_col0;
+    int32_t set_diag;
+};
+
+template <int VEC>
+__device__ __forceinline__ void vload(float (&d)[VEC], const float* p) {
+    if constexpr (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+    } else {
+        d[0] = *p;
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void vstore(float* p, const float (&d)[VEC]) {
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(d[0], d[1], d[2], d[3]);
+    } else {
+        *p = d[0];
+    }
+}
+
+constexpr int kWaves = 4;  // waves per workgroup
+
+template <int VEC, int LPR, bool TRANS, int RT, int UNROLL>
+__global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
+    constexpr int PW = VEC * LPR;  // panel width in floats
+    constexpr int G = 64 / LPR;    // neighbour rows gathered per load instruction
+    __shared__ float tbuf[TRANS ? kWaves * PW * (RT + 1) : 1];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // block -> (panel, row tile); blocks equal mod 8 share an XCD (speed only)
+    int panel, rt;
+    {
+        const int64_t bid = blockIdx.x;
+        if (p.xcd_map) {
+            const int x = int(bid & 7);
+            const int64_t local = bid >> 3;
+            panel = int(local / p.row_tiles) * 8 + x;
+            rt = int(local % p.row_tiles);
+        } else {
+            panel = int(bid / p.row_tiles);
+            rt = int(bid % p.row_tiles);
+        }
+    }
+    if (panel >= p.n_panels) return;  // uniform over the workgroup
+
+    const int64_t c0 = int64_t(panel) * PW;
+    const int g = lane / LPR;
+    const int q = lane % LPR;
+    const int64_t mycol = c0 + int64_t(q) * VEC;
+    const bool col_active = mycol < p.L;  // VEC=4: mycol+3 < ldx because ldx % 4 == 0
+    const int64_t row0 = (int64_t(rt) * kWaves + wave) * RT;
+    const float* __restrict__ Xc = p.X + mycol;
+    unsigned changed = 0;
+
+    for (int r = 0; r < RT; ++r) {
+        const int64_t a = row0 + r;
+        if (a >= p.M) break;  // wave-uniform
+        const int s = p.rowptr[a];
+        const int e = p.rowptr[a + 1];
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+
+        for (int base = s; base < e; base += 64) {
+            const int n = min(64, e - base);
+            // one coalesced load of up to 64 neighbour ids, handed out by shuffle
+            const int myidx = lane < n ? p.col[base + lane] : 0;
+            for (int k0 = 0; k0 < n; k0 += G * UNROLL) {
+                float v[UNROLL][VEC];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int k = k0 + u * G + g;
+                    const int idx = __shfl(myidx, k & 63);
+                    if (col_active && k < n) {
+                        vload<VEC>(v[u], Xc + int64_t(idx) * p.ldx);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
+            }
+        }
+        // combine the G neighbour groups, fixed order
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off);
+
+        if (g == 0 && col_active) {
+            const float sc = p.rowscale[a] * (p.has_ep ? p.coef : 1.0f);
+            float o[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) o[i] = acc[i] * sc;
+            if constexpr (TRANS) {
+                float* t = tbuf + (wave * PW + q * VEC) * (RT + 1) + r;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) t[i * (RT + 1)] = o[i];
+            } else {
+                const int nvalid = int(imin(VEC, p.L - mycol));
+                if (p.has_ep) {
+                    if (p.ev) {
+                        const uint8_t* ep = p.ev + a * p.ld_ev + mycol;
+                        unsigned cnt[VEC];
+                        if constexpr (VEC == 4) {
+                            const unsigned w = *reinterpret_cast<const unsigned*>(ep);
+                            cnt[0] = w & 255u; cnt[1] = (w >> 8) & 255u;
+                            cnt[2] = (w >> 16) & 255u; cnt[3] = w >> 24;
+                        } else {
+                            cnt[0] = ep[0];
+                        }
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i)
+                            o[i] *= 1.0f - __builtin_ldexpf(1.0f, -int(cnt[i]));
+                    }
+                    if (p.ap) {
+                        float pr[VEC];
+                        vload<VEC>(pr, p.ap + a * p.ld_ap + mycol);
+                        const float keep = 1.0f - p.lbd;
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) o[i] = keep * o[i] + p.lbd * pr[i];
+                    }
+                    if (p.set_diag) {
+                        const int64_t d = a - (p.diag_col0 + mycol);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i)
+                            if (d == i) o[i] = 1.0f;
+                    }
+                    if (p.prev) {
+                        float old[VEC];
+                        vload<VEC>(old, p.prev + a * p.ld_prev + mycol);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i)
+                            changed += (i < nvalid &&
+                                        fabs(double(o[i]) - double(old[i])) > p.eps) ? 1u : 0u;
+                    }
+                }
+                float* y = p.Y + a * p.ldy + mycol;
+                if (nvalid == VEC) {
+                    vstore<VEC>(y, o);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i)
+                        if (i < nvalid) y[i] = o[i];
+                }
+            }
+        }
+    }
+
+    if constexpr (TRANS) {
+        __syncthreads();
+        const int rows_done = int(imin(RT, p.M - row0));  // may be <= 0
+        const int cols_here = int(imin(PW, p.L - c0));
+        const int64_t tb = p.tblock;
+        const float* t = tbuf + wave * PW * (RT + 1);
+        for (int x = lane; x < PW * RT; x += 64) {
+            const int c = x / RT;
+            const int r = x % RT;
+            if (c < cols_here && r < rows_done) {
+                const int64_t a = row0 + r;
+                const int64_t blk = a / tb;
+                const int64_t a_in = a - blk * tb;
+                const int64_t stride = p.tstride ? p.tstride : imin(tb, p.M - blk * tb);
+                p.Y[blk * (p.L * tb) + (c0 + c) * stride + a_in] = t[c * (RT + 1) + r];
+            }
+        }
+    } else {
+        if (p.has_ep && p.prev) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) changed += __shfl_down(changed, off);
+            if (lane == 0 && changed) atomicAdd(p.n_changed, (unsigned long long)changed);
+        }
+    }
+}
+
+template <int VEC, int LPR, bool TRANS, int RT>
+static int launch_spmm(SpmmArgs a, hipStream_t st) {
+    constexpr int PW = VEC * LPR;
+    a.n_panels = int((a.L + PW - 1) / PW);
+    a.row_tiles = int((a.M + kWaves * RT - 1) / (kWaves * RT));
+    const int64_t panels_padded = a.xcd_map ? int64_t((a.n_panels + 7) / 8) * 8 : a.n_panels;
+    const int64_t grid = panels_padded * a.row_tiles;
+    SR_REQUIRE(grid > 0 && grid < (int64_t(1) << 31), "grid of %lld blocks", (long long)grid);
+    hipLaunchKernelGGL((spmm_gather_kernel<VEC, LPR, TRANS, RT, 4>), dim3((unsigned)grid),
+                       dim3(256), 0, st, a);
+    SR_HIP(hipGetLastError());
+    return SIMRANK_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// K0: identity columns
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fill_identity_kernel(float* S, int64_t n_rows,
+                                                            int64_t n_cols, int64_t ld,
+                                                            int64_t col0) {
+    const int64_t total = n_rows * n_cols;
+    for (int64_t t = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; t < total;
+         t += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t a = t / n_cols;
+        const int64_t c = t - a * n_cols;
+        S[a * ld + c] = (a == col0 + c) ? 1.0f : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K7: evidence counts.  One workgroup per row a: LDS counters for a chunk of columns,
+// incremented along every 2-hop path a <- i -> b; saturated to u8 on the way out.
+// ---------------------------------------------------------------------------------------
+constexpr int kEvChunk = 16384;  // columns per pass: 64 KiB of LDS counters
+
+__global__ __launch_bounds__(256) void evidence_counts_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const float* __restrict__ rowscale, const int32_t* __restrict__ t_rowptr,
+    const int32_t* __restrict__ t_col, int64_t M, int64_t col0, int n_cols, uint8_t* out,
+    int64_t ld) {
+    extern __shared__ unsigned cnt[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    for (int c = tid; c < n_cols; c += 256) cnt[c] = 0;
+    for (int64_t a = blockIdx.x; a < M; a += gridDim.x) {
+        __syncthreads();
+        if (rowscale[a] > 0.f) {
+            const int s = rowptr[a], e = rowptr[a + 1];
+            for (int j = s + wave; j < e; j += kWaves) {
+                const int i = col[j];
+                const int ts = t_rowptr[i], te = t_rowptr[i + 1];
+                for (int t = ts + lane; t < te; t += 64) {
+                    const int64_t b = t_col[t];
+                    const int64_t c = b - col0;
+                    if (c >= 0 && c < n_cols && rowscale[b] > 0.f) atomicAdd(&cnt[c], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        uint8_t* o = out + a * ld;
+        for (int c = tid; c < n_cols; c += 256) {
+            o[c] = (uint8_t)min(cnt[c], 255u);
+            cnt[c] = 0;
+        }
+    }
+}
+
+}  // namespace simrank
+
+using namespace simrank;
+
+extern "C" {
+
+int simrank_fill_identity(float* S, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t col0,
+                          void* stream) {
+    SR_REQUIRE(S && n_rows > 0 && n_cols > 0 && ld >= n_cols, "bad identity block");
+    const int64_t total = n_rows * n_cols;
+    const int grid = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(fill_identity_kernel, dim3(grid), dim3(256), 0, as_stream(stream), S,
+                       n_rows, n_cols, ld, col0);
+    SR_HIP(hipGetLastError());
+    return SIMRANK_OK;
+}
+
+int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_cols_x,
+                 float* Y, int64_t ldy, int32_t transpose_out, int64_t t_block,
+                 const simrank_epilogue* ep, void* stream) {
+    SR_REQUIRE(g && X && Y, "NULL argument");
+    SR_REQUIRE(n_cols_x > 0 && ldx >= n_cols_x, "X: %lld columns, ld %lld", (long long)n_cols_x,
+               (long long)ldx);
+    SR_REQUIRE(transpose_out || ldy >= n_cols_x, "Y: ld %lld < %lld columns", (long long)ldy,
+               (long long)n_cols_x);
+    SR_REQUIRE(!(transpose_out && ep), "an epilogue needs transpose_out = 0");
+    SpmmArgs a{};
+    a.rowptr = g->rowptr;
+    a.col = g->col;
+    a.rowscale = g->rowscale;
+    a.X = X;
+    a.ldx = ldx;
+    a.L = n_cols_x;
+    a.Y = Y;
+    a.ldy = ldy;
+    a.M = g->n_rows;
+    a.tblock = (t_block <= 0 || t_block > g->n_rows) ? g->n_rows : t_block;
+    a.tstride = (transpose_out && a.tblock == g->n_rows && ldy >= g->n_rows) ? ldy : 0;
+    a.xcd_map = (int)tuning().xcd_map;
+    bool vec_ok = aligned16(X) && ldx % 4 == 0;
+    if (!transpose_out) vec_ok = vec_ok && aligned16(Y) && ldy % 4 == 0;
+    hipStream_t st = as_stream(stream);
+    if (ep) {
+        a.has_ep = 1;
+        a.coef = ep->coef;
+        a.lbd = ep->lbd;
+        a.ev = ep->evidence;
+        a.ld_ev = ep->ld_evidence;
+        a.ap = ep->apriori;
+        a.ld_ap = ep->ld_apriori;
+        a.prev = ep->previous;
+        a.ld_prev = ep->ld_previous;
+        a.eps = ep->eps;
+        a.n_changed = ep->n_changed;
+        a.diag_col0 = ep->diag_col0;
+        a.set_diag = ep->set_diag;
+        SR_REQUIRE(!a.ev || a.ld_ev >= n_cols_x, "evidence ld too small");
+        SR_REQUIRE(!a.ap || a.ld_ap >= n_cols_x, "apriori ld too small");
+        SR_REQUIRE(!a.prev || (a.ld_prev >= n_cols_x && a.n_changed),
+                   "previous needs ld >= columns and a counter");
+        if (a.ev) vec_ok = vec_ok && (reinterpret_cast<uintptr_t>(a.ev) % 4 == 0) && a.ld_ev % 4 == 0;
+        if (a.ap) vec_ok = vec_ok && aligned16(a.ap) && a.ld_ap % 4 == 0;
+        if (a.prev) vec_ok = vec_ok && aligned16(a.prev) && a.ld_prev % 4 == 0;
+        if (a.prev) SR_HIP(hipMemsetAsync(a.n_changed, 0, sizeof(unsigned long long), st));
+    }
+    int64_t panel = tuning().panel;
+    if (panel == 0) panel = 32;
+    if (!vec_ok) {
+        return transpose_out ? launch_spmm<1, 32, true, 64>(a, st)
+                             : launch_spmm<1, 32, false, 64>(a, st);
+    }
+    if (transpose_out) {
+        if (panel > 64) panel = 64;  // wider panels would not leave LDS for the transpose tile
+        switch (panel) {
+            case 16: return launch_spmm<4, 4, true, 64>(a, st);
+            case 32: return launch_spmm<4, 8, true, 64>(a, st);
+            default: return launch_spmm<4, 16, true, 32>(a, st);
+        }
+    }
+    switch (panel) {
+        case 16: return launch_spmm<4, 4, false, 64>(a, st);
+        case 32: return launch_spmm<4, 8, false, 64>(a, st);
+        case 64: return launch_spmm<4, 16, false, 64>(a, st);
+        case 128: return launch_spmm<4, 32, false, 64>(a, st);
+        default: return launch_spmm<4, 64, false, 64>(a, st);
+    }
+}
+
+int simrank_evidence_counts(const simrank_graph* g, int64_t col0, int64_t n_cols,
+                            uint8_t* counts, int64_t ld, void* stream) {
+    SR_REQUIRE(g && counts, "NULL argument");
+    SR_REQUIRE(col0 >= 0 && n_cols > 0 && col0 + n_cols <= g->n_rows && ld >= n_cols,
+               "evidence block [%lld, %lld) of %lld, ld %lld", (long long)col0,
+               (long long)(col0 + n_cols), (long long)g->n_rows, (long long)ld);
+    const int grid = (int)std::min<int64_t>(g->n_rows, 256 * 2);
+    for (int64_t c = 0; c < n_cols; c += kEvChunk) {
+        const int nc = (int)std::min<int64_t>(kEvChunk, n_cols - c);
+        hipLaunchKernelGGL(evidence_counts_kernel, dim3(grid), dim3(256), size_t(nc) * 4,
+                           as_stream(stream), g->rowptr, g->col, g->rowscale, g->t_rowptr,
+                           g->t_col, g->n_rows, col0 + c, nc, counts + c, ld);
+        SR_HIP(hipGetLastError());
+    }
+    return SIMRANK_OK;
+}
+
+}  // extern "C"

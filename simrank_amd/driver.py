@@ -1,0 +1,329 @@
+"""Iteration driver: the loops of SimRank.py:129-140 / :288-302 / :351-362 / :410-424 /
+:443-454 / :478-492 on top of the kernel set of ``engine.HipOps``.
+
+One similarity update   S_out = coef . W . S_in . W^T (.*E) (+ lbd.A), diag <- 1   is two
+row-gather SpMMs because S_in is symmetric:
+
+    leg 1   Tt = (W . S_in)^T        stored transposed, in per-destination blocks
+    leg 2   S_out = W . Tt  + fused epilogue (also counts |S_out - S_prev| > eps)
+
+Sharding: every similarity matrix is split by COLUMN block over the ranks
+(by symmetry the block of rank r is also its ROW block, transposed).  Leg 1 needs only the
+rank's own columns of S_in; what leg 2 needs is the transpose of what leg 1 produced, so the
+one exchange per update is an ALL-TO-ALL of (N/P) x (N/P) tiles — each rank sends and
+receives N^2/P . (P-1)/P floats, P/… times less than all-gathering S (N^2 . (P-1)/P per rank).
+Each rank then reduces one integer (the convergence count).
+
+The driver is SPMD over "virtual ranks": with a real process group every process runs one;
+the loopback world runs P of them on one device (used to test the sharded path on the
+single GPU that is available, bit-for-bit against P = 1).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from .ingest import CSR, partition
+
+DENSE_THRESHOLD = 0.05   # density above which the MFMA GEMM legs beat the gather legs
+
+
+# --------------------------------------------------------------------------------------
+# worlds
+# --------------------------------------------------------------------------------------
+class LocalWorld:
+    """P virtual ranks inside this process (P = 1 is the ordinary single-GPU case)."""
+
+    def __init__(self, size: int = 1):
+        self.size = int(size)
+        self.local_ranks = list(range(self.size))
+        self.is_root = True
+
+    def exchange(self, sides):
+        """All-to-all of the transposed leg-1 tiles between the virtual ranks."""
+        if self.size == 1:
+            return                               # recv aliases send
+        for src in sides:
+            for dst in sides:
+                n = src.Lk * dst.Lm              # tile (columns of src) x (rows of dst)
+                src.ops.copy_bytes(dst.recv.ptr + 4 * src.k_lo * dst.Lm,
+                                   src.send.ptr + 4 * dst.rank * src.Lk * src.mb, 4 * n)
+
+    def sum_int(self, values):
+        return int(sum(values))
+
+    def gather_columns(self, blocks, n_rows, n_cols):
+        out = np.empty((n_rows, n_cols), dtype=np.float64)
+        for r, blk in blocks.items():
+            lo, hi = partition(n_cols, self.size, r)
+            out[:, lo:hi] = blk
+        return out
+
+
+class TorchWorld:
+    """One rank per process over torch.distributed (backend "nccl" = RCCL over xGMI on the
+    GPU box; "gloo" in the CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.local_ranks = [self.rank]
+        self.is_root = self.rank == 0
+
+    def exchange(self, sides):
+        (s,) = sides
+        ops = s.ops
+        ops.synchronize()                        # leg 1 finished on the engine's stream
+        in_splits = [s.Lk * (partition(s.M, self.size, h)[1] - partition(s.M, self.size, h)[0])
+                     for h in range(self.size)]
+        out_splits = [(partition(s.K, self.size, h)[1] - partition(s.K, self.size, h)[0]) * s.Lm
+                      for h in range(self.size)]
+        send = s.send_t[:sum(in_splits)]
+        recv = s.recv_t[:sum(out_splits)]
+        self.dist.all_to_all_single(recv, send, out_splits, in_splits, group=self.group)
+        ops.collective_done()
+
+    def sum_int(self, values):
+        import torch
+        (v,) = values
+        t = torch.tensor([v], dtype=torch.int64, device=self._dev())
+        self.dist.all_reduce(t, group=self.group)
+        return int(t.item())
+
+    def _dev(self):
+        import torch
+        if self.dist.get_backend(self.group) == "nccl":
+            return torch.device("cuda", torch.cuda.current_device())
+        return torch.device("cpu")
+
+    def gather_columns(self, blocks, n_rows, n_cols):
+        (blk,) = blocks.values()
+        parts = [None] * self.size
+        self.dist.all_gather_object(parts, blk, group=self.group)
+        return np.concatenate(parts, axis=1)
+
+
+# --------------------------------------------------------------------------------------
+# one side of an update, for one (virtual) rank
+# --------------------------------------------------------------------------------------
+@dataclass
+class SideSpec:
+    csr: CSR                     # W = diag(rowscale) . pattern, M x K
+    rowscale: np.ndarray         # float64 [M] actually used (weight-adjusted for SimRank++)
+    coef: float
+    evidence_from: CSR | None = None   # pattern whose common-neighbour counts gate the update
+    apriori: np.ndarray | None = None  # M x M prior
+    lbd: float = 0.0
+
+
+class Side:
+    def __init__(self, ops, spec: SideSpec, rank: int, world: int, mode: str, torch_buffers: bool):
+        self.ops, self.spec, self.rank, self.world, self.mode = ops, spec, rank, world, mode
+        csr = spec.csr
+        self.M, self.K = csr.n_rows, csr.n_cols
+        self.m_lo, self.m_hi = partition(self.M, world, rank)
+        self.k_lo, self.k_hi = partition(self.K, world, rank)
+        self.Lm, self.Lk = self.m_hi - self.m_lo, self.k_hi - self.k_lo
+        self.mb = -(-self.M // world)
+        self.graph = ops.graph(csr, spec.rowscale)
+        self.send_t = self.recv_t = None
+        if mode == "sparse":
+            if world == 1:
+                self.tt = ops.matrix(self.K, self.M)             # Tt, pitched
+                self.send = self.recv = self.tt
+            elif torch_buffers:
+                self.send_t = ops.exchange_buffer(self.M * self.Lk)
+                self.recv_t = ops.exchange_buffer(self.K * self.Lm)
+                self.send = ops.matrix(1, self.M * self.Lk, ld=self.M * self.Lk, external=self.send_t)
+                self.recv = ops.matrix(self.K, self.Lm, ld=max(1, self.Lm), external=self.recv_t)
+            else:
+                self.send = ops.matrix(1, self.M * self.Lk, ld=max(1, self.M * self.Lk))
+                self.recv = ops.matrix(self.K, self.Lm, ld=max(1, self.Lm))
+        else:                                                    # dense / hybrid: one rank only
+            assert world == 1, "dense and hybrid modes run on one rank"
+            self.wd = ops.matrix(self.M, self.K)
+            ops.densify(self.graph, self.wd)
+            self.t = ops.matrix(self.M, self.K)
+        self.ev = None
+        if spec.evidence_from is not None:
+            eg = self.graph if spec.evidence_from is csr else ops.graph(spec.evidence_from)
+            if eg.n_rows != self.M:
+                # quirk Q2: the reference multiplies an n2 x n2 update by Evidence_N1
+                raise ValueError(f"operands could not be broadcast together with shapes "
+                                 f"({eg.n_rows},{eg.n_rows}) ({self.M},{self.M}) ")
+            self.ev = ops.matrix(self.M, self.Lm, np.uint8)
+            ops.evidence_counts(eg, self.m_lo, self.ev)
+        self.ap = None
+        if spec.apriori is not None:
+            a = np.asarray(spec.apriori)
+            if a.shape != (self.M, self.M):
+                raise ValueError(f"operands could not be broadcast together with shapes "
+                                 f"({self.M},{self.M}) {a.shape} ")
+            self.ap = ops.matrix(self.M, self.Lm)
+            ops.upload(self.ap, a[:, self.m_lo:self.m_hi].astype(np.float32))
+
+    # S_in: K x Lk block of the (symmetric) input similarity
+    def leg1(self, S_in):
+        o = self.ops
+        if self.mode == "sparse":
+            if self.Lk:
+                o.spmm(self.graph, S_in, self.send, n_cols=self.Lk, transpose_out=True,
+                       t_block=self.mb if self.world > 1 else 0)
+        elif self.mode == "hybrid":
+            o.spmm(self.graph, S_in, self.t)                          # T = W.S, plain store
+        else:
+            o.gemm_nt(self.wd, S_in, self.t, self.M, self.K, self.K)  # T = Wd.S^T, S symmetric
+
+    def leg2(self, S_prev, S_out, eps):
+        o = self.ops
+        if not self.Lm:
+            return 0
+        ep = dict(coef=self.spec.coef, evidence=self.ev, apriori=self.ap, lbd=self.spec.lbd,
+                  previous=S_prev, eps=eps, diag_col0=self.m_lo, set_diag=True)
+        if self.mode == "sparse":
+            o.spmm(self.graph, self.recv, S_out, n_cols=self.Lm, epilogue=ep)
+        else:
+            o.gemm_nt(self.t, self.wd, S_out, self.M, self.M, self.K, epilogue=ep)
+        return None                                                   # counter read later
+
+
+def choose_mode(mode: str, csrs, world: int) -> str:
+    if mode not in ("auto", "sparse", "dense", "hybrid"):
+        raise ValueError(f"mode must be auto, sparse, dense or hybrid, not {mode!r}")
+    if mode == "auto":
+        dense = world == 1 and all(c.density > DENSE_THRESHOLD for c in csrs)
+        return "dense" if dense else "sparse"
+    if mode != "sparse" and world != 1:
+        raise ValueError("dense and hybrid modes are single-rank; use mode='sparse' when sharded")
+    return mode
+
+
+# --------------------------------------------------------------------------------------
+# solvers
+# --------------------------------------------------------------------------------------
+class Solver:
+    """Runs the reference loop for one or two coupled similarity matrices.
+
+    ``sides``: [spec] for the directed classes (S <- f(S)); [spec1, spec2] for the bipartite
+    ones (S1 <- f1(S2), then S2 <- f2(S1_new)).  ``make_ops(virtual_rank)`` returns the
+    kernel launcher of a virtual rank.
+    """
+
+    def __init__(self, make_ops, world, specs, mode="auto"):
+        self.world = world
+        self.specs = specs
+        self.bipartite = len(specs) == 2
+        self.mode = choose_mode(mode, [s.csr for s in specs], world.size)
+        torch_buffers = isinstance(world, TorchWorld)
+        self.ops = {r: make_ops(r) for r in world.local_ranks}
+        self.sides = [{r: Side(self.ops[r], sp, r, world.size, self.mode, torch_buffers)
+                       for r in world.local_ranks} for sp in specs]
+        # similarity matrices: index j -> size n_j; S_j is n_j x (block of n_j), ping-pong
+        if self.bipartite:
+            self.n = [specs[0].csr.n_rows, specs[1].csr.n_rows]
+        else:
+            self.n = [specs[0].csr.n_rows]
+        self.cur, self.nxt = [], []
+        for n in self.n:
+            c, x = {}, {}
+            for r in world.local_ranks:
+                lo, hi = partition(n, world.size, r)
+                c[r] = self.ops[r].matrix(n, hi - lo)
+                x[r] = self.ops[r].matrix(n, hi - lo)
+            self.cur.append(c)
+            self.nxt.append(x)
+        self.events = None
+        self.leg_ms = []
+
+    def reset(self):
+        for j, n in enumerate(self.n):
+            for r in self.world.local_ranks:
+                lo, _ = partition(n, self.world.size, r)
+                self.ops[r].fill_identity(self.cur[j][r], lo)
+
+    def enable_timing(self):
+        """Record HIP events around every leg on the engine's stream (rank-local)."""
+        self.events = []
+
+    def _timed(self, r, fn, tag):
+        if self.events is None:
+            return fn()
+        o = self.ops[r]
+        a, b = o.event(), o.event()
+        o.record(a)
+        out = fn()
+        o.record(b)
+        self.events.append((tag, r, a, b))
+        return out
+
+    def _update(self, side_idx, in_idx, out_idx, eps):
+        """One similarity update on every local virtual rank; returns the global count of
+        elements that moved by more than eps."""
+        sides = self.sides[side_idx]
+        for r in self.world.local_ranks:
+            self._timed(r, lambda: sides[r].leg1(self.cur[in_idx][r]), f"leg1.{side_idx}")
+        if self.mode == "sparse":
+            self.world.exchange([sides[r] for r in self.world.local_ranks])
+        counts = []
+        for r in self.world.local_ranks:
+            self._timed(r, lambda: sides[r].leg2(self.cur[out_idx][r], self.nxt[out_idx][r], eps),
+                        f"leg2.{side_idx}")
+            counts.append(self.ops[r].read_changed() if sides[r].Lm else 0)
+        for r in self.world.local_ranks:
+            self.cur[out_idx][r], self.nxt[out_idx][r] = self.nxt[out_idx][r], self.cur[out_idx][r]
+        return self.world.sum_int(counts)
+
+    def step(self, eps=0.0):
+        """One loop body of the reference (both updates for the bipartite classes)."""
+        if self.bipartite:
+            c1 = self._update(0, 1, 0, eps)      # S1 <- f1(S2)           SimRank.py:297-299
+            c2 = self._update(1, 0, 1, eps)      # S2 <- f2(S1 new)       SimRank.py:300-302
+            return c1 + c2
+        return self._update(0, 0, 0, eps)        #                        SimRank.py:138-140
+
+    def run(self, iterations, eps, on_iteration=None, on_converged=None):
+        """The loop of SimRank.py:129-140.  Returns k (loop index at which the test passed)
+        or None when ``iterations`` updates were applied."""
+        self.reset()
+        # test at k = 0 compares S_0 = I with S_-1 = 0: the diagonal differs by 1
+        changed = sum(self.n) if 1.0 > eps else 0
+        for k in range(iterations):
+            if changed == 0:
+                if on_converged:
+                    on_converged(k)
+                return k
+            if on_iteration:
+                on_iteration(k)
+            changed = self.step(eps)
+        return None
+
+    def result(self, j=0):
+        """Full similarity matrix j as float64 on the host (every rank gets it)."""
+        blocks = {r: self.ops[r].download_f64(self.cur[j][r]) for r in self.world.local_ranks}
+        return self.world.gather_columns(blocks, self.n[j], self.n[j])
+
+    def release(self):
+        """Free the work buffers; the evidence counts stay (the ``Evidence`` attributes of
+        the estimators read them lazily)."""
+        for group in (self.cur, self.nxt):
+            for per_rank in group:
+                for m in per_rank.values():
+                    m.free()
+        for sides in self.sides:
+            for s in sides.values():
+                for name in ("tt", "send", "recv", "wd", "t", "ap"):
+                    m = getattr(s, name, None)
+                    if m is not None:
+                        m.free()
+                s.send_t = s.recv_t = None
+
+    def leg_times(self):
+        """Mean milliseconds per tag from the recorded events."""
+        acc = {}
+        for tag, r, a, b in self.events or []:
+            acc.setdefault(tag, []).append(self.ops[r].elapsed_ms(a, b))
+        return {t: (float(np.mean(v)), len(v)) for t, v in acc.items()}

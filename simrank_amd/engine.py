@@ -1,0 +1,259 @@
+"""Device layer: thin Python objects over the C ABI (include/simrank_hip.h).
+
+``HipOps`` is the operation set the iteration driver (``driver.py``) is written against:
+allocate / upload / download matrices, upload a graph, and launch the kernels.  It owns
+no algorithm.  It fails loudly when the library or the GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Epilogue, SimRankHipError, check
+from .ingest import CSR
+
+
+class Matrix:
+    """Row-major device matrix (float32 or uint8) with a leading dimension."""
+
+    def __init__(self, ops, rows: int, cols: int, dtype, ld: int | None = None,
+                 external=None):
+        """``external``: an object with ``data_ptr()`` (a torch tensor) whose memory is
+        used instead of allocating; it is kept alive with the matrix."""
+        self.ops = ops
+        self.rows, self.cols = int(rows), int(cols)
+        self.dtype = np.dtype(dtype)
+        self.ld = int(ld if ld is not None else ops.pitch(cols, self.dtype))
+        self.nbytes = max(1, self.rows) * self.ld * self.dtype.itemsize
+        self.external = external
+        self.ptr = external.data_ptr() if external is not None else ops._malloc(self.nbytes)
+
+    def free(self):
+        if self.ptr and self.external is None:
+            self.ops._free(self.ptr)
+        self.ptr = 0
+        self.external = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Graph:
+    def __init__(self, ops, csr: CSR, rowscale: np.ndarray | None = None):
+        lib = ops.lib
+        rs = np.ascontiguousarray(csr.rowscale if rowscale is None else rowscale,
+                                  dtype=np.float32)
+        rowptr = np.ascontiguousarray(csr.rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(csr.col, dtype=np.int32)
+        h = C.c_void_p()
+        check(lib.simrank_graph_create(csr.n_rows, csr.n_cols, col.size, rowptr.ctypes.data,
+                                       col.ctypes.data if col.size else None, rs.ctypes.data,
+                                       C.byref(h)), "simrank_graph_create")
+        self.ops, self.handle = ops, h
+        self.n_rows, self.n_cols, self.nnz = csr.n_rows, csr.n_cols, int(col.size)
+
+    def free(self):
+        if self.handle:
+            self.ops.lib.simrank_graph_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class HipOps:
+    """Kernel launcher for one device.  ``pitch_pad``: extra elements added to the leading
+    dimension of matrices it allocates when that dimension is a large power of two (keeps
+    a panel's row segments from landing on one L2/HBM channel)."""
+
+    name = "hip"
+
+    def __init__(self, device: int | None = None, stream: int | None = None):
+        self.lib = _lib.load()
+        n = _lib.device_count()
+        if n <= 0:
+            raise SimRankHipError(
+                "no HIP device visible: the SimRank engine needs an MI355X (gfx950); "
+                "there is no CPU fallback")
+        self.device = 0 if device is None else int(device)
+        check(self.lib.simrank_set_device(self.device), "simrank_set_device")
+        self._own_stream = stream is None
+        if stream is None:
+            s = C.c_void_p()
+            check(self.lib.simrank_stream_create(C.byref(s)), "simrank_stream_create")
+            self.stream = s
+        else:
+            self.stream = C.c_void_p(stream)
+        self._counter = self._malloc(8)
+        self.pitch_pad = 32
+
+    # ---- memory ----
+    def _malloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        check(self.lib.simrank_malloc(C.byref(p), max(16, int(nbytes))), "simrank_malloc")
+        return p.value
+
+    def _free(self, ptr: int):
+        self.lib.simrank_free(C.c_void_p(ptr))
+
+    def pitch(self, cols: int, dtype) -> int:
+        unit = 16 // np.dtype(dtype).itemsize          # 16-byte rows for the vector kernels
+        ld = -(-cols // unit) * unit
+        if ld >= 4096 and (ld & (ld - 1)) == 0:
+            ld += self.pitch_pad
+        return ld
+
+    def matrix(self, rows, cols, dtype=np.float32, ld=None, external=None) -> Matrix:
+        return Matrix(self, rows, cols, dtype, ld, external)
+
+    def exchange_buffer(self, n_floats: int):
+        """Flat float32 buffer usable by torch.distributed collectives on this device."""
+        import torch
+        return torch.empty(max(1, n_floats), dtype=torch.float32, device=f"cuda:{self.device}")
+
+    def copy_bytes(self, dst_ptr: int, src_ptr: int, nbytes: int):
+        if nbytes:
+            check(self.lib.simrank_memcpy_d2d(C.c_void_p(dst_ptr), C.c_void_p(src_ptr), nbytes,
+                                              self.stream), "d2d")
+
+    def upload(self, m: Matrix, host: np.ndarray):
+        host = np.asarray(host)
+        assert host.shape == (m.rows, m.cols), (host.shape, m.rows, m.cols)
+        buf = np.zeros((m.rows, m.ld), dtype=m.dtype)
+        buf[:, :m.cols] = host
+        check(self.lib.simrank_memcpy_h2d(m.ptr, buf.ctypes.data, buf.nbytes, self.stream),
+              "simrank_memcpy_h2d")
+
+    def download(self, m: Matrix) -> np.ndarray:
+        """Device matrix -> host array of its own dtype."""
+        buf = np.empty((m.rows, m.ld), dtype=m.dtype)
+        check(self.lib.simrank_memcpy_d2h(buf.ctypes.data, m.ptr, buf.nbytes, self.stream),
+              "simrank_memcpy_d2h")
+        return buf[:, :m.cols] if m.ld == m.cols else np.ascontiguousarray(buf[:, :m.cols])
+
+    def download_rows(self, m: Matrix, rows) -> np.ndarray:
+        """Selected rows of a device matrix (partial hand-back: no N x N host copy)."""
+        out = np.empty((len(rows), m.cols), dtype=m.dtype)
+        isz = m.dtype.itemsize
+        for i, r in enumerate(rows):
+            check(self.lib.simrank_memcpy_d2h(out[i].ctypes.data, C.c_void_p(m.ptr + int(r) * m.ld * isz),
+                                              m.cols * isz, self.stream), "simrank_memcpy_d2h")
+        return out
+
+    def download_f64(self, m: Matrix, out: np.ndarray | None = None) -> np.ndarray:
+        """float32 device matrix -> float64 host array (pinned, pipelined staging)."""
+        if out is None:
+            out = np.empty((m.rows, m.cols), dtype=np.float64)
+        assert out.dtype == np.float64 and out.flags.c_contiguous
+        check(self.lib.simrank_download_f64(out.ctypes.data, out.shape[1], m.ptr, m.ld, m.rows,
+                                            m.cols, self.stream), "simrank_download_f64")
+        return out
+
+    def copy(self, dst: Matrix, src: Matrix):
+        assert dst.nbytes == src.nbytes
+        check(self.lib.simrank_memcpy_d2d(dst.ptr, src.ptr, src.nbytes, self.stream), "d2d")
+
+    def synchronize(self):
+        check(self.lib.simrank_stream_synchronize(self.stream), "stream_synchronize")
+
+    def collective_done(self):
+        """Make the engine's stream wait for a torch.distributed collective: the collective
+        was enqueued on torch's current stream, the kernels run on the engine's own."""
+        import torch
+        torch.cuda.current_stream(self.device).synchronize()
+
+    # ---- graph + kernels ----
+    def graph(self, csr: CSR, rowscale=None) -> Graph:
+        return Graph(self, csr, rowscale)
+
+    def fill_identity(self, S: Matrix, col0: int):
+        if S.rows and S.cols:
+            check(self.lib.simrank_fill_identity(S.ptr, S.rows, S.cols, S.ld, col0, self.stream),
+                  "simrank_fill_identity")
+
+    def _epilogue(self, coef, evidence=None, apriori=None, lbd=0.0, previous=None, eps=0.0,
+                  diag_col0=0, set_diag=True) -> Epilogue:
+        ep = Epilogue()
+        ep.coef = float(coef)
+        ep.lbd = float(lbd)
+        if evidence is not None:
+            ep.evidence, ep.ld_evidence = evidence.ptr, evidence.ld
+        if apriori is not None:
+            ep.apriori, ep.ld_apriori = apriori.ptr, apriori.ld
+        if previous is not None:
+            ep.previous, ep.ld_previous = previous.ptr, previous.ld
+            ep.n_changed = self._counter
+        ep.eps = float(eps)
+        ep.diag_col0 = int(diag_col0)
+        ep.set_diag = 1 if set_diag else 0
+        return ep
+
+    def spmm(self, g: Graph, X: Matrix, Y: Matrix, n_cols: int | None = None,
+             transpose_out: bool = False, t_block: int = 0, epilogue: dict | None = None):
+        """Y = diag(rowscale).A.X (+ fused epilogue); see simrank_spmm."""
+        n_cols = X.cols if n_cols is None else n_cols
+        ep = self._epilogue(**epilogue) if epilogue is not None else None
+        check(self.lib.simrank_spmm(g.handle, X.ptr, X.ld, n_cols, Y.ptr, Y.ld,
+                                    1 if transpose_out else 0, int(t_block),
+                                    C.byref(ep) if ep is not None else None, self.stream),
+              "simrank_spmm")
+
+    def gemm_nt(self, A: Matrix, B: Matrix, Cm: Matrix, M: int, N: int, K: int,
+                epilogue: dict | None = None):
+        ep = self._epilogue(**epilogue) if epilogue is not None else None
+        check(self.lib.simrank_gemm_nt(M, N, K, A.ptr, A.ld, B.ptr, B.ld, Cm.ptr, Cm.ld,
+                                       C.byref(ep) if ep is not None else None, self.stream),
+              "simrank_gemm_nt")
+
+    def densify(self, g: Graph, Wd: Matrix):
+        check(self.lib.simrank_graph_densify(g.handle, Wd.ptr, Wd.ld, self.stream),
+              "simrank_graph_densify")
+
+    def evidence_counts(self, g: Graph, col0: int, out: Matrix):
+        if out.cols:
+            check(self.lib.simrank_evidence_counts(g.handle, col0, out.cols, out.ptr, out.ld,
+                                                   self.stream), "simrank_evidence_counts")
+
+    def read_changed(self) -> int:
+        """Value of the convergence counter of the last epilogue with ``previous``."""
+        v = C.c_ulonglong(0)
+        check(self.lib.simrank_memcpy_d2h(C.byref(v), self._counter, 8, self.stream),
+              "read counter")
+        return int(v.value)
+
+    # ---- timing (HIP events on the engine's own stream) ----
+    def event(self) -> int:
+        e = C.c_void_p()
+        check(self.lib.simrank_event_create(C.byref(e)), "event_create")
+        return e.value
+
+    def record(self, ev: int):
+        check(self.lib.simrank_event_record(C.c_void_p(ev), self.stream), "event_record")
+
+    def elapsed_ms(self, start: int, stop: int) -> float:
+        ms = C.c_float(0)
+        check(self.lib.simrank_event_elapsed_ms(C.c_void_p(start), C.c_void_p(stop),
+                                                C.byref(ms)), "event_elapsed")
+        return float(ms.value)
+
+    def set_tuning(self, **kw):
+        for k, v in kw.items():
+            check(self.lib.simrank_set_tuning(k.encode(), int(v)), f"set_tuning({k})")
+
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(256)
+        arch = C.create_string_buffer(64)
+        mem = C.c_int64(0)
+        cus = C.c_int(0)
+        check(self.lib.simrank_device_info(self.device, name, 256, C.byref(mem), C.byref(cus),
+                                           arch, 64), "device_info")
+        return dict(name=name.value.decode(), arch=arch.value.decode(), total_bytes=mem.value,
+                    compute_units=cus.value)

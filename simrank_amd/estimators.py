@@ -1,0 +1,347 @@
+"""The reference's class surface, backed by the MI355X engine.
+
+Same class names, ``fit`` signatures (positional order and defaults), return types,
+post-fit attributes and console text as ysong1231/SimRank (SimRank/SimRank.py:8, :143,
+:305, :365, :427, :457), so ``from simrank_amd import SimRank`` is a drop-in for
+``from SimRank import SimRank``.  What differs is *how*: the edge list becomes a CSR graph
+(``ingest.py``), the loop runs as HIP kernels (``driver.py`` / ``csrc/``), the similarity
+matrix never exists densely on the host until the result is handed back, and the dense
+attributes the reference keeps (``Graph``, ``Weight``, ``Evidence`` …) are materialised only
+when read.
+
+Extra keyword-only arguments (defaults keep the reference's behaviour):
+    mode              "auto" | "sparse" | "dense" | "hybrid" — which kernels run the two legs
+    device            HIP device ordinal (default: LOCAL_RANK or 0)
+    world             ``driver.LocalWorld`` / ``driver.TorchWorld`` (sharded runs)
+    strict_reference  bipartite classes only; True keeps quirks Q1 (set-order labels on
+                      sorted-order data) and Q2 (Evidence_N1 on the group-2 update, a
+                      ValueError when n1 != n2); False labels correctly and uses Evidence_N2
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+import pandas as pd
+
+from . import ingest
+from .driver import LocalWorld, SideSpec, Solver
+from .progress import announce_converged, update_progress
+
+
+def _default_ops_factory(device):
+    from .engine import HipOps          # raises if the library or the GPU is missing
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    ops = HipOps(device)
+    return lambda rank: ops
+
+
+def _solve(specs, iterations, eps, verbose, mode, device, world, ops_factory=None):
+    world = world or LocalWorld(1)
+    solver = Solver(ops_factory or _default_ops_factory(device), world, specs, mode)
+    talk = verbose and world.is_root
+    if talk:
+        print("Start iterating...")
+    k = solver.run(iterations, eps,
+                   on_iteration=(lambda i: update_progress(i / iterations)) if talk else None,
+                   on_converged=announce_converged if talk else None)
+    return solver, k
+
+
+class _Lazy:
+    """Attribute that is computed on first read and can be overwritten like a plain one."""
+
+    def __init__(self, name, default):
+        self.name, self.default = "_lazy_" + name, default
+
+    def __get__(self, obj, owner):
+        if obj is None:
+            return self
+        v = obj.__dict__.get(self.name)
+        if v is None:
+            return self.default()
+        if callable(v):
+            v = v()
+            obj.__dict__[self.name] = v
+        return v
+
+    def __set__(self, obj, value):
+        obj.__dict__[self.name] = value
+
+
+def _evidence_from_counts(side):
+    """1 - 0.5**count as float64 (SimRank.py:316); counts saturate at 255 on the device,
+    and 0.5**54 already rounds 1 - x to 1.0, so saturation is exact."""
+    cnt = side.ops.download(side.ev).astype(np.float64)
+    return 1 - 0.5 ** cnt
+
+
+class SimRank(object):
+    """SimRank on a directed, optionally weighted graph (SimRank.py:8-141).
+
+    Attributes after ``fit``: ``Nodes`` (set), ``Graph`` (N x N DataFrame, built on read),
+    ``converged_at`` (loop index of convergence or None), ``engine_mode``.
+    """
+    Graph = _Lazy("Graph", pd.DataFrame)
+
+    def __init__(self):
+        self.Nodes = set()
+        self.Graph = pd.DataFrame()
+
+    # -- ingest ------------------------------------------------------------------------
+    def _create_graph(self, data, weighted, from_node_column, to_node_column, weight_column):
+        nodes, csr = ingest.directed(data, weighted, from_node_column, to_node_column,
+                                     weight_column)
+        self.Nodes = set(nodes)
+        self._order = nodes
+        self._csr = csr
+        self.Graph = lambda: pd.DataFrame(csr.dense(), index=nodes, columns=nodes)
+        return csr
+
+    def _side(self, csr, C):
+        return SideSpec(csr, csr.rowscale, C)
+
+    def _finish(self, solver, k):
+        self.converged_at = k
+        self.engine_mode = solver.mode
+        S = solver.result(0)
+        solver.release()
+        return pd.DataFrame(S, index=self._order, columns=self._order)
+
+    def fit(self, data, C=0.8, weighted=False, from_node_column="from", to_node_column="to",
+            weight_column="weight", iterations=100, eps=1e-4, verbose=True, *,
+            mode="auto", device=None, world=None, _ops_factory=None):
+        csr = self._create_graph(data, weighted, from_node_column, to_node_column, weight_column)
+        solver, k = _solve([self._side(csr, C)], iterations, eps, verbose, mode, device, world,
+                           _ops_factory)
+        return self._finish(solver, k)
+
+
+class SimRankPP(SimRank):
+    """SimRank++: evidence and spread weighting (SimRank.py:305-363)."""
+    Evidence = _Lazy("Evidence", pd.DataFrame)
+    Weight = _Lazy("Weight", pd.DataFrame)
+
+    def __init__(self):
+        super(SimRankPP, self).__init__()
+        self.Evidence = pd.DataFrame()
+        self.Weight = pd.DataFrame()
+
+    def _cal_Weight(self, csr, verbose):
+        """spread[v] . rowscale[v]: the per-row scale of W (SimRank.py:322-337)."""
+        if verbose:
+            print("Initializing Weight matrix...")
+        start = time.time()
+        scale = ingest.spread(csr) * csr.rowscale
+        if verbose:
+            print(f"Finished in {time.time() - start}s!")
+        return scale
+
+    def _pp_side(self, csr, C, verbose, apriori=None, lbd=0.0, evidence_from=None):
+        scale = self._cal_Weight(csr, verbose)
+        return SideSpec(csr, scale, C, evidence_from=evidence_from or csr, apriori=apriori,
+                        lbd=lbd)
+
+    def _fit_pp(self, data, C, weighted, from_node_column, to_node_column, weight_column,
+                iterations, eps, verbose, mode, device, world, ops_factory, apriori=None,
+                lbd=0.0):
+        csr = self._create_graph(data, weighted, from_node_column, to_node_column, weight_column)
+        talk = verbose and (world is None or world.is_root)
+        spec = self._pp_side(csr, C, talk, apriori, lbd)
+        self.Weight = lambda: csr.dense(spec.rowscale)
+        if talk:
+            print("Initializing Evidence matrix...")
+        start = time.time()
+        # the counts are produced on the device while the solver is set up
+        world = world or LocalWorld(1)
+        solver = Solver(ops_factory or _default_ops_factory(device), world, [spec], mode)
+        for o in solver.ops.values():
+            o.synchronize()
+        if talk:
+            print(f"Finished in {time.time() - start}s!")
+            print("Start iterating...")
+        k = solver.run(iterations, eps,
+                       on_iteration=(lambda i: update_progress(i / iterations)) if talk else None,
+                       on_converged=announce_converged if talk else None)
+        self.Evidence = _lazy_evidence(world, solver.sides[0], csr)
+        return self._finish(solver, k)
+
+    def fit(self, data, C=0.8, weighted=False, from_node_column="from", to_node_column="to",
+            weight_column="weight", iterations=100, eps=1e-4, verbose=True, *,
+            mode="auto", device=None, world=None, _ops_factory=None):
+        return self._fit_pp(data, C, weighted, from_node_column, to_node_column, weight_column,
+                            iterations, eps, verbose, mode, device, world, _ops_factory)
+
+
+class AprioriSimRank(SimRankPP):
+    """SimRank++ blended with a prior similarity matrix (SimRank.py:427-455)."""
+
+    def __init__(self):
+        super(AprioriSimRank, self).__init__()
+
+    def fit(self, data, AprioriSim, C=0.8, lbd=0.5, weighted=False, from_node_column="from",
+            to_node_column="to", weight_column="weight", iterations=100, eps=1e-4,
+            verbose=True, *, mode="auto", device=None, world=None, _ops_factory=None):
+        if not isinstance(AprioriSim, np.ndarray):
+            # the reference fails at np.fill_diagonal for anything but an ndarray
+            raise AttributeError(f"'{type(AprioriSim).__name__}' object has no attribute 'flat'")
+        return self._fit_pp(data, C, weighted, from_node_column, to_node_column, weight_column,
+                            iterations, eps, verbose, mode, device, world, _ops_factory,
+                            apriori=AprioriSim, lbd=lbd)
+
+
+# ----------------------------------------------------------------------------------------
+# bipartite
+# ----------------------------------------------------------------------------------------
+class BipartiteSimRank(object):
+    """SimRank on a bipartite graph: two similarity matrices updated alternately, the
+    second from the just-updated first (SimRank.py:143-303)."""
+    Graph_N1_N2 = _Lazy("Graph_N1_N2", pd.DataFrame)
+    Graph_N2_N1 = _Lazy("Graph_N2_N1", pd.DataFrame)
+
+    def __init__(self):
+        self.NodesGroup1 = set()
+        self.NodesGroup2 = set()
+        self.Graph_N1_N2 = pd.DataFrame()
+        self.Graph_N2_N1 = pd.DataFrame()
+
+    def _create_graph(self, data, weighted, node_group1_column, node_group2_column,
+                      weight_column):
+        set1, set2, lab1, lab2, g12, g21 = ingest.bipartite(
+            data, weighted, node_group1_column, node_group2_column, weight_column)
+        self.NodesGroup1, self.NodesGroup2 = set(set1), set(set2)
+        self._set_order = (set1, set2)
+        self._sorted = (lab1, lab2)
+        self._csr = (g12, g21)
+        self.Graph_N1_N2 = lambda: pd.DataFrame(g12.dense(), index=lab1, columns=lab2)
+        self.Graph_N2_N1 = lambda: pd.DataFrame(g21.dense(), index=lab2, columns=lab1)
+        return g12, g21
+
+    def _finish(self, solver, k, strict_reference):
+        self.converged_at = k
+        self.engine_mode = solver.mode
+        l1, l2 = self._set_order if strict_reference else map(list, self._sorted)
+        S1, S2 = solver.result(0), solver.result(1)
+        solver.release()
+        return (pd.DataFrame(S1, index=l1, columns=l1), pd.DataFrame(S2, index=l2, columns=l2))
+
+    def fit(self, data, C1=0.8, C2=0.8, weighted=False, node_group1_column="user",
+            node_group2_column="item", weight_column="weight", iterations=100, eps=1e-4,
+            verbose=True, *, mode="auto", device=None, world=None, strict_reference=True,
+            _ops_factory=None):
+        g12, g21 = self._create_graph(data, weighted, node_group1_column, node_group2_column,
+                                      weight_column)
+        specs = [SideSpec(g12, g12.rowscale, C1), SideSpec(g21, g21.rowscale, C2)]
+        solver, k = _solve(specs, iterations, eps, verbose, mode, device, world, _ops_factory)
+        return self._finish(solver, k, strict_reference)
+
+
+class BipartiteSimRankPP(SimRankPP):
+    """Bipartite SimRank++ (SimRank.py:365-425)."""
+    Graph_N1_N2 = _Lazy("Graph_N1_N2", pd.DataFrame)
+    Graph_N2_N1 = _Lazy("Graph_N2_N1", pd.DataFrame)
+    Evidence_N1 = _Lazy("Evidence_N1", pd.DataFrame)
+    Evidence_N2 = _Lazy("Evidence_N2", pd.DataFrame)
+    Weight_N1 = _Lazy("Weight_N1", pd.DataFrame)
+    Weight_N2 = _Lazy("Weight_N2", pd.DataFrame)
+
+    def __init__(self):
+        self.NodesGroup1 = set()
+        self.NodesGroup2 = set()
+        for name in ("Graph_N1_N2", "Graph_N2_N1", "Evidence_N1", "Evidence_N2", "Weight_N1",
+                     "Weight_N2"):
+            setattr(self, name, pd.DataFrame())
+
+    _create_graph = BipartiteSimRank._create_graph
+    _finish = BipartiteSimRank._finish
+
+    def _fit_bpp(self, data, C1, C2, weighted, node_group1_column, node_group2_column,
+                 weight_column, iterations, eps, verbose, mode, device, world, strict_reference,
+                 ops_factory, priors=(None, None), lbds=(0.0, 0.0)):
+        g12, g21 = self._create_graph(data, weighted, node_group1_column, node_group2_column,
+                                      weight_column)
+        world = world or LocalWorld(1)
+        talk = verbose and world.is_root
+        w1 = self._cal_Weight(g12, talk)                               # SimRank.py:396
+        w2 = self._cal_Weight(g21, talk)                               # :397
+        self.Weight_N1 = lambda: g12.dense(w1)
+        self.Weight_N2 = lambda: g21.dense(w2)
+        # quirk Q2 (:423, :491): the group-2 update is gated by Evidence_N1
+        ev2 = g12 if strict_reference else g21
+        specs = [SideSpec(g12, w1, C1, evidence_from=g12, apriori=priors[0], lbd=lbds[0]),
+                 SideSpec(g21, w2, C2, evidence_from=ev2, apriori=priors[1], lbd=lbds[1])]
+        if talk:
+            print("Initializing Evidence matrix...")
+        start = time.time()
+        solver = Solver(ops_factory or _default_ops_factory(device), world, specs, mode)
+        for o in solver.ops.values():
+            o.synchronize()
+        if talk:
+            print(f"Finished in {time.time() - start}s!")
+            print("Initializing Evidence matrix...")
+            print(f"Finished in {0.0}s!")
+            print("Start iterating...")
+        k = solver.run(iterations, eps,
+                       on_iteration=(lambda i: update_progress(i / iterations)) if talk else None,
+                       on_converged=announce_converged if talk else None)
+        s1, s2 = solver.sides
+        self.Evidence_N1 = _lazy_evidence(world, s1, g12)
+        self.Evidence_N2 = ((lambda: _host_evidence(g21)) if strict_reference
+                            else _lazy_evidence(world, s2, g21))
+        return self._finish(solver, k, strict_reference)
+
+    def fit(self, data, C1=0.8, C2=0.8, weighted=False, node_group1_column="user",
+            node_group2_column="item", weight_column="weight", iterations=100, eps=1e-4,
+            verbose=True, *, mode="auto", device=None, world=None, strict_reference=True,
+            _ops_factory=None):
+        return self._fit_bpp(data, C1, C2, weighted, node_group1_column, node_group2_column,
+                             weight_column, iterations, eps, verbose, mode, device, world,
+                             strict_reference, _ops_factory)
+
+
+class BipartitleAprioriSimRank(BipartiteSimRankPP):
+    """Bipartite SimRank++ with priors (SimRank.py:457-493; the class name is the
+    reference's spelling)."""
+
+    def __init__(self):
+        super(BipartitleAprioriSimRank, self).__init__()
+
+    def fit(self, data, AprioriSim1, AprioriSim2, C1=0.8, C2=0.8, lbd1=0.5, lbd2=0.5,
+            weighted=False, node_group1_column="user", node_group2_column="item",
+            weight_column="weight", iterations=100, eps=1e-4, verbose=True, *, mode="auto",
+            device=None, world=None, strict_reference=True, _ops_factory=None):
+        for a in (AprioriSim1, AprioriSim2):
+            if not isinstance(a, np.ndarray):
+                raise AttributeError(f"'{type(a).__name__}' object has no attribute 'flat'")
+        return self._fit_bpp(data, C1, C2, weighted, node_group1_column, node_group2_column,
+                             weight_column, iterations, eps, verbose, mode, device, world,
+                             strict_reference, _ops_factory, priors=(AprioriSim1, AprioriSim2),
+                             lbds=(lbd1, lbd2))
+
+
+def _lazy_evidence(world, sides, csr):
+    """Reader for an ``Evidence`` attribute.  With every shard in this process the counts
+    come back from the device; in a multi-process world a lazy read must not be a
+    collective (only some ranks may read it), so it is recomputed from the CSR."""
+    if isinstance(world, LocalWorld):
+        return lambda: world.gather_columns(
+            {r: _evidence_from_counts(s) for r, s in sides.items()}, csr.n_rows, csr.n_rows)
+    return lambda: _host_evidence(csr)
+
+
+def _host_evidence(csr):
+    """Evidence of a pattern computed on the host from the CSR (only for the attribute the
+    reference computes but never uses, Evidence_N2 in strict mode)."""
+    import scipy.sparse as sp
+    live = np.repeat(csr.rowscale > 0, np.diff(csr.rowptr))
+    pat = sp.csr_matrix((live.astype(np.int64), csr.col, csr.rowptr),
+                        shape=(csr.n_rows, csr.n_cols))
+    return 1 - 0.5 ** np.asarray((pat @ pat.T).todense(), dtype=np.float64)
+
+
+# spellings used by the reference README (README.md:16) and BASELINE.json
+BipartitleSimRank = BipartiteSimRank
+BipartitleSimRankPP = BipartiteSimRankPP
+BipartiteAprioriSimRank = BipartitleAprioriSimRank

@@ -1,0 +1,139 @@
+"""Edge list -> node order + CSR (host side of the drop-in boundary).
+
+Replaces ``_create_graph`` (SimRank.py:24-52 directed, :168-200 / :376-391 bipartite),
+``_cal_Weight`` (:322-337) and the pattern half of ``_cal_Evidence`` (:311-320), without
+ever forming an N x N array: the normalised adjacency the reference stores densely is
+``diag(rowscale) . A`` with A the 0/1 edge pattern, because every value it writes is
+1/in-degree (or 1/sum of weights) of the ROW node (quirks Q3, Q9 of SURVEY.md).
+
+Everything here is vectorised pandas/NumPy; no Python loop over edges or nodes.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import pandas as pd
+
+
+@dataclass
+class CSR:
+    """W = diag(rowscale) . pattern; rows = target/own-group nodes."""
+    n_rows: int
+    n_cols: int
+    rowptr: np.ndarray      # int32 [n_rows + 1]
+    col: np.ndarray         # int32 [nnz], ascending inside a row
+    rowscale: np.ndarray    # float64 [n_rows]; 0 for rows without entries
+
+    @property
+    def nnz(self) -> int:
+        return int(self.col.size)
+
+    @property
+    def density(self) -> float:
+        return self.nnz / float(self.n_rows * self.n_cols)
+
+    def dense(self, scale: np.ndarray | None = None) -> np.ndarray:
+        """The float64 matrix the reference keeps (``Graph`` / ``Weight``)."""
+        rs = self.rowscale if scale is None else scale
+        out = np.zeros((self.n_rows, self.n_cols))
+        rows = np.repeat(np.arange(self.n_rows), np.diff(self.rowptr))
+        out[rows, self.col] = rs[rows]
+        return out
+
+    def with_scale(self, rowscale: np.ndarray) -> "CSR":
+        return CSR(self.n_rows, self.n_cols, self.rowptr, self.col, rowscale)
+
+
+def _reciprocal(x) -> np.ndarray:
+    """1/x with +-inf replaced by 0 (SimRank.py:49, :197-198)."""
+    with np.errstate(divide="ignore"):
+        r = 1.0 / np.asarray(x, dtype=np.float64)
+    r[np.isinf(r)] = 0.0
+    return np.nan_to_num(r, nan=0.0, posinf=0.0, neginf=0.0)
+
+
+def _csr(rows: np.ndarray, cols: np.ndarray, n_rows: int, n_cols: int,
+         row_value: np.ndarray) -> CSR:
+    key = rows.astype(np.int64) * n_cols + cols.astype(np.int64)
+    key.sort()
+    if key.size > 1 and (key[1:] == key[:-1]).any():
+        # what DataFrame.pivot raises on a repeated (index, column) pair (SimRank.py:50)
+        raise ValueError("Index contains duplicate entries, cannot reshape")
+    r = key // n_cols
+    rowptr = np.zeros(n_rows + 1, dtype=np.int64)
+    np.cumsum(np.bincount(r, minlength=n_rows), out=rowptr[1:])
+    if rowptr[-1] >= 2**31:
+        raise ValueError("more than 2^31 edges")
+    return CSR(n_rows, n_cols, rowptr.astype(np.int32), (key % n_cols).astype(np.int32),
+               row_value)
+
+
+def directed(data: pd.DataFrame, weighted: bool, from_node_column: str, to_node_column: str,
+             weight_column: str):
+    """-> (nodes, CSR).  ``nodes`` is the list in the iteration order of the Python set
+    the reference builds at SimRank.py:42 (quirk Q0: that order *is* the row/column order
+    of every matrix and of the returned DataFrame)."""
+    src = data[from_node_column]
+    dst = data[to_node_column]
+    nodes = list(set(src.unique()) | set(dst.unique()))
+    index = pd.Index(nodes)
+    n = len(nodes)
+    if weighted:
+        per_target = data.groupby(to_node_column)[weight_column].sum()
+    else:
+        per_target = data.groupby(to_node_column)[from_node_column].count()
+    rowscale = np.zeros(n)
+    rowscale[index.get_indexer(per_target.index)] = _reciprocal(per_target.to_numpy())
+    return nodes, _csr(index.get_indexer(dst), index.get_indexer(src), n, n, rowscale)
+
+
+def bipartite(data: pd.DataFrame, weighted: bool, node_group1_column: str,
+              node_group2_column: str, weight_column: str):
+    """-> (set_order1, set_order2, sorted1, sorted2, CSR12, CSR21).
+
+    The reference's matrices come out of ``pivot`` (SimRank.py:199-200), i.e. in sorted
+    label order, while the labels it later attaches are in Python-set order (quirk Q1)."""
+    g1 = data[node_group1_column]
+    g2 = data[node_group2_column]
+    set1 = list(set(g1.unique()))
+    set2 = list(set(g2.unique()))
+    sorted1 = pd.Index(np.sort(g1.unique()), name=node_group1_column)
+    sorted2 = pd.Index(np.sort(g2.unique()), name=node_group2_column)
+    if weighted:
+        d1 = data.groupby(node_group1_column)[weight_column].sum()
+        d2 = data.groupby(node_group2_column)[weight_column].sum()
+    else:
+        d1 = data.groupby(node_group1_column)[node_group2_column].count()
+        d2 = data.groupby(node_group2_column)[node_group1_column].count()
+    n1, n2 = len(sorted1), len(sorted2)
+    rs1 = np.zeros(n1)
+    rs1[sorted1.get_indexer(d1.index)] = _reciprocal(d1.to_numpy())
+    rs2 = np.zeros(n2)
+    rs2[sorted2.get_indexer(d2.index)] = _reciprocal(d2.to_numpy())
+    i1 = sorted1.get_indexer(g1)
+    i2 = sorted2.get_indexer(g2)
+    return (set1, set2, sorted1, sorted2,
+            _csr(i1, i2, n1, n2, rs1), _csr(i2, i1, n2, n1, rs2))
+
+
+def spread(csr: CSR) -> np.ndarray:
+    """exp(-sample variance (ddof=1) of the non-zero entries of each row), NaN -> 0
+    (SimRank.py:326-332, quirk Q4).  Entries that are exactly 0 (rowscale 0) are not
+    "non-zero entries"; a row with fewer than two has variance NaN -> spread 1."""
+    deg = np.diff(csr.rowptr).astype(np.float64)
+    live = np.where(csr.rowscale != 0, deg, 0.0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        total = csr.rowscale * live
+        mean = np.where(live > 0, total / np.maximum(live, 1), 0.0)
+        var = live * (csr.rowscale - mean) ** 2 / (live - 1)
+    var = np.where(live > 1, var, 0.0)
+    return np.exp(-var)
+
+
+def partition(n: int, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous block [lo, hi) of rank ``rank``; every block but the last has
+    ceil(n/world) elements (the layout simrank_spmm's transposed store assumes)."""
+    b = -(-n // world)
+    lo = min(n, rank * b)
+    return lo, min(n, lo + b)

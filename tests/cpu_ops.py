@@ -1,0 +1,173 @@
+"""NumPy stand-in for ``simrank_amd.engine.HipOps`` — TEST INFRASTRUCTURE ONLY.
+
+It implements the documented semantics of the C ABI entry points (include/simrank_hip.h)
+on host arrays, so that the host logic above the ABI — ingest, the iteration driver, the
+sharded exchange layout, the estimators' console text and quirk handling — can be tested
+without a GPU (`-m "not gpu"`), including a world_size-2 ``gloo`` run.  It is never
+imported by the product package; the product path has no CPU fallback.
+"""
+import numpy as np
+import scipy.sparse as sp
+
+
+class NpMatrix:
+    _next_base = 1 << 40
+
+    def __init__(self, ops, rows, cols, dtype, ld=None, external=None):
+        self.ops = ops
+        self.rows, self.cols = int(rows), int(cols)
+        self.dtype = np.dtype(dtype)
+        self.ld = int(ld if ld is not None else ops.pitch(cols, self.dtype))
+        n = max(1, self.rows) * self.ld
+        if external is not None:
+            self.flat = external.numpy()[:n]          # torch CPU tensor: shared memory
+        else:
+            self.flat = np.full(n, 7, dtype=self.dtype)   # junk, like fresh device memory
+        self.external = external
+        self.ptr = NpMatrix._next_base
+        NpMatrix._next_base += 1 << 40
+        ops._buffers[self.ptr] = self
+        self.nbytes = n * self.dtype.itemsize
+
+    @property
+    def a(self):
+        return self.flat[: self.rows * self.ld].reshape(self.rows, self.ld)
+
+    def free(self):
+        self.ops._buffers.pop(self.ptr, None)
+
+
+class NpGraph:
+    def __init__(self, csr, rowscale):
+        self.n_rows, self.n_cols = csr.n_rows, csr.n_cols
+        self.rowscale = np.asarray(csr.rowscale if rowscale is None else rowscale,
+                                   dtype=np.float32)
+        self.pattern = sp.csr_matrix((np.ones(csr.col.size, dtype=np.float32), csr.col,
+                                      csr.rowptr), shape=(csr.n_rows, csr.n_cols))
+
+
+class NumpyOps:
+    name = "numpy-test-double"
+
+    def __init__(self):
+        self._buffers = {}
+        self._changed = 0
+        self.calls = []
+
+    def pitch(self, cols, dtype):
+        unit = 16 // np.dtype(dtype).itemsize
+        return -(-cols // unit) * unit
+
+    def matrix(self, rows, cols, dtype=np.float32, ld=None, external=None):
+        return NpMatrix(self, rows, cols, dtype, ld, external)
+
+    def exchange_buffer(self, n_floats):
+        import torch
+        return torch.full((max(1, n_floats),), 7.0, dtype=torch.float32)
+
+    def _locate(self, ptr):
+        base = ptr & ~((1 << 40) - 1)
+        return self._buffers[base], ptr - base
+
+    def copy_bytes(self, dst_ptr, src_ptr, nbytes):
+        if not nbytes:
+            return
+        d, do = self._locate(dst_ptr)
+        s, so = self._locate(src_ptr)
+        d.flat.view(np.uint8)[do:do + nbytes] = s.flat.view(np.uint8)[so:so + nbytes]
+
+    def upload(self, m, host):
+        m.a[:, :m.cols] = host
+
+    def download(self, m):
+        return m.a[:, :m.cols].copy()
+
+    def download_f64(self, m, out=None):
+        r = m.a[:, :m.cols].astype(np.float64)
+        if out is not None:
+            out[...] = r
+            return out
+        return r
+
+    def synchronize(self):
+        pass
+
+    def collective_done(self):
+        pass
+
+    def graph(self, csr, rowscale=None):
+        return NpGraph(csr, rowscale)
+
+    def fill_identity(self, S, col0):
+        S.a[:, :S.cols] = 0
+        for c in range(S.cols):
+            if col0 + c < S.rows:
+                S.a[col0 + c, c] = 1
+
+    def spmm(self, g, X, Y, n_cols=None, transpose_out=False, t_block=0, epilogue=None):
+        self.calls.append(("spmm", transpose_out, bool(epilogue)))
+        L = X.cols if n_cols is None else n_cols
+        M = g.n_rows
+        x = X.a[:g.n_cols, :L]
+        scale = g.rowscale * (np.float32(epilogue["coef"]) if epilogue else np.float32(1))
+        v = (g.pattern @ x) * scale[:, None]
+        if transpose_out:
+            assert epilogue is None
+            tb = M if (t_block <= 0 or t_block > M) else t_block
+            if tb == M and Y.ld >= M and Y.rows > 1:
+                Y.a[:L, :M] = v.T
+                return
+            for h in range(-(-M // tb)):
+                lo, hi = h * tb, min(M, (h + 1) * tb)
+                Y.flat[h * L * tb: h * L * tb + L * (hi - lo)] = v[lo:hi].T.reshape(-1)
+            return
+        if epilogue:
+            v = self._epilogue(v, epilogue, M, L)
+        Y.a[:M, :L] = v
+
+    def _epilogue(self, v, ep, M, L):
+        v = v.astype(np.float32)
+        if ep.get("evidence") is not None:
+            cnt = ep["evidence"].a[:M, :L].astype(np.int32)
+            v = v * (np.float32(1) - np.ldexp(np.float32(1), -cnt)).astype(np.float32)
+        if ep.get("apriori") is not None:
+            lbd = np.float32(ep["lbd"])
+            v = (np.float32(1) - lbd) * v + lbd * ep["apriori"].a[:M, :L]
+        if ep.get("set_diag", True):
+            d0 = ep.get("diag_col0", 0)
+            for c in range(L):
+                if 0 <= d0 + c < M:
+                    v[d0 + c, c] = 1
+        if ep.get("previous") is not None:
+            old = ep["previous"].a[:M, :L]
+            self._changed = int((np.abs(v.astype(np.float64) - old.astype(np.float64))
+                                 > ep["eps"]).sum())
+        return v
+
+    def gemm_nt(self, A, B, Cm, M, N, K, epilogue=None):
+        self.calls.append(("gemm_nt", bool(epilogue)))
+        v = A.a[:M, :K] @ B.a[:N, :K].T
+        if epilogue:
+            v = self._epilogue(v * np.float32(epilogue["coef"]), epilogue, M, N)
+        Cm.a[:M, :N] = v
+
+    def densify(self, g, Wd):
+        Wd.a[:, :] = 0
+        Wd.a[:g.n_rows, :g.n_cols] = (sp.diags(g.rowscale) @ g.pattern).toarray()
+
+    def evidence_counts(self, g, col0, out):
+        live = sp.diags((g.rowscale > 0).astype(np.float32)) @ g.pattern
+        cnt = (live @ live.T).toarray()
+        out.a[:, :out.cols] = np.minimum(cnt[:, col0:col0 + out.cols], 255).astype(np.uint8)
+
+    def read_changed(self):
+        return self._changed
+
+    def event(self):
+        return 0
+
+    def record(self, ev):
+        pass
+
+    def elapsed_ms(self, a, b):
+        return 0.0

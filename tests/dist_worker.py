@@ -1,0 +1,39 @@
+"""Worker of tests/test_distributed_gloo.py: one rank of a gloo world, launched by
+``python -m torch.distributed.run``.  Kernels = NumPy test double, collectives = real."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch.distributed as dist  # noqa: E402
+
+
+def main(names):
+    dist.init_process_group("gloo")
+    rank = dist.get_rank()
+    from simrank_amd.driver import TorchWorld
+    from tests.conftest import Golden
+    from tests.cpu_ops import NumpyOps
+    from tests.helpers import check_against_golden, run_estimator
+    for name in names:
+        g = Golden(name)
+        ops = NumpyOps()
+        est, res, text = run_estimator(g, lambda r: ops, world=TorchWorld(), mode="sparse")
+        if rank == 0:
+            check_against_golden(g, est, res, text)
+        else:                        # other ranks are silent but hold the same result
+            assert text == ""
+            first = res[0] if isinstance(res, tuple) else res
+            want = g.out["S1"] if isinstance(res, tuple) else g.out["S"]
+            np.testing.assert_allclose(first.values, want, rtol=1e-5, atol=1e-30)
+        assert any(c[0] == "spmm" and c[1] for c in ops.calls)
+    dist.barrier()
+    print(f"RANK {rank} ok", flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

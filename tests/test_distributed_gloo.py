@@ -1,0 +1,35 @@
+"""world_size-2 (and 3) run of the sharded driver over torch.distributed/gloo on CPU.
+
+Each process is one rank of ``driver.TorchWorld`` (launched exactly as the bench is, with
+``python -m torch.distributed.run``); the kernels are the NumPy test double
+(tests/cpu_ops.py), the exchange is a real ``all_to_all_single`` and the convergence count
+a real ``all_reduce``.  Every rank must end with the full matrix the reference produced."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAMES = ["SimRank_er64", "SimRankPP_er64_weighted", "AprioriSimRank_er64",
+         "BipartiteSimRank_b5030", "BipartiteSimRankPP_b40", "SimRank_toy5"]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_driver_over_gloo(world):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"),
+           *NAMES]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    for r in range(world):
+        assert f"RANK {r} ok" in p.stdout

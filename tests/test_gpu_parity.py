@@ -1,0 +1,202 @@
+"""End-to-end parity on a real MI355X: the estimators (class surface -> ingest -> C ABI ->
+HIP kernels) against (1) every golden vector the reference produced, (2) the oracle on
+seeded graphs at sizes it finishes in seconds, (3) size-independent properties at
+BASELINE.json's full sizes.  float32 S entries within 1e-5 relative; labels, convergence
+iteration, console text and the SimRank++ Evidence/Weight attributes exact."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import simrank_amd.SimRank as SRA
+from oracle import simrank_oracle as O
+from simrank_amd import ingest, synth
+from simrank_amd.driver import LocalWorld, SideSpec, Solver
+from tests.conftest import Golden, golden_names
+from tests.graphs import bipartite_random
+from tests.helpers import RTOL, assert_close, check_against_golden, run_estimator
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from simrank_amd.engine import HipOps
+    return HipOps(0)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_vectors(name):
+    g = Golden(name)
+    if g.raises:
+        with pytest.raises(ValueError):
+            run_estimator(g)
+        return
+    est, res, text = run_estimator(g)
+    check_against_golden(g, est, res, text)
+
+
+@pytest.mark.parametrize("mode", ["sparse", "dense", "hybrid"])
+@pytest.mark.parametrize("name", ["SimRank_er128", "SimRank_pl256", "SimRankPP_er64_weighted",
+                                  "SimRankPP_quirky", "AprioriSimRank_er64",
+                                  "BipartiteSimRank_b5030", "BipartiteSimRank_k10",
+                                  "BipartiteSimRankPP_b40", "BipartitleAprioriSimRank_b40"])
+def test_golden_vectors_in_every_mode(name, mode):
+    g = Golden(name)
+    est, res, text = run_estimator(g, mode=mode)
+    assert est.engine_mode == mode
+    check_against_golden(g, est, res, text, check_attrs=False)
+
+
+def test_auto_mode_dispatches_on_density():
+    est, _, _ = run_estimator(Golden("BipartiteSimRank_k10"))       # complete bipartite
+    assert est.engine_mode == "dense"
+    est, _, _ = run_estimator(Golden("SimRank_er256"))               # 3 % dense
+    assert est.engine_mode == "sparse"
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("name", ["SimRank_er128", "SimRankPP_quirky", "AprioriSimRank_er64",
+                                  "BipartiteSimRank_b5030", "BipartiteSimRankPP_b40",
+                                  "SimRank_toy5"])
+def test_logical_shards_on_one_gpu(name, world):
+    """P column shards on one device, all-to-all by device copies."""
+    g = Golden(name)
+    est, res, text = run_estimator(g, world=LocalWorld(world), mode="sparse")
+    check_against_golden(g, est, res, text)
+
+
+def test_logical_shards_are_bitwise_equal_to_one_shard():
+    df = synth.er_directed(1024, 0.01, seed=1)
+    one = SRA.SimRank().fit(df, iterations=6, eps=0, verbose=False, mode="sparse")
+    for world in (2, 4, 8):
+        many = SRA.SimRank().fit(df, iterations=6, eps=0, verbose=False, mode="sparse",
+                                 world=LocalWorld(world))
+        assert np.array_equal(one.values, many.values)
+
+
+def test_runs_are_bitwise_reproducible():
+    df = synth.powerlaw_directed(2048, 16, seed=3)
+    a = SRA.SimRankPP().fit(df, iterations=5, eps=0, verbose=False)
+    b = SRA.SimRankPP().fit(df, iterations=5, eps=0, verbose=False)
+    assert np.array_equal(a.values, b.values)
+
+
+@pytest.mark.parametrize("kind", ["er", "powerlaw"])
+@pytest.mark.parametrize("cls", ["SimRank", "SimRankPP"])
+def test_midsize_against_oracle(kind, cls):
+    df = (synth.er_directed(2048, 0.004, seed=11) if kind == "er"
+          else synth.powerlaw_directed(2048, 24, seed=12))
+    got = getattr(SRA, cls)().fit(df, verbose=False)
+    want = (O.fit_simrank if cls == "SimRank" else O.fit_simrank_pp)(df, verbose=False)
+    assert list(got.index) == want["labels"]
+    assert_close(got.values, want["S"])
+
+
+def test_midsize_weighted_and_prior_against_oracle():
+    df = synth.er_directed(1500, 0.006, seed=13)
+    rng = np.random.default_rng(0)
+    prior = rng.random((1500, 1500))
+    prior = (prior + prior.T) / 2
+    got = SRA.AprioriSimRank().fit(df, prior, lbd=0.2, weighted=True, verbose=False)
+    want = O.fit_simrank_pp(df, apriori=prior, lbd=0.2, weighted=True, verbose=False)
+    assert_close(got.values, want["S"])
+
+
+def test_midsize_bipartite_against_oracle():
+    df = bipartite_random(900, 500, 0.03, seed=14)
+    est = SRA.BipartiteSimRankPP()
+    s1, s2 = est.fit(df, verbose=False, strict_reference=False)
+    want = O.fit_bipartite_pp(df, verbose=False, strict_reference=False)
+    assert list(s1.index) == want["sorted1"]
+    assert_close(s1.values, want["S1"])
+    assert_close(s2.values, want["S2"])
+    assert est.converged_at == want["k"]
+    plain = SRA.BipartiteSimRank().fit(df, verbose=False)
+    wantp = O.fit_bipartite(df, verbose=False)
+    assert_close(plain[0].values, wantp["S1"])
+    assert_close(plain[1].values, wantp["S2"])
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE.json sizes: properties that do not need a dense float64 oracle run
+# ---------------------------------------------------------------------------------------
+def _sampled_rows_check(ops, solver, csr, rows, coef):
+    """Rows of one more update recomputed on the host in float64 from the device's S_k:
+    S_{k+1}[a, :] = coef . (W[a, :] . S_k) . W^T,  diag <- 1."""
+    need = sorted(set(np.concatenate([csr.col[csr.rowptr[a]:csr.rowptr[a + 1]] for a in rows])))
+    pos = {int(i): p for p, i in enumerate(need)}
+    part = ops.download_rows(solver.cur[0][0], need).astype(np.float64)
+    rs = csr.rowscale.astype(np.float32).astype(np.float64)
+    W = sp.diags(rs) @ sp.csr_matrix((np.ones(csr.col.size), csr.col, csr.rowptr),
+                                     shape=(csr.n_rows, csr.n_cols))
+    t_rows = {}
+    for a in rows:                         # t = W[a, :] . S_k : the rows a gathers
+        idx = [pos[int(i)] for i in csr.col[csr.rowptr[a]:csr.rowptr[a + 1]]]
+        t_rows[a] = rs[a] * part[idx].sum(axis=0)
+    solver.step(0.0)
+    S_n = ops.download(solver.cur[0][0])
+    for a in rows:
+        want = coef * (W @ t_rows[a])
+        want[a] = 1.0
+        np.testing.assert_allclose(S_n[a], want, rtol=RTOL, atol=1e-30)
+    return S_n
+
+
+@pytest.mark.parametrize("workload,iters", [("er8192", 8), ("pl32768", 3)])
+def test_full_size_properties(ops, workload, iters):
+    df = synth.WORKLOADS[workload][0]()
+    nodes, csr = ingest.directed(df, False, "from", "to", "weight")
+    n = csr.n_rows
+    assert n == int(workload[2:])
+    solver = Solver(lambda r: ops, LocalWorld(1), [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
+    solver.reset()
+    for _ in range(iters):
+        solver.step(0.0)
+    rows = [0, 1, n // 3, n - 1, int(np.argmax(np.diff(csr.rowptr)))]
+    S = _sampled_rows_check(ops, solver, csr, rows, 0.8)
+    assert np.array_equal(np.diag(S), np.ones(n, dtype=np.float32))
+    assert S.min() >= 0.0 and S.max() <= 1.0
+    # symmetry: both triangles come from different summation orders
+    blk = slice(0, 4096)
+    np.testing.assert_allclose(S[blk, :], S[:, blk].T, rtol=RTOL, atol=1e-30)
+    # nodes without in-edges keep the identity row (quirk Q6)
+    lonely = np.flatnonzero(np.diff(csr.rowptr) == 0)[:5]
+    for a in lonely:
+        assert S[a].sum() == 1.0
+    solver.release()
+
+
+def test_config3_movielens_shaped_bipartite_pp(ops):
+    """6040 x 3706, ~1.0 M ratings: runs only with the corrected
+    Evidence_N2 (the reference raises, quirk Q2); checked through sampled rows of one update
+    recomputed on the host in float64 and the identity PP-with-E==1 == plain."""
+    df = synth.WORKLOADS["ml1m"][0]()
+    with pytest.raises(ValueError, match="broadcast"):
+        SRA.BipartiteSimRankPP().fit(df, iterations=1, verbose=False)
+    est = SRA.BipartiteSimRankPP()
+    s1, s2 = est.fit(df, iterations=2, eps=0, verbose=False, strict_reference=False)
+    assert s1.shape == (6040, 6040) and s2.shape == (3706, 3706)
+    g12, g21 = est._csr
+
+    def W(c):
+        return sp.diags(c.rowscale.astype(np.float32).astype(np.float64)) @ sp.csr_matrix(
+            (np.ones(c.col.size), c.col, c.rowptr), shape=(c.n_rows, c.n_cols))
+    W12, W21 = W(g12), W(g21)
+    # iteration 1 from identity, then iteration 2, for sampled rows of S1 (float64 host)
+    P12 = (W12 != 0).astype(np.float64)
+    P21 = (W21 != 0).astype(np.float64)
+    rows = [0, 17, 3000, 6039]
+    S2_0 = sp.identity(3706, format="csr")
+    S1_1 = 0.8 * (W12 @ S2_0 @ W12.T).toarray()
+    E1 = 1 - 0.5 ** (P12 @ P12.T).toarray()
+    S1_1 *= E1
+    np.fill_diagonal(S1_1, 1)
+    S2_1 = 0.8 * (W21 @ sp.csr_matrix(S1_1) @ W21.T).toarray()
+    E2 = 1 - 0.5 ** (P21 @ P21.T).toarray()
+    S2_1 *= E2
+    np.fill_diagonal(S2_1, 1)
+    for a in rows:
+        want = 0.8 * (W12 @ (W12[a] @ S2_1).T).ravel() * E1[a]
+        want[a] = 1.0
+        np.testing.assert_allclose(s1.values[a], want, rtol=RTOL, atol=1e-30)
+    assert est.engine_mode in ("sparse", "dense")

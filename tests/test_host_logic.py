@@ -1,0 +1,147 @@
+"""Host logic above the C ABI, on CPU: ingest -> CSR, the iteration driver, console text,
+quirk handling, sharded exchange layout.  The kernels are replaced by the NumPy test double
+of tests/cpu_ops.py (the real kernels are checked by the `-m gpu` tests)."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from oracle import simrank_oracle as O
+from simrank_amd import ingest
+from simrank_amd.driver import LocalWorld
+from tests.conftest import Golden, golden_names
+from tests.cpu_ops import NumpyOps
+from tests.helpers import check_against_golden, run_estimator
+
+
+def _factory():
+    ops = NumpyOps()
+    return lambda rank: ops
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_estimators_match_reference_on_cpu_double(name):
+    g = Golden(name)
+    if g.raises:
+        with pytest.raises(ValueError):
+            run_estimator(g, _factory())
+        return
+    est, res, text = run_estimator(g, _factory())
+    check_against_golden(g, est, res, text)
+
+
+@pytest.mark.parametrize("mode", ["sparse", "dense", "hybrid"])
+@pytest.mark.parametrize("name", ["SimRank_er64", "SimRankPP_er64_weighted",
+                                  "AprioriSimRank_er64", "BipartiteSimRank_b5030",
+                                  "BipartiteSimRankPP_b40", "BipartitleAprioriSimRank_b40"])
+def test_every_mode_gives_the_same_answer(name, mode):
+    g = Golden(name)
+    est, res, text = run_estimator(g, _factory(), mode=mode)
+    assert est.engine_mode == mode
+    check_against_golden(g, est, res, text, check_attrs=False)
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+@pytest.mark.parametrize("name", ["SimRank_er64", "SimRankPP_quirky", "AprioriSimRank_er64",
+                                  "BipartiteSimRank_b5030", "BipartiteSimRankPP_b40",
+                                  "BipartitleAprioriSimRank_b40", "SimRank_toy5"])
+def test_virtual_ranks_loopback(name, world):
+    """P column shards with the all-to-all done by copies must reproduce P = 1."""
+    g = Golden(name)
+    est, res, text = run_estimator(g, _factory(), world=LocalWorld(world), mode="sparse")
+    check_against_golden(g, est, res, text)
+
+
+def test_ingest_matches_oracle_dense_graphs():
+    for name in golden_names("SimRank"):
+        g = Golden(name)
+        if g.raises:
+            continue
+        kw = {k: v for k, v in g.kwargs.items() if k.endswith("_column") or k == "weighted"}
+        nodes, csr = ingest.directed(g.frame, kw.get("weighted", False),
+                                     kw.get("from_node_column", "from"),
+                                     kw.get("to_node_column", "to"),
+                                     kw.get("weight_column", "weight"))
+        onodes, G = O.directed_graph(g.frame, **kw)
+        assert nodes == onodes
+        np.testing.assert_array_equal(csr.dense(), G)
+        assert (np.diff(csr.col.astype(np.int64))[np.diff(
+            np.repeat(np.arange(csr.n_rows), np.diff(csr.rowptr))) == 0] > 0).all()
+
+
+def test_duplicate_edges_raise_like_pivot():
+    d = pd.DataFrame({"from": [1, 1, 2], "to": [2, 2, 1]})
+    with pytest.raises(ValueError, match="duplicate entries"):
+        ingest.directed(d, False, "from", "to", "weight")
+    b = pd.DataFrame({"user": [1, 1], "item": [5, 5]})
+    with pytest.raises(ValueError, match="duplicate entries"):
+        ingest.bipartite(b, False, "user", "item", "weight")
+
+
+def test_missing_column_is_a_keyerror():
+    import simrank_amd.SimRank as SRA
+    with pytest.raises(KeyError):
+        SRA.SimRank().fit(pd.DataFrame({"a": [1], "b": [2]}), _ops_factory=_factory())
+
+
+def test_input_frame_is_not_mutated():
+    g = Golden("SimRankPP_er64_weighted")
+    before = g.frame.copy(deep=True)
+    run_estimator(g, _factory())
+    pd.testing.assert_frame_equal(g.frame, before)
+
+
+def test_strict_reference_off_corrects_labels_and_evidence():
+    """Q1: correct labels; Q2: Evidence_N2 on the group-2 update (runs when n1 != n2)."""
+    g = Golden("BipartiteSimRankPP_b5030")
+    with pytest.raises(ValueError, match="broadcast"):
+        run_estimator(g, _factory())
+    est, (s1, s2), _ = run_estimator(g, _factory(), strict_reference=False)
+    want = O.fit_bipartite_pp(g.frame, strict_reference=False, **g.kwargs)
+    assert list(s1.index) == want["sorted1"] and list(s2.index) == want["sorted2"]
+    np.testing.assert_allclose(s1.values, want["S1"], rtol=1e-5, atol=1e-30)
+    np.testing.assert_allclose(s2.values, want["S2"], rtol=1e-5, atol=1e-30)
+    np.testing.assert_array_equal(est.Evidence_N2, want["E2"])
+    # with the evidence switched off by an all-ones prior trick: PP with E == 1 is plain
+    gb = Golden("BipartiteSimRank_bigints")
+    _, (p1, _), _ = run_estimator(gb, _factory(), strict_reference=False)
+    assert list(p1.index) == sorted(p1.index)
+
+
+def test_apriori_must_be_ndarray():
+    import simrank_amd.SimRank as SRA
+    g = Golden("AprioriSimRank_toy5")
+    with pytest.raises(AttributeError, match="flat"):
+        SRA.AprioriSimRank().fit(g.frame, pd.DataFrame(g.args[0]), _ops_factory=_factory())
+
+
+def test_partition_covers_everything():
+    for n in (1, 5, 64, 1000):
+        for w in (1, 2, 3, 8):
+            blocks = [ingest.partition(n, w, r) for r in range(w)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            b = -(-n // w)
+            assert all(hi - lo == b for lo, hi in blocks if hi < n)
+
+
+def test_reference_class_names_and_signatures():
+    import inspect
+    import simrank_amd.SimRank as SRA
+    for name in ("SimRank", "SimRankPP", "BipartiteSimRank", "BipartiteSimRankPP",
+                 "AprioriSimRank", "BipartitleAprioriSimRank", "BipartitleSimRank",
+                 "BipartitleSimRankPP"):
+        assert inspect.isclass(getattr(SRA, name))
+    sig = inspect.signature(SRA.SimRank.fit)
+    assert list(sig.parameters)[:10] == ["self", "data", "C", "weighted", "from_node_column",
+                                         "to_node_column", "weight_column", "iterations", "eps",
+                                         "verbose"]
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert (d["C"], d["weighted"], d["iterations"], d["eps"], d["verbose"]) == (0.8, False, 100, 1e-4, True)
+    sig = inspect.signature(SRA.BipartiteSimRankPP.fit)
+    assert list(sig.parameters)[:11] == ["self", "data", "C1", "C2", "weighted",
+                                         "node_group1_column", "node_group2_column",
+                                         "weight_column", "iterations", "eps", "verbose"]
+    sig = inspect.signature(SRA.BipartitleAprioriSimRank.fit)
+    assert list(sig.parameters)[:8] == ["self", "data", "AprioriSim1", "AprioriSim2", "C1", "C2",
+                                        "lbd1", "lbd2"]
+    assert SRA.BAR_LENGTH == 30 and callable(SRA.update_progress)

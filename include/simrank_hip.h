@@ -41,6 +41,7 @@ extern "C" {
 #endif
 
 #define SIMRANK_ABI_VERSION 1
+#define SIMRANK_CHANGED_SLOTS 1024
 
 #if defined(__GNUC__)
 #define SIMRANK_API __attribute__((visibility("default")))
@@ -115,7 +116,9 @@ typedef struct simrank_epilogue {
     const float* previous;           /* device, previous iterate block or NULL            */
     int64_t ld_previous;
     double eps;                      /* strict |new - previous| > eps, every element      */
-    unsigned long long* n_changed;   /* device counter; zeroed by the call, then += count */
+    unsigned long long* n_changed;   /* device array of SIMRANK_CHANGED_SLOTS counters, zeroed
+                                        by the call; the count is their SUM (striped so the
+                                        workgroups do not serialise on one address)       */
     int64_t diag_col0;               /* global column index of local column 0             */
     int32_t set_diag;                /* 1: element (a, a - diag_col0) <- 1                */
     int32_t reserved;

@@ -285,6 +285,9 @@ int simrank_set_tuning(const char* key, int64_t value) {
         t.panel = value;
     } else if (!strcmp(key, "xcd_map")) {
         t.xcd_map = value ? 1 : 0;
+    } else if (!strcmp(key, "tile")) {
+        SR_REQUIRE(value == 0 || value == 16 || value == 32 || value == 64, "tile must be 0, 16, 32 or 64");
+        t.tile = value;
     } else if (!strcmp(key, "unroll")) {
         SR_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, "unroll must be 1,2,4,8");
         t.unroll = value;
@@ -300,6 +303,7 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     if (!strcmp(key, "panel")) *value = t.panel;
     else if (!strcmp(key, "xcd_map")) *value = t.xcd_map;
     else if (!strcmp(key, "unroll")) *value = t.unroll;
+    else if (!strcmp(key, "tile")) *value = t.tile;
     else SR_REQUIRE(false, "unknown tuning key '%s'", key);
     return SIMRANK_OK;
 }

@@ -34,6 +34,7 @@ struct Tuning {
     int64_t panel = 0;    // 0 = automatic
     int64_t xcd_map = 1;  // panel -> XCD affinity (blockIdx % 8 shares an L2)
     int64_t unroll = 4;
+    int64_t tile = 0;     // rows per wave tile (16, 32, 64; 0 = automatic)
 };
 Tuning& tuning();
 

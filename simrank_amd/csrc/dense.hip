@@ -173,7 +173,9 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const GemmArgs p) {
     if (p.has_ep && p.prev) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) changed += __shfl_down(changed, off);
-        if (lane == 0 && changed) atomicAdd(p.n_changed, (unsigned long long)changed);
+        if (lane == 0 && changed)
+                atomicAdd(p.n_changed + ((blockIdx.x * 4u + (threadIdx.x >> 6)) * 7u) % SIMRANK_CHANGED_SLOTS,
+                          (unsigned long long)changed);
     }
 }
 
@@ -231,7 +233,7 @@ int simrank_gemm_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
         a.eps = ep->eps; a.n_changed = ep->n_changed;
         a.diag_col0 = ep->diag_col0; a.set_diag = ep->set_diag;
         SR_REQUIRE(!a.prev || a.n_changed, "previous needs a counter");
-        if (a.prev) SR_HIP(hipMemsetAsync(a.n_changed, 0, sizeof(unsigned long long), st));
+        if (a.prev) SR_HIP(hipMemsetAsync(a.n_changed, 0, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS, st));
     }
     const int64_t grid = int64_t(a.nbm) * a.nbn;
     SR_REQUIRE(grid < (int64_t(1) << 31), "grid too large");

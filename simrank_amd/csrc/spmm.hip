@@ -76,12 +76,76 @@ __device__ __forceinline__ void vstore(float* p, const float (&d)[VEC]) {
     }
 }
 
-constexpr int kWaves = 4;  // waves per workgroup
+constexpr int kWaves = 4;   // waves per workgroup
+constexpr int kHeavy = 64;  // rows with at least this many entries are gathered cooperatively
+
+// One output row segment (VEC floats per lane, LPR lanes) -> epilogue -> memory / LDS tile.
+template <int VEC, int LPR, bool TRANS, int RT>
+__device__ __forceinline__ void emit_row(const SpmmArgs& p, float* tbuf_wave, int r_local,
+                                         int64_t a, int q, int64_t mycol, const float (&acc)[VEC],
+                                         unsigned& changed) {
+    const float sc = p.rowscale[a] * (p.has_ep ? p.coef : 1.0f);
+    float o[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] = acc[i] * sc;
+    if constexpr (TRANS) {
+        float* t = tbuf_wave + (q * VEC) * (RT + 1) + r_local;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) t[i * (RT + 1)] = o[i];
+    } else {
+        const int nvalid = int(imin(VEC, p.L - mycol));
+        if (p.has_ep) {
+            if (p.ev) {
+                const uint8_t* ep = p.ev + a * p.ld_ev + mycol;
+                unsigned cnt[VEC];
+                if constexpr (VEC == 4) {
+                    const unsigned w = *reinterpret_cast<const unsigned*>(ep);
+                    cnt[0] = w & 255u; cnt[1] = (w >> 8) & 255u;
+                    cnt[2] = (w >> 16) & 255u; cnt[3] = w >> 24;
+                } else {
+                    cnt[0] = ep[0];
+                }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) o[i] *= 1.0f - __builtin_ldexpf(1.0f, -int(cnt[i]));
+            }
+            if (p.ap) {
+                float pr[VEC];
+                vload<VEC>(pr, p.ap + a * p.ld_ap + mycol);
+                const float keep = 1.0f - p.lbd;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) o[i] = keep * o[i] + p.lbd * pr[i];
+            }
+            if (p.set_diag) {
+                const int64_t d = a - (p.diag_col0 + mycol);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                    if (d == i) o[i] = 1.0f;
+            }
+            if (p.prev) {
+                float old[VEC];
+                vload<VEC>(old, p.prev + a * p.ld_prev + mycol);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                    changed += (i < nvalid && fabs(double(o[i]) - double(old[i])) > p.eps) ? 1u : 0u;
+            }
+        }
+        float* y = p.Y + a * p.ldy + mycol;
+        if (nvalid == VEC) {
+            vstore<VEC>(y, o);
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                if (i < nvalid) y[i] = o[i];
+        }
+    }
+}
 
 template <int VEC, int LPR, bool TRANS, int RT, int UNROLL>
 __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
-    constexpr int PW = VEC * LPR;  // panel width in floats
-    constexpr int G = 64 / LPR;    // neighbour rows gathered per load instruction
+    static_assert(RT <= 64, "one lane per tile row");
+    constexpr int PW = VEC * LPR;            // panel width in floats
+    constexpr int G = 64 / LPR;              // lane groups = rows (or neighbours) in flight
+    constexpr int JU = LPR < 8 ? LPR : 8;    // gathers a group keeps in flight
     __shared__ float tbuf[TRANS ? kWaves * PW * (RT + 1) : 1];
 
     const int lane = threadIdx.x & 63;
@@ -106,24 +170,49 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
     const int64_t c0 = int64_t(panel) * PW;
     const int g = lane / LPR;
     const int q = lane % LPR;
+    const int gbase = lane - q;              // first lane of this lane's group
     const int64_t mycol = c0 + int64_t(q) * VEC;
     const bool col_active = mycol < p.L;  // VEC=4: mycol+3 < ldx because ldx % 4 == 0
     const int64_t row0 = (int64_t(rt) * kWaves + wave) * RT;
+    const int nrows = int(imin(RT, p.M - row0));  // rows of this wave's tile (may be <= 0)
     const float* __restrict__ Xc = p.X + mycol;
+    float* tbuf_wave = tbuf + (TRANS ? wave * PW * (RT + 1) : 0);
     unsigned changed = 0;
 
-    for (int r = 0; r < RT; ++r) {
-        const int64_t a = row0 + r;
-        if (a >= p.M) break;  // wave-uniform
-        const int s = p.rowptr[a];
-        const int e = p.rowptr[a + 1];
+    // ---- rows of the tile sorted by length, longest first (bitonic over the 64 lanes).
+    // key = length * 64 + tile row; lanes without a row get a negative key and sort last.
+    int my_start = 0, key = -64 + lane;
+    if (lane < nrows) {
+        my_start = p.rowptr[row0 + lane];
+        key = ((p.rowptr[row0 + lane + 1] - my_start) << 6) | lane;
+    }
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int other = __shfl_xor(key, j);
+            const bool desc = (lane & k) == 0;
+            const bool lower = (lane & j) == 0;
+            const bool take = (lower == desc) ? (other > key) : (other < key);
+            key = take ? other : key;
+        }
+    }
+    const int s_row = key & 63;              // tile row held by this sorted position
+    const int s_len = key >> 6;              // its length (-1: none)
+    const int s_start = __shfl(my_start, s_row);
+    const int n_heavy = __popcll(__ballot(s_len >= kHeavy));
+
+    // ---- phase A: long rows, one at a time; the G lane groups split the neighbours and
+    // their partial sums are combined by shuffles in a fixed order
+    for (int h = 0; h < n_heavy; ++h) {
+        const int r = __builtin_amdgcn_readfirstlane(__shfl(s_row, h));
+        const int s = __builtin_amdgcn_readfirstlane(__shfl(s_start, h));
+        const int e = s + __builtin_amdgcn_readfirstlane(__shfl(s_len, h));
         float acc[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-
         for (int base = s; base < e; base += 64) {
             const int n = min(64, e - base);
-            // one coalesced load of up to 64 neighbour ids, handed out by shuffle
             const int myidx = lane < n ? p.col[base + lane] : 0;
             for (int k0 = 0; k0 < n; k0 += G * UNROLL) {
                 float v[UNROLL][VEC];
@@ -144,94 +233,77 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
                     for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
             }
         }
-        // combine the G neighbour groups, fixed order
 #pragma unroll
         for (int off = LPR; off < 64; off <<= 1)
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off);
+        if (g == 0 && col_active)
+            emit_row<VEC, LPR, TRANS, RT>(p, tbuf_wave, r, row0 + r, q, mycol, acc, changed);
+    }
 
-        if (g == 0 && col_active) {
-            const float sc = p.rowscale[a] * (p.has_ep ? p.coef : 1.0f);
-            float o[VEC];
+    // ---- phase B: the other rows, G at a time, one row per lane group: no cross-lane
+    // reduction, G independent gather streams per wave, JU loads in flight in each
+    for (int pos = n_heavy; pos < nrows; pos += G) {
+        const int src = pos + g;
+        const bool have = src < nrows;
+        const int r = __shfl(s_row, src & 63);
+        const int st = __shfl(s_start, src & 63);
+        const int len_src = __shfl(s_len, src & 63);  // every lane takes part in the shuffle
+        const int len = have ? len_src : 0;
+        const int maxlen = __builtin_amdgcn_readfirstlane(__shfl(s_len, pos));  // sorted: longest of the pass
+        float acc[VEC];
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) o[i] = acc[i] * sc;
-            if constexpr (TRANS) {
-                float* t = tbuf + (wave * PW + q * VEC) * (RT + 1) + r;
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+        for (int t0 = 0; t0 < maxlen; t0 += LPR) {
+            // the group's next LPR neighbour ids: one coalesced load, handed out by shuffle
+            const int iv = (t0 + q < len) ? p.col[st + t0 + q] : 0;
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) t[i * (RT + 1)] = o[i];
-            } else {
-                const int nvalid = int(imin(VEC, p.L - mycol));
-                if (p.has_ep) {
-                    if (p.ev) {
-                        const uint8_t* ep = p.ev + a * p.ld_ev + mycol;
-                        unsigned cnt[VEC];
-                        if constexpr (VEC == 4) {
-                            const unsigned w = *reinterpret_cast<const unsigned*>(ep);
-                            cnt[0] = w & 255u; cnt[1] = (w >> 8) & 255u;
-                            cnt[2] = (w >> 16) & 255u; cnt[3] = w >> 24;
+            for (int jb = 0; jb < LPR; jb += JU) {
+                if (t0 + jb < maxlen) {
+                    float v[JU][VEC];
+#pragma unroll
+                    for (int j = 0; j < JU; ++j) {
+                        const int idx = __shfl(iv, gbase + jb + j);
+                        if (col_active && t0 + jb + j < len) {
+                            vload<VEC>(v[j], Xc + int64_t(idx) * p.ldx);
                         } else {
-                            cnt[0] = ep[0];
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) v[j][i] = 0.f;
                         }
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i)
-                            o[i] *= 1.0f - __builtin_ldexpf(1.0f, -int(cnt[i]));
                     }
-                    if (p.ap) {
-                        float pr[VEC];
-                        vload<VEC>(pr, p.ap + a * p.ld_ap + mycol);
-                        const float keep = 1.0f - p.lbd;
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) o[i] = keep * o[i] + p.lbd * pr[i];
-                    }
-                    if (p.set_diag) {
-                        const int64_t d = a - (p.diag_col0 + mycol);
+                    for (int j = 0; j < JU; ++j)
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i)
-                            if (d == i) o[i] = 1.0f;
-                    }
-                    if (p.prev) {
-                        float old[VEC];
-                        vload<VEC>(old, p.prev + a * p.ld_prev + mycol);
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i)
-                            changed += (i < nvalid &&
-                                        fabs(double(o[i]) - double(old[i])) > p.eps) ? 1u : 0u;
-                    }
-                }
-                float* y = p.Y + a * p.ldy + mycol;
-                if (nvalid == VEC) {
-                    vstore<VEC>(y, o);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i)
-                        if (i < nvalid) y[i] = o[i];
+                        for (int i = 0; i < VEC; ++i) acc[i] += v[j][i];
                 }
             }
         }
+        if (have && col_active)
+            emit_row<VEC, LPR, TRANS, RT>(p, tbuf_wave, r, row0 + r, q, mycol, acc, changed);
     }
 
     if constexpr (TRANS) {
         __syncthreads();
-        const int rows_done = int(imin(RT, p.M - row0));  // may be <= 0
         const int cols_here = int(imin(PW, p.L - c0));
         const int64_t tb = p.tblock;
-        const float* t = tbuf + wave * PW * (RT + 1);
         for (int x = lane; x < PW * RT; x += 64) {
             const int c = x / RT;
             const int r = x % RT;
-            if (c < cols_here && r < rows_done) {
+            if (c < cols_here && r < nrows) {
                 const int64_t a = row0 + r;
                 const int64_t blk = a / tb;
                 const int64_t a_in = a - blk * tb;
                 const int64_t stride = p.tstride ? p.tstride : imin(tb, p.M - blk * tb);
-                p.Y[blk * (p.L * tb) + (c0 + c) * stride + a_in] = t[c * (RT + 1) + r];
+                p.Y[blk * (p.L * tb) + (c0 + c) * stride + a_in] = tbuf_wave[c * (RT + 1) + r];
             }
         }
     } else {
         if (p.has_ep && p.prev) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) changed += __shfl_down(changed, off);
-            if (lane == 0 && changed) atomicAdd(p.n_changed, (unsigned long long)changed);
+            if (lane == 0 && changed)
+                atomicAdd(p.n_changed + ((blockIdx.x * 4u + (threadIdx.x >> 6)) * 7u) % SIMRANK_CHANGED_SLOTS,
+                          (unsigned long long)changed);
         }
     }
 }
@@ -367,29 +439,41 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
         if (a.ev) vec_ok = vec_ok && (reinterpret_cast<uintptr_t>(a.ev) % 4 == 0) && a.ld_ev % 4 == 0;
         if (a.ap) vec_ok = vec_ok && aligned16(a.ap) && a.ld_ap % 4 == 0;
         if (a.prev) vec_ok = vec_ok && aligned16(a.prev) && a.ld_prev % 4 == 0;
-        if (a.prev) SR_HIP(hipMemsetAsync(a.n_changed, 0, sizeof(unsigned long long), st));
+        if (a.prev) SR_HIP(hipMemsetAsync(a.n_changed, 0, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS, st));
     }
+    // automatic choice (profiles/ sweep_r01.log): 32 rows per wave tile; 32-float panels for
+    // the transposed leg (keeps its LDS tile at 17 KiB -> 7 workgroups per CU), 64 otherwise
     int64_t panel = tuning().panel;
-    if (panel == 0) panel = 32;
+    if (panel == 0) panel = transpose_out ? 32 : 64;
+    int64_t tile = tuning().tile;
+    if (tile == 0) tile = 32;
     if (!vec_ok) {
-        return transpose_out ? launch_spmm<1, 32, true, 64>(a, st)
-                             : launch_spmm<1, 32, false, 64>(a, st);
+        return transpose_out ? launch_spmm<1, 32, true, 32>(a, st)
+                             : launch_spmm<1, 32, false, 32>(a, st);
+    }
+#define SR_TILE_SWITCH(LPR, TR)                                             \
+    switch (tile) {                                                         \
+        case 16: return launch_spmm<4, LPR, TR, 16>(a, st);                 \
+        case 32: return launch_spmm<4, LPR, TR, 32>(a, st);                 \
+        default: return launch_spmm<4, LPR, TR, 64>(a, st);                 \
     }
     if (transpose_out) {
         if (panel > 64) panel = 64;  // wider panels would not leave LDS for the transpose tile
+        if (panel == 64 && tile > 32) tile = 32;
         switch (panel) {
-            case 16: return launch_spmm<4, 4, true, 64>(a, st);
-            case 32: return launch_spmm<4, 8, true, 64>(a, st);
-            default: return launch_spmm<4, 16, true, 32>(a, st);
+            case 16: SR_TILE_SWITCH(4, true)
+            case 32: SR_TILE_SWITCH(8, true)
+            default: SR_TILE_SWITCH(16, true)
         }
     }
     switch (panel) {
-        case 16: return launch_spmm<4, 4, false, 64>(a, st);
-        case 32: return launch_spmm<4, 8, false, 64>(a, st);
-        case 64: return launch_spmm<4, 16, false, 64>(a, st);
-        case 128: return launch_spmm<4, 32, false, 64>(a, st);
-        default: return launch_spmm<4, 64, false, 64>(a, st);
+        case 16: SR_TILE_SWITCH(4, false)
+        case 32: SR_TILE_SWITCH(8, false)
+        case 64: SR_TILE_SWITCH(16, false)
+        case 128: SR_TILE_SWITCH(32, false)
+        default: SR_TILE_SWITCH(64, false)
     }
+#undef SR_TILE_SWITCH
 }
 
 int simrank_evidence_counts(const simrank_graph* g, int64_t col0, int64_t n_cols,

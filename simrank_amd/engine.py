@@ -15,6 +15,9 @@ from ._lib import Epilogue, SimRankHipError, check
 from .ingest import CSR
 
 
+CHANGED_SLOTS = 1024      # SIMRANK_CHANGED_SLOTS of include/simrank_hip.h
+
+
 class Matrix:
     """Row-major device matrix (float32 or uint8) with a leading dimension."""
 
@@ -92,7 +95,7 @@ class HipOps:
             self.stream = s
         else:
             self.stream = C.c_void_p(stream)
-        self._counter = self._malloc(8)
+        self._counter = self._malloc(8 * CHANGED_SLOTS)
         self.pitch_pad = 32
 
     # ---- memory ----
@@ -224,10 +227,10 @@ class HipOps:
 
     def read_changed(self) -> int:
         """Value of the convergence counter of the last epilogue with ``previous``."""
-        v = C.c_ulonglong(0)
-        check(self.lib.simrank_memcpy_d2h(C.byref(v), self._counter, 8, self.stream),
+        v = (C.c_ulonglong * CHANGED_SLOTS)()
+        check(self.lib.simrank_memcpy_d2h(v, self._counter, 8 * CHANGED_SLOTS, self.stream),
               "read counter")
-        return int(v.value)
+        return int(sum(v))
 
     # ---- timing (HIP events on the engine's own stream) ----
     def event(self) -> int:

@@ -1,0 +1,34 @@
+#!/bin/bash
+# rocprofv3 kernel stats + PMC passes for the bench workload.  usage: bash tools/gpu_profile.sh TAG [bench args]
+set -u
+TAG=${1:-r1}; shift || true
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+BENCH="python3 $PWD/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras $*"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -- $BENCH > $OUT/pmc_l2.log 2>&1
+rocprofv3 --pmc TCC_BUSY_avr GRBM_GUI_ACTIVE TA_BUSY_avr --output-format csv -d $OUT/pmc_busy -- $BENCH > $OUT/pmc_busy.log 2>&1
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_TAG_STALL_sum --output-format csv -d $OUT/pmc_ea -- $BENCH > $OUT/pmc_ea.log 2>&1
+rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum --output-format csv -d $OUT/pmc_tcp -- $BENCH > $OUT/pmc_tcp.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq -- $BENCH > $OUT/pmc_sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1
+cd - > /dev/null
+find $OUT -name "*.csv" | head -20
+python3 - <<PY
+import csv, glob, collections
+for f in glob.glob("$OUT/stats/**/*kernel_stats.csv", recursive=True):
+    print(open(f).read()[:2500])
+for tag in ("pmc_l2", "pmc_busy", "pmc_ea", "pmc_tcp", "pmc_sq", "pmc_fetch", "pmc_write"):
+    for f in glob.glob(f"$OUT/{tag}/**/*counter_collection.csv", recursive=True):
+        acc = collections.defaultdict(lambda: [0.0, 0])
+        for r in csv.DictReader(open(f)):
+            if "spmm" not in r["Kernel_Name"] and "gemm" not in r["Kernel_Name"]:
+                continue
+            k = (r["Kernel_Name"][:62], r["Counter_Name"])
+            acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
+        for k, (v, n) in sorted(acc.items()):
+            print(tag, k, "mean per dispatch", v / n, "n", n)
+PY

@@ -139,6 +139,14 @@ SIMRANK_API int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx
                  float* Y, int64_t ldy, int32_t transpose_out, int64_t t_block,
                  const simrank_epilogue* epilogue, void* stream);
 
+/* ---- K4/K5 alone: Y = epilogue(Q), element-wise over an n_rows x n_cols block (Q and Y may be
+ *      the same buffer).  Used when an update cannot fuse its epilogue into leg 2: a prior
+ *      that is not symmetric makes S asymmetric, and leg 2 must then store its product
+ *      transposed (no epilogue) before SimRank.py:453 is applied. */
+SIMRANK_API int simrank_epilogue_apply(const float* Q, int64_t ldq, float* Y, int64_t ldy,
+                                       int64_t n_rows, int64_t n_cols,
+                                       const simrank_epilogue* epilogue, void* stream);
+
 /* ---- K7: counts of common in-neighbours, saturated at 255, for columns
  *      [col0, col0+n_cols) of the n_rows x n_rows evidence matrix; only rows with
  *      rowscale > 0 take part (pattern G > 0).  Replaces the int64 matmul of

@@ -28,7 +28,11 @@ __device__ __forceinline__ int64_t imin(int64_t a, int64_t b) { return a < b ? a
 
 struct SpmmArgs {
     const int32_t* rowptr;
-    const int32_t* col;
+    const int32_t* col;       // neighbour ids; with HUB: hubs encoded as -1 - rank (colx)
+    const int32_t* colx;      // col with hub columns encoded (-1 - slot)
+    const int32_t* hub_rows;  // slot -> row of X
+    int32_t n_hub;            // ranks cached in LDS by each workgroup
+    int32_t tpw;              // row tiles a wave walks
     const float* rowscale;
     const float* X;
     int64_t ldx;
@@ -77,7 +81,8 @@ __device__ __forceinline__ void vstore(float* p, const float (&d)[VEC]) {
 }
 
 constexpr int kWaves = 4;   // waves per workgroup
-constexpr int kHeavy = 64;  // rows with at least this many entries are gathered cooperatively
+constexpr int kHeavy = 64;
+constexpr int kSkip = INT32_MIN;  // "no neighbour in this slot"  // rows with at least this many entries are gathered cooperatively
 
 // One output row segment (VEC floats per lane, LPR lanes) -> epilogue -> memory / LDS tile.
 template <int VEC, int LPR, bool TRANS, int RT>
@@ -140,18 +145,23 @@ __device__ __forceinline__ void emit_row(const SpmmArgs& p, float* tbuf_wave, in
     }
 }
 
-template <int VEC, int LPR, bool TRANS, int RT, int UNROLL>
+// Neighbour ids >= 0 are rows of X; with HUB, ids < 0 are -1 - slot of the workgroup's LDS
+// copy of a hub row's panel segment.  A batch issues all its global loads, then all its LDS
+// reads, then adds in neighbour order: the hub cache changes where bytes come from, never
+// the arithmetic or its order.
+template <int VEC, int LPR, bool TRANS, int RT, bool HUB>
 __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
     static_assert(RT <= 64, "one lane per tile row");
     constexpr int PW = VEC * LPR;            // panel width in floats
     constexpr int G = 64 / LPR;              // lane groups = rows (or neighbours) in flight
     constexpr int JU = LPR < 8 ? LPR : 8;    // gathers a group keeps in flight
-    __shared__ float tbuf[TRANS ? kWaves * PW * (RT + 1) : 1];
+    constexpr int UNROLL = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [hub cache][transpose tiles]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    // block -> (panel, row tile); blocks equal mod 8 share an XCD (speed only)
+    // block -> (panel, row-tile group); blocks equal mod 8 share an XCD (speed only)
     int panel, rt;
     {
         const int64_t bid = blockIdx.x;
@@ -173,11 +183,27 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
     const int gbase = lane - q;              // first lane of this lane's group
     const int64_t mycol = c0 + int64_t(q) * VEC;
     const bool col_active = mycol < p.L;  // VEC=4: mycol+3 < ldx because ldx % 4 == 0
-    const int64_t row0 = (int64_t(rt) * kWaves + wave) * RT;
-    const int nrows = int(imin(RT, p.M - row0));  // rows of this wave's tile (may be <= 0)
     const float* __restrict__ Xc = p.X + mycol;
-    float* tbuf_wave = tbuf + (TRANS ? wave * PW * (RT + 1) : 0);
+    const float* hub = smem;
+    float* tbuf_wave = smem + (HUB ? p.n_hub * PW : 0) + (TRANS ? wave * PW * (RT + 1) : 0);
     unsigned changed = 0;
+
+    if constexpr (HUB) {
+        // the workgroup's copy of the panel segments of the n_hub most referenced rows
+        for (int h = wave * G + g; h < p.n_hub; h += kWaves * G) {
+            float seg[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) seg[i] = 0.f;
+            if (col_active) vload<VEC>(seg, Xc + int64_t(p.hub_rows[h]) * p.ldx);
+            vstore<VEC>(smem + h * PW + q * VEC, seg);
+        }
+        __syncthreads();
+    }
+
+    const int n_tw = HUB ? p.tpw : 1;
+    for (int tw = 0; tw < n_tw; ++tw) {
+    const int64_t row0 = ((int64_t(rt) * n_tw + tw) * kWaves + wave) * RT;
+    const int nrows = int(imin(RT, p.M - row0));  // rows of this wave's tile (may be <= 0)
 
     // ---- rows of the tile sorted by length, longest first (bitonic over the 64 lanes).
     // key = length * 64 + tile row; lanes without a row get a negative key and sort last.
@@ -216,16 +242,27 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
             const int myidx = lane < n ? p.col[base + lane] : 0;
             for (int k0 = 0; k0 < n; k0 += G * UNROLL) {
                 float v[UNROLL][VEC];
+                int idx[UNROLL];
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
                     const int k = k0 + u * G + g;
-                    const int idx = __shfl(myidx, k & 63);
-                    if (col_active && k < n) {
-                        vload<VEC>(v[u], Xc + int64_t(idx) * p.ldx);
+                    idx[u] = __shfl(myidx, k & 63);
+                    if (!(col_active && k < n)) idx[u] = kSkip;
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    if (idx[u] >= 0) {
+                        vload<VEC>(v[u], Xc + int64_t(idx[u]) * p.ldx);
                     } else {
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
                     }
+                }
+                if constexpr (HUB) {
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u)
+                        if (idx[u] < 0 && idx[u] != kSkip)
+                            vload<VEC>(v[u], hub + (-1 - idx[u]) * PW + q * VEC);
                 }
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u)
@@ -242,34 +279,64 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
     }
 
     // ---- phase B: the other rows, G at a time, one row per lane group: no cross-lane
-    // reduction, G independent gather streams per wave, JU loads in flight in each
-    for (int pos = n_heavy; pos < nrows; pos += G) {
-        const int src = pos + g;
-        const bool have = src < nrows;
-        const int r = __shfl(s_row, src & 63);
-        const int st = __shfl(s_start, src & 63);
-        const int len_src = __shfl(s_len, src & 63);  // every lane takes part in the shuffle
-        const int len = have ? len_src : 0;
-        const int maxlen = __builtin_amdgcn_readfirstlane(__shfl(s_len, pos));  // sorted: longest of the pass
+    // reduction, G independent gather streams per wave, JU loads in flight in each.
+    // The walk over (pass, chunk of LPR neighbours) is software-pipelined: the ids of the
+    // NEXT chunk are requested before the current chunk's gathers, so a wave pays one
+    // memory latency per chunk instead of two.
+    if (n_heavy < nrows) {
+        int pos = n_heavy, t0 = 0;
+        int src = pos + g;
+        int r = __shfl(s_row, src & 63);
+        int st = __shfl(s_start, src & 63);
+        int len = __shfl(s_len, src & 63);
+        if (src >= nrows) len = 0;
+        int maxlen = __builtin_amdgcn_readfirstlane(__shfl(s_len, pos));  // sorted: longest of the pass
+        int iv = (q < len) ? p.col[st + q] : 0;
         float acc[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-        for (int t0 = 0; t0 < maxlen; t0 += LPR) {
-            // the group's next LPR neighbour ids: one coalesced load, handed out by shuffle
-            const int iv = (t0 + q < len) ? p.col[st + t0 + q] : 0;
+        while (true) {
+            // where the walk goes next (wave-uniform)
+            const bool same_pass = t0 + LPR < maxlen;
+            const int npos = same_pass ? pos : pos + G;
+            const int nt0 = same_pass ? t0 + LPR : 0;
+            const bool more = npos < nrows;
+            int nr = r, nst = st, nlen = len, nmax = maxlen, niv = 0;
+            if (!same_pass) {
+                const int nsrc = npos + g;
+                nr = __shfl(s_row, nsrc & 63);
+                nst = __shfl(s_start, nsrc & 63);
+                nlen = __shfl(s_len, nsrc & 63);
+                if (nsrc >= nrows) nlen = 0;
+                nmax = __builtin_amdgcn_readfirstlane(__shfl(s_len, npos & 63));
+            }
+            if (more && nt0 + q < nlen) niv = p.col[nst + nt0 + q];
+
+            // the current chunk: up to LPR neighbours of each of the G rows
 #pragma unroll
             for (int jb = 0; jb < LPR; jb += JU) {
                 if (t0 + jb < maxlen) {
                     float v[JU][VEC];
+                    int idx[JU];
 #pragma unroll
                     for (int j = 0; j < JU; ++j) {
-                        const int idx = __shfl(iv, gbase + jb + j);
-                        if (col_active && t0 + jb + j < len) {
-                            vload<VEC>(v[j], Xc + int64_t(idx) * p.ldx);
+                        idx[j] = __shfl(iv, gbase + jb + j);
+                        if (!(col_active && t0 + jb + j < len)) idx[j] = kSkip;
+                    }
+#pragma unroll
+                    for (int j = 0; j < JU; ++j) {
+                        if (idx[j] >= 0) {
+                            vload<VEC>(v[j], Xc + int64_t(idx[j]) * p.ldx);
                         } else {
 #pragma unroll
                             for (int i = 0; i < VEC; ++i) v[j][i] = 0.f;
                         }
+                    }
+                    if constexpr (HUB) {
+#pragma unroll
+                        for (int j = 0; j < JU; ++j)
+                            if (idx[j] < 0 && idx[j] != kSkip)
+                                vload<VEC>(v[j], hub + (-1 - idx[j]) * PW + q * VEC);
                     }
 #pragma unroll
                     for (int j = 0; j < JU; ++j)
@@ -277,9 +344,15 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
                         for (int i = 0; i < VEC; ++i) acc[i] += v[j][i];
                 }
             }
+            if (!same_pass) {
+                if (pos + g < nrows && col_active)
+                    emit_row<VEC, LPR, TRANS, RT>(p, tbuf_wave, r, row0 + r, q, mycol, acc, changed);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+            }
+            if (!more) break;
+            pos = npos; t0 = nt0; r = nr; st = nst; len = nlen; maxlen = nmax; iv = niv;
         }
-        if (have && col_active)
-            emit_row<VEC, LPR, TRANS, RT>(p, tbuf_wave, r, row0 + r, q, mycol, acc, changed);
     }
 
     if constexpr (TRANS) {
@@ -297,7 +370,10 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
                 p.Y[blk * (p.L * tb) + (c0 + c) * stride + a_in] = tbuf_wave[c * (RT + 1) + r];
             }
         }
-    } else {
+    }
+    }  // row tiles of this wave
+
+    if constexpr (!TRANS) {
         if (p.has_ep && p.prev) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) changed += __shfl_down(changed, off);
@@ -308,18 +384,38 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
     }
 }
 
-template <int VEC, int LPR, bool TRANS, int RT>
-static int launch_spmm(SpmmArgs a, hipStream_t st) {
+template <int VEC, int LPR, bool TRANS, int RT, bool HUB>
+static int launch_spmm_impl(SpmmArgs a, hipStream_t st) {
     constexpr int PW = VEC * LPR;
     a.n_panels = int((a.L + PW - 1) / PW);
-    a.row_tiles = int((a.M + kWaves * RT - 1) / (kWaves * RT));
+    const int64_t rows_per_block = int64_t(kWaves) * RT * a.tpw;
+    a.row_tiles = int((a.M + rows_per_block - 1) / rows_per_block);
     const int64_t panels_padded = a.xcd_map ? int64_t((a.n_panels + 7) / 8) * 8 : a.n_panels;
     const int64_t grid = panels_padded * a.row_tiles;
     SR_REQUIRE(grid > 0 && grid < (int64_t(1) << 31), "grid of %lld blocks", (long long)grid);
-    hipLaunchKernelGGL((spmm_gather_kernel<VEC, LPR, TRANS, RT, 4>), dim3((unsigned)grid),
-                       dim3(256), 0, st, a);
+    const size_t lds = sizeof(float) * (size_t(HUB ? a.n_hub : 0) * PW +
+                                        (TRANS ? size_t(kWaves) * PW * (RT + 1) : 0));
+    auto kern = spmm_gather_kernel<VEC, LPR, TRANS, RT, HUB>;
+    if (lds > 48 * 1024)
+        SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);
     SR_HIP(hipGetLastError());
     return SIMRANK_OK;
+}
+
+template <int VEC, int LPR, bool TRANS, int RT>
+static int launch_spmm(SpmmArgs a, hipStream_t st) {
+    if constexpr (VEC == 4) {
+        // the hub copy may take at most 64 KiB of LDS; wider panels run without it
+        if (a.n_hub > 0 && a.n_hub * (VEC * LPR) <= 16384) {
+            a.col = a.colx;
+            return launch_spmm_impl<VEC, LPR, TRANS, RT, true>(a, st);
+        }
+    }
+    a.n_hub = 0;
+    a.tpw = 1;
+    return launch_spmm_impl<VEC, LPR, TRANS, RT, false>(a, st);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -334,6 +430,34 @@ __global__ __launch_bounds__(256) void fill_identity_kernel(float* S, int64_t n_
         const int64_t a = t / n_cols;
         const int64_t c = t - a * n_cols;
         S[a * ld + c] = (a == col0 + c) ? 1.0f : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K4/K5 stand-alone: element-wise epilogue over a block (asymmetric-prior path)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void epilogue_kernel(const float* __restrict__ Q, int64_t ldq,
+                                                       float* Y, int64_t ldy, int64_t n_rows,
+                                                       int64_t n_cols, const SpmmArgs p) {
+    const int64_t total = n_rows * n_cols;
+    unsigned changed = 0;
+    for (int64_t t = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; t < total;
+         t += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t a = t / n_cols;
+        const int64_t c = t - a * n_cols;
+        float v = Q[a * ldq + c] * p.coef;
+        if (p.ev) v *= 1.0f - __builtin_ldexpf(1.0f, -int(p.ev[a * p.ld_ev + c]));
+        if (p.ap) v = (1.0f - p.lbd) * v + p.lbd * p.ap[a * p.ld_ap + c];
+        if (p.set_diag && a == p.diag_col0 + c) v = 1.0f;
+        if (p.prev) changed += fabs(double(v) - double(p.prev[a * p.ld_prev + c])) > p.eps ? 1u : 0u;
+        Y[a * ldy + c] = v;
+    }
+    if (p.prev) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) changed += __shfl_down(changed, off);
+        if ((threadIdx.x & 63) == 0 && changed)
+            atomicAdd(p.n_changed + ((blockIdx.x * 4u + (threadIdx.x >> 6)) * 7u) % SIMRANK_CHANGED_SLOTS,
+                      (unsigned long long)changed);
     }
 }
 
@@ -405,7 +529,9 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
     SpmmArgs a{};
     a.rowptr = g->rowptr;
     a.col = g->col;
+    a.colx = g->colx;
     a.rowscale = g->rowscale;
+    a.hub_rows = g->hub_rows;
     a.X = X;
     a.ldx = ldx;
     a.L = n_cols_x;
@@ -447,6 +573,11 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
     if (panel == 0) panel = transpose_out ? 32 : 64;
     int64_t tile = tuning().tile;
     if (tile == 0) tile = 32;
+    // hub cache: worth its LDS when few rows of X carry a large share of the references
+    int64_t hub = g->n_hubs;       // fixed when the graph was created (colx encodes exactly these)
+    if (!vec_ok || tuning().hub == 0) hub = 0;
+    a.n_hub = (int32_t)hub;
+    a.tpw = (int32_t)(tuning().tpw > 0 ? tuning().tpw : 4);
     if (!vec_ok) {
         return transpose_out ? launch_spmm<1, 32, true, 32>(a, st)
                              : launch_spmm<1, 32, false, 32>(a, st);
@@ -474,6 +605,34 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
         default: SR_TILE_SWITCH(64, false)
     }
 #undef SR_TILE_SWITCH
+}
+
+int simrank_epilogue_apply(const float* Q, int64_t ldq, float* Y, int64_t ldy, int64_t n_rows,
+                           int64_t n_cols, const simrank_epilogue* ep, void* stream) {
+    SR_REQUIRE(Q && Y && ep, "NULL argument");
+    SR_REQUIRE(n_rows > 0 && n_cols > 0 && ldq >= n_cols && ldy >= n_cols, "bad block shape");
+    SpmmArgs a{};
+    a.has_ep = 1;
+    a.coef = ep->coef;
+    a.lbd = ep->lbd;
+    a.ev = ep->evidence;
+    a.ld_ev = ep->ld_evidence;
+    a.ap = ep->apriori;
+    a.ld_ap = ep->ld_apriori;
+    a.prev = ep->previous;
+    a.ld_prev = ep->ld_previous;
+    a.eps = ep->eps;
+    a.n_changed = ep->n_changed;
+    a.diag_col0 = ep->diag_col0;
+    a.set_diag = ep->set_diag;
+    SR_REQUIRE(!a.prev || a.n_changed, "previous needs a counter");
+    hipStream_t st = as_stream(stream);
+    if (a.prev)
+        SR_HIP(hipMemsetAsync(a.n_changed, 0, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS, st));
+    const int grid = (int)std::min<int64_t>((n_rows * n_cols + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(epilogue_kernel, dim3(grid), dim3(256), 0, st, Q, ldq, Y, ldy, n_rows, n_cols, a);
+    SR_HIP(hipGetLastError());
+    return SIMRANK_OK;
 }
 
 int simrank_evidence_counts(const simrank_graph* g, int64_t col0, int64_t n_cols,

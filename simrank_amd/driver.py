@@ -32,6 +32,28 @@ DENSE_THRESHOLD = 0.05   # density above which the MFMA GEMM legs beat the gathe
 # --------------------------------------------------------------------------------------
 # worlds
 # --------------------------------------------------------------------------------------
+@dataclass
+class Xfer:
+    """One rank's part of the all-to-all that transposes a column-sharded product.
+
+    The rank computed ``ncols`` columns (global offset ``col_lo``, out of ``col_dim``) for all
+    ``row_dim`` rows and stored them with simrank_spmm(transpose_out=1, t_block=mb): block h
+    of ``send`` is the (ncols x rows of rank h) transpose meant for rank h.  After the
+    exchange ``recv`` is col_dim x (rows of this rank), row-major."""
+    ops: object
+    rank: int
+    send: object
+    recv: object
+    ncols: int
+    col_lo: int
+    col_dim: int
+    row_dim: int
+    mb: int
+    nrows: int                 # rows of this rank (width of recv)
+    send_t: object = None      # torch views of send / recv (TorchWorld)
+    recv_t: object = None
+
+
 class LocalWorld:
     """P virtual ranks inside this process (P = 1 is the ordinary single-GPU case)."""
 
@@ -40,15 +62,15 @@ class LocalWorld:
         self.local_ranks = list(range(self.size))
         self.is_root = True
 
-    def exchange(self, sides):
-        """All-to-all of the transposed leg-1 tiles between the virtual ranks."""
+    def exchange(self, parts):
+        """All-to-all of the transposed tiles between the virtual ranks (device copies)."""
         if self.size == 1:
             return                               # recv aliases send
-        for src in sides:
-            for dst in sides:
-                n = src.Lk * dst.Lm              # tile (columns of src) x (rows of dst)
-                src.ops.copy_bytes(dst.recv.ptr + 4 * src.k_lo * dst.Lm,
-                                   src.send.ptr + 4 * dst.rank * src.Lk * src.mb, 4 * n)
+        for src in parts:
+            for dst in parts:
+                n = src.ncols * dst.nrows        # tile (columns of src) x (rows of dst)
+                src.ops.copy_bytes(dst.recv.ptr + 4 * src.col_lo * dst.nrows,
+                                   src.send.ptr + 4 * dst.rank * src.ncols * src.mb, 4 * n)
 
     def sum_int(self, values):
         return int(sum(values))
@@ -74,18 +96,15 @@ class TorchWorld:
         self.local_ranks = [self.rank]
         self.is_root = self.rank == 0
 
-    def exchange(self, sides):
-        (s,) = sides
-        ops = s.ops
-        ops.synchronize()                        # leg 1 finished on the engine's stream
-        in_splits = [s.Lk * (partition(s.M, self.size, h)[1] - partition(s.M, self.size, h)[0])
-                     for h in range(self.size)]
-        out_splits = [(partition(s.K, self.size, h)[1] - partition(s.K, self.size, h)[0]) * s.Lm
-                      for h in range(self.size)]
-        send = s.send_t[:sum(in_splits)]
-        recv = s.recv_t[:sum(out_splits)]
-        self.dist.all_to_all_single(recv, send, out_splits, in_splits, group=self.group)
-        ops.collective_done()
+    def exchange(self, parts):
+        (x,) = parts
+        x.ops.synchronize()                      # the producing leg finished on the engine's stream
+        span = lambda n, h: partition(n, self.size, h)[1] - partition(n, self.size, h)[0]
+        in_splits = [x.ncols * span(x.row_dim, h) for h in range(self.size)]
+        out_splits = [span(x.col_dim, h) * x.nrows for h in range(self.size)]
+        self.dist.all_to_all_single(x.recv_t[:sum(out_splits)], x.send_t[:sum(in_splits)],
+                                    out_splits, in_splits, group=self.group)
+        x.ops.collective_done()
 
     def sum_int(self, values):
         import torch
@@ -118,6 +137,7 @@ class SideSpec:
     evidence_from: CSR | None = None   # pattern whose common-neighbour counts gate the update
     apriori: np.ndarray | None = None  # M x M prior
     lbd: float = 0.0
+    symmetric: bool = True       # False: a non-symmetric prior makes the iterates asymmetric
 
 
 class Side:
@@ -130,19 +150,15 @@ class Side:
         self.Lm, self.Lk = self.m_hi - self.m_lo, self.k_hi - self.k_lo
         self.mb = -(-self.M // world)
         self.graph = ops.graph(csr, spec.rowscale)
-        self.send_t = self.recv_t = None
+        self.symmetric = spec.symmetric
+        self.x1 = self.x2 = None
         if mode == "sparse":
-            if world == 1:
-                self.tt = ops.matrix(self.K, self.M)             # Tt, pitched
-                self.send = self.recv = self.tt
-            elif torch_buffers:
-                self.send_t = ops.exchange_buffer(self.M * self.Lk)
-                self.recv_t = ops.exchange_buffer(self.K * self.Lm)
-                self.send = ops.matrix(1, self.M * self.Lk, ld=self.M * self.Lk, external=self.send_t)
-                self.recv = ops.matrix(self.K, self.Lm, ld=max(1, self.Lm), external=self.recv_t)
-            else:
-                self.send = ops.matrix(1, self.M * self.Lk, ld=max(1, self.M * self.Lk))
-                self.recv = ops.matrix(self.K, self.Lm, ld=max(1, self.Lm))
+            # exchange 1: leg-1 product (M rows x my Lk of K columns) -> K x Lm
+            self.x1 = self._xfer(self.Lk, self.k_lo, self.K, torch_buffers)
+            self.send, self.recv = self.x1.send, self.x1.recv
+            if not self.symmetric and world > 1:
+                # exchange 2: raw leg-2 product (M rows x my Lm of M columns) -> M x Lm
+                self.x2 = self._xfer(self.Lm, self.m_lo, self.M, torch_buffers)
         else:                                                    # dense / hybrid: one rank only
             assert world == 1, "dense and hybrid modes run on one rank"
             self.wd = ops.matrix(self.M, self.K)
@@ -166,7 +182,22 @@ class Side:
             self.ap = ops.matrix(self.M, self.Lm)
             ops.upload(self.ap, a[:, self.m_lo:self.m_hi].astype(np.float32))
 
-    # S_in: K x Lk block of the (symmetric) input similarity
+    def _xfer(self, ncols, col_lo, col_dim, torch_buffers) -> Xfer:
+        o = self.ops
+        x = Xfer(o, self.rank, None, None, ncols, col_lo, col_dim, self.M, self.mb, self.Lm)
+        if self.world == 1:
+            x.send = x.recv = o.matrix(col_dim, self.M)          # pitched; recv aliases send
+        elif torch_buffers:
+            x.send_t = o.exchange_buffer(self.M * ncols)
+            x.recv_t = o.exchange_buffer(col_dim * self.Lm)
+            x.send = o.matrix(1, self.M * ncols, ld=max(1, self.M * ncols), external=x.send_t)
+            x.recv = o.matrix(col_dim, self.Lm, ld=max(1, self.Lm), external=x.recv_t)
+        else:
+            x.send = o.matrix(1, self.M * ncols, ld=max(1, self.M * ncols))
+            x.recv = o.matrix(col_dim, self.Lm, ld=max(1, self.Lm))
+        return x
+
+    # S_in: K x Lk block of the input similarity
     def leg1(self, S_in):
         o = self.ops
         if self.mode == "sparse":
@@ -178,22 +209,40 @@ class Side:
         else:
             o.gemm_nt(self.wd, S_in, self.t, self.M, self.K, self.K)  # T = Wd.S^T, S symmetric
 
+    def _ep(self, S_prev, eps):
+        return dict(coef=self.spec.coef, evidence=self.ev, apriori=self.ap, lbd=self.spec.lbd,
+                    previous=S_prev, eps=eps, diag_col0=self.m_lo, set_diag=True)
+
     def leg2(self, S_prev, S_out, eps):
+        """Symmetric iterates: S_out = W . Tt with the fused epilogue.
+        Otherwise only the raw product, stored transposed (what W . Tt yields is the
+        TRANSPOSE of the wanted block); ``finish`` applies the epilogue after exchange 2."""
         o = self.ops
         if not self.Lm:
-            return 0
-        ep = dict(coef=self.spec.coef, evidence=self.ev, apriori=self.ap, lbd=self.spec.lbd,
-                  previous=S_prev, eps=eps, diag_col0=self.m_lo, set_diag=True)
-        if self.mode == "sparse":
-            o.spmm(self.graph, self.recv, S_out, n_cols=self.Lm, epilogue=ep)
+            return
+        if self.mode != "sparse":
+            o.gemm_nt(self.t, self.wd, S_out, self.M, self.M, self.K, epilogue=self._ep(S_prev, eps))
+        elif self.symmetric:
+            o.spmm(self.graph, self.recv, S_out, n_cols=self.Lm, epilogue=self._ep(S_prev, eps))
+        elif self.world == 1:
+            o.spmm(self.graph, self.recv, S_out, n_cols=self.Lm, transpose_out=True)
         else:
-            o.gemm_nt(self.t, self.wd, S_out, self.M, self.M, self.K, epilogue=ep)
-        return None                                                   # counter read later
+            o.spmm(self.graph, self.recv, self.x2.send, n_cols=self.Lm, transpose_out=True,
+                   t_block=self.mb)
+
+    def finish(self, S_prev, S_out, eps):
+        """Second half of an update with asymmetric iterates: the stand-alone epilogue."""
+        if self.symmetric or not self.Lm:
+            return
+        raw = S_out if self.world == 1 else self.x2.recv
+        self.ops.epilogue_apply(raw, S_out, self.M, self.Lm, self._ep(S_prev, eps))
 
 
-def choose_mode(mode: str, csrs, world: int) -> str:
+def choose_mode(mode: str, csrs, world: int, symmetric: bool = True) -> str:
     if mode not in ("auto", "sparse", "dense", "hybrid"):
         raise ValueError(f"mode must be auto, sparse, dense or hybrid, not {mode!r}")
+    if not symmetric:
+        return "sparse"       # the NT GEMM legs rely on S == S^T; the gather legs do not
     if mode == "auto":
         dense = world == 1 and all(c.density > DENSE_THRESHOLD for c in csrs)
         return "dense" if dense else "sparse"
@@ -217,7 +266,8 @@ class Solver:
         self.world = world
         self.specs = specs
         self.bipartite = len(specs) == 2
-        self.mode = choose_mode(mode, [s.csr for s in specs], world.size)
+        self.mode = choose_mode(mode, [s.csr for s in specs], world.size,
+                                all(s.symmetric for s in specs))
         torch_buffers = isinstance(world, TorchWorld)
         self.ops = {r: make_ops(r) for r in world.local_ranks}
         self.sides = [{r: Side(self.ops[r], sp, r, world.size, self.mode, torch_buffers)
@@ -266,13 +316,22 @@ class Solver:
         sides = self.sides[side_idx]
         for r in self.world.local_ranks:
             self._timed(r, lambda: sides[r].leg1(self.cur[in_idx][r]), f"leg1.{side_idx}")
+        local = self.world.local_ranks
         if self.mode == "sparse":
-            self.world.exchange([sides[r] for r in self.world.local_ranks])
+            self.world.exchange([sides[r].x1 for r in local])
+        fused = sides[local[0]].symmetric
         counts = []
-        for r in self.world.local_ranks:
+        for r in local:
             self._timed(r, lambda: sides[r].leg2(self.cur[out_idx][r], self.nxt[out_idx][r], eps),
                         f"leg2.{side_idx}")
-            counts.append(self.ops[r].read_changed() if sides[r].Lm else 0)
+            if fused:       # virtual ranks may share one device counter: read it per launch
+                counts.append(self.ops[r].read_changed() if sides[r].Lm else 0)
+        if not fused:
+            if self.world.size > 1:
+                self.world.exchange([sides[r].x2 for r in local])
+            for r in local:
+                sides[r].finish(self.cur[out_idx][r], self.nxt[out_idx][r], eps)
+                counts.append(self.ops[r].read_changed() if sides[r].Lm else 0)
         for r in self.world.local_ranks:
             self.cur[out_idx][r], self.nxt[out_idx][r] = self.nxt[out_idx][r], self.cur[out_idx][r]
         return self.world.sum_int(counts)
@@ -315,11 +374,15 @@ class Solver:
                     m.free()
         for sides in self.sides:
             for s in sides.values():
-                for name in ("tt", "send", "recv", "wd", "t", "ap"):
+                for name in ("wd", "t", "ap"):
                     m = getattr(s, name, None)
                     if m is not None:
                         m.free()
-                s.send_t = s.recv_t = None
+                for x in (s.x1, s.x2):
+                    if x is not None:
+                        x.send.free()
+                        x.recv.free()
+                        x.send_t = x.recv_t = None
 
     def leg_times(self):
         """Mean milliseconds per tag from the recorded events."""

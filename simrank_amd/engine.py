@@ -209,6 +209,12 @@ class HipOps:
                                     C.byref(ep) if ep is not None else None, self.stream),
               "simrank_spmm")
 
+    def epilogue_apply(self, Q: Matrix, Y: Matrix, n_rows: int, n_cols: int, epilogue: dict):
+        """Y = epilogue(Q) element-wise; see simrank_epilogue_apply."""
+        ep = self._epilogue(**epilogue)
+        check(self.lib.simrank_epilogue_apply(Q.ptr, Q.ld, Y.ptr, Y.ld, n_rows, n_cols,
+                                              C.byref(ep), self.stream), "simrank_epilogue_apply")
+
     def gemm_nt(self, A: Matrix, B: Matrix, Cm: Matrix, M: int, N: int, K: int,
                 epilogue: dict | None = None):
         ep = self._epilogue(**epilogue) if epilogue is not None else None

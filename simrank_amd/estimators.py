@@ -71,6 +71,15 @@ class _Lazy:
         obj.__dict__[self.name] = value
 
 
+def _is_symmetric(prior) -> bool:
+    """The fused two-gather update needs symmetric iterates; everything the reference builds
+    is symmetric except what a user-supplied prior (SimRank.py:453) brings in."""
+    if prior is None:
+        return True
+    a = np.asarray(prior)
+    return a.ndim == 2 and a.shape[0] == a.shape[1] and bool(np.array_equal(a, a.T))
+
+
 def _evidence_from_counts(side):
     """1 - 0.5**count as float64 (SimRank.py:316); counts saturate at 255 on the device,
     and 0.5**54 already rounds 1 - x to 1.0, so saturation is exact."""
@@ -142,7 +151,7 @@ class SimRankPP(SimRank):
     def _pp_side(self, csr, C, verbose, apriori=None, lbd=0.0, evidence_from=None):
         scale = self._cal_Weight(csr, verbose)
         return SideSpec(csr, scale, C, evidence_from=evidence_from or csr, apriori=apriori,
-                        lbd=lbd)
+                        lbd=lbd, symmetric=_is_symmetric(apriori))
 
     def _fit_pp(self, data, C, weighted, from_node_column, to_node_column, weight_column,
                 iterations, eps, verbose, mode, device, world, ops_factory, apriori=None,
@@ -270,8 +279,12 @@ class BipartiteSimRankPP(SimRankPP):
         self.Weight_N2 = lambda: g21.dense(w2)
         # quirk Q2 (:423, :491): the group-2 update is gated by Evidence_N1
         ev2 = g12 if strict_reference else g21
-        specs = [SideSpec(g12, w1, C1, evidence_from=g12, apriori=priors[0], lbd=lbds[0]),
-                 SideSpec(g21, w2, C2, evidence_from=ev2, apriori=priors[1], lbd=lbds[1])]
+        # a non-symmetric prior on either side makes BOTH iterates non-symmetric
+        sym = _is_symmetric(priors[0]) and _is_symmetric(priors[1])
+        specs = [SideSpec(g12, w1, C1, evidence_from=g12, apriori=priors[0], lbd=lbds[0],
+                          symmetric=sym),
+                 SideSpec(g21, w2, C2, evidence_from=ev2, apriori=priors[1], lbd=lbds[1],
+                          symmetric=sym)]
         if talk:
             print("Initializing Evidence matrix...")
         start = time.time()

@@ -144,6 +144,11 @@ class NumpyOps:
                                  > ep["eps"]).sum())
         return v
 
+    def epilogue_apply(self, Q, Y, n_rows, n_cols, epilogue):
+        self.calls.append(("epilogue_apply",))
+        v = Q.a[:n_rows, :n_cols] * np.float32(epilogue["coef"])
+        Y.a[:n_rows, :n_cols] = self._epilogue(v, epilogue, n_rows, n_cols)
+
     def gemm_nt(self, A, B, Cm, M, N, K, epilogue=None):
         self.calls.append(("gemm_nt", bool(epilogue)))
         v = A.a[:M, :K] @ B.a[:N, :K].T

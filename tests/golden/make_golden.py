@@ -128,6 +128,10 @@ def cases():
     pr64 = rng.random((len(set(er64["from"]) | set(er64["to"])),) * 2)
     pr64 = (pr64 + pr64.T) / 2
     add("AprioriSimRank_er64", "AprioriSimRank", er64, (pr64,), lbd=0.3)
+    # a prior that is NOT symmetric: the iterates stop being symmetric (SimRank.py:453)
+    add("AprioriSimRank_er64_asym", "AprioriSimRank", er64, (rng.random(pr64.shape),), lbd=0.4)
+    add("AprioriSimRank_quirky_asym", "AprioriSimRank", qk, (rng.random((12, 12)),), lbd=0.25,
+        iterations=7)
 
     k10 = complete_bipartite(K10_USERS, K10_MOVIES)
     b40 = bipartite_random(40, 40, 0.15, seed=40)
@@ -149,6 +153,8 @@ def cases():
     p2 = rng.random((40, 40)); p2 = (p2 + p2.T) / 2
     add("BipartitleAprioriSimRank_b40", "BipartitleAprioriSimRank", b40, (p1, p2),
         lbd1=0.4, lbd2=0.2)
+    add("BipartitleAprioriSimRank_b40_asym", "BipartitleAprioriSimRank", b40,
+        (rng.random((40, 40)), p2), lbd1=0.3, lbd2=0.3)
     return out
 
 

@@ -13,7 +13,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = ["SimRank_er64", "SimRankPP_er64_weighted", "AprioriSimRank_er64",
-         "BipartiteSimRank_b5030", "BipartiteSimRankPP_b40", "SimRank_toy5"]
+         "BipartiteSimRank_b5030", "BipartiteSimRankPP_b40", "SimRank_toy5",
+         "AprioriSimRank_er64_asym", "BipartitleAprioriSimRank_b40_asym"]
 
 
 def _free_port():

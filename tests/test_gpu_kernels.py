@@ -219,3 +219,46 @@ def test_download_f64_matches_plain_download(ops):
     h = rng.random((700, 333)).astype(np.float32)
     m = put(ops, h)
     np.testing.assert_array_equal(ops.download_f64(m), h.astype(np.float64))
+
+
+def test_epilogue_apply_standalone(ops):
+    """The un-fused epilogue (asymmetric-prior path), in place and out of place."""
+    M, L, c0 = 150, 77, 20
+    rng = np.random.default_rng(6)
+    Q = rng.random((M, L)).astype(np.float32)
+    cnt = rng.integers(0, 4, size=(M, L)).astype(np.uint8)
+    prior = rng.random((M, L)).astype(np.float32)
+    prev = rng.random((M, L)).astype(np.float32)
+    ep = dict(coef=0.8, evidence=put(ops, cnt, dtype=np.uint8), apriori=put(ops, prior), lbd=0.4,
+              previous=put(ops, prev), eps=0.2, diag_col0=c0)
+    want = 0.8 * Q.astype(np.float64) * (1 - 0.5 ** cnt.astype(np.float64))
+    want = (1 - np.float32(0.4)) * want + np.float32(0.4) * prior.astype(np.float64)
+    for c in range(L):
+        want[c0 + c, c] = 1.0
+    q = put(ops, Q)
+    y = ops.matrix(M, L)
+    ops.epilogue_apply(q, y, M, L, ep)
+    got = ops.download(y)
+    np.testing.assert_allclose(got, want, rtol=RTOL)
+    assert ops.read_changed() == int((np.abs(got.astype(np.float64) - prev) > 0.2).sum())
+    ops.epilogue_apply(q, q, M, L, ep)
+    np.testing.assert_array_equal(ops.download(q), got)
+
+
+def test_hub_cache_is_bit_identical(ops):
+    """Serving the most referenced rows from LDS must not change a single bit."""
+    M, K, L = 700, 500, 200
+    csr = random_csr(M, K, 14, seed=77, heavy={5: 400, 9: 100})
+    X = np.random.default_rng(3).random((K, L)).astype(np.float32)
+    outs = []
+    for hub in (0, 64, 256):
+        ops.set_tuning(hub=hub)
+        g = ops.graph(csr)
+        x, y, yt = put(ops, X), ops.matrix(M, L), ops.matrix(L, M)
+        ops.spmm(g, x, y)
+        ops.spmm(g, x, yt, transpose_out=True)
+        outs.append((ops.download(y), ops.download(yt)))
+    ops.set_tuning(hub=-1)
+    for y, yt in outs[1:]:
+        assert np.array_equal(y, outs[0][0]) and np.array_equal(yt, outs[0][1])
+    np.testing.assert_allclose(outs[0][0], outs[0][1].T, rtol=RTOL, atol=1e-30)

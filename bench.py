@@ -57,12 +57,13 @@ def cpu_baseline(csr, S_host, coef, budget_s=20.0):
         threads = os.cpu_count()
     n = csr.n_rows
     G = csr.dense()                                        # what the reference keeps as `Graph`
-    probe = slice(0, 32)
+    probe = slice(0, 128)
+    O.update_rows(G, S_host, coef, slice(0, 8))            # warm the BLAS threads
     t0 = time.perf_counter()
     O.update_rows(G, S_host, coef, probe)
     t_probe = time.perf_counter() - t0
-    rows = int(min(n, max(64, 32 * budget_s / max(t_probe, 1e-3))))
-    rows = min(rows, 4096)
+    rows = int(min(n, max(128, 128 * budget_s / max(t_probe, 1e-3))))
+    rows = min(rows, 8192)
     slab = slice(0, rows)
     t0 = time.perf_counter()
     new = O.update_rows(G, S_host, coef, slab)
@@ -90,6 +91,8 @@ def main():
     ap.add_argument("--panel", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="use the torch.distributed world even with one rank (exercises RCCL)")
     args = ap.parse_args()
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,9 +111,13 @@ def main():
     from simrank_amd.engine import HipOps
 
     torch.cuda.set_device(local_rank)
-    if world_size > 1:
+    use_dist = world_size > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size,
+                                device_id=torch.device("cuda", local_rank))
         world = TorchWorld()
     else:
         world = LocalWorld(1)
@@ -130,7 +137,7 @@ def main():
     def barrier():
         ops.synchronize()
         torch.cuda.synchronize()
-        if world_size > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -142,14 +149,14 @@ def main():
         solver.step(0.0)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world_size > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     legs = solver.leg_times()                 # mean ms per launch, measured by HIP events
     solver.events = None
-    side = solver.sides[0][rank if world_size > 1 else 0]
+    side = solver.sides[0][rank if use_dist else 0]
     out = {
         "metric": "simrank_iterations_per_sec", "value": args.steps / elapsed,
         "unit": "iterations/s", "n_gpus": world_size, "steps": args.steps,
@@ -219,7 +226,7 @@ def main():
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))
-    if world_size > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

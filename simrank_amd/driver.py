@@ -185,15 +185,15 @@ class Side:
     def _xfer(self, ncols, col_lo, col_dim, torch_buffers) -> Xfer:
         o = self.ops
         x = Xfer(o, self.rank, None, None, ncols, col_lo, col_dim, self.M, self.mb, self.Lm)
-        if self.world == 1:
+        if self.world == 1 and not torch_buffers:
             x.send = x.recv = o.matrix(col_dim, self.M)          # pitched; recv aliases send
-        elif torch_buffers:
+        elif torch_buffers:                                      # chunks of M_h-float rows
             x.send_t = o.exchange_buffer(self.M * ncols)
             x.recv_t = o.exchange_buffer(col_dim * self.Lm)
-            x.send = o.matrix(1, self.M * ncols, ld=max(1, self.M * ncols), external=x.send_t)
+            x.send = o.matrix(max(1, ncols), self.M, ld=self.M, external=x.send_t)
             x.recv = o.matrix(col_dim, self.Lm, ld=max(1, self.Lm), external=x.recv_t)
         else:
-            x.send = o.matrix(1, self.M * ncols, ld=max(1, self.M * ncols))
+            x.send = o.matrix(max(1, ncols), self.M, ld=self.M)
             x.recv = o.matrix(col_dim, self.Lm, ld=max(1, self.Lm))
         return x
 
@@ -203,7 +203,7 @@ class Side:
         if self.mode == "sparse":
             if self.Lk:
                 o.spmm(self.graph, S_in, self.send, n_cols=self.Lk, transpose_out=True,
-                       t_block=self.mb if self.world > 1 else 0)
+                       t_block=self.mb)
         elif self.mode == "hybrid":
             o.spmm(self.graph, S_in, self.t)                          # T = W.S, plain store
         else:

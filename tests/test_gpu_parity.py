@@ -200,3 +200,42 @@ def test_config3_movielens_shaped_bipartite_pp(ops):
         want[a] = 1.0
         np.testing.assert_allclose(s1.values[a], want, rtol=RTOL, atol=1e-30)
     assert est.engine_mode in ("sparse", "dense")
+
+
+def test_integration_stub_of_the_reference_binding():
+    """examples/reference_hip_stub.py: ctypes-only binding fed with the
+    reference's dense Graph; must reproduce the reference's S and convergence iteration."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                        "examples", "reference_hip_stub.py")
+    spec = importlib.util.spec_from_file_location("reference_hip_stub", path)
+    stub = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(stub)
+    for name in ("SimRank_toy5", "SimRank_er128", "SimRank_quirky_weighted"):
+        g = Golden(name)
+        S, k = stub.iterate(g.out["G"], g.kwargs.get("C", 0.8), g.kwargs.get("iterations", 100),
+                            g.kwargs.get("eps", 1e-4))
+        assert_close(S, g.out["S"])
+        assert k == g.k
+
+
+def test_rccl_world_of_one_rank():
+    """bench.py --force-dist under torch.distributed.run with one rank: the TorchWorld path
+    (RCCL init, torch-owned exchange buffers handed to the C ABI, all_to_all_single,
+    all_reduce, stream hand-over) on the single GPU that is available; its result must be the
+    same iterations/s order as the local world and the run must exit cleanly."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", "29571", os.path.join(root, "bench.py"),
+           "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "er8192", "--force-dist",
+           "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 100 and out["converge"]["iterations"] == 5

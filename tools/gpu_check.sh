@@ -14,7 +14,7 @@ timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -8 | 
 echo "== bench er8192 =="
 timeout 900 python bench.py --workload er8192 --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -3 | tee gpurun_out/bench_er8192.log
 echo "== bench pl32768 =="
-timeout 1200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -3 | tee gpurun_out/bench_pl32768.log
+timeout 1200 python bench.py 2>&1 | tail -3 | tee gpurun_out/bench_pl32768.log
 if [ "$MODE" = "full" ]; then
   echo "== parity tests =="
   timeout 3000 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -25 | tee gpurun_out/parity.log

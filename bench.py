@@ -181,6 +181,9 @@ def main():
                        "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                        "ms": ms, "algorithmic_bytes": b,
                        "gathered_bytes": 4 * nnz * (side.Lk if "leg 1" in name else side.Lm)})
+        if world_size == 1:
+            rl[1]["note"] = ("single rank: leg 2 computes the tiles on/above the diagonal and stores "
+                             "their mirror image (S' is symmetric); bytes are those of the full matrix")
         rl.sort(key=lambda r: -r["ms"])
         out["roofline"], out["roofline_other"] = rl[0], rl[1]
     else:

@@ -121,7 +121,11 @@ typedef struct simrank_epilogue {
                                         workgroups do not serialise on one address)       */
     int64_t diag_col0;               /* global column index of local column 0             */
     int32_t set_diag;                /* 1: element (a, a - diag_col0) <- 1                */
-    int32_t reserved;
+    int32_t symmetric;               /* 1: the block is the whole n x n result and evidence,
+                                        prior and previous iterate are exactly symmetric: the
+                                        kernel may compute the upper triangle only and store
+                                        its mirror image (off-diagonal tiles come out exactly
+                                        symmetric; n_changed counts mirrored elements twice) */
 } simrank_epilogue;
 
 /* ---- K2 (+K3 sparse form, K4, K5): Y = diag(rowscale).A.X with optional transposed
@@ -164,8 +168,14 @@ SIMRANK_API int simrank_gemm_nt(int64_t M, int64_t N, int64_t K, const float* A,
                     const float* B, int64_t ldb, float* C, int64_t ldc,
                     const simrank_epilogue* epilogue, void* stream);
 
-/* ---- tuning knobs (measurement harness): "panel" = columns per gather panel
- *      (16, 32, 64, 128, 256; 0 = automatic), "xcd_map" = 0/1 ---------------------- */
+/* ---- tuning knobs (measurement harness; defaults are the tuned values):
+ *      "panel"    columns per gather panel (16, 32, 64, 128, 256; 0 = automatic)
+ *      "tile"     rows per wave tile (16, 32, 64; 0 = automatic)
+ *      "xcd_map"  0/1  panel -> XCD affinity
+ *      "triangle" 0/1  allow the upper-triangle + mirror form when epilogue.symmetric
+ *      "stream_nt" 0/1 non-temporal access for streamed-once data
+ *      "hub", "tpw"    LDS hub-cache experiment: rows cached per workgroup (read when a
+ *                      graph is created; -1/0 = off) and row tiles a wave walks ----------- */
 SIMRANK_API int simrank_set_tuning(const char* key, int64_t value);
 SIMRANK_API int simrank_get_tuning(const char* key, int64_t* value);
 

@@ -32,7 +32,7 @@ class Epilogue(C.Structure):
         ("n_changed", C.c_void_p),
         ("diag_col0", C.c_int64),
         ("set_diag", C.c_int32),
-        ("reserved", C.c_int32),
+        ("symmetric", C.c_int32),
     ]
 
 

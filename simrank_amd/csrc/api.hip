@@ -327,12 +327,13 @@ int simrank_set_tuning(const char* key, int64_t value) {
     } else if (!strcmp(key, "hub")) {
         SR_REQUIRE(value >= -1 && value <= kHubMax, "hub must be -1 (auto) .. %d", kHubMax);
         t.hub = value;
+    } else if (!strcmp(key, "triangle")) {
+        t.triangle = value ? 1 : 0;
     } else if (!strcmp(key, "tpw")) {
         SR_REQUIRE(value >= 0 && value <= 64, "tpw must be 0 (auto) .. 64");
         t.tpw = value;
-    } else if (!strcmp(key, "unroll")) {
-        SR_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, "unroll must be 1,2,4,8");
-        t.unroll = value;
+    } else if (!strcmp(key, "stream_nt")) {
+        t.stream_nt = value ? 1 : 0;
     } else {
         SR_REQUIRE(false, "unknown tuning key '%s'", key);
     }
@@ -344,10 +345,11 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     const Tuning& t = tuning();
     if (!strcmp(key, "panel")) *value = t.panel;
     else if (!strcmp(key, "xcd_map")) *value = t.xcd_map;
-    else if (!strcmp(key, "unroll")) *value = t.unroll;
+    else if (!strcmp(key, "stream_nt")) *value = t.stream_nt;
     else if (!strcmp(key, "tile")) *value = t.tile;
     else if (!strcmp(key, "hub")) *value = t.hub;
     else if (!strcmp(key, "tpw")) *value = t.tpw;
+    else if (!strcmp(key, "triangle")) *value = t.triangle;
     else SR_REQUIRE(false, "unknown tuning key '%s'", key);
     return SIMRANK_OK;
 }

@@ -33,10 +33,11 @@ void set_error(const char* fmt, ...);
 struct Tuning {
     int64_t panel = 0;    // 0 = automatic
     int64_t xcd_map = 1;  // panel -> XCD affinity (blockIdx % 8 shares an L2)
-    int64_t unroll = 4;
+    int64_t stream_nt = 1; // non-temporal loads/stores for streamed-once data
     int64_t tile = 0;     // rows per wave tile (16, 32, 64; 0 = automatic)
     int64_t hub = -1;     // hub rows cached in LDS per workgroup (-1 = automatic, 0 = off)
     int64_t tpw = 0;      // row tiles a wave walks per workgroup (0 = automatic)
+    int64_t triangle = 1; // allow the upper-triangle + mirror form of a symmetric leg 2
 };
 Tuning& tuning();
 

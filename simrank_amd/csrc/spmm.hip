@@ -1,23 +1,28 @@
-// Sparse legs of the SimRank update for gfx950 (MI355X), plus identity init and the
-// SimRank++ evidence counts.
+// Sparse legs of the SimRank update for gfx950 (MI355X), plus identity init, the stand-alone
+// epilogue and the SimRank++ evidence counts.
 //
 //   Y = diag(rowscale) . A . X          A = 0/1 CSR pattern, X dense row-major
 //
-// Row-gather form: output row a is rowscale[a] times the sum of the rows of X listed in
-// CSR row a.  The kernel is HBM/L2-bandwidth work, not arithmetic:
-//   * a launch is tiled into column PANELS of PW = VEC*LPR floats; inside a panel one
-//     64-lane wave owns RT consecutive output rows.  LPR lanes cover one neighbour row
-//     segment (16 B per lane when VEC = 4), so a wave gathers G = 64/LPR different
-//     neighbour rows per load instruction and keeps UNROLL of those in flight;
-//   * the G partial sums are combined with cross-lane shuffles in a fixed order (the
-//     result is bitwise reproducible; no float atomics anywhere);
-//   * all workgroups whose blockIdx is congruent mod 8 share an XCD and therefore an L2:
-//     panel p is given to the blocks with blockIdx % 8 == p % 8, in row-tile order, so
-//     the N x PW slice of X a panel re-reads (deg times on average) stays in that L2;
-//   * leg 1 stores its tile TRANSPOSED (through a per-wave LDS tile, RT consecutive
-//     floats per output row segment) so that leg 2 is the same row gather;
+// Row-gather form: output row a is rowscale[a] times the sum of the rows of X listed in CSR
+// row a.  This is bandwidth work, not arithmetic:
+//   * a launch is tiled into column PANELS of PW = VEC*LPR floats; inside a panel one 64-lane
+//     wave owns a tile of RT consecutive output rows.  LPR lanes cover one neighbour-row
+//     segment (16 B per lane), so one load instruction gathers G = 64/LPR different rows;
+//   * the wave sorts its tile's rows by length (bitonic network in registers).  Long rows
+//     (>= kHeavy entries) are gathered one at a time, the G lane groups splitting the
+//     neighbours, partial sums combined by shuffles in a fixed order.  All other rows go G at
+//     a time, ONE ROW PER LANE GROUP: no cross-lane reduction, G independent gather streams,
+//     8 loads in flight in each, neighbour ids requested one chunk ahead;
+//   * results are bitwise reproducible: fixed summation order, integer atomics only;
+//   * blocks equal mod 8 share an XCD and its L2 (observed dispatch order; speed only):
+//     panel p is processed by the blocks with blockIdx % 8 == p % 8, in row-tile order, so
+//     the K x PW slice of X that a panel re-reads deg times stays hot in that L2;
+//   * leg 1 stores its tile TRANSPOSED through a per-wave LDS tile (RT-float row segments,
+//     optionally in per-destination blocks for the all-to-all), so leg 2 is the same gather;
 //   * leg 2 fuses the whole reference epilogue: coef, evidence 1-2^-count, prior blend,
-//     diag <- 1, and the |new-old| > eps count of `_converged` (SimRank.py:74,139-140).
+//     diag <- 1 and the |new-old| > eps count of `_converged` (SimRank.py:74,139-140); on a
+//     single rank it computes only the tiles on/above the diagonal of the symmetric result
+//     and stores their mirror image (kSym).
 #include <algorithm>
 
 #include "common.h"
@@ -33,6 +38,7 @@ struct SpmmArgs {
     const int32_t* hub_rows;  // slot -> row of X
     int32_t n_hub;            // ranks cached in LDS by each workgroup
     int32_t tpw;              // row tiles a wave walks
+    int32_t nt;               // non-temporal output stores
     const float* rowscale;
     const float* X;
     int64_t ldx;
@@ -80,15 +86,54 @@ __device__ __forceinline__ void vstore(float* p, const float (&d)[VEC]) {
     }
 }
 
+// Streamed-once traffic (previous iterate, prior, evidence, the output rows) is loaded /
+// stored non-temporally so it does not push the panel of X out of the XCD's L2.
+template <int VEC>
+__device__ __forceinline__ void vload_nt(float (&d)[VEC], const float* p) {
+    if constexpr (VEC == 4) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+        d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+    } else {
+        d[0] = __builtin_nontemporal_load(p);
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void vstore_nt(float* p, const float (&d)[VEC]) {
+    if constexpr (VEC == 4) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 t;
+        t.x = d[0]; t.y = d[1]; t.z = d[2]; t.w = d[3];
+        __builtin_nontemporal_store(t, reinterpret_cast<f4*>(p));
+    } else {
+        __builtin_nontemporal_store(d[0], p);
+    }
+}
+
+// neighbour ids are streamed once per panel pass; keep them from displacing X in L2
+__device__ __forceinline__ int ldidx(const SpmmArgs& p, int j) {
+    return p.nt ? __builtin_nontemporal_load(p.col + j) : p.col[j];
+}
+
 constexpr int kWaves = 4;   // waves per workgroup
 constexpr int kHeavy = 64;
 constexpr int kSkip = INT32_MIN;  // "no neighbour in this slot"  // rows with at least this many entries are gathered cooperatively
 
 // One output row segment (VEC floats per lane, LPR lanes) -> epilogue -> memory / LDS tile.
-template <int VEC, int LPR, bool TRANS, int RT>
+// MODE: how a tile leaves the wave.
+//   kPlain  Y[a][c]                       (+ fused epilogue)
+//   kTrans  Y^T, through the wave's LDS tile (leg 1)
+//   kSym    kPlain for the tiles on or above the diagonal of a symmetric result, which are
+//           ALSO stored mirrored (through the LDS tile); tiles below the diagonal are
+//           never computed.  Halves the gathers of leg 2 on a single rank.
+constexpr int kPlain = 0, kTrans = 1, kSym = 2;
+
+template <int VEC, int LPR, int MODE, int RT>
 __device__ __forceinline__ void emit_row(const SpmmArgs& p, float* tbuf_wave, int r_local,
                                          int64_t a, int q, int64_t mycol, const float (&acc)[VEC],
-                                         unsigned& changed) {
+                                         unsigned& changed, bool mirror) {
+    constexpr bool TRANS = MODE == kTrans;
     const float sc = p.rowscale[a] * (p.has_ep ? p.coef : 1.0f);
     float o[VEC];
 #pragma unroll
@@ -104,7 +149,7 @@ __device__ __forceinline__ void emit_row(const SpmmArgs& p, float* tbuf_wave, in
                 const uint8_t* ep = p.ev + a * p.ld_ev + mycol;
                 unsigned cnt[VEC];
                 if constexpr (VEC == 4) {
-                    const unsigned w = *reinterpret_cast<const unsigned*>(ep);
+                    const unsigned w = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(ep));
                     cnt[0] = w & 255u; cnt[1] = (w >> 8) & 255u;
                     cnt[2] = (w >> 16) & 255u; cnt[3] = w >> 24;
                 } else {
@@ -115,7 +160,7 @@ __device__ __forceinline__ void emit_row(const SpmmArgs& p, float* tbuf_wave, in
             }
             if (p.ap) {
                 float pr[VEC];
-                vload<VEC>(pr, p.ap + a * p.ld_ap + mycol);
+                vload_nt<VEC>(pr, p.ap + a * p.ld_ap + mycol);
                 const float keep = 1.0f - p.lbd;
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) o[i] = keep * o[i] + p.lbd * pr[i];
@@ -128,15 +173,23 @@ __device__ __forceinline__ void emit_row(const SpmmArgs& p, float* tbuf_wave, in
             }
             if (p.prev) {
                 float old[VEC];
-                vload<VEC>(old, p.prev + a * p.ld_prev + mycol);
+                vload_nt<VEC>(old, p.prev + a * p.ld_prev + mycol);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i)
-                    changed += (i < nvalid && fabs(double(o[i]) - double(old[i])) > p.eps) ? 1u : 0u;
+                    changed += (i < nvalid && fabs(double(o[i]) - double(old[i])) > p.eps)
+                                   ? (mirror ? 2u : 1u) : 0u;
+            }
+        }
+        if constexpr (MODE == kSym) {
+            if (mirror) {
+                float* t = tbuf_wave + (q * VEC) * (RT + 1) + r_local;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) t[i * (RT + 1)] = o[i];
             }
         }
         float* y = p.Y + a * p.ldy + mycol;
         if (nvalid == VEC) {
-            vstore<VEC>(y, o);
+            if (p.nt) vstore_nt<VEC>(y, o); else vstore<VEC>(y, o);
         } else {
 #pragma unroll
             for (int i = 0; i < VEC; ++i)
@@ -149,9 +202,12 @@ __device__ __forceinline__ void emit_row(const SpmmArgs& p, float* tbuf_wave, in
 // copy of a hub row's panel segment.  A batch issues all its global loads, then all its LDS
 // reads, then adds in neighbour order: the hub cache changes where bytes come from, never
 // the arithmetic or its order.
-template <int VEC, int LPR, bool TRANS, int RT, bool HUB>
+template <int VEC, int LPR, int MODE, int RT, bool HUB>
 __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
     static_assert(RT <= 64, "one lane per tile row");
+    static_assert(MODE != kSym || VEC * LPR == RT, "mirrored tiles are square");
+    constexpr bool TRANS = MODE == kTrans;
+    constexpr bool TILE = MODE != kPlain;    // the wave owns an LDS tile
     constexpr int PW = VEC * LPR;            // panel width in floats
     constexpr int G = 64 / LPR;              // lane groups = rows (or neighbours) in flight
     constexpr int JU = LPR < 8 ? LPR : 8;    // gathers a group keeps in flight
@@ -185,7 +241,7 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
     const bool col_active = mycol < p.L;  // VEC=4: mycol+3 < ldx because ldx % 4 == 0
     const float* __restrict__ Xc = p.X + mycol;
     const float* hub = smem;
-    float* tbuf_wave = smem + (HUB ? p.n_hub * PW : 0) + (TRANS ? wave * PW * (RT + 1) : 0);
+    float* tbuf_wave = smem + (HUB ? p.n_hub * PW : 0) + (TILE ? wave * PW * (RT + 1) : 0);
     unsigned changed = 0;
 
     if constexpr (HUB) {
@@ -203,7 +259,12 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
     const int n_tw = HUB ? p.tpw : 1;
     for (int tw = 0; tw < n_tw; ++tw) {
     const int64_t row0 = ((int64_t(rt) * n_tw + tw) * kWaves + wave) * RT;
-    const int nrows = int(imin(RT, p.M - row0));  // rows of this wave's tile (may be <= 0)
+    int nrows = int(imin(RT, p.M - row0));  // rows of this wave's tile (may be <= 0)
+    bool mirror = false;
+    if constexpr (MODE == kSym) {
+        if (row0 > c0) nrows = 0;   // below the diagonal: some other tile's mirror image
+        mirror = row0 < c0;         // strictly above: store the mirror image too
+    }
 
     // ---- rows of the tile sorted by length, longest first (bitonic over the 64 lanes).
     // key = length * 64 + tile row; lanes without a row get a negative key and sort last.
@@ -239,7 +300,7 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
         for (int base = s; base < e; base += 64) {
             const int n = min(64, e - base);
-            const int myidx = lane < n ? p.col[base + lane] : 0;
+            const int myidx = lane < n ? ldidx(p, base + lane) : 0;
             for (int k0 = 0; k0 < n; k0 += G * UNROLL) {
                 float v[UNROLL][VEC];
                 int idx[UNROLL];
@@ -275,7 +336,7 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off);
         if (g == 0 && col_active)
-            emit_row<VEC, LPR, TRANS, RT>(p, tbuf_wave, r, row0 + r, q, mycol, acc, changed);
+            emit_row<VEC, LPR, MODE, RT>(p, tbuf_wave, r, row0 + r, q, mycol, acc, changed, mirror);
     }
 
     // ---- phase B: the other rows, G at a time, one row per lane group: no cross-lane
@@ -291,7 +352,7 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
         int len = __shfl(s_len, src & 63);
         if (src >= nrows) len = 0;
         int maxlen = __builtin_amdgcn_readfirstlane(__shfl(s_len, pos));  // sorted: longest of the pass
-        int iv = (q < len) ? p.col[st + q] : 0;
+        int iv = (q < len) ? ldidx(p, st + q) : 0;
         float acc[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
@@ -310,7 +371,7 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
                 if (nsrc >= nrows) nlen = 0;
                 nmax = __builtin_amdgcn_readfirstlane(__shfl(s_len, npos & 63));
             }
-            if (more && nt0 + q < nlen) niv = p.col[nst + nt0 + q];
+            if (more && nt0 + q < nlen) niv = ldidx(p, nst + nt0 + q);
 
             // the current chunk: up to LPR neighbours of each of the G rows
 #pragma unroll
@@ -346,7 +407,7 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
             }
             if (!same_pass) {
                 if (pos + g < nrows && col_active)
-                    emit_row<VEC, LPR, TRANS, RT>(p, tbuf_wave, r, row0 + r, q, mycol, acc, changed);
+                    emit_row<VEC, LPR, MODE, RT>(p, tbuf_wave, r, row0 + r, q, mycol, acc, changed, mirror);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
             }
@@ -355,19 +416,22 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
         }
     }
 
-    if constexpr (TRANS) {
+    if constexpr (TILE) {
         __syncthreads();
         const int cols_here = int(imin(PW, p.L - c0));
         const int64_t tb = p.tblock;
+        const int rows_out = (TRANS || mirror) ? nrows : 0;
         for (int x = lane; x < PW * RT; x += 64) {
             const int c = x / RT;
             const int r = x % RT;
-            if (c < cols_here && r < nrows) {
+            if (c < cols_here && r < rows_out) {
                 const int64_t a = row0 + r;
                 const int64_t blk = a / tb;
                 const int64_t a_in = a - blk * tb;
                 const int64_t stride = p.tstride ? p.tstride : imin(tb, p.M - blk * tb);
-                p.Y[blk * (p.L * tb) + (c0 + c) * stride + a_in] = tbuf_wave[c * (RT + 1) + r];
+                float* dst = p.Y + blk * (p.L * tb) + (c0 + c) * stride + a_in;
+                if (p.nt) __builtin_nontemporal_store(tbuf_wave[c * (RT + 1) + r], dst);
+                else *dst = tbuf_wave[c * (RT + 1) + r];
             }
         }
     }
@@ -384,7 +448,7 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
     }
 }
 
-template <int VEC, int LPR, bool TRANS, int RT, bool HUB>
+template <int VEC, int LPR, int MODE, int RT, bool HUB>
 static int launch_spmm_impl(SpmmArgs a, hipStream_t st) {
     constexpr int PW = VEC * LPR;
     a.n_panels = int((a.L + PW - 1) / PW);
@@ -394,8 +458,8 @@ static int launch_spmm_impl(SpmmArgs a, hipStream_t st) {
     const int64_t grid = panels_padded * a.row_tiles;
     SR_REQUIRE(grid > 0 && grid < (int64_t(1) << 31), "grid of %lld blocks", (long long)grid);
     const size_t lds = sizeof(float) * (size_t(HUB ? a.n_hub : 0) * PW +
-                                        (TRANS ? size_t(kWaves) * PW * (RT + 1) : 0));
-    auto kern = spmm_gather_kernel<VEC, LPR, TRANS, RT, HUB>;
+                                        (MODE != kPlain ? size_t(kWaves) * PW * (RT + 1) : 0));
+    auto kern = spmm_gather_kernel<VEC, LPR, MODE, RT, HUB>;
     if (lds > 48 * 1024)
         SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -404,18 +468,18 @@ static int launch_spmm_impl(SpmmArgs a, hipStream_t st) {
     return SIMRANK_OK;
 }
 
-template <int VEC, int LPR, bool TRANS, int RT>
+template <int VEC, int LPR, int MODE, int RT>
 static int launch_spmm(SpmmArgs a, hipStream_t st) {
     if constexpr (VEC == 4) {
         // the hub copy may take at most 64 KiB of LDS; wider panels run without it
         if (a.n_hub > 0 && a.n_hub * (VEC * LPR) <= 16384) {
             a.col = a.colx;
-            return launch_spmm_impl<VEC, LPR, TRANS, RT, true>(a, st);
+            return launch_spmm_impl<VEC, LPR, MODE, RT, true>(a, st);
         }
     }
     a.n_hub = 0;
     a.tpw = 1;
-    return launch_spmm_impl<VEC, LPR, TRANS, RT, false>(a, st);
+    return launch_spmm_impl<VEC, LPR, MODE, RT, false>(a, st);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -578,9 +642,12 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
     if (!vec_ok || tuning().hub == 0) hub = 0;
     a.n_hub = (int32_t)hub;
     a.tpw = (int32_t)(tuning().tpw > 0 ? tuning().tpw : 4);
+    a.nt = (int32_t)tuning().stream_nt;
+    const bool want_sym = ep && ep->symmetric && tuning().triangle && vec_ok && !transpose_out &&
+                          n_cols_x == g->n_rows && ep->diag_col0 == 0 && g->n_rows >= 64;
     if (!vec_ok) {
-        return transpose_out ? launch_spmm<1, 32, true, 32>(a, st)
-                             : launch_spmm<1, 32, false, 32>(a, st);
+        return transpose_out ? launch_spmm<1, 32, kTrans, 32>(a, st)
+                             : launch_spmm<1, 32, kPlain, 32>(a, st);
     }
 #define SR_TILE_SWITCH(LPR, TR)                                             \
     switch (tile) {                                                         \
@@ -588,21 +655,27 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
         case 32: return launch_spmm<4, LPR, TR, 32>(a, st);                 \
         default: return launch_spmm<4, LPR, TR, 64>(a, st);                 \
     }
+    if (want_sym) {
+        // upper triangle + mirror: square 32 x 32 wave tiles
+        a.tblock = g->n_rows;
+        a.tstride = ldy;
+        return launch_spmm<4, 8, kSym, 32>(a, st);
+    }
     if (transpose_out) {
         if (panel > 64) panel = 64;  // wider panels would not leave LDS for the transpose tile
         if (panel == 64 && tile > 32) tile = 32;
         switch (panel) {
-            case 16: SR_TILE_SWITCH(4, true)
-            case 32: SR_TILE_SWITCH(8, true)
-            default: SR_TILE_SWITCH(16, true)
+            case 16: SR_TILE_SWITCH(4, kTrans)
+            case 32: SR_TILE_SWITCH(8, kTrans)
+            default: SR_TILE_SWITCH(16, kTrans)
         }
     }
     switch (panel) {
-        case 16: SR_TILE_SWITCH(4, false)
-        case 32: SR_TILE_SWITCH(8, false)
-        case 64: SR_TILE_SWITCH(16, false)
-        case 128: SR_TILE_SWITCH(32, false)
-        default: SR_TILE_SWITCH(64, false)
+        case 16: SR_TILE_SWITCH(4, kPlain)
+        case 32: SR_TILE_SWITCH(8, kPlain)
+        case 64: SR_TILE_SWITCH(16, kPlain)
+        case 128: SR_TILE_SWITCH(32, kPlain)
+        default: SR_TILE_SWITCH(64, kPlain)
     }
 #undef SR_TILE_SWITCH
 }

@@ -223,7 +223,10 @@ class Side:
         if self.mode != "sparse":
             o.gemm_nt(self.t, self.wd, S_out, self.M, self.M, self.K, epilogue=self._ep(S_prev, eps))
         elif self.symmetric:
-            o.spmm(self.graph, self.recv, S_out, n_cols=self.Lm, epilogue=self._ep(S_prev, eps))
+            ep = self._ep(S_prev, eps)
+            # one rank holds the whole symmetric matrix: upper triangle + mirror image
+            ep["symmetric"] = self.world == 1
+            o.spmm(self.graph, self.recv, S_out, n_cols=self.Lm, epilogue=ep)
         elif self.world == 1:
             o.spmm(self.graph, self.recv, S_out, n_cols=self.Lm, transpose_out=True)
         else:

@@ -183,7 +183,7 @@ class HipOps:
                   "simrank_fill_identity")
 
     def _epilogue(self, coef, evidence=None, apriori=None, lbd=0.0, previous=None, eps=0.0,
-                  diag_col0=0, set_diag=True) -> Epilogue:
+                  diag_col0=0, set_diag=True, symmetric=False) -> Epilogue:
         ep = Epilogue()
         ep.coef = float(coef)
         ep.lbd = float(lbd)
@@ -197,6 +197,7 @@ class HipOps:
         ep.eps = float(eps)
         ep.diag_col0 = int(diag_col0)
         ep.set_diag = 1 if set_diag else 0
+        ep.symmetric = 1 if symmetric else 0
         return ep
 
     def spmm(self, g: Graph, X: Matrix, Y: Matrix, n_cols: int | None = None,

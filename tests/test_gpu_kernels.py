@@ -262,3 +262,37 @@ def test_hub_cache_is_bit_identical(ops):
     for y, yt in outs[1:]:
         assert np.array_equal(y, outs[0][0]) and np.array_equal(yt, outs[0][1])
     np.testing.assert_allclose(outs[0][0], outs[0][1].T, rtol=RTOL, atol=1e-30)
+
+
+@pytest.mark.parametrize("n", [64, 200, 1000, 1031])
+def test_symmetric_leg2_upper_triangle_and_mirror(ops, n):
+    """ep.symmetric: only tiles on/above the diagonal are computed, the rest is their mirror
+    image.  Same values as the full computation (to rounding), exactly symmetric, and the
+    convergence count equals the count over the full matrix."""
+    csr = random_csr(n, n, 10, seed=n, heavy={3: min(n, 300), 40: min(n, 90)})
+    rng = np.random.default_rng(n)
+    S = rng.random((n, n)).astype(np.float32)
+    S = ((S + S.T) / 2).astype(np.float32)
+    np.fill_diagonal(S, 1)
+    cnt = rng.integers(0, 5, size=(n, n))
+    cnt = np.minimum(cnt, cnt.T).astype(np.uint8)
+    g, s_in, tt = ops.graph(csr), put(ops, S), ops.matrix(n, n)
+    ops.spmm(g, s_in, tt, transpose_out=True)                    # leg 1
+    outs = {}
+    for sym in (False, True):
+        y = ops.matrix(n, n)
+        ep = dict(coef=0.8, evidence=put(ops, cnt, dtype=np.uint8), previous=s_in, eps=0.05,
+                  diag_col0=0, symmetric=sym)
+        ops.spmm(g, tt, y, epilogue=ep)
+        outs[sym] = (ops.download(y), ops.read_changed())
+    full, mirrored = outs[False][0], outs[True][0]
+    np.testing.assert_allclose(mirrored, full, rtol=RTOL, atol=1e-30)
+    assert np.array_equal(mirrored[:32, 32:], mirrored[32:, :32].T)       # mirrored tiles: same bits
+    assert outs[True][1] == int((np.abs(mirrored.astype(np.float64) - S) > 0.05).sum())
+    assert outs[False][1] == int((np.abs(full.astype(np.float64) - S) > 0.05).sum())
+    ops.set_tuning(triangle=0)
+    y = ops.matrix(n, n)
+    ops.spmm(g, tt, y, epilogue=dict(coef=0.8, evidence=put(ops, cnt, dtype=np.uint8), previous=s_in,
+                                     eps=0.05, diag_col0=0, symmetric=True))
+    ops.set_tuning(triangle=1)
+    assert np.array_equal(ops.download(y), full)                  # knob off -> plain path

@@ -66,8 +66,17 @@ def test_logical_shards_on_one_gpu(name, world):
 
 
 def test_logical_shards_are_bitwise_equal_to_one_shard():
+    from simrank_amd.engine import HipOps
     df = synth.er_directed(1024, 0.01, seed=1)
-    one = SRA.SimRank().fit(df, iterations=6, eps=0, verbose=False, mode="sparse")
+    knob = HipOps(0)
+    knob.set_tuning(triangle=0)      # P = 1 without the single-rank upper-triangle shortcut
+    try:
+        one = SRA.SimRank().fit(df, iterations=6, eps=0, verbose=False, mode="sparse")
+    finally:
+        knob.set_tuning(triangle=1)
+    tri = SRA.SimRank().fit(df, iterations=6, eps=0, verbose=False, mode="sparse")
+    assert np.array_equal(tri.values[:32, 32:], tri.values[32:, :32].T)   # mirrored tiles: same bits
+    np.testing.assert_allclose(tri.values, one.values, rtol=1e-6, atol=1e-30)
     for world in (2, 4, 8):
         many = SRA.SimRank().fit(df, iterations=6, eps=0, verbose=False, mode="sparse",
                                  world=LocalWorld(world))

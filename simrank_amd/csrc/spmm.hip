@@ -219,7 +219,20 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
 
     // block -> (panel, row-tile group); blocks equal mod 8 share an XCD (speed only)
     int panel, rt;
-    {
+    if constexpr (MODE == kSym) {
+        // only the (panel, row block) pairs that touch the upper triangle are launched.
+        // XCD x owns panels x + 8j; panel p needs row blocks 0 .. p/4 (128 rows per block,
+        // 32 columns per panel), i.e. 2j + b of them with b = x/4 + 1; prefix j^2 + (b-1)j.
+        const int x = int(blockIdx.x & 7);
+        const int t = int(blockIdx.x >> 3);
+        const int b1 = x >> 2;                           // b - 1
+        int j = int((sqrtf(float(b1 * b1 + 4 * t)) - float(b1)) * 0.5f);
+        while ((j + 1) * (j + 1) + b1 * (j + 1) <= t) ++j;
+        while (j * j + b1 * j > t) --j;
+        panel = x + 8 * j;
+        rt = t - (j * j + b1 * j);
+        if (rt > panel / 4) return;                      // padding of the shorter XCD lists
+    } else {
         const int64_t bid = blockIdx.x;
         if (p.xcd_map) {
             const int x = int(bid & 7);
@@ -455,7 +468,12 @@ static int launch_spmm_impl(SpmmArgs a, hipStream_t st) {
     const int64_t rows_per_block = int64_t(kWaves) * RT * a.tpw;
     a.row_tiles = int((a.M + rows_per_block - 1) / rows_per_block);
     const int64_t panels_padded = a.xcd_map ? int64_t((a.n_panels + 7) / 8) * 8 : a.n_panels;
-    const int64_t grid = panels_padded * a.row_tiles;
+    int64_t grid = panels_padded * a.row_tiles;
+    if constexpr (MODE == kSym) {
+        static_assert(PW == 32 && RT == 32, "triangular block map assumes 128-row blocks, 32-col panels");
+        const int64_t J = (a.n_panels + 7) / 8;      // panels per XCD
+        grid = 8 * (J * J + J);                       // longest list (b = 2), others padded
+    }
     SR_REQUIRE(grid > 0 && grid < (int64_t(1) << 31), "grid of %lld blocks", (long long)grid);
     const size_t lds = sizeof(float) * (size_t(HUB ? a.n_hub : 0) * PW +
                                         (MODE != kPlain ? size_t(kWaves) * PW * (RT + 1) : 0));

@@ -54,3 +54,30 @@ if "--cfg3" in sys.argv:
         print(f"cfg3 BipartiteSimRankPP mode={mode}: setup (graphs + evidence) {t_setup:.2f} s, "
               f"{dt * 1e3:.2f} ms/iteration, legs {sol.leg_times()}", flush=True)
         sol.release()
+
+if "--cfg5" in sys.argv:
+    # config 5 shape: N = 65536 SimRank++ (evidence), one GPU, f32 gather legs
+    df = synth.WORKLOADS["pl65536"][0]()
+    _, csr = ingest.directed(df, False, "from", "to", "weight")
+    print(f"cfg5: N={csr.n_rows} nnz={csr.nnz}", flush=True)
+    t0 = time.perf_counter()
+    spec = SideSpec(csr, ingest.spread(csr) * csr.rowscale, 0.8, evidence_from=csr)
+    sol = Solver(lambda r: ops, LocalWorld(1), [spec], "sparse")
+    ops.synchronize()
+    t_setup = time.perf_counter() - t0
+    sol.reset()
+    sol.step(0.0)
+    sol.enable_timing()
+    ops.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        sol.step(0.0)
+    ops.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    t0 = time.perf_counter()
+    k = sol.run(100, 1e-4)
+    ops.synchronize()
+    print(f"cfg5 SimRankPP N=65536: setup (graph + evidence counts) {t_setup:.2f} s, "
+          f"{dt * 1e3:.1f} ms/iteration, legs {sol.leg_times()}, converged at {k} in "
+          f"{time.perf_counter() - t0:.2f} s", flush=True)
+    sol.release()

@@ -392,4 +392,9 @@ class Solver:
         acc = {}
         for tag, r, a, b in self.events or []:
             acc.setdefault(tag, []).append(self.ops[r].elapsed_ms(a, b))
+            if hasattr(self.ops[r], "event_destroy"):
+                self.ops[r].event_destroy(a)
+                self.ops[r].event_destroy(b)
+        if self.events:
+            self.events = []
         return {t: (float(np.mean(v)), len(v)) for t, v in acc.items()}

@@ -248,11 +248,30 @@ class HipOps:
     def record(self, ev: int):
         check(self.lib.simrank_event_record(C.c_void_p(ev), self.stream), "event_record")
 
+    def event_destroy(self, ev: int):
+        self.lib.simrank_event_destroy(C.c_void_p(ev))
+
     def elapsed_ms(self, start: int, stop: int) -> float:
         ms = C.c_float(0)
         check(self.lib.simrank_event_elapsed_ms(C.c_void_p(start), C.c_void_p(stop),
                                                 C.byref(ms)), "event_elapsed")
         return float(ms.value)
+
+    def close(self):
+        """Release the stream and the counter (matrices and graphs free themselves)."""
+        if getattr(self, "_counter", 0):
+            self._free(self._counter)
+            self._counter = 0
+        if getattr(self, "_own_stream", False) and self.stream:
+            self.lib.simrank_stream_destroy(self.stream)
+            self.stream = None
+            self._own_stream = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def set_tuning(self, **kw):
         for k, v in kw.items():

@@ -248,3 +248,30 @@ def test_rccl_world_of_one_rank():
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 100 and out["converge"]["iterations"] == 5
+
+
+@pytest.mark.parametrize("cls", ["SimRank", "SimRankPP"])
+def test_directed_edge_cases_on_gpu(cls):
+    """Degenerate and extreme graphs (N = 1, stars with one 899-entry row, complete graph,
+    chain, string labels) through the HIP path, against the oracle."""
+    from tests.edge_cases import directed_cases
+    for name, df in directed_cases().items():
+        est = getattr(SRA, cls)()
+        got = est.fit(df, verbose=False)
+        want = (O.fit_simrank if cls == "SimRank" else O.fit_simrank_pp)(df, verbose=False)
+        assert list(got.index) == want["labels"], name
+        np.testing.assert_allclose(got.values, want["S"], rtol=RTOL, atol=1e-30, err_msg=name)
+        assert est.converged_at == want["k"], name
+        if name == "complete_40":
+            assert est.engine_mode == "dense"
+
+
+def test_bipartite_edge_cases_on_gpu():
+    from tests.edge_cases import bipartite_cases
+    for name, df in bipartite_cases().items():
+        est = SRA.BipartiteSimRankPP()
+        s1, s2 = est.fit(df, verbose=False, strict_reference=False)
+        want = O.fit_bipartite_pp(df, verbose=False, strict_reference=False)
+        np.testing.assert_allclose(s1.values, want["S1"], rtol=RTOL, atol=1e-30, err_msg=name)
+        np.testing.assert_allclose(s2.values, want["S2"], rtol=RTOL, atol=1e-30, err_msg=name)
+        assert est.converged_at == want["k"], name

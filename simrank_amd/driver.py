@@ -76,6 +76,8 @@ class LocalWorld:
         return int(sum(values))
 
     def gather_columns(self, blocks, n_rows, n_cols):
+        if self.size == 1:
+            return blocks[0]                     # the one block is the matrix: no host copy
         out = np.empty((n_rows, n_cols), dtype=np.float64)
         for r, blk in blocks.items():
             lo, hi = partition(n_cols, self.size, r)

@@ -275,3 +275,45 @@ def test_bipartite_edge_cases_on_gpu():
         np.testing.assert_allclose(s1.values, want["S1"], rtol=RTOL, atol=1e-30, err_msg=name)
         np.testing.assert_allclose(s2.values, want["S2"], rtol=RTOL, atol=1e-30, err_msg=name)
         assert est.converged_at == want["k"], name
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomized_against_oracle(seed):
+    """Random size / density / class / sharding / mode, every result against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(33, 700))
+    kind = ["er", "pl", "bip"][seed % 3]
+    world = LocalWorld(int(rng.integers(1, 5)))
+    mode = "sparse" if world.size > 1 else str(rng.choice(["auto", "sparse", "dense", "hybrid"]))
+    weighted = bool(rng.integers(0, 2))
+    if kind == "bip":
+        n2 = int(rng.integers(20, 300))
+        df = bipartite_random(n, n2, float(rng.uniform(0.01, 0.2)), seed=seed)
+        pp = bool(rng.integers(0, 2))
+        est = (SRA.BipartiteSimRankPP if pp else SRA.BipartiteSimRank)()
+        kw = dict(weighted=weighted, verbose=False, C1=0.7, C2=0.85)
+        extra = dict(strict_reference=False) if pp else {}
+        s1, s2 = est.fit(df, world=world, mode=mode, **kw, **extra)
+        want = (O.fit_bipartite_pp if pp else O.fit_bipartite)(df, **kw, **extra)
+        sorted_labels = pp
+        assert list(s1.index) == (want["sorted1"] if sorted_labels else want["labels1"])
+        assert_close(s1.values, want["S1"])
+        assert_close(s2.values, want["S2"])
+    else:
+        df = (synth.er_directed(n, float(rng.uniform(0.005, 0.15)), seed) if kind == "er"
+              else synth.powerlaw_directed(n, float(rng.uniform(2, 30)), seed))
+        cls = str(rng.choice(["SimRank", "SimRankPP", "AprioriSimRank"]))
+        kw = dict(weighted=weighted, verbose=False, C=float(rng.uniform(0.5, 0.9)))
+        if cls == "AprioriSimRank":
+            prior = rng.random((n, n))
+            if rng.integers(0, 2):
+                prior = (prior + prior.T) / 2
+            got = SRA.AprioriSimRank().fit(df, prior, lbd=0.3, world=world, mode=mode, **kw)
+            want = O.fit_simrank_pp(df, apriori=prior, lbd=0.3, **kw)
+        else:
+            est = getattr(SRA, cls)()
+            got = est.fit(df, world=world, mode=mode, **kw)
+            want = (O.fit_simrank if cls == "SimRank" else O.fit_simrank_pp)(df, **kw)
+            assert est.converged_at == want["k"]
+        assert list(got.index) == want["labels"]
+        assert_close(got.values, want["S"])

@@ -50,11 +50,11 @@ def iterate(G, C_, iterations, eps):
         if changed == 0:
             k_conv = k
             break
-        _ok(_lib.simrank_spmm(g, S, i64(ld), i64(n), Tt, i64(ld), C.c_int32(1), i64(0),
+        _ok(_lib.simrank_spmm(g, S, i64(ld), i64(n), Tt, i64(ld), C.c_int32(1), i64(0), i64(0),
                               None, None))                        # Tt = (G.S)^T
         ep = Epilogue(coef=C_, previous=S.value, ld_previous=ld, eps=eps,
                       n_changed=cnt.value, set_diag=1)
-        _ok(_lib.simrank_spmm(g, Tt, i64(ld), i64(n), Sn, i64(ld), C.c_int32(0), i64(0),
+        _ok(_lib.simrank_spmm(g, Tt, i64(ld), i64(n), Sn, i64(ld), C.c_int32(0), i64(0), i64(0),
                               C.byref(ep), None))                 # S' = C.G.Tt, diag <- 1
         slots = (C.c_ulonglong * SLOTS)()
         _ok(_lib.simrank_memcpy_d2h(slots, cnt, C.c_size_t(8 * SLOTS), None))

@@ -132,15 +132,17 @@ typedef struct simrank_epilogue {
  *      store and fused epilogue.  X: n_cols(g) x n_cols_x, Y: n_rows(g) x n_cols_x.
  *      transpose_out = 0: Y[a*ldy + c]
  *      transpose_out = 1: rows are grouped in blocks of t_block rows (t_block <= 0 or
- *        >= n_rows(g): one block); block h holds Y^T of its rows, contiguous:
- *        Y[h*n_cols_x*t_block + c*rows_in_block(h) + (a - h*t_block)]
+ *        >= n_rows(g): one block); block h holds Y^T of its rows, contiguous, its rows
+ *        padded by t_pad floats (so the receiver's leading dimension need not be a power
+ *        of two):
+ *        Y[h*n_cols_x*(t_block+t_pad) + c*(rows_in_block(h)+t_pad) + (a - h*t_block)]
  *        (ldy is ignored, except that with a single block and ldy >= n_rows(g) it is the
  *        row stride of Y^T: Y[c*ldy + a])
  *      This is the layout an all-to-all between column-sharded ranks needs.
  *      (first `.dot` of SimRank.py:139/:298/:301/:361/:420/:423; with the epilogue also
  *      the second, using S' = W.(W.S)^T for symmetric S.) */
 SIMRANK_API int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_cols_x,
-                 float* Y, int64_t ldy, int32_t transpose_out, int64_t t_block,
+                 float* Y, int64_t ldy, int32_t transpose_out, int64_t t_block, int64_t t_pad,
                  const simrank_epilogue* epilogue, void* stream);
 
 /* ---- K4/K5 alone: Y = epilogue(Q), element-wise over an n_rows x n_cols block (Q and Y may be

@@ -342,6 +342,9 @@ int simrank_set_tuning(const char* key, int64_t value) {
     } else if (!strcmp(key, "hub")) {
         SR_REQUIRE(value >= -1 && value <= kHubMax, "hub must be -1 (auto) .. %d", kHubMax);
         t.hub = value;
+    } else if (!strcmp(key, "huge")) {
+        SR_REQUIRE(value >= 64 && value <= (1 << 30), "huge must be >= 64");
+        t.huge = value;
     } else if (!strcmp(key, "triangle")) {
         t.triangle = value ? 1 : 0;
     } else if (!strcmp(key, "tpw")) {
@@ -365,6 +368,7 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     else if (!strcmp(key, "hub")) *value = t.hub;
     else if (!strcmp(key, "tpw")) *value = t.tpw;
     else if (!strcmp(key, "triangle")) *value = t.triangle;
+    else if (!strcmp(key, "huge")) *value = t.huge;
     else SR_REQUIRE(false, "unknown tuning key '%s'", key);
     return SIMRANK_OK;
 }

@@ -37,6 +37,7 @@ struct Tuning {
     int64_t tile = 0;     // rows per wave tile (16, 32, 64; 0 = automatic)
     int64_t hub = -1;     // hub rows cached in LDS per workgroup (-1 = automatic, 0 = off)
     int64_t tpw = 0;      // row tiles a wave walks per workgroup (0 = automatic)
+    int64_t huge = 512;   // rows of at least this many entries are split over a workgroup's waves
     int64_t triangle = 1; // allow the upper-triangle + mirror form of a symmetric leg 2
 };
 Tuning& tuning();

@@ -39,6 +39,8 @@ struct SpmmArgs {
     int32_t n_hub;            // ranks cached in LDS by each workgroup
     int32_t tpw;              // row tiles a wave walks
     int32_t nt;               // non-temporal output stores
+    int32_t has_huge;         // the graph has rows of >= huge_len entries
+    int32_t huge_len;         // rows this long are split over the waves of a workgroup
     const float* rowscale;
     const float* X;
     int64_t ldx;
@@ -48,6 +50,7 @@ struct SpmmArgs {
     int64_t M;       // rows of the graph = rows of Y
     int64_t tblock;  // rows per transposed block (TRANS only)
     int64_t tstride; // TRANS, single block: row stride of Y^T (0 = rows in block)
+    int64_t tpad;    // TRANS, blocked: padding floats per row of a block
     int32_t n_panels;
     int32_t row_tiles;
     int32_t xcd_map;
@@ -202,6 +205,57 @@ __device__ __forceinline__ void emit_row(const SpmmArgs& p, float* tbuf_wave, in
 // copy of a hub row's panel segment.  A batch issues all its global loads, then all its LDS
 // reads, then adds in neighbour order: the hub cache changes where bytes come from, never
 // the arithmetic or its order.
+constexpr int kMaxHuge = 8;    // ... at most this many per workgroup and tile round
+
+// Sum of the X segments of the neighbours at CSR positions [s, e): the G lane groups take
+// them round-robin, UNROLL loads in flight each; partial sums combined by shuffles in a
+// fixed order.  Every lane ends with the total of its VEC columns.
+template <int VEC, int LPR, bool HUB>
+__device__ __forceinline__ void gather_range(const SpmmArgs& p, const float* __restrict__ Xc,
+                                             const float* hub, int s, int e, int lane, int g,
+                                             int q, bool col_active, float (&acc)[VEC]) {
+    constexpr int PW = VEC * LPR, G = 64 / LPR, UNROLL = 4;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    for (int base = s; base < e; base += 64) {
+        const int n = min(64, e - base);
+        const int myidx = lane < n ? ldidx(p, base + lane) : 0;
+        for (int k0 = 0; k0 < n; k0 += G * UNROLL) {
+            float v[UNROLL][VEC];
+            int idx[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int k = k0 + u * G + g;
+                idx[u] = __shfl(myidx, k & 63);
+                if (!(col_active && k < n)) idx[u] = kSkip;
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                if (idx[u] >= 0) {
+                    vload<VEC>(v[u], Xc + int64_t(idx[u]) * p.ldx);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
+                }
+            }
+            if constexpr (HUB) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u)
+                    if (idx[u] < 0 && idx[u] != kSkip)
+                        vload<VEC>(v[u], hub + (-1 - idx[u]) * PW + q * VEC);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
+        }
+    }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off);
+}
+
 template <int VEC, int LPR, int MODE, int RT, bool HUB>
 __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
     static_assert(RT <= 64, "one lane per tile row");
@@ -211,7 +265,6 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
     constexpr int PW = VEC * LPR;            // panel width in floats
     constexpr int G = 64 / LPR;              // lane groups = rows (or neighbours) in flight
     constexpr int JU = LPR < 8 ? LPR : 8;    // gathers a group keeps in flight
-    constexpr int UNROLL = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [hub cache][transpose tiles]
 
     const int lane = threadIdx.x & 63;
@@ -302,52 +355,67 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
     const int s_start = __shfl(my_start, s_row);
     const int n_heavy = __popcll(__ballot(s_len >= kHeavy));
 
-    // ---- phase A: long rows, one at a time; the G lane groups split the neighbours and
-    // their partial sums are combined by shuffles in a fixed order
-    for (int h = 0; h < n_heavy; ++h) {
+    // ---- phase A0: huge rows (>= huge_len entries, default 512).  One wave would need ~0.7 ms for the
+    // 15 336-entry row of the bench graph — longer than a whole sharded launch — so the owner
+    // posts them in LDS and all four waves of the workgroup take a quarter of the neighbours
+    // each; the owner adds the four partial sums in wave order and emits the row.
+    int posted = 0;
+    if (p.has_huge) {
+        int* hmeta = reinterpret_cast<int*>(smem + (HUB ? p.n_hub * PW : 0) +
+                                            (TILE ? kWaves * PW * (RT + 1) : 0));
+        float* hpart = reinterpret_cast<float*>(hmeta + 64);
+        const int n_huge = __popcll(__ballot(s_len >= p.huge_len));
+        if (threadIdx.x == 0) hmeta[0] = 0;
+        __syncthreads();
+        if (n_huge > 0) {
+            int slot0 = 0;
+            if (lane == 0) slot0 = atomicAdd(&hmeta[0], n_huge);
+            slot0 = __builtin_amdgcn_readfirstlane(slot0);
+            posted = max(0, min(n_huge, kMaxHuge - slot0));
+            if (lane < posted) {
+                int* d = hmeta + 4 + 4 * (slot0 + lane);
+                d[0] = s_row; d[1] = s_start; d[2] = s_len; d[3] = wave;
+            }
+        }
+        __syncthreads();
+        const int nh = min(hmeta[0], kMaxHuge);
+        for (int i = 0; i < nh; ++i) {
+            const int* d = hmeta + 4 + 4 * i;
+            const int hs = d[1], hl = d[2];
+            const int chunk = ((hl + kWaves - 1) / kWaves + 63) & ~63;
+            const int s = hs + wave * chunk;
+            const int e = min(hs + hl, s + chunk);
+            float part[VEC];
+            gather_range<VEC, LPR, HUB>(p, Xc, hub, s, e, lane, g, q, col_active, part);
+            if (g == 0) vstore<VEC>(hpart + (i * kWaves + wave) * PW + q * VEC, part);
+        }
+        __syncthreads();
+        for (int i = 0; i < nh; ++i) {
+            const int* d = hmeta + 4 + 4 * i;
+            if (d[3] == wave && g == 0 && col_active) {
+                float acc[VEC], t[VEC];
+                vload<VEC>(acc, hpart + (i * kWaves + 0) * PW + q * VEC);
+#pragma unroll
+                for (int w = 1; w < kWaves; ++w) {
+                    vload<VEC>(t, hpart + (i * kWaves + w) * PW + q * VEC);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] += t[k];
+                }
+                const int r = d[0];
+                emit_row<VEC, LPR, MODE, RT>(p, tbuf_wave, r, row0 + r, q, mycol, acc, changed, mirror);
+            }
+        }
+        __syncthreads();   // descriptors may be rewritten by the next tile round
+    }
+
+    // ---- phase A: the other long rows, one at a time per wave; the G lane groups split the
+    // neighbours and their partial sums are combined by shuffles in a fixed order
+    for (int h = posted; h < n_heavy; ++h) {
         const int r = __builtin_amdgcn_readfirstlane(__shfl(s_row, h));
         const int s = __builtin_amdgcn_readfirstlane(__shfl(s_start, h));
         const int e = s + __builtin_amdgcn_readfirstlane(__shfl(s_len, h));
         float acc[VEC];
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-        for (int base = s; base < e; base += 64) {
-            const int n = min(64, e - base);
-            const int myidx = lane < n ? ldidx(p, base + lane) : 0;
-            for (int k0 = 0; k0 < n; k0 += G * UNROLL) {
-                float v[UNROLL][VEC];
-                int idx[UNROLL];
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    const int k = k0 + u * G + g;
-                    idx[u] = __shfl(myidx, k & 63);
-                    if (!(col_active && k < n)) idx[u] = kSkip;
-                }
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    if (idx[u] >= 0) {
-                        vload<VEC>(v[u], Xc + int64_t(idx[u]) * p.ldx);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
-                    }
-                }
-                if constexpr (HUB) {
-#pragma unroll
-                    for (int u = 0; u < UNROLL; ++u)
-                        if (idx[u] < 0 && idx[u] != kSkip)
-                            vload<VEC>(v[u], hub + (-1 - idx[u]) * PW + q * VEC);
-                }
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
-            }
-        }
-#pragma unroll
-        for (int off = LPR; off < 64; off <<= 1)
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off);
+        gather_range<VEC, LPR, HUB>(p, Xc, hub, s, e, lane, g, q, col_active, acc);
         if (g == 0 && col_active)
             emit_row<VEC, LPR, MODE, RT>(p, tbuf_wave, r, row0 + r, q, mycol, acc, changed, mirror);
     }
@@ -441,8 +509,8 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
                 const int64_t a = row0 + r;
                 const int64_t blk = a / tb;
                 const int64_t a_in = a - blk * tb;
-                const int64_t stride = p.tstride ? p.tstride : imin(tb, p.M - blk * tb);
-                float* dst = p.Y + blk * (p.L * tb) + (c0 + c) * stride + a_in;
+                const int64_t stride = p.tstride ? p.tstride : imin(tb, p.M - blk * tb) + p.tpad;
+                float* dst = p.Y + blk * (p.L * (tb + p.tpad)) + (c0 + c) * stride + a_in;
                 if (p.nt) __builtin_nontemporal_store(tbuf_wave[c * (RT + 1) + r], dst);
                 else *dst = tbuf_wave[c * (RT + 1) + r];
             }
@@ -476,7 +544,8 @@ static int launch_spmm_impl(SpmmArgs a, hipStream_t st) {
     }
     SR_REQUIRE(grid > 0 && grid < (int64_t(1) << 31), "grid of %lld blocks", (long long)grid);
     const size_t lds = sizeof(float) * (size_t(HUB ? a.n_hub : 0) * PW +
-                                        (MODE != kPlain ? size_t(kWaves) * PW * (RT + 1) : 0));
+                                        (MODE != kPlain ? size_t(kWaves) * PW * (RT + 1) : 0) +
+                                        (a.has_huge ? 64 + size_t(kMaxHuge) * kWaves * PW : 0));
     auto kern = spmm_gather_kernel<VEC, LPR, MODE, RT, HUB>;
     if (lds > 48 * 1024)
         SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -600,8 +669,9 @@ int simrank_fill_identity(float* S, int64_t n_rows, int64_t n_cols, int64_t ld, 
 }
 
 int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_cols_x,
-                 float* Y, int64_t ldy, int32_t transpose_out, int64_t t_block,
+                 float* Y, int64_t ldy, int32_t transpose_out, int64_t t_block, int64_t t_pad,
                  const simrank_epilogue* ep, void* stream) {
+    SR_REQUIRE(t_pad >= 0 && t_pad < 4096, "t_pad out of range");
     SR_REQUIRE(g && X && Y, "NULL argument");
     SR_REQUIRE(n_cols_x > 0 && ldx >= n_cols_x, "X: %lld columns, ld %lld", (long long)n_cols_x,
                (long long)ldx);
@@ -614,6 +684,8 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
     a.colx = g->colx;
     a.rowscale = g->rowscale;
     a.hub_rows = g->hub_rows;
+    a.huge_len = (int32_t)std::max<int64_t>(kHeavy, tuning().huge);
+    a.has_huge = g->max_row_nnz >= a.huge_len ? 1 : 0;
     a.X = X;
     a.ldx = ldx;
     a.L = n_cols_x;
@@ -622,6 +694,7 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
     a.M = g->n_rows;
     a.tblock = (t_block <= 0 || t_block > g->n_rows) ? g->n_rows : t_block;
     a.tstride = (transpose_out && a.tblock == g->n_rows && ldy >= g->n_rows) ? ldy : 0;
+    a.tpad = a.tstride ? 0 : t_pad;
     a.xcd_map = (int)tuning().xcd_map;
     bool vec_ok = aligned16(X) && ldx % 4 == 0;
     if (!transpose_out) vec_ok = vec_ok && aligned16(Y) && ldy % 4 == 0;

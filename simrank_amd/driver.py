@@ -27,6 +27,7 @@ import numpy as np
 from .ingest import CSR, partition
 
 DENSE_THRESHOLD = 0.05   # density above which the MFMA GEMM legs beat the gather legs
+PAD_MIN_ROWS, PAD_MULTIPLE = 1024, 256   # when exchanged chunk rows get padded (row_pad)
 
 
 # --------------------------------------------------------------------------------------
@@ -50,8 +51,18 @@ class Xfer:
     row_dim: int
     mb: int
     nrows: int                 # rows of this rank (width of recv)
+    pad: int = 0               # floats appended to every row of a chunk (see row_pad)
     send_t: object = None      # torch views of send / recv (TorchWorld)
     recv_t: object = None
+
+
+def row_pad(block_rows: int) -> int:
+    """Padding of the rows of an exchanged chunk.  A chunk row has `rows of the receiving
+    rank` floats and becomes a row of the receiver's gather operand; when that length is a
+    large power-of-two multiple, consecutive rows of a panel fall on the same L2 channels
+    and sets, so 32 floats (one 128-byte line) are appended.  Every rank derives it from the
+    full block size, so senders and receivers agree."""
+    return 32 if block_rows >= PAD_MIN_ROWS and block_rows % PAD_MULTIPLE == 0 else 0
 
 
 class LocalWorld:
@@ -68,9 +79,11 @@ class LocalWorld:
             return                               # recv aliases send
         for src in parts:
             for dst in parts:
-                n = src.ncols * dst.nrows        # tile (columns of src) x (rows of dst)
-                src.ops.copy_bytes(dst.recv.ptr + 4 * src.col_lo * dst.nrows,
-                                   src.send.ptr + 4 * dst.rank * src.ncols * src.mb, 4 * n)
+                w = dst.nrows + src.pad          # padded row of a chunk
+                n = src.ncols * w                # tile (columns of src) x (rows of dst)
+                src.ops.copy_bytes(dst.recv.ptr + 4 * src.col_lo * w,
+                                   src.send.ptr + 4 * dst.rank * src.ncols * (src.mb + src.pad),
+                                   4 * n)
 
     def sum_int(self, values):
         return int(sum(values))
@@ -102,8 +115,8 @@ class TorchWorld:
         (x,) = parts
         x.ops.synchronize()                      # the producing leg finished on the engine's stream
         span = lambda n, h: partition(n, self.size, h)[1] - partition(n, self.size, h)[0]
-        in_splits = [x.ncols * span(x.row_dim, h) for h in range(self.size)]
-        out_splits = [span(x.col_dim, h) * x.nrows for h in range(self.size)]
+        in_splits = [x.ncols * (span(x.row_dim, h) + x.pad) for h in range(self.size)]
+        out_splits = [span(x.col_dim, h) * (x.nrows + x.pad) for h in range(self.size)]
         self.dist.all_to_all_single(x.recv_t[:sum(out_splits)], x.send_t[:sum(in_splits)],
                                     out_splits, in_splits, group=self.group)
         x.ops.collective_done()
@@ -189,14 +202,18 @@ class Side:
         x = Xfer(o, self.rank, None, None, ncols, col_lo, col_dim, self.M, self.mb, self.Lm)
         if self.world == 1 and not torch_buffers:
             x.send = x.recv = o.matrix(col_dim, self.M)          # pitched; recv aliases send
-        elif torch_buffers:                                      # chunks of M_h-float rows
-            x.send_t = o.exchange_buffer(self.M * ncols)
-            x.recv_t = o.exchange_buffer(col_dim * self.Lm)
-            x.send = o.matrix(max(1, ncols), self.M, ld=self.M, external=x.send_t)
-            x.recv = o.matrix(col_dim, self.Lm, ld=max(1, self.Lm), external=x.recv_t)
+            return x
+        x.pad = row_pad(self.mb)
+        send_ld = self.M + self.world * x.pad                    # floats per column, all chunks
+        recv_ld = max(1, self.Lm + x.pad)
+        if torch_buffers:                                        # chunks of (M_h + pad)-float rows
+            x.send_t = o.exchange_buffer(send_ld * ncols)
+            x.recv_t = o.exchange_buffer(col_dim * recv_ld)
+            x.send = o.matrix(max(1, ncols), send_ld, ld=send_ld, external=x.send_t)
+            x.recv = o.matrix(col_dim, self.Lm, ld=recv_ld, external=x.recv_t)
         else:
-            x.send = o.matrix(max(1, ncols), self.M, ld=self.M)
-            x.recv = o.matrix(col_dim, self.Lm, ld=max(1, self.Lm))
+            x.send = o.matrix(max(1, ncols), send_ld, ld=send_ld)
+            x.recv = o.matrix(col_dim, self.Lm, ld=recv_ld)
         return x
 
     # S_in: K x Lk block of the input similarity
@@ -205,7 +222,7 @@ class Side:
         if self.mode == "sparse":
             if self.Lk:
                 o.spmm(self.graph, S_in, self.send, n_cols=self.Lk, transpose_out=True,
-                       t_block=self.mb)
+                       t_block=self.mb, t_pad=self.x1.pad)
         elif self.mode == "hybrid":
             o.spmm(self.graph, S_in, self.t)                          # T = W.S, plain store
         else:
@@ -233,7 +250,7 @@ class Side:
             o.spmm(self.graph, self.recv, S_out, n_cols=self.Lm, transpose_out=True)
         else:
             o.spmm(self.graph, self.recv, self.x2.send, n_cols=self.Lm, transpose_out=True,
-                   t_block=self.mb)
+                   t_block=self.mb, t_pad=self.x2.pad)
 
     def finish(self, S_prev, S_out, eps):
         """Second half of an update with asymmetric iterates: the stand-alone epilogue."""

@@ -201,12 +201,13 @@ class HipOps:
         return ep
 
     def spmm(self, g: Graph, X: Matrix, Y: Matrix, n_cols: int | None = None,
-             transpose_out: bool = False, t_block: int = 0, epilogue: dict | None = None):
+             transpose_out: bool = False, t_block: int = 0, t_pad: int = 0,
+             epilogue: dict | None = None):
         """Y = diag(rowscale).A.X (+ fused epilogue); see simrank_spmm."""
         n_cols = X.cols if n_cols is None else n_cols
         ep = self._epilogue(**epilogue) if epilogue is not None else None
         check(self.lib.simrank_spmm(g.handle, X.ptr, X.ld, n_cols, Y.ptr, Y.ld,
-                                    1 if transpose_out else 0, int(t_block),
+                                    1 if transpose_out else 0, int(t_block), int(t_pad),
                                     C.byref(ep) if ep is not None else None, self.stream),
               "simrank_spmm")
 

@@ -104,7 +104,7 @@ class NumpyOps:
             if col0 + c < S.rows:
                 S.a[col0 + c, c] = 1
 
-    def spmm(self, g, X, Y, n_cols=None, transpose_out=False, t_block=0, epilogue=None):
+    def spmm(self, g, X, Y, n_cols=None, transpose_out=False, t_block=0, t_pad=0, epilogue=None):
         self.calls.append(("spmm", transpose_out, bool(epilogue)))
         L = X.cols if n_cols is None else n_cols
         M = g.n_rows
@@ -119,7 +119,9 @@ class NumpyOps:
                 return
             for h in range(-(-M // tb)):
                 lo, hi = h * tb, min(M, (h + 1) * tb)
-                Y.flat[h * L * tb: h * L * tb + L * (hi - lo)] = v[lo:hi].T.reshape(-1)
+                w = hi - lo + t_pad
+                blk = Y.flat[h * L * (tb + t_pad): h * L * (tb + t_pad) + L * w].reshape(L, w)
+                blk[:, :hi - lo] = v[lo:hi].T
             return
         if epilogue:
             v = self._epilogue(v, epilogue, M, L)

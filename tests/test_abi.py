@@ -42,7 +42,7 @@ def test_argument_checks_need_no_device():
     lib = _lib.load()
     h = ctypes.c_void_p()
     assert lib.simrank_graph_create(0, 4, 0, None, None, None, ctypes.byref(h)) == -1
-    assert lib.simrank_spmm(None, None, 0, 0, None, 0, 0, 0, None, None) == -1
+    assert lib.simrank_spmm(None, None, 0, 0, None, 0, 0, 0, 0, None, None) == -1
     assert lib.simrank_gemm_nt(4, 4, 4, None, 4, None, 4, None, 4, None, None) == -1
 
 

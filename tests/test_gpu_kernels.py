@@ -98,14 +98,17 @@ def test_spmm_transposed_store(ops, panel, shape, tb):
         y = ops.matrix(L, M)
         ops.spmm(g, x, y, transpose_out=True)
         np.testing.assert_allclose(ops.download(y), want.T, rtol=RTOL, atol=1e-30)
-    else:                             # per-destination blocks, contiguous
-        y = ops.matrix(1, M * L, ld=M * L)
-        ops.spmm(g, x, y, transpose_out=True, t_block=tb)
-        flat = ops.download(y).ravel()
-        for h in range(-(-M // tb)):
-            lo, hi = h * tb, min(M, (h + 1) * tb)
-            blk = flat[h * L * tb: h * L * tb + L * (hi - lo)].reshape(L, hi - lo)
-            np.testing.assert_allclose(blk, want[lo:hi].T, rtol=RTOL, atol=1e-30)
+    else:                             # per-destination blocks, contiguous, rows padded
+        for pad in (0, 5):
+            nblk = -(-M // tb)
+            y = ops.matrix(1, nblk * L * (tb + pad), ld=nblk * L * (tb + pad))
+            ops.spmm(g, x, y, transpose_out=True, t_block=tb, t_pad=pad)
+            flat = ops.download(y).ravel()
+            for h in range(nblk):
+                lo, hi = h * tb, min(M, (h + 1) * tb)
+                w = hi - lo + pad
+                blk = flat[h * L * (tb + pad): h * L * (tb + pad) + L * w].reshape(L, w)
+                np.testing.assert_allclose(blk[:, :hi - lo], want[lo:hi].T, rtol=RTOL, atol=1e-30)
 
 
 @pytest.mark.parametrize("aligned", [True, False])
@@ -296,3 +299,24 @@ def test_symmetric_leg2_upper_triangle_and_mirror(ops, n):
                                      eps=0.05, diag_col0=0, symmetric=True))
     ops.set_tuning(triangle=1)
     assert np.array_equal(ops.download(y), full)                  # knob off -> plain path
+
+
+@pytest.mark.parametrize("panel", [0, 32, 128])
+def test_huge_rows_are_split_over_the_workgroup(ops, panel):
+    """Rows of >= 1024 entries: four waves take a quarter each (phase A0); more huge rows in
+    one workgroup than descriptor slots fall back to the owner wave."""
+    M, K, L = 400, 3000, 70
+    heavy = {0: 3000, 5: 1024, 6: 1025, 130: 2047, 131: 1500, 390: 1100}
+    heavy.update({a: 1030 + a for a in range(256, 268)})        # 12 huge rows in one workgroup
+    csr = random_csr(M, K, 20, seed=4, heavy=heavy)
+    X = np.random.default_rng(9).random((K, L)).astype(np.float32)
+    ops.set_tuning(panel=panel)
+    g, x = ops.graph(csr), put(ops, X)
+    want = dense64(csr) @ X.astype(np.float64)
+    y = ops.matrix(M, L)
+    ops.spmm(g, x, y)
+    np.testing.assert_allclose(ops.download(y), want, rtol=RTOL, atol=1e-30)
+    yt = ops.matrix(L, M)
+    ops.spmm(g, x, yt, transpose_out=True)
+    np.testing.assert_allclose(ops.download(yt), want.T, rtol=RTOL, atol=1e-30)
+    ops.set_tuning(panel=0)

@@ -317,3 +317,21 @@ def test_randomized_against_oracle(seed):
             assert est.converged_at == want["k"]
         assert list(got.index) == want["labels"]
         assert_close(got.values, want["S"])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_logical_shards_with_padded_chunks(world, monkeypatch):
+    """The padded chunk layout (t_pad) through the real kernels, forced on at small size and
+    natural at N = 4096 (blocks of 2048 / 1024 rows)."""
+    import simrank_amd.driver as drv
+    g = Golden("SimRankPP_er128")
+    monkeypatch.setattr(drv, "PAD_MIN_ROWS", 1)
+    monkeypatch.setattr(drv, "PAD_MULTIPLE", 1)
+    est, res, text = run_estimator(g, world=LocalWorld(world), mode="sparse")
+    check_against_golden(g, est, res, text)
+    monkeypatch.undo()
+    df = synth.er_directed(4096, 0.003, seed=2)
+    one = SRA.SimRank().fit(df, iterations=4, eps=0, verbose=False, mode="sparse")
+    many = SRA.SimRank().fit(df, iterations=4, eps=0, verbose=False, mode="sparse",
+                             world=LocalWorld(world))
+    np.testing.assert_allclose(many.values, one.values, rtol=1e-6, atol=1e-30)

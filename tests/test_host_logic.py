@@ -145,3 +145,15 @@ def test_reference_class_names_and_signatures():
     assert list(sig.parameters)[:8] == ["self", "data", "AprioriSim1", "AprioriSim2", "C1", "C2",
                                         "lbd1", "lbd2"]
     assert SRA.BAR_LENGTH == 30 and callable(SRA.update_progress)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name", ["SimRank_er64", "AprioriSimRank_er64_asym", "BipartiteSimRank_b5030"])
+def test_virtual_ranks_with_padded_chunks(name, world, monkeypatch):
+    """Exchanged chunk rows padded by 32 floats (what large power-of-two blocks get)."""
+    import simrank_amd.driver as drv
+    monkeypatch.setattr(drv, "PAD_MIN_ROWS", 1)
+    monkeypatch.setattr(drv, "PAD_MULTIPLE", 1)
+    g = Golden(name)
+    est, res, text = run_estimator(g, _factory(), world=LocalWorld(world), mode="sparse")
+    check_against_golden(g, est, res, text)

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Per-rank kernel times of the sharded path, emulated on ONE GPU: LocalWorld(P) runs the P
+column shards one after another (exchange = device copies), so the mean leg time per virtual
+rank is what each of P real GPUs would spend computing; the all-to-all itself is not timed."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from simrank_amd import ingest, synth                           # noqa: E402
+from simrank_amd.driver import LocalWorld, SideSpec, Solver     # noqa: E402
+from simrank_amd.engine import HipOps                           # noqa: E402
+
+ops = HipOps(0)
+w = sys.argv[1] if len(sys.argv) > 1 else "pl32768"
+df = synth.WORKLOADS[w][0]()
+_, csr = ingest.directed(df, False, "from", "to", "weight")
+n = csr.n_rows
+import itertools
+huges = [int(x) for x in os.environ.get('HUGE', '1024').split(',')]
+for huge, P in itertools.product(huges, (1, 8) if len(huges) > 1 else (1, 2, 4, 8)):
+    ops.set_tuning(huge=huge)
+    s = Solver(lambda r: ops, LocalWorld(P), [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
+    s.reset()
+    s.step(0.0)
+    s.enable_timing()
+    for _ in range(3):
+        s.step(0.0)
+    t = s.leg_times()
+    l1, l2 = t["leg1.0"][0], t["leg2.0"][0]
+    xfer = 4.0 * n * n / P * (P - 1) / P
+    print(f"{w} huge={huge} P={P}: per-rank leg1 {l1:.3f} ms, leg2 {l2:.3f} ms -> compute {l1 + l2:.3f} ms/iteration; "
+          f"all-to-all payload per rank {xfer / 2**20:.0f} MiB out + in", flush=True)
+    s.release()
+    del s

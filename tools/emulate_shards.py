@@ -16,7 +16,7 @@ df = synth.WORKLOADS[w][0]()
 _, csr = ingest.directed(df, False, "from", "to", "weight")
 n = csr.n_rows
 import itertools
-huges = [int(x) for x in os.environ.get('HUGE', '1024').split(',')]
+huges = [int(x) for x in os.environ.get('HUGE', '512').split(',')]
 for huge, P in itertools.product(huges, (1, 8) if len(huges) > 1 else (1, 2, 4, 8)):
     ops.set_tuning(huge=huge)
     s = Solver(lambda r: ops, LocalWorld(P), [SideSpec(csr, csr.rowscale, 0.8)], "sparse")

@@ -212,6 +212,35 @@ def main():
         barrier()
         out["converge"] = {"eps": 1e-4, "iterations": k, "seconds": time.perf_counter() - t0}
 
+    if not args.no_extras and world_size == 1 and args.workload != "er8192":
+        # BASELINE.json configs[1] (ER N=8192, p=0.001) next to the headline configuration
+        try:
+            df2 = synth.WORKLOADS["er8192"][0]()
+            _, csr2 = ingest.directed(df2, False, "from", "to", "weight")
+            s2 = Solver(lambda r: ops, world, [SideSpec(csr2, csr2.rowscale, coef)], args.mode)
+            s2.reset()
+            for _ in range(3):
+                s2.step(0.0)
+            s2.enable_timing()
+            ops.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                s2.step(0.0)
+            ops.synchronize()
+            dt = (time.perf_counter() - t0) / 50
+            lt = s2.leg_times()
+            n2, z2 = csr2.n_rows, csr2.nnz
+            out["secondary"] = {
+                "workload": f"er8192: synthetic ER directed graph N={n2} nnz={z2} SimRank C=0.8 fp32",
+                "value": 1.0 / dt, "unit": "iterations/s", "ms_per_step": dt * 1e3,
+                "leg1_ms": lt["leg1.0"][0], "leg2_ms": lt["leg2.0"][0],
+                "leg1_algorithmic_GBps": leg_bytes(n2, n2, n2, z2, False) / (lt["leg1.0"][0] * 1e-3) / 1e9,
+                "leg2_algorithmic_GBps": leg_bytes(n2, n2, n2, z2, True) / (lt["leg2.0"][0] * 1e-3) / 1e9}
+            s2.release()
+            del s2
+        except Exception as e:
+            out["secondary"] = {"error": f"{type(e).__name__}: {e}"}
+
     if not args.no_extras and world_size == 1 and solver.mode == "sparse" and n <= 32768:
         # BASELINE.json's literal recipe — sparse leg 1, dense f32 MFMA GEMM for leg 2 —
         # measured on the same workload so the dispatch decision is a number, not a claim

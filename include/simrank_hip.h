@@ -176,8 +176,7 @@ SIMRANK_API int simrank_gemm_nt(int64_t M, int64_t N, int64_t K, const float* A,
  *      "xcd_map"  0/1  panel -> XCD affinity
  *      "triangle" 0/1  allow the upper-triangle + mirror form when epilogue.symmetric
  *      "stream_nt" 0/1 non-temporal access for streamed-once data
- *      "hub", "tpw"    LDS hub-cache experiment: rows cached per workgroup (read when a
- *                      graph is created; -1/0 = off) and row tiles a wave walks ----------- */
+ *      "huge"     rows of at least this many entries are split over a workgroup's waves ---- */
 SIMRANK_API int simrank_set_tuning(const char* key, int64_t value);
 SIMRANK_API int simrank_get_tuning(const char* key, int64_t* value);
 

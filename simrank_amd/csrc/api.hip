@@ -239,39 +239,7 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
         for (int64_t a = 0; a < n_rows; ++a)
             for (int32_t j = rowptr[a]; j < rowptr[a + 1]; ++j) t_col[cur[col[j]]++] = (int32_t)a;
     }
-    // hub ranking by column frequency (ties: lower index first)
-    std::vector<int32_t> order(static_cast<size_t>(n_cols));
-    for (int64_t i = 0; i < n_cols; ++i) order[i] = (int32_t)i;
-    const int32_t n_rank = (int32_t)std::min<int64_t>(kHubMax, n_cols);
-    auto freq = [&](int32_t i) { return t_rowptr[size_t(i) + 1] - t_rowptr[i]; };
-    std::partial_sort(order.begin(), order.begin() + n_rank, order.end(),
-                      [&](int32_t a, int32_t b) {
-                          return freq(a) != freq(b) ? freq(a) > freq(b) : a < b;
-                      });
     simrank_graph* g = new simrank_graph;
-    std::vector<int32_t> hub_rows(kHubMax, 0), rank_of(static_cast<size_t>(n_cols), -1);
-    {
-        const int steps[5] = {64, 128, 256, 512, 1024};
-        int64_t run = 0;
-        int r = 0;
-        for (int k = 0; k < 5; ++k) {
-            for (; r < std::min(steps[k], n_rank); ++r) run += freq(order[r]);
-            g->hub_cover[k] = nnz ? double(run) / double(nnz) : 0.0;
-        }
-    }
-    // how many rows to cache: the "hub" tuning knob.  Automatic (-1) currently means none:
-    // on MI355X the LDS copy costs more (occupancy, second load kind per slot) than the L2
-    // requests it removes — profiles/sweep_r01_hub.log — so it stays an opt-in experiment.
-    int64_t want = tuning().hub;
-    if (want < 0) want = 0;
-    const int32_t n_hubs = (int32_t)std::min<int64_t>(want, n_rank);
-    for (int32_t r = 0; r < n_hubs; ++r) {
-        hub_rows[r] = order[r];
-        rank_of[order[r]] = r;
-    }
-    std::vector<int32_t> colx(std::max<size_t>(1, size_t(nnz)));
-    for (int64_t j = 0; j < nnz; ++j) colx[j] = rank_of[col[j]] >= 0 ? -1 - rank_of[col[j]] : col[j];
-    g->n_hubs = n_hubs;
     g->n_rows = n_rows;
     g->n_cols = n_cols;
     g->nnz = nnz;
@@ -292,8 +260,6 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
     if (!rc) rc = up((void**)&g->rowscale, rowscale, size_t(n_rows) * 4);
     if (!rc) rc = up((void**)&g->t_rowptr, t_rowptr.data(), size_t(n_cols + 1) * 4);
     if (!rc) rc = up((void**)&g->t_col, t_col.data(), size_t(nnz) * 4);
-    if (!rc) rc = up((void**)&g->colx, colx.data(), size_t(nnz) * 4);
-    if (!rc) rc = up((void**)&g->hub_rows, hub_rows.data(), size_t(kHubMax) * 4);
     if (rc) {
         simrank_graph_destroy(g);
         return rc;
@@ -309,8 +275,6 @@ int simrank_graph_destroy(simrank_graph* g) {
     (void)hipFree(g->rowscale);
     (void)hipFree(g->t_rowptr);
     (void)hipFree(g->t_col);
-    (void)hipFree(g->colx);
-    (void)hipFree(g->hub_rows);
     delete g;
     return SIMRANK_OK;
 }
@@ -339,17 +303,11 @@ int simrank_set_tuning(const char* key, int64_t value) {
     } else if (!strcmp(key, "tile")) {
         SR_REQUIRE(value == 0 || value == 16 || value == 32 || value == 64, "tile must be 0, 16, 32 or 64");
         t.tile = value;
-    } else if (!strcmp(key, "hub")) {
-        SR_REQUIRE(value >= -1 && value <= kHubMax, "hub must be -1 (auto) .. %d", kHubMax);
-        t.hub = value;
     } else if (!strcmp(key, "huge")) {
         SR_REQUIRE(value >= 64 && value <= (1 << 30), "huge must be >= 64");
         t.huge = value;
     } else if (!strcmp(key, "triangle")) {
         t.triangle = value ? 1 : 0;
-    } else if (!strcmp(key, "tpw")) {
-        SR_REQUIRE(value >= 0 && value <= 64, "tpw must be 0 (auto) .. 64");
-        t.tpw = value;
     } else if (!strcmp(key, "stream_nt")) {
         t.stream_nt = value ? 1 : 0;
     } else {
@@ -365,8 +323,6 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     else if (!strcmp(key, "xcd_map")) *value = t.xcd_map;
     else if (!strcmp(key, "stream_nt")) *value = t.stream_nt;
     else if (!strcmp(key, "tile")) *value = t.tile;
-    else if (!strcmp(key, "hub")) *value = t.hub;
-    else if (!strcmp(key, "tpw")) *value = t.tpw;
     else if (!strcmp(key, "triangle")) *value = t.triangle;
     else if (!strcmp(key, "huge")) *value = t.huge;
     else SR_REQUIRE(false, "unknown tuning key '%s'", key);

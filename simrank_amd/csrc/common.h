@@ -35,8 +35,6 @@ struct Tuning {
     int64_t xcd_map = 1;  // panel -> XCD affinity (blockIdx % 8 shares an L2)
     int64_t stream_nt = 1; // non-temporal loads/stores for streamed-once data
     int64_t tile = 0;     // rows per wave tile (16, 32, 64; 0 = automatic)
-    int64_t hub = -1;     // hub rows cached in LDS per workgroup (-1 = automatic, 0 = off)
-    int64_t tpw = 0;      // row tiles a wave walks per workgroup (0 = automatic)
     int64_t huge = 512;   // rows of at least this many entries are split over a workgroup's waves
     int64_t triangle = 1; // allow the upper-triangle + mirror form of a symmetric leg 2
 };
@@ -57,12 +55,4 @@ struct simrank_graph {
     int32_t* t_rowptr = nullptr;  // [n_cols+1]  transposed pattern
     int32_t* t_col = nullptr;     // [nnz]       row ids, ascending per column
     int32_t max_row_nnz = 0;
-    // "hubs": the kHubMax columns that occur most often in the pattern, most frequent
-    // first.  colx is col with hub columns replaced by -1 - rank, so a gather kernel can
-    // serve the first H ranks from an LDS copy of those rows' panel segments.
-    int32_t* colx = nullptr;      // [nnz]
-    int32_t* hub_rows = nullptr;  // [kHubMax] column index of each rank (padded with 0)
-    int32_t n_hubs = 0;           // ranks that exist (<= kHubMax)
-    double hub_cover[5] = {0, 0, 0, 0, 0};  // share of nnz covered by the top 64/128/256/512/1024
 };
-constexpr int kHubMax = 1024;

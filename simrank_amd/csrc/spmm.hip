@@ -33,11 +33,7 @@ __device__ __forceinline__ int64_t imin(int64_t a, int64_t b) { return a < b ? a
 
 struct SpmmArgs {
     const int32_t* rowptr;
-    const int32_t* col;       // neighbour ids; with HUB: hubs encoded as -1 - rank (colx)
-    const int32_t* colx;      // col with hub columns encoded (-1 - slot)
-    const int32_t* hub_rows;  // slot -> row of X
-    int32_t n_hub;            // ranks cached in LDS by each workgroup
-    int32_t tpw;              // row tiles a wave walks
+    const int32_t* col;       // neighbour ids, ascending per row
     int32_t nt;               // non-temporal output stores
     int32_t has_huge;         // the graph has rows of >= huge_len entries
     int32_t huge_len;         // rows this long are split over the waves of a workgroup
@@ -201,20 +197,16 @@ __device__ __forceinline__ void emit_row(const SpmmArgs& p, float* tbuf_wave, in
     }
 }
 
-// Neighbour ids >= 0 are rows of X; with HUB, ids < 0 are -1 - slot of the workgroup's LDS
-// copy of a hub row's panel segment.  A batch issues all its global loads, then all its LDS
-// reads, then adds in neighbour order: the hub cache changes where bytes come from, never
-// the arithmetic or its order.
 constexpr int kMaxHuge = 8;    // ... at most this many per workgroup and tile round
 
 // Sum of the X segments of the neighbours at CSR positions [s, e): the G lane groups take
 // them round-robin, UNROLL loads in flight each; partial sums combined by shuffles in a
 // fixed order.  Every lane ends with the total of its VEC columns.
-template <int VEC, int LPR, bool HUB>
+template <int VEC, int LPR>
 __device__ __forceinline__ void gather_range(const SpmmArgs& p, const float* __restrict__ Xc,
-                                             const float* hub, int s, int e, int lane, int g,
-                                             int q, bool col_active, float (&acc)[VEC]) {
-    constexpr int PW = VEC * LPR, G = 64 / LPR, UNROLL = 4;
+                                             int s, int e, int lane, int g, bool col_active,
+                                             float (&acc)[VEC]) {
+    constexpr int G = 64 / LPR, UNROLL = 4;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
     for (int base = s; base < e; base += 64) {
@@ -238,12 +230,6 @@ __device__ __forceinline__ void gather_range(const SpmmArgs& p, const float* __r
                     for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
                 }
             }
-            if constexpr (HUB) {
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u)
-                    if (idx[u] < 0 && idx[u] != kSkip)
-                        vload<VEC>(v[u], hub + (-1 - idx[u]) * PW + q * VEC);
-            }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
@@ -256,7 +242,7 @@ __device__ __forceinline__ void gather_range(const SpmmArgs& p, const float* __r
         for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off);
 }
 
-template <int VEC, int LPR, int MODE, int RT, bool HUB>
+template <int VEC, int LPR, int MODE, int RT>
 __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
     static_assert(RT <= 64, "one lane per tile row");
     static_assert(MODE != kSym || VEC * LPR == RT, "mirrored tiles are square");
@@ -265,7 +251,7 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
     constexpr int PW = VEC * LPR;            // panel width in floats
     constexpr int G = 64 / LPR;              // lane groups = rows (or neighbours) in flight
     constexpr int JU = LPR < 8 ? LPR : 8;    // gathers a group keeps in flight
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [hub cache][transpose tiles]
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [wave tiles][huge-row area]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -306,25 +292,12 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
     const int64_t mycol = c0 + int64_t(q) * VEC;
     const bool col_active = mycol < p.L;  // VEC=4: mycol+3 < ldx because ldx % 4 == 0
     const float* __restrict__ Xc = p.X + mycol;
-    const float* hub = smem;
-    float* tbuf_wave = smem + (HUB ? p.n_hub * PW : 0) + (TILE ? wave * PW * (RT + 1) : 0);
+    float* tbuf_wave = smem + (TILE ? wave * PW * (RT + 1) : 0);
     unsigned changed = 0;
 
-    if constexpr (HUB) {
-        // the workgroup's copy of the panel segments of the n_hub most referenced rows
-        for (int h = wave * G + g; h < p.n_hub; h += kWaves * G) {
-            float seg[VEC];
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) seg[i] = 0.f;
-            if (col_active) vload<VEC>(seg, Xc + int64_t(p.hub_rows[h]) * p.ldx);
-            vstore<VEC>(smem + h * PW + q * VEC, seg);
-        }
-        __syncthreads();
-    }
 
-    const int n_tw = HUB ? p.tpw : 1;
-    for (int tw = 0; tw < n_tw; ++tw) {
-    const int64_t row0 = ((int64_t(rt) * n_tw + tw) * kWaves + wave) * RT;
+    {
+    const int64_t row0 = (int64_t(rt) * kWaves + wave) * RT;
     int nrows = int(imin(RT, p.M - row0));  // rows of this wave's tile (may be <= 0)
     bool mirror = false;
     if constexpr (MODE == kSym) {
@@ -361,8 +334,7 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
     // each; the owner adds the four partial sums in wave order and emits the row.
     int posted = 0;
     if (p.has_huge) {
-        int* hmeta = reinterpret_cast<int*>(smem + (HUB ? p.n_hub * PW : 0) +
-                                            (TILE ? kWaves * PW * (RT + 1) : 0));
+        int* hmeta = reinterpret_cast<int*>(smem + (TILE ? kWaves * PW * (RT + 1) : 0));
         float* hpart = reinterpret_cast<float*>(hmeta + 64);
         const int n_huge = __popcll(__ballot(s_len >= p.huge_len));
         if (threadIdx.x == 0) hmeta[0] = 0;
@@ -386,7 +358,7 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
             const int s = hs + wave * chunk;
             const int e = min(hs + hl, s + chunk);
             float part[VEC];
-            gather_range<VEC, LPR, HUB>(p, Xc, hub, s, e, lane, g, q, col_active, part);
+            gather_range<VEC, LPR>(p, Xc, s, e, lane, g, col_active, part);
             if (g == 0) vstore<VEC>(hpart + (i * kWaves + wave) * PW + q * VEC, part);
         }
         __syncthreads();
@@ -415,7 +387,7 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
         const int s = __builtin_amdgcn_readfirstlane(__shfl(s_start, h));
         const int e = s + __builtin_amdgcn_readfirstlane(__shfl(s_len, h));
         float acc[VEC];
-        gather_range<VEC, LPR, HUB>(p, Xc, hub, s, e, lane, g, q, col_active, acc);
+        gather_range<VEC, LPR>(p, Xc, s, e, lane, g, col_active, acc);
         if (g == 0 && col_active)
             emit_row<VEC, LPR, MODE, RT>(p, tbuf_wave, r, row0 + r, q, mycol, acc, changed, mirror);
     }
@@ -474,12 +446,6 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
                             for (int i = 0; i < VEC; ++i) v[j][i] = 0.f;
                         }
                     }
-                    if constexpr (HUB) {
-#pragma unroll
-                        for (int j = 0; j < JU; ++j)
-                            if (idx[j] < 0 && idx[j] != kSkip)
-                                vload<VEC>(v[j], hub + (-1 - idx[j]) * PW + q * VEC);
-                    }
 #pragma unroll
                     for (int j = 0; j < JU; ++j)
 #pragma unroll
@@ -516,7 +482,7 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
             }
         }
     }
-    }  // row tiles of this wave
+    }
 
     if constexpr (!TRANS) {
         if (p.has_ep && p.prev) {
@@ -529,11 +495,11 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
     }
 }
 
-template <int VEC, int LPR, int MODE, int RT, bool HUB>
-static int launch_spmm_impl(SpmmArgs a, hipStream_t st) {
+template <int VEC, int LPR, int MODE, int RT>
+static int launch_spmm(SpmmArgs a, hipStream_t st) {
     constexpr int PW = VEC * LPR;
     a.n_panels = int((a.L + PW - 1) / PW);
-    const int64_t rows_per_block = int64_t(kWaves) * RT * a.tpw;
+    const int64_t rows_per_block = int64_t(kWaves) * RT;
     a.row_tiles = int((a.M + rows_per_block - 1) / rows_per_block);
     const int64_t panels_padded = a.xcd_map ? int64_t((a.n_panels + 7) / 8) * 8 : a.n_panels;
     int64_t grid = panels_padded * a.row_tiles;
@@ -543,30 +509,15 @@ static int launch_spmm_impl(SpmmArgs a, hipStream_t st) {
         grid = 8 * (J * J + J);                       // longest list (b = 2), others padded
     }
     SR_REQUIRE(grid > 0 && grid < (int64_t(1) << 31), "grid of %lld blocks", (long long)grid);
-    const size_t lds = sizeof(float) * (size_t(HUB ? a.n_hub : 0) * PW +
-                                        (MODE != kPlain ? size_t(kWaves) * PW * (RT + 1) : 0) +
+    const size_t lds = sizeof(float) * ((MODE != kPlain ? size_t(kWaves) * PW * (RT + 1) : 0) +
                                         (a.has_huge ? 64 + size_t(kMaxHuge) * kWaves * PW : 0));
-    auto kern = spmm_gather_kernel<VEC, LPR, MODE, RT, HUB>;
+    auto kern = spmm_gather_kernel<VEC, LPR, MODE, RT>;
     if (lds > 48 * 1024)
         SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);
     SR_HIP(hipGetLastError());
     return SIMRANK_OK;
-}
-
-template <int VEC, int LPR, int MODE, int RT>
-static int launch_spmm(SpmmArgs a, hipStream_t st) {
-    if constexpr (VEC == 4) {
-        // the hub copy may take at most 64 KiB of LDS; wider panels run without it
-        if (a.n_hub > 0 && a.n_hub * (VEC * LPR) <= 16384) {
-            a.col = a.colx;
-            return launch_spmm_impl<VEC, LPR, MODE, RT, true>(a, st);
-        }
-    }
-    a.n_hub = 0;
-    a.tpw = 1;
-    return launch_spmm_impl<VEC, LPR, MODE, RT, false>(a, st);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -681,9 +632,7 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
     SpmmArgs a{};
     a.rowptr = g->rowptr;
     a.col = g->col;
-    a.colx = g->colx;
     a.rowscale = g->rowscale;
-    a.hub_rows = g->hub_rows;
     a.huge_len = (int32_t)std::max<int64_t>(kHeavy, tuning().huge);
     a.has_huge = g->max_row_nnz >= a.huge_len ? 1 : 0;
     a.X = X;
@@ -728,11 +677,6 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
     if (panel == 0) panel = transpose_out ? 32 : 64;
     int64_t tile = tuning().tile;
     if (tile == 0) tile = 32;
-    // hub cache: worth its LDS when few rows of X carry a large share of the references
-    int64_t hub = g->n_hubs;       // fixed when the graph was created (colx encodes exactly these)
-    if (!vec_ok || tuning().hub == 0) hub = 0;
-    a.n_hub = (int32_t)hub;
-    a.tpw = (int32_t)(tuning().tpw > 0 ? tuning().tpw : 4);
     a.nt = (int32_t)tuning().stream_nt;
     const bool want_sym = ep && ep->symmetric && tuning().triangle && vec_ok && !transpose_out &&
                           n_cols_x == g->n_rows && ep->diag_col0 == 0 && g->n_rows >= 64;

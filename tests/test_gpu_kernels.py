@@ -248,25 +248,6 @@ def test_epilogue_apply_standalone(ops):
     np.testing.assert_array_equal(ops.download(q), got)
 
 
-def test_hub_cache_is_bit_identical(ops):
-    """Serving the most referenced rows from LDS must not change a single bit."""
-    M, K, L = 700, 500, 200
-    csr = random_csr(M, K, 14, seed=77, heavy={5: 400, 9: 100})
-    X = np.random.default_rng(3).random((K, L)).astype(np.float32)
-    outs = []
-    for hub in (0, 64, 256):
-        ops.set_tuning(hub=hub)
-        g = ops.graph(csr)
-        x, y, yt = put(ops, X), ops.matrix(M, L), ops.matrix(L, M)
-        ops.spmm(g, x, y)
-        ops.spmm(g, x, yt, transpose_out=True)
-        outs.append((ops.download(y), ops.download(yt)))
-    ops.set_tuning(hub=-1)
-    for y, yt in outs[1:]:
-        assert np.array_equal(y, outs[0][0]) and np.array_equal(yt, outs[0][1])
-    np.testing.assert_allclose(outs[0][0], outs[0][1].T, rtol=RTOL, atol=1e-30)
-
-
 @pytest.mark.parametrize("n", [64, 200, 1000, 1031])
 def test_symmetric_leg2_upper_triangle_and_mirror(ops, n):
     """ep.symmetric: only tiles on/above the diagonal are computed, the rest is their mirror

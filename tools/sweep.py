@@ -17,7 +17,7 @@ for w in workloads:
     _, csr = ingest.directed(df, False, "from", "to", "weight")
     print(f"# {w}: N={csr.n_rows} nnz={csr.nnz}", flush=True)
     for hubn, tpw, panel in itertools.product([4, 8], [0], [0]):
-        ops.set_tuning(panel=panel, hub=0, stream_nt=1 if hubn == 4 else 0)
+        ops.set_tuning(panel=panel, stream_nt=1 if hubn == 4 else 0)
         s = Solver(lambda r: ops, LocalWorld(1), [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
         s.reset()
         for _ in range(2):

@@ -47,6 +47,7 @@ struct SpmmArgs {
     int64_t tblock;  // rows per transposed block (TRANS only)
     int64_t tstride; // TRANS, single block: row stride of Y^T (0 = rows in block)
     int64_t tpad;    // TRANS, blocked: padding floats per row of a block
+    int32_t tvec;    // transposed stores may use 16-byte pieces (alignment checked on the host)
     int32_t n_panels;
     int32_t row_tiles;
     int32_t xcd_map;
@@ -468,6 +469,21 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
         const int cols_here = int(imin(PW, p.L - c0));
         const int64_t tb = p.tblock;
         const int rows_out = (TRANS || mirror) ? nrows : 0;
+        if (MODE == kTrans && p.tvec && rows_out == RT && cols_here == PW) {
+            // whole tile, aligned destination: 16-byte stores of 4 consecutive rows
+            for (int x = lane; x < PW * (RT / 4); x += 64) {
+                const int c = x / (RT / 4);
+                const int r = (x % (RT / 4)) * 4;
+                const float* t = tbuf_wave + c * (RT + 1) + r;
+                const float v4[4] = {t[0], t[1], t[2], t[3]};
+                const int64_t a = row0 + r;
+                const int64_t blk = a / tb;
+                const int64_t a_in = a - blk * tb;
+                const int64_t stride = p.tstride ? p.tstride : imin(tb, p.M - blk * tb) + p.tpad;
+                float* dst = p.Y + blk * (p.L * (tb + p.tpad)) + (c0 + c) * stride + a_in;
+                if (p.nt) vstore_nt<4>(dst, v4); else vstore<4>(dst, v4);
+            }
+        } else {
         for (int x = lane; x < PW * RT; x += 64) {
             const int c = x / RT;
             const int r = x % RT;
@@ -480,6 +496,7 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
                 if (p.nt) __builtin_nontemporal_store(tbuf_wave[c * (RT + 1) + r], dst);
                 else *dst = tbuf_wave[c * (RT + 1) + r];
             }
+        }
         }
     }
     }
@@ -644,6 +661,10 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
     a.tblock = (t_block <= 0 || t_block > g->n_rows) ? g->n_rows : t_block;
     a.tstride = (transpose_out && a.tblock == g->n_rows && ldy >= g->n_rows) ? ldy : 0;
     a.tpad = a.tstride ? 0 : t_pad;
+    // 16-byte transposed stores: every 4-row piece of a full tile must be 16-byte aligned
+    // and inside one block (tiles are 16/32/64 rows, blocks start at multiples of t_block)
+    a.tvec = aligned16(Y) && (a.tstride ? a.tstride % 4 == 0
+                                        : (a.tblock % 4 == 0 && a.tpad % 4 == 0 && g->n_rows % 4 == 0));
     a.xcd_map = (int)tuning().xcd_map;
     bool vec_ok = aligned16(X) && ldx % 4 == 0;
     if (!transpose_out) vec_ok = vec_ok && aligned16(Y) && ldy % 4 == 0;

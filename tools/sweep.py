@@ -16,8 +16,8 @@ for w in workloads:
     df = synth.WORKLOADS[w][0]()
     _, csr = ingest.directed(df, False, "from", "to", "weight")
     print(f"# {w}: N={csr.n_rows} nnz={csr.nnz}", flush=True)
-    for hubn, tpw, panel in itertools.product([4, 8], [0], [0]):
-        ops.set_tuning(panel=panel, stream_nt=1 if hubn == 4 else 0)
+    for tile, _unused, panel in itertools.product([16, 32, 64], [0], [16, 32, 64]):
+        ops.set_tuning(panel=panel, tile=tile)
         s = Solver(lambda r: ops, LocalWorld(1), [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
         s.reset()
         for _ in range(2):
@@ -28,7 +28,7 @@ for w in workloads:
         t = s.leg_times()
         l1, l2 = t["leg1.0"][0], t["leg2.0"][0]
         gb = 4e-9 * csr.nnz * csr.n_rows
-        print(f"{w} nt={'on' if hubn == 4 else 'off'} panel={panel:3d}  leg1 {l1:8.3f} ms ({gb / l1:6.2f} TB/s gathered)"
+        print(f"{w} tile={tile:2d} panel={panel:3d}  leg1 {l1:8.3f} ms ({gb / l1:6.2f} TB/s gathered)"
               f"  leg2 {l2:8.3f} ms ({gb / l2:6.2f} TB/s)", flush=True)
         s.release()
         del s

@@ -153,6 +153,16 @@ SIMRANK_API int simrank_epilogue_apply(const float* Q, int64_t ldq, float* Y, in
                                        int64_t n_rows, int64_t n_cols,
                                        const simrank_epilogue* epilogue, void* stream);
 
+/* ---- partial hand-back: the k largest entries of every row of an n_rows x n_cols block,
+ *      largest first, ties by lower column; with exclude_diag the element (a, a - col0) is
+ *      skipped.  idx_out[a*k + j] is a GLOBAL column (col0 + c), -1 when the row has fewer
+ *      than k candidates.  Lets a caller take "the 10 most similar nodes" of every node
+ *      without moving N^2 floats over PCIe (the reference returns the dense matrix,
+ *      SimRank.py:141). */
+SIMRANK_API int simrank_topk_rows(const float* S, int64_t ld, int64_t n_rows, int64_t n_cols,
+                                  int64_t col0, int32_t k, int32_t exclude_diag,
+                                  int32_t* idx_out, float* val_out, void* stream);
+
 /* ---- K7: counts of common in-neighbours, saturated at 255, for columns
  *      [col0, col0+n_cols) of the n_rows x n_rows evidence matrix; only rows with
  *      rowscale > 0 take part (pattern G > 0).  Replaces the int64 matmul of

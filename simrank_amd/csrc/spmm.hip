@@ -581,6 +581,54 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------
+// top-k per row: one wave per row, k rounds of "largest element after the previous pick" in
+// the total order (value descending, column ascending).  Exact and deterministic; the row is
+// re-read k times from L2 (a 128 KiB row stays resident).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ S, int64_t ld,
+                                                        int64_t n_rows, int64_t n_cols,
+                                                        int64_t col0, int k, int exclude_diag,
+                                                        int32_t* idx_out, float* val_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * int64_t(blockDim.x) + threadIdx.x) >> 6;
+    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    for (int64_t a = wave; a < n_rows; a += nwaves) {
+        const float* row = S + a * ld;
+        const int64_t skip = exclude_diag ? a - col0 : -1;
+        float pv = __builtin_inff();   // previous pick: everything is "after" (+inf, -1)
+        int pi = -1;
+        for (int j = 0; j < k; ++j) {
+            float bv = -__builtin_inff();
+            int bi = 0x7fffffff;
+            for (int64_t c = lane; c < n_cols; c += 64) {
+                const float v = row[c];
+                const bool after = (v < pv) || (v == pv && int(c) > pi);
+                const bool better = (v > bv) || (v == bv && int(c) < bi);
+                if (c != skip && after && better) { bv = v; bi = int(c); }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ov = __shfl_xor(bv, off);
+                const int oi = __shfl_xor(bi, off);
+                if ((ov > bv) || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            const bool found = bi != 0x7fffffff;
+            if (lane == 0) {
+                idx_out[a * k + j] = found ? int32_t(col0 + bi) : -1;
+                val_out[a * k + j] = found ? bv : 0.f;
+            }
+            if (!found) {
+                for (int jj = j + 1; jj < k; ++jj)
+                    if (lane == 0) { idx_out[a * k + jj] = -1; val_out[a * k + jj] = 0.f; }
+                break;
+            }
+            pv = bv;
+            pi = bi;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // K7: evidence counts.  One workgroup per row a: LDS counters for a chunk of columns,
 // incremented along every 2-hop path a <- i -> b; saturated to u8 on the way out.
 // ---------------------------------------------------------------------------------------
@@ -760,6 +808,19 @@ int simrank_epilogue_apply(const float* Q, int64_t ldq, float* Y, int64_t ldy, i
         SR_HIP(hipMemsetAsync(a.n_changed, 0, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS, st));
     const int grid = (int)std::min<int64_t>((n_rows * n_cols + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(epilogue_kernel, dim3(grid), dim3(256), 0, st, Q, ldq, Y, ldy, n_rows, n_cols, a);
+    SR_HIP(hipGetLastError());
+    return SIMRANK_OK;
+}
+
+int simrank_topk_rows(const float* S, int64_t ld, int64_t n_rows, int64_t n_cols, int64_t col0,
+                      int32_t k, int32_t exclude_diag, int32_t* idx_out, float* val_out,
+                      void* stream) {
+    SR_REQUIRE(S && idx_out && val_out, "NULL argument");
+    SR_REQUIRE(n_rows > 0 && n_cols > 0 && ld >= n_cols && n_cols < (int64_t(1) << 31) && k > 0 &&
+                   k <= 1024, "bad top-k request");
+    const int grid = (int)std::min<int64_t>((n_rows + 3) / 4, 256 * 8);
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), S, ld, n_rows,
+                       n_cols, col0, k, exclude_diag, idx_out, val_out);
     SR_HIP(hipGetLastError());
     return SIMRANK_OK;
 }

@@ -88,6 +88,9 @@ class LocalWorld:
     def sum_int(self, values):
         return int(sum(values))
 
+    def gather_list(self, per_rank):
+        return [per_rank[r] for r in self.local_ranks]
+
     def gather_columns(self, blocks, n_rows, n_cols):
         if self.size == 1:
             return blocks[0]                     # the one block is the matrix: no host copy
@@ -133,6 +136,12 @@ class TorchWorld:
         if self.dist.get_backend(self.group) == "nccl":
             return torch.device("cuda", torch.cuda.current_device())
         return torch.device("cpu")
+
+    def gather_list(self, per_rank):
+        (mine,) = per_rank.values()
+        parts = [None] * self.size
+        self.dist.all_gather_object(parts, mine, group=self.group)
+        return parts
 
     def gather_columns(self, blocks, n_rows, n_cols):
         (blk,) = blocks.values()
@@ -386,6 +395,28 @@ class Solver:
         """Full similarity matrix j as float64 on the host (every rank gets it)."""
         blocks = {r: self.ops[r].download_f64(self.cur[j][r]) for r in self.world.local_ranks}
         return self.world.gather_columns(blocks, self.n[j], self.n[j])
+
+    def topk(self, j, k, exclude_diag=True):
+        """k most similar columns of every row of similarity matrix j, found on the device
+        shard by shard and merged on the host: (column ids [n, k], values [n, k]); -1 / 0
+        where a row has fewer than k other columns.  Moves n.k.P values instead of n^2."""
+        n = self.n[j]
+        k = int(min(k, max(1, n - (1 if exclude_diag else 0))))
+        per_rank = {}
+        for r in self.world.local_ranks:
+            lo, hi = partition(n, self.world.size, r)
+            if hi > lo:
+                per_rank[r] = self.ops[r].topk_rows(self.cur[j][r], min(k, hi - lo), col0=lo,
+                                                    exclude_diag=exclude_diag)
+            else:
+                per_rank[r] = (np.full((n, 1), -1, np.int32), np.zeros((n, 1), np.float32))
+        parts = self.world.gather_list(per_rank)
+        idx = np.concatenate([p[0] for p in parts], axis=1)
+        val = np.concatenate([p[1] for p in parts], axis=1).astype(np.float64)
+        key = np.where(idx >= 0, val, -np.inf)
+        order = np.lexsort((idx, -key), axis=1)[:, :k]
+        rows = np.arange(n)[:, None]
+        return idx[rows, order], np.where(idx[rows, order] >= 0, val[rows, order], 0.0)
 
     def release(self):
         """Free the work buffers; the evidence counts stay (the ``Evidence`` attributes of

@@ -151,6 +151,20 @@ class HipOps:
                                               m.cols * isz, self.stream), "simrank_memcpy_d2h")
         return out
 
+    def topk_rows(self, m: Matrix, k: int, col0: int = 0, exclude_diag: bool = True):
+        """(global column ids int32 [rows, k], values float32 [rows, k]) of the k largest
+        entries of every row, computed on the device; -1 / 0 where a row has fewer."""
+        k = int(k)
+        idx = self.matrix(m.rows, k, np.int32, ld=k)
+        val = self.matrix(m.rows, k, np.float32, ld=k)
+        check(self.lib.simrank_topk_rows(m.ptr, m.ld, m.rows, m.cols, int(col0), k,
+                                         1 if exclude_diag else 0, idx.ptr, val.ptr, self.stream),
+              "simrank_topk_rows")
+        out = self.download(idx), self.download(val)
+        idx.free()
+        val.free()
+        return out
+
     def download_f64(self, m: Matrix, out: np.ndarray | None = None) -> np.ndarray:
         """float32 device matrix -> float64 host array (pinned, pipelined staging)."""
         if out is None:

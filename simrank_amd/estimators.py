@@ -13,6 +13,9 @@ Extra keyword-only arguments (defaults keep the reference's behaviour):
     mode              "auto" | "sparse" | "dense" | "hybrid" — which kernels run the two legs
     device            HIP device ordinal (default: LOCAL_RANK or 0)
     world             ``driver.LocalWorld`` / ``driver.TorchWorld`` (sharded runs)
+    top_k             return, instead of the dense matrix, a long-format frame (node, rank,
+                      neighbor, similarity) with the k most similar other nodes of every node,
+                      selected on the device (no N x N transfer)
     strict_reference  bipartite classes only; True keeps quirks Q1 (set-order labels on
                       sorted-order data) and Q2 (Evidence_N1 on the group-2 update, a
                       ValueError when n1 != n2); False labels correctly and uses Evidence_N2
@@ -71,6 +74,19 @@ class _Lazy:
         obj.__dict__[self.name] = value
 
 
+def _topk_frame(solver, j, k, labels):
+    """Long-format hand-back: one row per (node, rank) with the k most similar OTHER nodes."""
+    idx, val = solver.topk(j, k)
+    n, kk = idx.shape
+    lab = pd.Index(labels)
+    keep = idx.ravel() >= 0
+    return pd.DataFrame({
+        "node": lab.take(np.repeat(np.arange(n), kk)[keep]),
+        "rank": np.tile(np.arange(1, kk + 1), n)[keep],
+        "neighbor": lab.take(idx.ravel()[keep]),
+        "similarity": val.ravel()[keep]})
+
+
 def _is_symmetric(prior) -> bool:
     """The fused two-gather update needs symmetric iterates; everything the reference builds
     is symmetric except what a user-supplied prior (SimRank.py:453) brings in."""
@@ -112,20 +128,24 @@ class SimRank(object):
     def _side(self, csr, C):
         return SideSpec(csr, csr.rowscale, C)
 
-    def _finish(self, solver, k):
+    def _finish(self, solver, k, top_k=None):
         self.converged_at = k
         self.engine_mode = solver.mode
+        if top_k:
+            out = _topk_frame(solver, 0, top_k, self._order)
+            solver.release()
+            return out
         S = solver.result(0)
         solver.release()
         return pd.DataFrame(S, index=self._order, columns=self._order)
 
     def fit(self, data, C=0.8, weighted=False, from_node_column="from", to_node_column="to",
             weight_column="weight", iterations=100, eps=1e-4, verbose=True, *,
-            mode="auto", device=None, world=None, _ops_factory=None):
+            mode="auto", device=None, world=None, top_k=None, _ops_factory=None):
         csr = self._create_graph(data, weighted, from_node_column, to_node_column, weight_column)
         solver, k = _solve([self._side(csr, C)], iterations, eps, verbose, mode, device, world,
                            _ops_factory)
-        return self._finish(solver, k)
+        return self._finish(solver, k, top_k)
 
 
 class SimRankPP(SimRank):
@@ -155,7 +175,7 @@ class SimRankPP(SimRank):
 
     def _fit_pp(self, data, C, weighted, from_node_column, to_node_column, weight_column,
                 iterations, eps, verbose, mode, device, world, ops_factory, apriori=None,
-                lbd=0.0):
+                lbd=0.0, top_k=None):
         csr = self._create_graph(data, weighted, from_node_column, to_node_column, weight_column)
         talk = verbose and (world is None or world.is_root)
         spec = self._pp_side(csr, C, talk, apriori, lbd)
@@ -175,13 +195,14 @@ class SimRankPP(SimRank):
                        on_iteration=(lambda i: update_progress(i / iterations)) if talk else None,
                        on_converged=announce_converged if talk else None)
         self.Evidence = _lazy_evidence(world, solver.sides[0], csr)
-        return self._finish(solver, k)
+        return self._finish(solver, k, top_k)
 
     def fit(self, data, C=0.8, weighted=False, from_node_column="from", to_node_column="to",
             weight_column="weight", iterations=100, eps=1e-4, verbose=True, *,
-            mode="auto", device=None, world=None, _ops_factory=None):
+            mode="auto", device=None, world=None, top_k=None, _ops_factory=None):
         return self._fit_pp(data, C, weighted, from_node_column, to_node_column, weight_column,
-                            iterations, eps, verbose, mode, device, world, _ops_factory)
+                            iterations, eps, verbose, mode, device, world, _ops_factory,
+                            top_k=top_k)
 
 
 class AprioriSimRank(SimRankPP):
@@ -192,13 +213,14 @@ class AprioriSimRank(SimRankPP):
 
     def fit(self, data, AprioriSim, C=0.8, lbd=0.5, weighted=False, from_node_column="from",
             to_node_column="to", weight_column="weight", iterations=100, eps=1e-4,
-            verbose=True, *, mode="auto", device=None, world=None, _ops_factory=None):
+            verbose=True, *, mode="auto", device=None, world=None, top_k=None,
+            _ops_factory=None):
         if not isinstance(AprioriSim, np.ndarray):
             # the reference fails at np.fill_diagonal for anything but an ndarray
             raise AttributeError(f"'{type(AprioriSim).__name__}' object has no attribute 'flat'")
         return self._fit_pp(data, C, weighted, from_node_column, to_node_column, weight_column,
                             iterations, eps, verbose, mode, device, world, _ops_factory,
-                            apriori=AprioriSim, lbd=lbd)
+                            apriori=AprioriSim, lbd=lbd, top_k=top_k)
 
 
 # ----------------------------------------------------------------------------------------
@@ -228,10 +250,14 @@ class BipartiteSimRank(object):
         self.Graph_N2_N1 = lambda: pd.DataFrame(g21.dense(), index=lab2, columns=lab1)
         return g12, g21
 
-    def _finish(self, solver, k, strict_reference):
+    def _finish(self, solver, k, strict_reference, top_k=None):
         self.converged_at = k
         self.engine_mode = solver.mode
         l1, l2 = self._set_order if strict_reference else map(list, self._sorted)
+        if top_k:
+            out = (_topk_frame(solver, 0, top_k, l1), _topk_frame(solver, 1, top_k, l2))
+            solver.release()
+            return out
         S1, S2 = solver.result(0), solver.result(1)
         solver.release()
         return (pd.DataFrame(S1, index=l1, columns=l1), pd.DataFrame(S2, index=l2, columns=l2))
@@ -239,12 +265,12 @@ class BipartiteSimRank(object):
     def fit(self, data, C1=0.8, C2=0.8, weighted=False, node_group1_column="user",
             node_group2_column="item", weight_column="weight", iterations=100, eps=1e-4,
             verbose=True, *, mode="auto", device=None, world=None, strict_reference=True,
-            _ops_factory=None):
+            top_k=None, _ops_factory=None):
         g12, g21 = self._create_graph(data, weighted, node_group1_column, node_group2_column,
                                       weight_column)
         specs = [SideSpec(g12, g12.rowscale, C1), SideSpec(g21, g21.rowscale, C2)]
         solver, k = _solve(specs, iterations, eps, verbose, mode, device, world, _ops_factory)
-        return self._finish(solver, k, strict_reference)
+        return self._finish(solver, k, strict_reference, top_k)
 
 
 class BipartiteSimRankPP(SimRankPP):
@@ -268,7 +294,7 @@ class BipartiteSimRankPP(SimRankPP):
 
     def _fit_bpp(self, data, C1, C2, weighted, node_group1_column, node_group2_column,
                  weight_column, iterations, eps, verbose, mode, device, world, strict_reference,
-                 ops_factory, priors=(None, None), lbds=(0.0, 0.0)):
+                 ops_factory, priors=(None, None), lbds=(0.0, 0.0), top_k=None):
         g12, g21 = self._create_graph(data, weighted, node_group1_column, node_group2_column,
                                       weight_column)
         world = world or LocalWorld(1)
@@ -303,15 +329,15 @@ class BipartiteSimRankPP(SimRankPP):
         self.Evidence_N1 = _lazy_evidence(world, s1, g12)
         self.Evidence_N2 = ((lambda: _host_evidence(g21)) if strict_reference
                             else _lazy_evidence(world, s2, g21))
-        return self._finish(solver, k, strict_reference)
+        return self._finish(solver, k, strict_reference, top_k)
 
     def fit(self, data, C1=0.8, C2=0.8, weighted=False, node_group1_column="user",
             node_group2_column="item", weight_column="weight", iterations=100, eps=1e-4,
             verbose=True, *, mode="auto", device=None, world=None, strict_reference=True,
-            _ops_factory=None):
+            top_k=None, _ops_factory=None):
         return self._fit_bpp(data, C1, C2, weighted, node_group1_column, node_group2_column,
                              weight_column, iterations, eps, verbose, mode, device, world,
-                             strict_reference, _ops_factory)
+                             strict_reference, _ops_factory, top_k=top_k)
 
 
 class BipartitleAprioriSimRank(BipartiteSimRankPP):
@@ -324,14 +350,14 @@ class BipartitleAprioriSimRank(BipartiteSimRankPP):
     def fit(self, data, AprioriSim1, AprioriSim2, C1=0.8, C2=0.8, lbd1=0.5, lbd2=0.5,
             weighted=False, node_group1_column="user", node_group2_column="item",
             weight_column="weight", iterations=100, eps=1e-4, verbose=True, *, mode="auto",
-            device=None, world=None, strict_reference=True, _ops_factory=None):
+            device=None, world=None, strict_reference=True, top_k=None, _ops_factory=None):
         for a in (AprioriSim1, AprioriSim2):
             if not isinstance(a, np.ndarray):
                 raise AttributeError(f"'{type(a).__name__}' object has no attribute 'flat'")
         return self._fit_bpp(data, C1, C2, weighted, node_group1_column, node_group2_column,
                              weight_column, iterations, eps, verbose, mode, device, world,
                              strict_reference, _ops_factory, priors=(AprioriSim1, AprioriSim2),
-                             lbds=(lbd1, lbd2))
+                             lbds=(lbd1, lbd2), top_k=top_k)
 
 
 def _lazy_evidence(world, sides, csr):

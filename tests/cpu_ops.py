@@ -89,6 +89,17 @@ class NumpyOps:
             return out
         return r
 
+    def topk_rows(self, m, k, col0=0, exclude_diag=True):
+        a = m.a[:, :m.cols].astype(np.float32)
+        idx = np.full((m.rows, k), -1, dtype=np.int32)
+        val = np.zeros((m.rows, k), dtype=np.float32)
+        for r in range(m.rows):
+            cols = [c for c in range(m.cols) if not (exclude_diag and c == r - col0)]
+            cols.sort(key=lambda c: (-a[r, c], c))
+            for j, c in enumerate(cols[:k]):
+                idx[r, j], val[r, j] = col0 + c, a[r, c]
+        return idx, val
+
     def synchronize(self):
         pass
 

@@ -301,3 +301,22 @@ def test_huge_rows_are_split_over_the_workgroup(ops, panel):
     ops.spmm(g, x, yt, transpose_out=True)
     np.testing.assert_allclose(ops.download(yt), want.T, rtol=RTOL, atol=1e-30)
     ops.set_tuning(panel=0)
+
+
+@pytest.mark.parametrize("shape,k,c0", [((300, 257), 7, 0), ((64, 64), 63, 0), ((100, 40), 5, 30),
+                                        ((50, 3), 10, 0), ((1000, 1000), 16, 0)])
+def test_topk_rows(ops, shape, k, c0):
+    """k largest entries per row, largest first, ties by lower column, diagonal skipped,
+    -1 padding when a row has fewer candidates — against a NumPy sort."""
+    rows, cols = shape
+    rng = np.random.default_rng(rows + k)
+    h = rng.integers(0, 50, size=(rows, cols)).astype(np.float32) / 50      # many ties
+    m = put(ops, h)
+    idx, val = ops.topk_rows(m, k, col0=c0, exclude_diag=True)
+    for r in range(rows):
+        cand = [c for c in range(cols) if c != r - c0]
+        cand.sort(key=lambda c: (-h[r, c], c))
+        want = cand[:k]
+        assert list(idx[r, :len(want)]) == [c0 + c for c in want]
+        assert (idx[r, len(want):] == -1).all()
+        np.testing.assert_array_equal(val[r, :len(want)], h[r, want])

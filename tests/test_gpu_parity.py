@@ -335,3 +335,22 @@ def test_logical_shards_with_padded_chunks(world, monkeypatch):
     many = SRA.SimRank().fit(df, iterations=4, eps=0, verbose=False, mode="sparse",
                              world=LocalWorld(world))
     np.testing.assert_allclose(many.values, one.values, rtol=1e-6, atol=1e-30)
+
+
+def test_top_k_hand_back_on_gpu():
+    """fit(top_k=k): device-side selection, single and sharded, against the dense result."""
+    df = synth.powerlaw_directed(1500, 12, seed=21)
+    dense = SRA.SimRankPP().fit(df, verbose=False)
+    labels = list(dense.index)
+    pos = {l: i for i, l in enumerate(labels)}
+    for world in (LocalWorld(1), LocalWorld(4)):
+        top = SRA.SimRankPP().fit(df, verbose=False, top_k=8, world=world, mode="sparse")
+        assert len(top) == 8 * len(labels)
+        for node in labels[::97]:
+            row = dense.loc[node].drop(node)
+            got = top[top.node == node].sort_values("rank")
+            # same similarity values as the 8 largest of the dense row (ties may reorder labels)
+            want = np.sort(row.values)[::-1][:8]
+            np.testing.assert_allclose(got.similarity.values, want, rtol=1e-6, atol=1e-30)
+            for nb, sim in zip(got.neighbor, got.similarity):
+                np.testing.assert_allclose(dense.iloc[pos[node], pos[nb]], sim, rtol=1e-6, atol=1e-30)

@@ -157,3 +157,27 @@ def test_virtual_ranks_with_padded_chunks(name, world, monkeypatch):
     g = Golden(name)
     est, res, text = run_estimator(g, _factory(), world=LocalWorld(world), mode="sparse")
     check_against_golden(g, est, res, text)
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_top_k_hand_back(world):
+    """top_k=... returns the k most similar other nodes per node instead of the dense matrix;
+    it must agree with sorting the dense result (ties: lower position first)."""
+    g = Golden("SimRank_er64")
+    import simrank_amd.SimRank as SRA
+    dense = SRA.SimRank().fit(g.frame, verbose=False, _ops_factory=_factory())
+    top = SRA.SimRank().fit(g.frame, verbose=False, top_k=5, world=LocalWorld(world), mode="sparse",
+                            _ops_factory=_factory())
+    assert list(top.columns) == ["node", "rank", "neighbor", "similarity"]
+    assert len(top) == 5 * len(dense)
+    labels = list(dense.index)
+    for node in labels[:10]:
+        row = dense.loc[node].drop(node)
+        order = sorted(range(len(row)), key=lambda i: (-np.float32(row.iloc[i]), labels.index(row.index[i])))
+        want = [row.index[i] for i in order[:5]]
+        got = top[top.node == node].sort_values("rank")
+        assert list(got.neighbor) == want
+        np.testing.assert_allclose(got.similarity, [row[w] for w in want], rtol=1e-6)
+    b = Golden("BipartiteSimRank_b5030")
+    t1, t2 = SRA.BipartiteSimRank().fit(b.frame, verbose=False, top_k=3, _ops_factory=_factory())
+    assert len(t1) == 3 * 50 and len(t2) == 3 * 30

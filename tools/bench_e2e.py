@@ -23,3 +23,12 @@ for w in sys.argv[1:] or ["bts300", "er8192", "pl32768"]:
           f"fit() end to end {t_fit:.3f} s for {est.converged_at} iterations "
           f"({S.values.nbytes / 2**30:.2f} GiB float64 result)", flush=True)
     del S
+
+if "--topk" in sys.argv or True:
+    df = synth.WORKLOADS["pl32768"][0]()
+    for rep in range(2):
+        t0 = time.perf_counter()
+        top = SRA.SimRank().fit(df, verbose=False, top_k=10)
+        t_fit = time.perf_counter() - t0
+    print(f"pl32768 fit(top_k=10): {t_fit:.3f} s end to end, {len(top)} rows "
+          f"({top.memory_usage(deep=True).sum() / 2**20:.0f} MiB instead of 8 GiB)", flush=True)

@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--panel", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--stages", type=int, default=4,
+                    help="pipeline depth of the sharded exchange (all_to_all_single calls per update)")
     ap.add_argument("--force-dist", action="store_true",
                     help="use the torch.distributed world even with one rank (exercises RCCL)")
     args = ap.parse_args()
@@ -118,7 +120,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29555")
         dist.init_process_group("nccl", rank=rank, world_size=world_size,
                                 device_id=torch.device("cuda", local_rank))
-        world = TorchWorld()
+        world = TorchWorld(stages=args.stages, stage_single_rank=args.force_dist)
     else:
         world = LocalWorld(1)
 
@@ -166,7 +168,8 @@ def main():
         "config": {"workload": f"{args.workload}: synthetic directed graph N={n} nnz={nnz} "
                                f"SimRank C=0.8 fp32, eps test every iteration",
                    "N": n, "nnz": nnz, "mode": solver.mode,
-                   "sharding": f"S column-sharded over {world_size} rank(s), all-to-all per update"},
+                   "sharding": f"S column-sharded over {world_size} rank(s), all-to-all per update"
+                               + (f" in {world.stages} overlapped stages" if use_dist else "")},
     }
     if solver.mode == "sparse":
         l1 = legs["leg1.0"][0]

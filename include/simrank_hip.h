@@ -82,6 +82,7 @@ SIMRANK_API int simrank_stream_synchronize(void* stream);
 SIMRANK_API int simrank_event_create(void** event);
 SIMRANK_API int simrank_event_destroy(void* event);
 SIMRANK_API int simrank_event_record(void* event, void* stream);
+SIMRANK_API int simrank_event_synchronize(void* event);   /* host waits for the recorded point */
 /* waits for `stop`, then returns the time between the two records in milliseconds */
 SIMRANK_API int simrank_event_elapsed_ms(void* start, void* stop, float* ms);
 

@@ -60,6 +60,7 @@ PROTOTYPES = {
     "simrank_event_create": [_pvp],
     "simrank_event_destroy": [_vp],
     "simrank_event_record": [_vp, _vp],
+    "simrank_event_synchronize": [_vp],
     "simrank_event_elapsed_ms": [_vp, _vp, C.POINTER(C.c_float)],
     "simrank_graph_create": [_i64, _i64, _i64, _vp, _vp, _vp, _pvp],
     "simrank_graph_destroy": [_vp],

@@ -198,6 +198,10 @@ int simrank_event_record(void* event, void* stream) {
     SR_HIP(hipEventRecord((hipEvent_t)event, as_stream(stream)));
     return SIMRANK_OK;
 }
+int simrank_event_synchronize(void* event) {
+    SR_HIP(hipEventSynchronize((hipEvent_t)event));
+    return SIMRANK_OK;
+}
 int simrank_event_elapsed_ms(void* start, void* stop, float* ms) {
     SR_REQUIRE(ms, "ms is NULL");
     SR_HIP(hipEventSynchronize((hipEvent_t)stop));

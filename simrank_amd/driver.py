@@ -28,6 +28,7 @@ from .ingest import CSR, partition
 
 DENSE_THRESHOLD = 0.05   # density above which the MFMA GEMM legs beat the gather legs
 PAD_MIN_ROWS, PAD_MULTIPLE = 1024, 256   # when exchanged chunk rows get padded (row_pad)
+STAGE_ALIGN = 32         # stage widths of a pipelined exchange are multiples of this (panels)
 
 
 # --------------------------------------------------------------------------------------
@@ -52,6 +53,8 @@ class Xfer:
     mb: int
     nrows: int                 # rows of this rank (width of recv)
     pad: int = 0               # floats appended to every row of a chunk (see row_pad)
+    stages: list | None = None  # pipelined exchange: per stage (x_col0, ncols, send_off, recv_off,
+                                # in_splits, out_splits, event); None = one all-to-all
     send_t: object = None      # torch views of send / recv (TorchWorld)
     recv_t: object = None
 
@@ -65,6 +68,40 @@ def row_pad(block_rows: int) -> int:
     return 32 if block_rows >= PAD_MIN_ROWS and block_rows % PAD_MULTIPLE == 0 else 0
 
 
+def stage_widths(n_cols: int, n_stages: int):
+    """Column counts of the stages a rank cuts its n_cols product columns into: equal
+    pieces rounded up to 32 columns (whole gather panels), the last one shorter or empty."""
+    q = -(-n_cols // n_stages)
+    q = -(-q // STAGE_ALIGN) * STAGE_ALIGN
+    return [max(0, min(q, n_cols - s * q)) for s in range(n_stages)]
+
+
+def staged_row_order(k_dim: int, world: int, n_stages: int) -> np.ndarray:
+    """Row order of the leg-2 operand when the exchange runs in stages: stage by stage, inside
+    a stage rank by rank (what consecutive all_to_all_single calls deliver).  Returns
+    perm with perm[k] = row of the operand that holds global row k."""
+    widths = [stage_widths(partition(k_dim, world, h)[1] - partition(k_dim, world, h)[0], n_stages)
+              for h in range(world)]
+    perm = np.empty(k_dim, dtype=np.int64)
+    row = 0
+    for s in range(n_stages):
+        for h in range(world):
+            lo = partition(k_dim, world, h)[0] + sum(widths[h][:s])
+            n = widths[h][s]
+            perm[lo:lo + n] = np.arange(row, row + n)
+            row += n
+    return perm
+
+
+def permute_columns(csr: CSR, perm: np.ndarray) -> CSR:
+    """The same pattern with column j renamed perm[j] (columns re-sorted inside each row)."""
+    rows = np.repeat(np.arange(csr.n_rows, dtype=np.int64), np.diff(csr.rowptr))
+    key = rows * csr.n_cols + perm[csr.col]
+    key.sort()
+    return CSR(csr.n_rows, csr.n_cols, csr.rowptr, (key % csr.n_cols).astype(np.int32),
+               csr.rowscale)
+
+
 class LocalWorld:
     """P virtual ranks inside this process (P = 1 is the ordinary single-GPU case)."""
 
@@ -72,6 +109,7 @@ class LocalWorld:
         self.size = int(size)
         self.local_ranks = list(range(self.size))
         self.is_root = True
+        self.stages = 1
 
     def exchange(self, parts):
         """All-to-all of the transposed tiles between the virtual ranks (device copies)."""
@@ -105,7 +143,10 @@ class TorchWorld:
     """One rank per process over torch.distributed (backend "nccl" = RCCL over xGMI on the
     GPU box; "gloo" in the CPU tests)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, stages: int = 4, stage_single_rank: bool = False):
+        """``stages``: leg 1 is cut into that many column slices, each exchanged by its own
+        all_to_all_single as soon as its kernel has finished, so the transfers over xGMI overlap
+        the remaining leg-1 kernels (1 = one exchange after the whole leg)."""
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -113,9 +154,24 @@ class TorchWorld:
         self.rank = dist.get_rank(group)
         self.local_ranks = [self.rank]
         self.is_root = self.rank == 0
+        # (a one-rank world stages only on request: that is how the path is exercised on one GPU)
+        self.stages = max(1, int(stages)) if (self.size > 1 or stage_single_rank) else 1
 
     def exchange(self, parts):
         (x,) = parts
+        if x.stages is not None:
+            works = []
+            for st in x.stages:
+                x.ops.event_synchronize(st["event"])      # this slice's kernel has finished
+                if sum(st["in_splits"]) or sum(st["out_splits"]):
+                    works.append(self.dist.all_to_all_single(
+                        x.recv_t[st["recv_off"]:st["recv_off"] + sum(st["out_splits"])],
+                        x.send_t[st["send_off"]:st["send_off"] + sum(st["in_splits"])],
+                        st["out_splits"], st["in_splits"], group=self.group, async_op=True))
+            for w in works:
+                w.wait()
+            x.ops.collective_done()
+            return
         x.ops.synchronize()                      # the producing leg finished on the engine's stream
         span = lambda n, h: partition(n, self.size, h)[1] - partition(n, self.size, h)[0]
         in_splits = [x.ncols * (span(x.row_dim, h) + x.pad) for h in range(self.size)]
@@ -165,8 +221,10 @@ class SideSpec:
 
 
 class Side:
-    def __init__(self, ops, spec: SideSpec, rank: int, world: int, mode: str, torch_buffers: bool):
+    def __init__(self, ops, spec: SideSpec, rank: int, world: int, mode: str, torch_buffers: bool,
+                 stages: int = 1):
         self.ops, self.spec, self.rank, self.world, self.mode = ops, spec, rank, world, mode
+        self.n_stages = stages if (torch_buffers and mode == "sparse") else 1
         csr = spec.csr
         self.M, self.K = csr.n_rows, csr.n_cols
         self.m_lo, self.m_hi = partition(self.M, world, rank)
@@ -180,6 +238,9 @@ class Side:
             # exchange 1: leg-1 product (M rows x my Lk of K columns) -> K x Lm
             self.x1 = self._xfer(self.Lk, self.k_lo, self.K, torch_buffers)
             self.send, self.recv = self.x1.send, self.x1.recv
+            self.graph2 = self.graph
+            if self.n_stages > 1:
+                self._plan_stages()
             if not self.symmetric and world > 1:
                 # exchange 2: raw leg-2 product (M rows x my Lm of M columns) -> M x Lm
                 self.x2 = self._xfer(self.Lm, self.m_lo, self.M, torch_buffers)
@@ -225,10 +286,39 @@ class Side:
             x.recv = o.matrix(col_dim, self.Lm, ld=recv_ld)
         return x
 
+    def _plan_stages(self):
+        """Cut exchange 1 into stages (see TorchWorld): per stage the slice of my columns, where
+        its chunks sit in the send buffer, where the received slices land, and the split
+        sizes.  Leg 2 then gathers from an operand whose rows are in stage order, so it gets
+        the graph with its columns renamed accordingly."""
+        P, S, x = self.world, self.n_stages, self.x1
+        span = lambda n, h: partition(n, P, h)[1] - partition(n, P, h)[0]
+        widths = [stage_widths(span(self.K, h), S) for h in range(P)]
+        mine = widths[self.rank]
+        chunk_rows = [span(self.M, h) + x.pad for h in range(P)]     # floats per column, per peer
+        x.stages, send_off, recv_off, col0 = [], 0, 0, 0
+        for s in range(S):
+            in_splits = [mine[s] * chunk_rows[h] for h in range(P)]
+            out_splits = [widths[h][s] * (self.Lm + x.pad) for h in range(P)]
+            x.stages.append(dict(x_col0=col0, ncols=mine[s], send_off=send_off, recv_off=recv_off,
+                                 in_splits=in_splits, out_splits=out_splits, event=self.ops.event()))
+            send_off += sum(in_splits)
+            recv_off += sum(out_splits)
+            col0 += mine[s]
+        perm = staged_row_order(self.K, P, S)
+        self.graph2 = self.ops.graph(permute_columns(self.spec.csr, perm), self.spec.rowscale)
+
     # S_in: K x Lk block of the input similarity
     def leg1(self, S_in):
         o = self.ops
-        if self.mode == "sparse":
+        if self.mode == "sparse" and self.x1.stages is not None:
+            for st in self.x1.stages:
+                if st["ncols"]:
+                    o.spmm(self.graph, S_in, self.send, n_cols=st["ncols"], transpose_out=True,
+                           t_block=self.mb, t_pad=self.x1.pad, x_col0=st["x_col0"],
+                           y_offset=st["send_off"])
+                o.record(st["event"])
+        elif self.mode == "sparse":
             if self.Lk:
                 o.spmm(self.graph, S_in, self.send, n_cols=self.Lk, transpose_out=True,
                        t_block=self.mb, t_pad=self.x1.pad)
@@ -254,11 +344,11 @@ class Side:
             ep = self._ep(S_prev, eps)
             # one rank holds the whole symmetric matrix: upper triangle + mirror image
             ep["symmetric"] = self.world == 1
-            o.spmm(self.graph, self.recv, S_out, n_cols=self.Lm, epilogue=ep)
+            o.spmm(self.graph2, self.recv, S_out, n_cols=self.Lm, epilogue=ep)
         elif self.world == 1:
-            o.spmm(self.graph, self.recv, S_out, n_cols=self.Lm, transpose_out=True)
+            o.spmm(self.graph2, self.recv, S_out, n_cols=self.Lm, transpose_out=True)
         else:
-            o.spmm(self.graph, self.recv, self.x2.send, n_cols=self.Lm, transpose_out=True,
+            o.spmm(self.graph2, self.recv, self.x2.send, n_cols=self.Lm, transpose_out=True,
                    t_block=self.mb, t_pad=self.x2.pad)
 
     def finish(self, S_prev, S_out, eps):
@@ -301,7 +391,8 @@ class Solver:
                                 all(s.symmetric for s in specs))
         torch_buffers = isinstance(world, TorchWorld)
         self.ops = {r: make_ops(r) for r in world.local_ranks}
-        self.sides = [{r: Side(self.ops[r], sp, r, world.size, self.mode, torch_buffers)
+        self.sides = [{r: Side(self.ops[r], sp, r, world.size, self.mode, torch_buffers,
+                               getattr(world, "stages", 1))
                        for r in world.local_ranks} for sp in specs]
         # similarity matrices: index j -> size n_j; S_j is n_j x (block of n_j), ping-pong
         if self.bipartite:
@@ -436,6 +527,9 @@ class Solver:
                         x.send.free()
                         x.recv.free()
                         x.send_t = x.recv_t = None
+                        for st in x.stages or []:
+                            s.ops.event_destroy(st["event"])
+                        x.stages = None
 
     def leg_times(self):
         """Mean milliseconds per tag from the recorded events."""

@@ -216,11 +216,13 @@ class HipOps:
 
     def spmm(self, g: Graph, X: Matrix, Y: Matrix, n_cols: int | None = None,
              transpose_out: bool = False, t_block: int = 0, t_pad: int = 0,
-             epilogue: dict | None = None):
-        """Y = diag(rowscale).A.X (+ fused epilogue); see simrank_spmm."""
+             epilogue: dict | None = None, x_col0: int = 0, y_offset: int = 0):
+        """Y = diag(rowscale).A.X (+ fused epilogue); see simrank_spmm.  ``x_col0`` selects a
+        column sub-block of X (first column), ``y_offset`` an element offset into Y."""
         n_cols = X.cols if n_cols is None else n_cols
         ep = self._epilogue(**epilogue) if epilogue is not None else None
-        check(self.lib.simrank_spmm(g.handle, X.ptr, X.ld, n_cols, Y.ptr, Y.ld,
+        check(self.lib.simrank_spmm(g.handle, X.ptr + 4 * int(x_col0), X.ld, n_cols,
+                                    Y.ptr + 4 * int(y_offset), Y.ld,
                                     1 if transpose_out else 0, int(t_block), int(t_pad),
                                     C.byref(ep) if ep is not None else None, self.stream),
               "simrank_spmm")
@@ -262,6 +264,9 @@ class HipOps:
 
     def record(self, ev: int):
         check(self.lib.simrank_event_record(C.c_void_p(ev), self.stream), "event_record")
+
+    def event_synchronize(self, ev: int):
+        check(self.lib.simrank_event_synchronize(C.c_void_p(ev)), "event_synchronize")
 
     def event_destroy(self, ev: int):
         self.lib.simrank_event_destroy(C.c_void_p(ev))

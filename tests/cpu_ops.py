@@ -115,23 +115,25 @@ class NumpyOps:
             if col0 + c < S.rows:
                 S.a[col0 + c, c] = 1
 
-    def spmm(self, g, X, Y, n_cols=None, transpose_out=False, t_block=0, t_pad=0, epilogue=None):
+    def spmm(self, g, X, Y, n_cols=None, transpose_out=False, t_block=0, t_pad=0, epilogue=None,
+             x_col0=0, y_offset=0):
         self.calls.append(("spmm", transpose_out, bool(epilogue)))
         L = X.cols if n_cols is None else n_cols
         M = g.n_rows
-        x = X.a[:g.n_cols, :L]
+        x = X.a[:g.n_cols, x_col0:x_col0 + L]
+        yflat = Y.flat[y_offset:]
         scale = g.rowscale * (np.float32(epilogue["coef"]) if epilogue else np.float32(1))
         v = (g.pattern @ x) * scale[:, None]
         if transpose_out:
             assert epilogue is None
             tb = M if (t_block <= 0 or t_block > M) else t_block
-            if tb == M and Y.ld >= M and Y.rows > 1:
+            if tb == M and Y.ld >= M and Y.rows > 1 and not y_offset:
                 Y.a[:L, :M] = v.T
                 return
             for h in range(-(-M // tb)):
                 lo, hi = h * tb, min(M, (h + 1) * tb)
                 w = hi - lo + t_pad
-                blk = Y.flat[h * L * (tb + t_pad): h * L * (tb + t_pad) + L * w].reshape(L, w)
+                blk = yflat[h * L * (tb + t_pad): h * L * (tb + t_pad) + L * w].reshape(L, w)
                 blk[:, :hi - lo] = v[lo:hi].T
             return
         if epilogue:
@@ -183,6 +185,12 @@ class NumpyOps:
 
     def event(self):
         return 0
+
+    def event_synchronize(self, ev):
+        pass
+
+    def event_destroy(self, ev):
+        pass
 
     def record(self, ev):
         pass

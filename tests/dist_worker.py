@@ -11,9 +11,12 @@ sys.path.insert(0, ROOT)
 import torch.distributed as dist  # noqa: E402
 
 
-def main(names):
+def main(argv):
+    stages, names = int(argv[0]), argv[1:]
     dist.init_process_group("gloo")
     rank = dist.get_rank()
+    import simrank_amd.driver as drv
+    drv.STAGE_ALIGN = 4              # small fixtures: let the stages really split the columns
     from simrank_amd.driver import TorchWorld
     from tests.conftest import Golden
     from tests.cpu_ops import NumpyOps
@@ -21,7 +24,7 @@ def main(names):
     for name in names:
         g = Golden(name)
         ops = NumpyOps()
-        est, res, text = run_estimator(g, lambda r: ops, world=TorchWorld(), mode="sparse")
+        est, res, text = run_estimator(g, lambda r: ops, world=TorchWorld(stages=stages), mode="sparse")
         if rank == 0:
             check_against_golden(g, est, res, text)
         else:                        # other ranks are silent but hold the same result

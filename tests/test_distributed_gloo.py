@@ -23,12 +23,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_driver_over_gloo(world):
+@pytest.mark.parametrize("world,stages", [(2, 1), (3, 1), (2, 3), (3, 2)])
+def test_sharded_driver_over_gloo(world, stages):
+    """stages > 1: leg 1 cut into column slices, one asynchronous all_to_all_single per slice
+    (the transfer of a slice overlaps the kernels of the next ones on the GPU)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
            f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"),
-           *NAMES]
+           str(stages), *NAMES]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]

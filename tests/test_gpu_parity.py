@@ -231,8 +231,8 @@ def test_integration_stub_of_the_reference_binding():
 
 def test_rccl_world_of_one_rank():
     """bench.py --force-dist under torch.distributed.run with one rank: the TorchWorld path
-    (RCCL init, torch-owned exchange buffers handed to the C ABI, all_to_all_single,
-    all_reduce, stream hand-over) on the single GPU that is available; its result must be the
+    (RCCL init, torch-owned exchange buffers handed to the C ABI, three staged asynchronous
+    all_to_all_single calls per update, all_reduce, stream hand-over) on the single GPU that is available; its result must be the
     same iterations/s order as the local world and the run must exit cleanly."""
     import json
     import os
@@ -242,7 +242,7 @@ def test_rccl_world_of_one_rank():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
            "--master-addr", "127.0.0.1", "--master-port", "29571", os.path.join(root, "bench.py"),
            "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "er8192", "--force-dist",
-           "--no-cpu-baseline"]
+           "--stages", "3", "--no-cpu-baseline"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]

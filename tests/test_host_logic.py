@@ -181,3 +181,19 @@ def test_top_k_hand_back(world):
     b = Golden("BipartiteSimRank_b5030")
     t1, t2 = SRA.BipartiteSimRank().fit(b.frame, verbose=False, top_k=3, _ops_factory=_factory())
     assert len(t1) == 3 * 50 and len(t2) == 3 * 30
+
+
+def test_stage_plan_is_a_permutation():
+    from simrank_amd.driver import stage_widths, staged_row_order, permute_columns
+    for k, world, stages in [(64, 2, 3), (1000, 3, 4), (32768, 8, 4), (5, 2, 4)]:
+        perm = staged_row_order(k, world, stages)
+        assert sorted(perm.tolist()) == list(range(k))
+        for h in range(world):
+            lo, hi = ingest.partition(k, world, h)
+            assert sum(stage_widths(hi - lo, stages)) == hi - lo
+    g = Golden("SimRank_er64")
+    _, csr = ingest.directed(g.frame, False, "from", "to", "weight")
+    perm = staged_row_order(csr.n_cols, 2, 3)
+    p = permute_columns(csr, perm)
+    d = csr.dense()
+    np.testing.assert_array_equal(p.dense()[:, perm], d)

@@ -100,4 +100,6 @@ WORKLOADS = {
     "ml1m": (lambda: bipartite_zipf(6040, 3706, 1_000_209, 1), "bipartite"),
     "pl32768": (lambda: powerlaw_directed(32768, 32, 32768), "directed"),
     "pl65536": (lambda: powerlaw_directed(65536, 32, 65536), "directed"),
+    # not a BASELINE.json configuration: same size and average degree as pl32768 without the skew
+    "er32768": (lambda: er_directed(32768, 32 / 32768, 32768), "directed"),
 }

@@ -1,23 +1,42 @@
 #!/usr/bin/env python3
-"""Leg timings over the tuning knobs (panel width, XCD map, pitch padding).
-usage: python tools/sweep.py [workload ...]   -> table on stdout"""
+"""Leg timings over the tuning knobs of the gather kernel (include/simrank_hip.h,
+simrank_set_tuning).  Used for the profiles/sweep_r01_*.log tables.
+
+    python tools/sweep.py [--workload pl32768] [--panel 32,64] [--tile 16,32,64]
+                          [--xcd 1,0] [--huge 512] [--triangle 1]
+"""
+import argparse
 import itertools
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from simrank_amd import ingest, synth          # noqa: E402
-from simrank_amd.driver import LocalWorld, SideSpec, Solver   # noqa: E402
-from simrank_amd.engine import HipOps           # noqa: E402
+from simrank_amd import ingest, synth                              # noqa: E402
+from simrank_amd.driver import LocalWorld, SideSpec, Solver        # noqa: E402
+from simrank_amd.engine import HipOps                              # noqa: E402
+
+
+def ints(text):
+    return [int(v) for v in text.split(",")]
+
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="er8192,pl32768")
+ap.add_argument("--panel", type=ints, default=[0])
+ap.add_argument("--tile", type=ints, default=[0])
+ap.add_argument("--xcd", type=ints, default=[1])
+ap.add_argument("--huge", type=ints, default=[512])
+ap.add_argument("--triangle", type=ints, default=[1])
+args = ap.parse_args()
 
 ops = HipOps(0)
-workloads = sys.argv[1:] or ["er8192", "pl32768"]
-for w in workloads:
+for w in args.workload.split(","):
     df = synth.WORKLOADS[w][0]()
     _, csr = ingest.directed(df, False, "from", "to", "weight")
     print(f"# {w}: N={csr.n_rows} nnz={csr.nnz}", flush=True)
-    for tile, _unused, panel in itertools.product([16, 32, 64], [0], [16, 32, 64]):
-        ops.set_tuning(panel=panel, tile=tile)
+    for panel, tile, xcd, huge, tri in itertools.product(args.panel, args.tile, args.xcd, args.huge,
+                                                         args.triangle):
+        ops.set_tuning(panel=panel, tile=tile, xcd_map=xcd, huge=huge, triangle=tri)
         s = Solver(lambda r: ops, LocalWorld(1), [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
         s.reset()
         for _ in range(2):
@@ -28,7 +47,8 @@ for w in workloads:
         t = s.leg_times()
         l1, l2 = t["leg1.0"][0], t["leg2.0"][0]
         gb = 4e-9 * csr.nnz * csr.n_rows
-        print(f"{w} tile={tile:2d} panel={panel:3d}  leg1 {l1:8.3f} ms ({gb / l1:6.2f} TB/s gathered)"
-              f"  leg2 {l2:8.3f} ms ({gb / l2:6.2f} TB/s)", flush=True)
+        print(f"{w} panel={panel:3d} tile={tile:2d} xcd={xcd} huge={huge} triangle={tri}  "
+              f"leg1 {l1:8.3f} ms ({gb / l1:6.2f} TB/s gathered)  leg2 {l2:8.3f} ms", flush=True)
         s.release()
         del s
+ops.set_tuning(panel=0, tile=0, xcd_map=1, huge=512, triangle=1)

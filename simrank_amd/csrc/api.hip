@@ -3,6 +3,7 @@
 // (densify + f32 MFMA GEMM).
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -111,14 +112,40 @@ int simrank_download_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
     if (n_rows == 0 || n_cols == 0) return SIMRANK_OK;
     SR_REQUIRE(dst && src, "NULL pointer");
     // staged through pinned slabs so the PCIe copy of slab k+1 overlaps the f32->f64
-    // widening of slab k on the host
-    const int64_t slab_rows = std::max<int64_t>(1, (int64_t(32) << 20) / (n_cols * 4));
+    // widening of slab k on the host.  The two slabs (and their events) are kept for the
+    // life of the process: allocating 64 MB of pinned memory costs more than a small download.
+    struct PinCache {
+        float* pin[2] = {nullptr, nullptr};
+        hipEvent_t done[2];
+        size_t cap = 0;
+        bool have_events = false;
+    };
+    static std::mutex pin_mutex;
+    static PinCache caches[16];                       // one per device (events are per device)
+    std::lock_guard<std::mutex> lock(pin_mutex);
+    int dev = 0;
+    SR_HIP(hipGetDevice(&dev));
+    PinCache& pc = caches[dev & 15];
+    float** pin = pc.pin;
+    hipEvent_t* done = pc.done;
+    size_t& pin_cap = pc.cap;
+    bool& have_events = pc.have_events;
+    const int64_t row_bytes = n_cols * 4;
+    const int64_t slab_rows = std::max<int64_t>(1, std::min<int64_t>(n_rows, (int64_t(32) << 20) / row_bytes));
+    const size_t need = size_t(slab_rows) * row_bytes;
     const int64_t n_threads = std::max<unsigned>(1, std::min<unsigned>(16, std::thread::hardware_concurrency()));
-    float* pin[2] = {nullptr, nullptr};
-    hipEvent_t done[2];
-    for (int i = 0; i < 2; ++i) {
-        SR_HIP(hipHostMalloc((void**)&pin[i], size_t(slab_rows) * n_cols * 4, hipHostMallocDefault));
-        SR_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    if (!have_events) {
+        for (int i = 0; i < 2; ++i) SR_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        have_events = true;
+    }
+    if (need > pin_cap) {
+        for (int i = 0; i < 2; ++i) {
+            if (pin[i]) (void)hipHostFree(pin[i]);
+            pin[i] = nullptr;
+        }
+        pin_cap = 0;
+        for (int i = 0; i < 2; ++i) SR_HIP(hipHostMalloc((void**)&pin[i], need, hipHostMallocPortable));
+        pin_cap = need;
     }
     hipStream_t st = as_stream(stream);
     auto issue = [&](int64_t r0, int buf) -> hipError_t {
@@ -161,10 +188,6 @@ int simrank_download_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
         rc = SIMRANK_ERR_HIP;
     }
     (void)hipStreamSynchronize(st);
-    for (int i = 0; i < 2; ++i) {
-        (void)hipHostFree(pin[i]);
-        (void)hipEventDestroy(done[i]);
-    }
     return rc;
 }
 

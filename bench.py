@@ -239,6 +239,19 @@ def main():
                 "leg1_ms": lt["leg1.0"][0], "leg2_ms": lt["leg2.0"][0],
                 "leg1_algorithmic_GBps": leg_bytes(n2, n2, n2, z2, False) / (lt["leg1.0"][0] * 1e-3) / 1e9,
                 "leg2_algorithmic_GBps": leg_bytes(n2, n2, n2, z2, True) / (lt["leg2.0"][0] * 1e-3) / 1e9}
+            if rank == 0 and not args.no_cpu_baseline:
+                # the oracle on the whole N=8192 workload (no sampling needed at this size)
+                from oracle import simrank_oracle as O
+                G2 = csr2.dense()
+                S2 = s2.result(0)
+                O.update_rows(G2, S2, coef, slice(0, 8))
+                t0 = time.perf_counter()
+                new = O.update(G2, S2, coef)
+                O.converged(S2.copy(), new, 1e-4)
+                t_cpu = time.perf_counter() - t0
+                out["secondary"]["cpu_baseline"] = {
+                    "value": 1.0 / t_cpu, "unit": "iterations/s", "kind": "port",
+                    "sample": f"one full oracle iteration (dense f64, N={n2}): {t_cpu:.2f} s"}
             s2.release()
             del s2
         except Exception as e:

@@ -73,6 +73,11 @@ PROTOTYPES = {
     "simrank_graph_densify": [_vp, _vp, _i64, _vp],
     "simrank_gemm_nt": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64,
                         C.POINTER(Epilogue), _vp],
+    "simrank_lds_supported": [_vp, C.POINTER(_i32)],
+    "simrank_spmm_lds": [_vp, _vp, _i64, _vp, C.POINTER(Epilogue), _vp],
+    "simrank_b4_identity": [_vp, _i64, _vp],
+    "simrank_b4_unpack": [_vp, _i64, _i64, _vp, _i64, _vp],
+    "simrank_b4_pack": [_vp, _i64, _i64, _i64, _i32, _vp, _vp],
     "simrank_set_tuning": [C.c_char_p, _i64],
     "simrank_get_tuning": [C.c_char_p, C.POINTER(_i64)],
 }

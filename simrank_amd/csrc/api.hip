@@ -271,6 +271,8 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
     g->n_cols = n_cols;
     g->nnz = nnz;
     g->max_row_nnz = max_row;
+    g->h_rowptr.assign(rowptr, rowptr + n_rows + 1);
+    g->h_col.assign(col, col + nnz);
     auto up = [&](void** d, const void* h, size_t bytes) -> int {
         size_t alloc = std::max<size_t>(bytes, 16);
         hipError_t e = hipMalloc(d, alloc);
@@ -302,6 +304,7 @@ int simrank_graph_destroy(simrank_graph* g) {
     (void)hipFree(g->rowscale);
     (void)hipFree(g->t_rowptr);
     (void)hipFree(g->t_col);
+    free_lds_plan(g->lds_plan);
     delete g;
     return SIMRANK_OK;
 }

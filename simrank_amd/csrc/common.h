@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <vector>
 
 #include "simrank_hip.h"
 
@@ -45,6 +46,9 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace simrank
 
+struct simrank_lds_plan;   // lds.hip: SELL / long-row packing for the LDS-tiled kernel
+namespace simrank { void free_lds_plan(simrank_lds_plan* p); }
+
 // The graph object: device CSR of the 0/1 pattern + per-row scale, and the transposed
 // pattern (CSC) used by the evidence kernel.
 struct simrank_graph {
@@ -55,4 +59,8 @@ struct simrank_graph {
     int32_t* t_rowptr = nullptr;  // [n_cols+1]  transposed pattern
     int32_t* t_col = nullptr;     // [nnz]       row ids, ascending per column
     int32_t max_row_nnz = 0;
+    // host copies, kept for the lazily built LDS plan (lds.hip)
+    std::vector<int32_t> h_rowptr, h_col;
+    simrank_lds_plan* lds_plan = nullptr;
+    bool lds_plan_failed = false;
 };

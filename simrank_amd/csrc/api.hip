@@ -273,6 +273,58 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
     g->max_row_nnz = max_row;
     g->h_rowptr.assign(rowptr, rowptr + n_rows + 1);
     g->h_col.assign(col, col + nnz);
+
+    // ---- hub plan: the most referenced columns, served from LDS by spmm_hub_kernel.
+    // Automatic: graphs with enough rows to amortise the tile and whose top columns carry at
+    // least a quarter of the entries (power-law in-degrees; uniform graphs stay as they are).
+    std::vector<int32_t> col_dev, col_enc, hub_ids;
+    {
+        const Tuning& tn = tuning();
+        const int nw = tn.hub_waves == 12 ? 12 : (tn.hub_waves == 16 ? 16 : 8);
+        int64_t h = tn.hub < 0 ? hub_capacity(nw) / 32 * 32 : std::min<int64_t>(tn.hub, hub_capacity(nw));
+        h = std::min<int64_t>(h, n_cols);
+        if (h > 0 && nnz > 0 && (tn.hub > 0 || (n_rows >= 4096 && nnz >= 4 * n_rows))) {
+            std::vector<int32_t> order(size_t(n_cols), 0);
+            for (int64_t i = 0; i < n_cols; ++i) order[size_t(i)] = (int32_t)i;
+            auto refs = [&](int32_t c) { return t_rowptr[size_t(c) + 1] - t_rowptr[size_t(c)]; };
+            std::partial_sort(order.begin(), order.begin() + h, order.end(), [&](int32_t x, int32_t y) {
+                const int32_t rx = refs(x), ry = refs(y);
+                return rx != ry ? rx > ry : x < y;
+            });
+            int64_t covered = 0;
+            for (int64_t k = 0; k < h; ++k) covered += refs(order[size_t(k)]);
+            const double share = double(covered) / double(nnz);
+            if (tn.hub > 0 || share >= 0.25) {
+                std::vector<int32_t> slot(size_t(n_cols), -1);
+                hub_ids.assign(order.begin(), order.begin() + h);
+                for (int64_t k = 0; k < h; ++k) slot[size_t(hub_ids[size_t(k)])] = (int32_t)k;
+                col_dev.resize(size_t(nnz));
+                col_enc.resize(size_t(nnz));
+                std::vector<int32_t> hubs;
+                for (int64_t a = 0; a < n_rows; ++a) {
+                    hubs.clear();
+                    for (int32_t j = rowptr[a]; j < rowptr[a + 1]; ++j)
+                        if (slot[size_t(col[j])] >= 0) hubs.push_back(slot[size_t(col[j])]);
+                    std::sort(hubs.begin(), hubs.end());
+                    int32_t w = rowptr[a];
+                    for (int32_t sl : hubs) {
+                        col_dev[size_t(w)] = hub_ids[size_t(sl)];
+                        col_enc[size_t(w)] = -1 - sl;
+                        ++w;
+                    }
+                    for (int32_t j = rowptr[a]; j < rowptr[a + 1]; ++j)
+                        if (slot[size_t(col[j])] < 0) {
+                            col_dev[size_t(w)] = col[j];
+                            col_enc[size_t(w)] = col[j];
+                            ++w;
+                        }
+                }
+                g->hub_n = (int32_t)h;
+                g->hub_waves = nw;
+                g->hub_share = share;
+            }
+        }
+    }
     auto up = [&](void** d, const void* h, size_t bytes) -> int {
         size_t alloc = std::max<size_t>(bytes, 16);
         hipError_t e = hipMalloc(d, alloc);
@@ -285,7 +337,9 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
         return SIMRANK_OK;
     };
     int rc = up((void**)&g->rowptr, rowptr, size_t(n_rows + 1) * 4);
-    if (!rc) rc = up((void**)&g->col, col, size_t(nnz) * 4);
+    if (!rc) rc = up((void**)&g->col, g->hub_n ? col_dev.data() : col, size_t(nnz) * 4);
+    if (!rc && g->hub_n) rc = up((void**)&g->col_enc, col_enc.data(), size_t(nnz) * 4);
+    if (!rc && g->hub_n) rc = up((void**)&g->hub_ids, hub_ids.data(), size_t(g->hub_n) * 4);
     if (!rc) rc = up((void**)&g->rowscale, rowscale, size_t(n_rows) * 4);
     if (!rc) rc = up((void**)&g->t_rowptr, t_rowptr.data(), size_t(n_cols + 1) * 4);
     if (!rc) rc = up((void**)&g->t_col, t_col.data(), size_t(nnz) * 4);
@@ -304,6 +358,11 @@ int simrank_graph_destroy(simrank_graph* g) {
     (void)hipFree(g->rowscale);
     (void)hipFree(g->t_rowptr);
     (void)hipFree(g->t_col);
+    (void)hipFree(g->col_enc);
+    (void)hipFree(g->hub_ids);
+    (void)hipFree(g->huge_rows);
+    (void)hipFree(g->col_s);
+    (void)hipFree(g->col_enc_s);
     free_lds_plan(g->lds_plan);
     delete g;
     return SIMRANK_OK;
@@ -340,6 +399,15 @@ int simrank_set_tuning(const char* key, int64_t value) {
         t.triangle = value ? 1 : 0;
     } else if (!strcmp(key, "stream_nt")) {
         t.stream_nt = value ? 1 : 0;
+    } else if (!strcmp(key, "hub")) {
+        SR_REQUIRE(value >= -1 && value <= 1280, "hub must be -1 (automatic), 0 (off) or a row count");
+        t.hub = value;
+    } else if (!strcmp(key, "hub_waves")) {
+        SR_REQUIRE(value == 8 || value == 12 || value == 16, "hub_waves must be 8, 12 or 16");
+        t.hub_waves = value;
+    } else if (!strcmp(key, "hub_rounds")) {
+        SR_REQUIRE(value >= 0 && value <= 4096, "hub_rounds must be 0 (automatic) .. 4096");
+        t.hub_rounds = value;
     } else {
         SR_REQUIRE(false, "unknown tuning key '%s'", key);
     }
@@ -355,6 +423,9 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     else if (!strcmp(key, "tile")) *value = t.tile;
     else if (!strcmp(key, "triangle")) *value = t.triangle;
     else if (!strcmp(key, "huge")) *value = t.huge;
+    else if (!strcmp(key, "hub")) *value = t.hub;
+    else if (!strcmp(key, "hub_waves")) *value = t.hub_waves;
+    else if (!strcmp(key, "hub_rounds")) *value = t.hub_rounds;
     else SR_REQUIRE(false, "unknown tuning key '%s'", key);
     return SIMRANK_OK;
 }

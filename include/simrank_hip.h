@@ -164,6 +164,22 @@ SIMRANK_API int simrank_topk_rows(const float* S, int64_t ld, int64_t n_rows, in
                                   int64_t col0, int32_t k, int32_t exclude_diag,
                                   int32_t* idx_out, float* val_out, void* stream);
 
+/* The same with the ids of the block's columns given explicitly (device array col_ids[n_cols];
+ * NULL = col0 + c): ids are what is reported and what breaks ties.  For callers that keep the
+ * matrix in a permuted node order (the host side sorts nodes by row length). */
+SIMRANK_API int simrank_topk_rows_ids(const float* S, int64_t ld, int64_t n_rows, int64_t n_cols,
+                                      int64_t col0, const int32_t* col_ids, int32_t k,
+                                      int32_t exclude_diag, int32_t* idx_out, float* val_out,
+                                      void* stream);
+
+/* ---- dst[i][j] = src[row_idx[i]][col_idx[j]] for an n_rows x n_cols destination; a NULL
+ *      index list is the identity.  elem_bytes 4 (f32) or 1 (u8 evidence counts).  Moves
+ *      priors into, and results out of, the permuted node order; the reference has no
+ *      counterpart (it keeps list(self.Nodes) order throughout, SimRank.py:43,141). */
+SIMRANK_API int simrank_permute(const void* src, int64_t ld_src, void* dst, int64_t ld_dst,
+                                int64_t n_rows, int64_t n_cols, const int32_t* row_idx,
+                                const int32_t* col_idx, int32_t elem_bytes, void* stream);
+
 /* ---- K7: counts of common in-neighbours, saturated at 255, for columns
  *      [col0, col0+n_cols) of the n_rows x n_rows evidence matrix; only rows with
  *      rowscale > 0 take part (pattern G > 0).  Replaces the int64 matmul of
@@ -209,7 +225,9 @@ SIMRANK_API int simrank_b4_pack(const void* in, int64_t ld, int64_t n_rows, int6
  *      "xcd_map"  0/1  panel -> XCD affinity
  *      "triangle" 0/1  allow the upper-triangle + mirror form when epilogue.symmetric
  *      "stream_nt" 0/1 non-temporal access for streamed-once data
- *      "huge"     rows of at least this many entries are split over a workgroup's waves ---- */
+ *      "huge"     rows of at least this many entries are split over a workgroup's waves
+ *      "balance"  32-row tiles heavier than this many times the mean tile are cut in halves
+ *                 (read when a graph is created; 0 = uniform tiles) ---- */
 SIMRANK_API int simrank_set_tuning(const char* key, int64_t value);
 SIMRANK_API int simrank_get_tuning(const char* key, int64_t* value);
 

@@ -69,6 +69,8 @@ PROTOTYPES = {
     "simrank_spmm": [_vp, _vp, _i64, _i64, _vp, _i64, _i32, _i64, _i64, C.POINTER(Epilogue), _vp],
     "simrank_epilogue_apply": [_vp, _i64, _vp, _i64, _i64, _i64, C.POINTER(Epilogue), _vp],
     "simrank_topk_rows": [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp],
+    "simrank_topk_rows_ids": [_vp, _i64, _i64, _i64, _i64, _vp, _i32, _i32, _vp, _vp, _vp],
+    "simrank_permute": [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i32, _vp],
     "simrank_evidence_counts": [_vp, _i64, _i64, _vp, _i64, _vp],
     "simrank_graph_densify": [_vp, _vp, _i64, _vp],
     "simrank_gemm_nt": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64,

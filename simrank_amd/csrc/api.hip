@@ -273,57 +273,55 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
     g->max_row_nnz = max_row;
     g->h_rowptr.assign(rowptr, rowptr + n_rows + 1);
     g->h_col.assign(col, col + nnz);
-
-    // ---- hub plan: the most referenced columns, served from LDS by spmm_hub_kernel.
-    // Automatic: graphs with enough rows to amortise the tile and whose top columns carry at
-    // least a quarter of the entries (power-law in-degrees; uniform graphs stay as they are).
-    std::vector<int32_t> col_dev, col_enc, hub_ids;
-    {
-        const Tuning& tn = tuning();
-        const int nw = tn.hub_waves == 12 ? 12 : (tn.hub_waves == 16 ? 16 : 8);
-        int64_t h = tn.hub < 0 ? hub_capacity(nw) / 32 * 32 : std::min<int64_t>(tn.hub, hub_capacity(nw));
-        h = std::min<int64_t>(h, n_cols);
-        if (h > 0 && nnz > 0 && (tn.hub > 0 || (n_rows >= 4096 && nnz >= 4 * n_rows))) {
-            std::vector<int32_t> order(size_t(n_cols), 0);
-            for (int64_t i = 0; i < n_cols; ++i) order[size_t(i)] = (int32_t)i;
-            auto refs = [&](int32_t c) { return t_rowptr[size_t(c) + 1] - t_rowptr[size_t(c)]; };
-            std::partial_sort(order.begin(), order.begin() + h, order.end(), [&](int32_t x, int32_t y) {
-                const int32_t rx = refs(x), ry = refs(y);
-                return rx != ry ? rx > ry : x < y;
-            });
-            int64_t covered = 0;
-            for (int64_t k = 0; k < h; ++k) covered += refs(order[size_t(k)]);
-            const double share = double(covered) / double(nnz);
-            if (tn.hub > 0 || share >= 0.25) {
-                std::vector<int32_t> slot(size_t(n_cols), -1);
-                hub_ids.assign(order.begin(), order.begin() + h);
-                for (int64_t k = 0; k < h; ++k) slot[size_t(hub_ids[size_t(k)])] = (int32_t)k;
-                col_dev.resize(size_t(nnz));
-                col_enc.resize(size_t(nnz));
-                std::vector<int32_t> hubs;
-                for (int64_t a = 0; a < n_rows; ++a) {
-                    hubs.clear();
-                    for (int32_t j = rowptr[a]; j < rowptr[a + 1]; ++j)
-                        if (slot[size_t(col[j])] >= 0) hubs.push_back(slot[size_t(col[j])]);
-                    std::sort(hubs.begin(), hubs.end());
-                    int32_t w = rowptr[a];
-                    for (int32_t sl : hubs) {
-                        col_dev[size_t(w)] = hub_ids[size_t(sl)];
-                        col_enc[size_t(w)] = -1 - sl;
-                        ++w;
-                    }
-                    for (int32_t j = rowptr[a]; j < rowptr[a + 1]; ++j)
-                        if (slot[size_t(col[j])] < 0) {
-                            col_dev[size_t(w)] = col[j];
-                            col_enc[size_t(w)] = col[j];
-                            ++w;
-                        }
+    // ---- balanced tiling: 32-row blocks whose cost (entries) exceeds `balance` times the mean
+    // are cut into aligned halves, down to single rows, so that no wave is left with a tile
+    // many times the others' (a power-law row order sorted by length puts all long rows
+    // in a few blocks).  For the upper-triangle leg 2: the (panel, workgroup) launch list.
+    std::vector<int32_t> tile_row0, sym_map;
+    if (tuning().balance > 0 && nnz > 0) {
+        const int64_t nblk = (n_rows + 31) / 32;
+        const int64_t limit = std::max<int64_t>(tuning().balance * ((nnz + nblk - 1) / nblk), 256);
+        std::vector<std::pair<int64_t, int64_t>> stack;
+        for (int64_t b = 0; b < nblk; ++b) {
+            stack.clear();
+            stack.emplace_back(b * 32, std::min<int64_t>(n_rows, b * 32 + 32));
+            while (!stack.empty()) {
+                const auto [lo, hi] = stack.back();
+                stack.pop_back();
+                if (rowptr[hi] - rowptr[lo] <= limit || hi - lo <= 1) {
+                    tile_row0.push_back((int32_t)lo);
+                } else {
+                    const int64_t mid = lo + (hi - lo + 1) / 2;
+                    stack.emplace_back(mid, hi);       // popped second: tiles stay in row order
+                    stack.emplace_back(lo, mid);
                 }
-                g->hub_n = (int32_t)h;
-                g->hub_waves = nw;
-                g->hub_share = share;
             }
         }
+        tile_row0.push_back((int32_t)n_rows);
+        const int64_t n_tiles = (int64_t)tile_row0.size() - 1;
+        if (n_rows >= 64) {
+            std::vector<std::vector<int32_t>> lists(8);
+            size_t t_end = 0;                            // tiles with row0 < 32 (p + 1)
+            for (int64_t pnl = 0; pnl < nblk; ++pnl) {
+                while (t_end < (size_t)n_tiles && tile_row0[t_end] < 32 * (pnl + 1)) ++t_end;
+                const int64_t groups = ((int64_t)t_end + 3) / 4;
+                std::vector<int32_t>& l = lists[size_t(pnl & 7)];
+                for (int64_t rt = groups - 1; rt >= 0; --rt) {     // heavy (late) groups first
+                    l.push_back((int32_t)pnl);
+                    l.push_back((int32_t)rt);
+                }
+            }
+            size_t longest = 0;
+            for (const auto& l : lists) longest = std::max(longest, l.size() / 2);
+            sym_map.assign(longest * 8 * 2, -1);
+            for (size_t x = 0; x < 8; ++x)
+                for (size_t k = 0; k < lists[x].size() / 2; ++k) {
+                    sym_map[2 * (8 * k + x)] = lists[x][2 * k];
+                    sym_map[2 * (8 * k + x) + 1] = lists[x][2 * k + 1];
+                }
+        }
+        g->n_tiles = (int32_t)n_tiles;
+        g->sym_blocks = (int32_t)(sym_map.size() / 2);
     }
     auto up = [&](void** d, const void* h, size_t bytes) -> int {
         size_t alloc = std::max<size_t>(bytes, 16);
@@ -337,12 +335,12 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
         return SIMRANK_OK;
     };
     int rc = up((void**)&g->rowptr, rowptr, size_t(n_rows + 1) * 4);
-    if (!rc) rc = up((void**)&g->col, g->hub_n ? col_dev.data() : col, size_t(nnz) * 4);
-    if (!rc && g->hub_n) rc = up((void**)&g->col_enc, col_enc.data(), size_t(nnz) * 4);
-    if (!rc && g->hub_n) rc = up((void**)&g->hub_ids, hub_ids.data(), size_t(g->hub_n) * 4);
+    if (!rc) rc = up((void**)&g->col, col, size_t(nnz) * 4);
     if (!rc) rc = up((void**)&g->rowscale, rowscale, size_t(n_rows) * 4);
     if (!rc) rc = up((void**)&g->t_rowptr, t_rowptr.data(), size_t(n_cols + 1) * 4);
     if (!rc) rc = up((void**)&g->t_col, t_col.data(), size_t(nnz) * 4);
+    if (!rc && g->n_tiles) rc = up((void**)&g->tile_row0, tile_row0.data(), tile_row0.size() * 4);
+    if (!rc && g->sym_blocks) rc = up((void**)&g->sym_map, sym_map.data(), sym_map.size() * 4);
     if (rc) {
         simrank_graph_destroy(g);
         return rc;
@@ -358,11 +356,8 @@ int simrank_graph_destroy(simrank_graph* g) {
     (void)hipFree(g->rowscale);
     (void)hipFree(g->t_rowptr);
     (void)hipFree(g->t_col);
-    (void)hipFree(g->col_enc);
-    (void)hipFree(g->hub_ids);
-    (void)hipFree(g->huge_rows);
-    (void)hipFree(g->col_s);
-    (void)hipFree(g->col_enc_s);
+    (void)hipFree(g->tile_row0);
+    (void)hipFree(g->sym_map);
     free_lds_plan(g->lds_plan);
     delete g;
     return SIMRANK_OK;
@@ -399,15 +394,9 @@ int simrank_set_tuning(const char* key, int64_t value) {
         t.triangle = value ? 1 : 0;
     } else if (!strcmp(key, "stream_nt")) {
         t.stream_nt = value ? 1 : 0;
-    } else if (!strcmp(key, "hub")) {
-        SR_REQUIRE(value >= -1 && value <= 1280, "hub must be -1 (automatic), 0 (off) or a row count");
-        t.hub = value;
-    } else if (!strcmp(key, "hub_waves")) {
-        SR_REQUIRE(value == 8 || value == 12 || value == 16, "hub_waves must be 8, 12 or 16");
-        t.hub_waves = value;
-    } else if (!strcmp(key, "hub_rounds")) {
-        SR_REQUIRE(value >= 0 && value <= 4096, "hub_rounds must be 0 (automatic) .. 4096");
-        t.hub_rounds = value;
+    } else if (!strcmp(key, "balance")) {
+        SR_REQUIRE(value >= 0 && value <= 1024, "balance must be 0 (uniform tiles) .. 1024");
+        t.balance = value;
     } else {
         SR_REQUIRE(false, "unknown tuning key '%s'", key);
     }
@@ -423,9 +412,7 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     else if (!strcmp(key, "tile")) *value = t.tile;
     else if (!strcmp(key, "triangle")) *value = t.triangle;
     else if (!strcmp(key, "huge")) *value = t.huge;
-    else if (!strcmp(key, "hub")) *value = t.hub;
-    else if (!strcmp(key, "hub_waves")) *value = t.hub_waves;
-    else if (!strcmp(key, "hub_rounds")) *value = t.hub_rounds;
+    else if (!strcmp(key, "balance")) *value = t.balance;
     else SR_REQUIRE(false, "unknown tuning key '%s'", key);
     return SIMRANK_OK;
 }

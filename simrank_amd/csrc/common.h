@@ -38,9 +38,7 @@ struct Tuning {
     int64_t tile = 0;     // rows per wave tile (16, 32, 64; 0 = automatic)
     int64_t huge = 512;   // rows of at least this many entries are split over a workgroup's waves
     int64_t triangle = 1; // allow the upper-triangle + mirror form of a symmetric leg 2
-    int64_t hub = -1;     // rows of X kept in LDS by spmm_hub_kernel: -1 automatic, 0 off, n forced
-    int64_t hub_waves = 8;   // waves per hub workgroup (8, 12, 16)
-    int64_t hub_rounds = 0;  // tile rounds per hub workgroup (0 = automatic)
+    int64_t balance = 4;  // cut 32-row tiles heavier than balance x the mean tile (0 = uniform tiles)
 };
 Tuning& tuning();
 
@@ -50,10 +48,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 }  // namespace simrank
 
 struct simrank_lds_plan;   // lds.hip: SELL / long-row packing for the LDS-tiled kernel
-namespace simrank {
-void free_lds_plan(simrank_lds_plan* p);
-int hub_capacity(int n_waves);   // spmm.hip: rows of X a hub workgroup's LDS tile can hold
-}
+namespace simrank { void free_lds_plan(simrank_lds_plan* p); }
 
 // The graph object: device CSR of the 0/1 pattern + per-row scale, and the transposed
 // pattern (CSC) used by the evidence kernel.
@@ -65,19 +60,13 @@ struct simrank_graph {
     int32_t* t_rowptr = nullptr;  // [n_cols+1]  transposed pattern
     int32_t* t_col = nullptr;     // [nnz]       row ids, ascending per column
     int32_t max_row_nnz = 0;
-    // hub plan (api.hip: build_hub_plan; spmm.hip: spmm_hub_kernel).  When hub_n > 0, `col`
-    // lists each row's hub entries first (by slot), then the others (ascending), and
-    // `col_enc` is the same list with the hub entries written as -1-slot.
-    int32_t hub_n = 0, hub_waves = 0;
-    int32_t* hub_ids = nullptr;   // [hub_n] slot -> column
-    int32_t* col_enc = nullptr;   // [nnz]
-    double hub_share = 0.0;       // fraction of the entries that are hub entries
-    // `col` / `col_enc` with every id >= 0 multiplied by scaled_ld / 4 (spmm.hip: scaled_ids)
-    int32_t* col_s = nullptr;
-    int32_t* col_enc_s = nullptr;
-    int64_t scaled_ld = 0;
-    int32_t* huge_rows = nullptr; // rows of >= huge_len_built entries, ascending (built on demand)
-    int32_t n_huge_rows = 0, huge_len_built = 0;
+    // balanced tiling of the rows (api.hip: build_tiles): tile t = rows [tile_row0[t],
+    // tile_row0[t+1]) — 32-row blocks, the heavy ones cut into aligned halves — and, for the
+    // upper-triangle form of leg 2, the per-XCD list of (panel, workgroup) pairs to launch
+    int32_t* tile_row0 = nullptr;
+    int32_t n_tiles = 0;
+    int32_t* sym_map = nullptr;
+    int32_t sym_blocks = 0;
     // host copies, kept for the lazily built LDS plan (lds.hip)
     std::vector<int32_t> h_rowptr, h_col;
     simrank_lds_plan* lds_plan = nullptr;

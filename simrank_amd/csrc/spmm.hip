@@ -24,8 +24,6 @@
 //     single rank it computes only the tiles on/above the diagonal of the symmetric result
 //     and stores their mirror image (kSym).
 #include <algorithm>
-#include <mutex>
-#include <vector>
 
 #include "common.h"
 
@@ -35,8 +33,7 @@ __device__ __forceinline__ int64_t imin(int64_t a, int64_t b) { return a < b ? a
 
 struct SpmmArgs {
     const int32_t* rowptr;
-    const int32_t* col;       // VEC 4: neighbour id * (ldx / 4), i.e. the row's offset in 16-byte
-                              // units (scaled_ids); VEC 1: the plain id.  < 0: see fetch_add
+    const int32_t* col;       // neighbour ids, ascending per row
     int32_t nt;               // non-temporal output stores
     int32_t has_huge;         // the graph has rows of >= huge_len entries
     int32_t huge_len;         // rows this long are split over the waves of a workgroup
@@ -52,7 +49,13 @@ struct SpmmArgs {
     int64_t tpad;    // TRANS, blocked: padding floats per row of a block
     int32_t tvec;    // transposed stores may use 16-byte pieces (alignment checked on the host)
     int32_t n_panels;
-    int32_t row_tiles;
+    int32_t row_tiles;        // workgroups per panel (kWaves tiles each)
+    // balanced tiling (RT = 32 only): tile t covers rows [tile_row0[t], tile_row0[t+1]), at
+    // most 32 of them and never across a multiple of 32; NULL = uniform RT-row tiles
+    const int32_t* tile_row0;
+    int32_t n_tiles;
+    const int32_t* sym_map;   // kSym + tile list: blockIdx -> (panel, workgroup of the panel) pairs
+    int32_t sym_blocks;
     int32_t xcd_map;
     int32_t has_ep;
     // epilogue (has_ep)
@@ -68,14 +71,6 @@ struct SpmmArgs {
     unsigned long long* n_changed;
     int64_t diag_col0;
     int32_t set_diag;
-    // hub tile (spmm_hub_kernel): `col` then holds -1-slot for the entries served from LDS
-    const int32_t* hub_ids;   // slot -> row of X
-    int32_t hub_n;
-    int32_t hub_off;          // float offset of the hub tile in dynamic LDS
-    int32_t rounds;           // tile rounds per workgroup
-    int32_t chunks;           // workgroups per panel
-    const int32_t* huge_rows; // rows of >= huge_len entries, ascending (hub kernel)
-    int32_t n_huge_rows;
 };
 
 template <int VEC>
@@ -127,93 +122,17 @@ __device__ __forceinline__ int ldidx(const SpmmArgs& p, int j) {
     return p.nt ? __builtin_nontemporal_load(p.col + j) : p.col[j];
 }
 
-constexpr int kWaves = 4;   // waves per workgroup (spmm_gather_kernel)
-constexpr int kHeavy = 64;  // rows with at least this many entries are gathered cooperatively
-constexpr int kSkip = INT32_MIN;  // "no neighbour in this slot"
-constexpr int kParts = 4;   // a huge row is always split in this many parts (any workgroup size)
+constexpr int kWaves = 4;   // waves per workgroup
+constexpr int kHeavy = 64;
+constexpr int kSkip = INT32_MIN;  // "no neighbour in this slot"  // rows with at least this many entries are gathered cooperatively
 
-// Neighbour ids: idx >= 0 is row idx of X (through L1/L2).  HUB only: idx = -1 - slot reads
-// slot `slot` of the workgroup's LDS tile of the most referenced rows instead.
-// `hubq` is the LDS byte address of this lane's 16 bytes of slot 0 (explicit LDS pointers:
-// the tile must be read with ds_read_b128, never through the flat path).
-typedef float f4v __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) f4v lds_f4v;
-typedef __attribute__((address_space(3))) float lds_f32;
-
-// Address of a neighbour's segment.  VEC 4: `id` is the pre-scaled row offset in 16-byte units
-// (one shift-add per gather instead of a 64-bit multiply); VEC 1: the row number.
-template <int VEC>
-__device__ __forceinline__ const float* row_ptr(const SpmmArgs& p, const float* __restrict__ Xc, int id) {
-    if constexpr (VEC == 4) return Xc + (uint64_t(uint32_t(id)) << 2);
-    else return Xc + int64_t(id) * p.ldx;
-}
-
-// N segments known to exist (no skips, no hub entries, panel inside the matrix): nothing but
-// address, load, add.
-template <int VEC, int N>
-__device__ __forceinline__ void fetch_add_full(float (&acc)[VEC], const SpmmArgs& p,
-                                               const float* __restrict__ Xc, const int (&idx)[N]) {
-    float vg[N][VEC];
-#pragma unroll
-    for (int j = 0; j < N; ++j) vload<VEC>(vg[j], row_ptr<VEC>(p, Xc, idx[j]));
-#pragma unroll
-    for (int j = 0; j < N; ++j)
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] += vg[j][i];
-}
-
-// A batch of N neighbour segments added to acc in batch order.  The global loads are all
-// issued first (N in flight), the LDS reads after them into registers of their own — a load
-// into a register another load still owes would force a wait between the two.  Hub entries
-// come first in a row, so "LDS values, then global values" IS the batch order.
-template <int VEC, int PW, bool HUB, int N>
-__device__ __forceinline__ void fetch_add(float (&acc)[VEC], const SpmmArgs& p,
-                                          const float* __restrict__ Xc, unsigned hubq,
-                                          const int (&idx)[N], int n_act = N) {
-    // n_act (wave-uniform): entries from n_act on are known to be kSkip
-    float vg[N][VEC];
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        if (j < n_act && idx[j] >= 0) {
-            vload<VEC>(vg[j], row_ptr<VEC>(p, Xc, idx[j]));
-        } else {
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) vg[j][i] = 0.f;
-        }
-    }
-    if constexpr (HUB && VEC == 4) {
-        // branch-free, 8 at a time: every lane reads some slot (slot 0 when it has no hub
-        // entry), then selects
-        constexpr int B = N < 8 ? N : 8;
-        static_assert(N % B == 0, "batches of B");
-#pragma unroll
-        for (int j0 = 0; j0 < N; j0 += B) {
-            if (j0 < n_act) {
-                f4v vl[B];
-#pragma unroll
-                for (int j = 0; j < B; ++j) {
-                    const int id = idx[j0 + j];
-                    const bool on = id < 0 && id != kSkip;
-                    vl[j] = *(const lds_f4v*)(uintptr_t)(hubq + (on ? unsigned(~id) : 0u) * unsigned(PW * 4));
-                }
-#pragma unroll
-                for (int j = 0; j < B; ++j) {
-                    const int id = idx[j0 + j];
-                    const bool on = id < 0 && id != kSkip;
-                    acc[0] += on ? vl[j].x : 0.f; acc[1] += on ? vl[j].y : 0.f;
-                    acc[2] += on ? vl[j].z : 0.f; acc[3] += on ? vl[j].w : 0.f;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < N; ++j)
-        if (j < n_act) {
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[i] += vg[j][i];
-        }
-}
-
+// One output row segment (VEC floats per lane, LPR lanes) -> epilogue -> memory / LDS tile.
+// MODE: how a tile leaves the wave.
+//   kPlain  Y[a][c]                       (+ fused epilogue)
+//   kTrans  Y^T, through the wave's LDS tile (leg 1)
+//   kSym    kPlain for the tiles on or above the diagonal of a symmetric result, which are
+//           ALSO stored mirrored (through the LDS tile); tiles below the diagonal are
+//           never computed.  Halves the gathers of leg 2 on a single rank.
 constexpr int kPlain = 0, kTrans = 1, kSym = 2;
 
 template <int VEC, int LPR, int MODE, int RT>
@@ -285,15 +204,15 @@ __device__ __forceinline__ void emit_row(const SpmmArgs& p, float* tbuf_wave, in
     }
 }
 
-constexpr int kMaxHuge = 8;    // ... at most this many per group of kParts waves and tile round
+constexpr int kMaxHuge = 8;    // ... at most this many per workgroup and tile round
 
 // Sum of the X segments of the neighbours at CSR positions [s, e): the G lane groups take
 // them round-robin, UNROLL loads in flight each; partial sums combined by shuffles in a
 // fixed order.  Every lane ends with the total of its VEC columns.
-template <int VEC, int LPR, bool HUB>
+template <int VEC, int LPR>
 __device__ __forceinline__ void gather_range(const SpmmArgs& p, const float* __restrict__ Xc,
-                                             unsigned hubq, int s, int e, int lane, int g,
-                                             bool col_active, bool full_panel, float (&acc)[VEC]) {
+                                             int s, int e, int lane, int g, bool col_active,
+                                             float (&acc)[VEC]) {
     constexpr int G = 64 / LPR, UNROLL = 4;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
@@ -301,17 +220,27 @@ __device__ __forceinline__ void gather_range(const SpmmArgs& p, const float* __r
         const int n = min(64, e - base);
         const int myidx = lane < n ? ldidx(p, base + lane) : 0;
         for (int k0 = 0; k0 < n; k0 += G * UNROLL) {
+            float v[UNROLL][VEC];
             int idx[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) idx[u] = __shfl(myidx, (k0 + u * G + g) & 63);
-            if (!HUB && full_panel && k0 + G * UNROLL <= n) {
-                fetch_add_full<VEC, UNROLL>(acc, p, Xc, idx);
-            } else {
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u)
-                    if (!(col_active && k0 + u * G + g < n)) idx[u] = kSkip;
-                fetch_add<VEC, VEC * LPR, HUB, UNROLL>(acc, p, Xc, hubq, idx);
+            for (int u = 0; u < UNROLL; ++u) {
+                const int k = k0 + u * G + g;
+                idx[u] = __shfl(myidx, k & 63);
+                if (!(col_active && k < n)) idx[u] = kSkip;
             }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                if (idx[u] >= 0) {
+                    vload<VEC>(v[u], Xc + int64_t(idx[u]) * p.ldx);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
         }
     }
 #pragma unroll
@@ -320,54 +249,81 @@ __device__ __forceinline__ void gather_range(const SpmmArgs& p, const float* __r
         for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off);
 }
 
-// A huge row summed the way phase A0 sums it — kParts consecutive parts, each a gather_range,
-// added in part order — but by one wave: used where no group of waves is at hand, so that a
-// row's value never depends on who computed it.
-template <int VEC, int LPR, bool HUB>
-__device__ __forceinline__ void gather_split(const SpmmArgs& p, const float* __restrict__ Xc,
-                                             unsigned hubq, int s, int len, int lane, int g,
-                                             bool col_active, bool full_panel, float (&acc)[VEC]) {
-    const int chunk = ((len + kParts - 1) / kParts + 63) & ~63;
-    gather_range<VEC, LPR, HUB>(p, Xc, hubq, s, min(s + len, s + chunk), lane, g, col_active, full_panel, acc);
-    for (int w = 1; w < kParts; ++w) {
-        float part[VEC];
-        gather_range<VEC, LPR, HUB>(p, Xc, hubq, s + w * chunk, min(s + len, s + (w + 1) * chunk),
-                                    lane, g, col_active, full_panel, part);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] += part[i];
-    }
-}
-
-constexpr int kHubHuge = 32;   // huge rows a hub workgroup precomputes per chunk
-
-// One round of tiles: wave `wave` of the NW waves of a workgroup takes the RT rows starting at
-// (rt * NW + wave) * RT of panel `panel`.  Shared by the two kernels below.
-template <int VEC, int LPR, int MODE, int RT, int NW, bool HUB>
-__device__ __forceinline__ void tile_round(const SpmmArgs& p, float* smem, unsigned hubq, int hn,
-                                           int panel, int rt, int lane, int wave,
-                                           unsigned& changed) {
-    static_assert(NW % kParts == 0, "huge rows are split over groups of kParts waves");
+template <int VEC, int LPR, int MODE, int RT>
+__global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
+    static_assert(RT <= 64, "one lane per tile row");
+    static_assert(MODE != kSym || VEC * LPR == RT, "mirrored tiles are square");
     constexpr bool TRANS = MODE == kTrans;
     constexpr bool TILE = MODE != kPlain;    // the wave owns an LDS tile
     constexpr int PW = VEC * LPR;            // panel width in floats
     constexpr int G = 64 / LPR;              // lane groups = rows (or neighbours) in flight
     constexpr int JU = LPR < 8 ? LPR : 8;    // gathers a group keeps in flight
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [wave tiles][huge-row area]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // block -> (panel, row-tile group); blocks equal mod 8 share an XCD (speed only)
+    int panel, rt;
+    if (MODE == kSym && p.sym_map) {
+        // balanced tiles: the host lists the (panel, workgroup) pairs that touch the upper
+        // triangle, per XCD (blockIdx % 8), heavy workgroups of a panel first
+        panel = p.sym_map[2 * blockIdx.x];
+        rt = p.sym_map[2 * blockIdx.x + 1];
+        if (panel < 0) return;                           // padding of the shorter XCD lists
+    } else if constexpr (MODE == kSym) {
+        // only the (panel, row block) pairs that touch the upper triangle are launched.
+        // XCD x owns panels x + 8j; panel p needs row blocks 0 .. p/4 (128 rows per block,
+        // 32 columns per panel), i.e. 2j + b of them with b = x/4 + 1; prefix j^2 + (b-1)j.
+        const int x = int(blockIdx.x & 7);
+        const int t = int(blockIdx.x >> 3);
+        const int b1 = x >> 2;                           // b - 1
+        int j = int((sqrtf(float(b1 * b1 + 4 * t)) - float(b1)) * 0.5f);
+        while ((j + 1) * (j + 1) + b1 * (j + 1) <= t) ++j;
+        while (j * j + b1 * j > t) --j;
+        panel = x + 8 * j;
+        rt = t - (j * j + b1 * j);
+        if (rt > panel / 4) return;                      // padding of the shorter XCD lists
+    } else {
+        const int64_t bid = blockIdx.x;
+        if (p.xcd_map) {
+            const int x = int(bid & 7);
+            const int64_t local = bid >> 3;
+            panel = int(local / p.row_tiles) * 8 + x;
+            rt = int(local % p.row_tiles);
+        } else {
+            panel = int(bid / p.row_tiles);
+            rt = int(bid % p.row_tiles);
+        }
+        // last workgroups first: with rows in ascending length order those are the long ones
+        if (p.tile_row0) rt = p.row_tiles - 1 - rt;
+    }
+    if (panel >= p.n_panels) return;  // uniform over the workgroup
+
     const int64_t c0 = int64_t(panel) * PW;
     const int g = lane / LPR;
     const int q = lane % LPR;
     const int gbase = lane - q;              // first lane of this lane's group
     const int64_t mycol = c0 + int64_t(q) * VEC;
     const bool col_active = mycol < p.L;  // VEC=4: mycol+3 < ldx because ldx % 4 == 0
-    const bool full_panel = c0 + PW <= p.L;   // wave-uniform: no lane of the panel is masked
     const float* __restrict__ Xc = p.X + mycol;
     float* tbuf_wave = smem + (TILE ? wave * PW * (RT + 1) : 0);
+    unsigned changed = 0;
 
-    const int64_t row0 = (int64_t(rt) * NW + wave) * RT;
+
+    {
+    int64_t row0 = (int64_t(rt) * kWaves + wave) * RT;
     int nrows = int(imin(RT, p.M - row0));  // rows of this wave's tile (may be <= 0)
+    if (RT == 32 && p.tile_row0) {          // balanced tiling: heavy 32-row blocks are cut up
+        const int t = rt * kWaves + wave;
+        row0 = t < p.n_tiles ? p.tile_row0[t] : p.M;
+        nrows = t < p.n_tiles ? p.tile_row0[t + 1] - int(row0) : 0;
+    }
     bool mirror = false;
     if constexpr (MODE == kSym) {
-        if (row0 > c0) nrows = 0;   // below the diagonal: some other tile's mirror image
-        mirror = row0 < c0;         // strictly above: store the mirror image too
+        const int64_t rb = row0 & ~int64_t(RT - 1);   // the tile's 32-row block
+        if (rb > c0) nrows = 0;     // below the diagonal: some other tile's mirror image
+        mirror = rb < c0;           // strictly above: store the mirror image too
     }
 
     // ---- rows of the tile sorted by length, longest first (bitonic over the 64 lanes).
@@ -398,73 +354,46 @@ __device__ __forceinline__ void tile_round(const SpmmArgs& p, float* smem, unsig
     // posts them in LDS and all four waves of the workgroup take a quarter of the neighbours
     // each; the owner adds the four partial sums in wave order and emits the row.
     int posted = 0;
-    if constexpr (HUB) {
-        // the workgroup summed its chunk's huge rows before the rounds (spmm_hub_kernel); the
-        // wave only picks the sums up — no barrier inside a round, waves drift freely
-        if (p.has_huge) {
-            const float* hres = smem + (TILE ? NW * PW * (RT + 1) : 0) + NW * PW;
-            const int* hrow = reinterpret_cast<const int*>(hres + kHubHuge * PW);
-            posted = __popcll(__ballot(s_len >= p.huge_len));
-            for (int h = 0; h < posted; ++h) {
-                const int r = __builtin_amdgcn_readfirstlane(__shfl(s_row, h));
-                const int s = __builtin_amdgcn_readfirstlane(__shfl(s_start, h));
-                const int len = __builtin_amdgcn_readfirstlane(__shfl(s_len, h));
-                const unsigned long long hit =
-                    __ballot(lane < hn && hrow[lane < hn ? lane : 0] == int(row0 + r));
-                float acc[VEC];
-                if (hit) {
-                    vload<VEC>(acc, hres + (__ffsll(hit) - 1) * PW + q * VEC);
-                } else {   // more huge rows in the chunk than the prologue takes
-                    gather_split<VEC, LPR, HUB>(p, Xc, hubq, s, len, lane, g, col_active, full_panel, acc);
-                }
-                if (g == 0 && col_active)
-                    emit_row<VEC, LPR, MODE, RT>(p, tbuf_wave, r, row0 + r, q, mycol, acc, changed, mirror);
-            }
-        }
-    } else if (p.has_huge) {
-        // every group of kParts waves has its own descriptors (the same rows are posted whatever
-        // the workgroup size); slots are handed out in wave order, so the split is reproducible
-        constexpr int kGroupFloats = 64 + kMaxHuge * kParts * PW;
-        const int part_id = wave % kParts;
-        int* hmeta = reinterpret_cast<int*>(smem + (TILE ? NW * PW * (RT + 1) : 0) +
-                                            (wave / kParts) * kGroupFloats);
+    if (p.has_huge) {
+        int* hmeta = reinterpret_cast<int*>(smem + (TILE ? kWaves * PW * (RT + 1) : 0));
         float* hpart = reinterpret_cast<float*>(hmeta + 64);
         const int n_huge = __popcll(__ballot(s_len >= p.huge_len));
-        if (lane == 0) hmeta[60 + part_id] = n_huge;
+        // slots are handed out in wave order: which rows get one never depends on timing
+        if (lane == 0) hmeta[60 + wave] = n_huge;
         __syncthreads();
         int slot0 = 0, total = 0;
 #pragma unroll
-        for (int w = 0; w < kParts; ++w) {
+        for (int w = 0; w < kWaves; ++w) {
             const int c = hmeta[60 + w];
-            slot0 += w < part_id ? c : 0;
+            slot0 += w < wave ? c : 0;
             total += c;
         }
         posted = max(0, min(n_huge, kMaxHuge - slot0));
         if (lane < posted) {
             int* d = hmeta + 4 + 4 * (slot0 + lane);
-            d[0] = s_row; d[1] = s_start; d[2] = s_len; d[3] = part_id;
+            d[0] = s_row; d[1] = s_start; d[2] = s_len; d[3] = wave;
         }
         __syncthreads();
         const int nh = min(total, kMaxHuge);
         for (int i = 0; i < nh; ++i) {
             const int* d = hmeta + 4 + 4 * i;
             const int hs = d[1], hl = d[2];
-            const int chunk = ((hl + kParts - 1) / kParts + 63) & ~63;
-            const int s = hs + part_id * chunk;
+            const int chunk = ((hl + kWaves - 1) / kWaves + 63) & ~63;
+            const int s = hs + wave * chunk;
             const int e = min(hs + hl, s + chunk);
             float part[VEC];
-            gather_range<VEC, LPR, HUB>(p, Xc, hubq, s, e, lane, g, col_active, full_panel, part);
-            if (g == 0) vstore<VEC>(hpart + (i * kParts + part_id) * PW + q * VEC, part);
+            gather_range<VEC, LPR>(p, Xc, s, e, lane, g, col_active, part);
+            if (g == 0) vstore<VEC>(hpart + (i * kWaves + wave) * PW + q * VEC, part);
         }
         __syncthreads();
         for (int i = 0; i < nh; ++i) {
             const int* d = hmeta + 4 + 4 * i;
-            if (d[3] == part_id && g == 0 && col_active) {
+            if (d[3] == wave && g == 0 && col_active) {
                 float acc[VEC], t[VEC];
-                vload<VEC>(acc, hpart + (i * kParts + 0) * PW + q * VEC);
+                vload<VEC>(acc, hpart + (i * kWaves + 0) * PW + q * VEC);
 #pragma unroll
-                for (int w = 1; w < kParts; ++w) {
-                    vload<VEC>(t, hpart + (i * kParts + w) * PW + q * VEC);
+                for (int w = 1; w < kWaves; ++w) {
+                    vload<VEC>(t, hpart + (i * kWaves + w) * PW + q * VEC);
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) acc[k] += t[k];
                 }
@@ -480,12 +409,9 @@ __device__ __forceinline__ void tile_round(const SpmmArgs& p, float* smem, unsig
     for (int h = posted; h < n_heavy; ++h) {
         const int r = __builtin_amdgcn_readfirstlane(__shfl(s_row, h));
         const int s = __builtin_amdgcn_readfirstlane(__shfl(s_start, h));
-        const int len = __builtin_amdgcn_readfirstlane(__shfl(s_len, h));
+        const int e = s + __builtin_amdgcn_readfirstlane(__shfl(s_len, h));
         float acc[VEC];
-        if (p.has_huge && len >= p.huge_len)   // no descriptor slot left: same parts, one wave
-            gather_split<VEC, LPR, HUB>(p, Xc, hubq, s, len, lane, g, col_active, full_panel, acc);
-        else
-            gather_range<VEC, LPR, HUB>(p, Xc, hubq, s, s + len, lane, g, col_active, full_panel, acc);
+        gather_range<VEC, LPR>(p, Xc, s, e, lane, g, col_active, acc);
         if (g == 0 && col_active)
             emit_row<VEC, LPR, MODE, RT>(p, tbuf_wave, r, row0 + r, q, mycol, acc, changed, mirror);
     }
@@ -496,10 +422,6 @@ __device__ __forceinline__ void tile_round(const SpmmArgs& p, float* smem, unsig
     // NEXT chunk are requested before the current chunk's gathers, so a wave pays one
     // memory latency per chunk instead of two.
     if (n_heavy < nrows) {
-        // a step takes CH id chunks (of LPR) per row: the hub kernel runs few waves per CU and
-        // makes up for it with CH * LPR gathers in flight per lane group
-        constexpr int CH = !HUB ? 1 : (NW <= 8 ? 3 : (NW <= 12 ? 2 : 1));
-        constexpr int STEP = LPR * CH;
         int pos = n_heavy, t0 = 0;
         int src = pos + g;
         int r = __shfl(s_row, src & 63);
@@ -507,22 +429,17 @@ __device__ __forceinline__ void tile_round(const SpmmArgs& p, float* smem, unsig
         int len = __shfl(s_len, src & 63);
         if (src >= nrows) len = 0;
         int maxlen = __builtin_amdgcn_readfirstlane(__shfl(s_len, pos));  // sorted: longest of the pass
-        // ... and its shortest row: steps below it need no masks at all
-        int minlen = pos + G <= nrows ? __builtin_amdgcn_readfirstlane(__shfl(s_len, (pos + G - 1) & 63)) : 0;
-        int iv[CH];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) iv[c] = (c * LPR + q < len) ? ldidx(p, st + c * LPR + q) : 0;
+        int iv = (q < len) ? ldidx(p, st + q) : 0;
         float acc[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
         while (true) {
             // where the walk goes next (wave-uniform)
-            const bool same_pass = t0 + STEP < maxlen;
+            const bool same_pass = t0 + LPR < maxlen;
             const int npos = same_pass ? pos : pos + G;
-            const int nt0 = same_pass ? t0 + STEP : 0;
+            const int nt0 = same_pass ? t0 + LPR : 0;
             const bool more = npos < nrows;
-            int nr = r, nst = st, nlen = len, nmax = maxlen, nmin = minlen;
-            int niv[CH];
+            int nr = r, nst = st, nlen = len, nmax = maxlen, niv = 0;
             if (!same_pass) {
                 const int nsrc = npos + g;
                 nr = __shfl(s_row, nsrc & 63);
@@ -530,37 +447,33 @@ __device__ __forceinline__ void tile_round(const SpmmArgs& p, float* smem, unsig
                 nlen = __shfl(s_len, nsrc & 63);
                 if (nsrc >= nrows) nlen = 0;
                 nmax = __builtin_amdgcn_readfirstlane(__shfl(s_len, npos & 63));
-                nmin = npos + G <= nrows ? __builtin_amdgcn_readfirstlane(__shfl(s_len, (npos + G - 1) & 63)) : 0;
             }
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-                niv[c] = (more && nt0 + c * LPR + q < nlen) ? ldidx(p, nst + nt0 + c * LPR + q) : 0;
+            if (more && nt0 + q < nlen) niv = ldidx(p, nst + nt0 + q);
 
-            // the current step: up to STEP neighbours of each of the G rows
-            if constexpr (HUB) {
-                int idx[STEP];
+            // the current chunk: up to LPR neighbours of each of the G rows
 #pragma unroll
-                for (int j = 0; j < STEP; ++j) {
-                    idx[j] = __shfl(iv[j / LPR], gbase + j % LPR);
-                    if (!(col_active && t0 + j < len)) idx[j] = kSkip;
-                }
-                fetch_add<VEC, PW, HUB, STEP>(acc, p, Xc, hubq, idx, min(STEP, maxlen - t0));
-            } else {
+            for (int jb = 0; jb < LPR; jb += JU) {
+                if (t0 + jb < maxlen) {
+                    float v[JU][VEC];
+                    int idx[JU];
 #pragma unroll
-                for (int jb = 0; jb < LPR; jb += JU) {
-                    if (t0 + jb < maxlen) {
-                        int idx[JU];
+                    for (int j = 0; j < JU; ++j) {
+                        idx[j] = __shfl(iv, gbase + jb + j);
+                        if (!(col_active && t0 + jb + j < len)) idx[j] = kSkip;
+                    }
 #pragma unroll
-                        for (int j = 0; j < JU; ++j) idx[j] = __shfl(iv[0], gbase + jb + j);
-                        if (full_panel && t0 + jb + JU <= minlen) {
-                            fetch_add_full<VEC, JU>(acc, p, Xc, idx);
+                    for (int j = 0; j < JU; ++j) {
+                        if (idx[j] >= 0) {
+                            vload<VEC>(v[j], Xc + int64_t(idx[j]) * p.ldx);
                         } else {
 #pragma unroll
-                            for (int j = 0; j < JU; ++j)
-                                if (!(col_active && t0 + jb + j < len)) idx[j] = kSkip;
-                            fetch_add<VEC, PW, HUB, JU>(acc, p, Xc, hubq, idx);
+                            for (int i = 0; i < VEC; ++i) v[j][i] = 0.f;
                         }
                     }
+#pragma unroll
+                    for (int j = 0; j < JU; ++j)
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) acc[i] += v[j][i];
                 }
             }
             if (!same_pass) {
@@ -570,21 +483,12 @@ __device__ __forceinline__ void tile_round(const SpmmArgs& p, float* smem, unsig
                 for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
             }
             if (!more) break;
-            pos = npos; t0 = nt0; r = nr; st = nst; len = nlen; maxlen = nmax; minlen = nmin;
-#pragma unroll
-            for (int c = 0; c < CH; ++c) iv[c] = niv[c];
+            pos = npos; t0 = nt0; r = nr; st = nst; len = nlen; maxlen = nmax; iv = niv;
         }
     }
 
     if constexpr (TILE) {
-        if constexpr (HUB) {
-            // the tile is the wave's own: order its LDS writes before its reads, nothing more
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        } else {
-            __syncthreads();
-        }
+        __syncthreads();
         const int cols_here = int(imin(PW, p.L - c0));
         const int64_t tb = p.tblock;
         const int rows_out = (TRANS || mirror) ? nrows : 0;
@@ -618,51 +522,7 @@ __device__ __forceinline__ void tile_round(const SpmmArgs& p, float* smem, unsig
         }
         }
     }
-}
-
-template <int VEC, int LPR, int MODE, int RT>
-__global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
-    static_assert(RT <= 64, "one lane per tile row");
-    static_assert(MODE != kSym || VEC * LPR == RT, "mirrored tiles are square");
-    constexpr bool TRANS = MODE == kTrans;
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [wave tiles][huge-row area]
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    // block -> (panel, row-tile group); blocks equal mod 8 share an XCD (speed only)
-    int panel, rt;
-    if constexpr (MODE == kSym) {
-        // only the (panel, row block) pairs that touch the upper triangle are launched.
-        // XCD x owns panels x + 8j; panel p needs row blocks 0 .. p/4 (128 rows per block,
-        // 32 columns per panel), i.e. 2j + b of them with b = x/4 + 1; prefix j^2 + (b-1)j.
-        const int x = int(blockIdx.x & 7);
-        const int t = int(blockIdx.x >> 3);
-        const int b1 = x >> 2;                           // b - 1
-        int j = int((sqrtf(float(b1 * b1 + 4 * t)) - float(b1)) * 0.5f);
-        while ((j + 1) * (j + 1) + b1 * (j + 1) <= t) ++j;
-        while (j * j + b1 * j > t) --j;
-        panel = x + 8 * j;
-        rt = t - (j * j + b1 * j);
-        if (rt > panel / 4) return;                      // padding of the shorter XCD lists
-    } else {
-        const int64_t bid = blockIdx.x;
-        if (p.xcd_map) {
-            const int x = int(bid & 7);
-            const int64_t local = bid >> 3;
-            panel = int(local / p.row_tiles) * 8 + x;
-            rt = int(local % p.row_tiles);
-        } else {
-            panel = int(bid / p.row_tiles);
-            rt = int(bid % p.row_tiles);
-        }
     }
-    if (panel >= p.n_panels) return;  // uniform over the workgroup
-
-    unsigned changed = 0;
-
-
-    tile_round<VEC, LPR, MODE, RT, kWaves, false>(p, smem, 0u, 0, panel, rt, lane, wave, changed);
 
     if constexpr (!TRANS) {
         if (p.has_ep && p.prev) {
@@ -675,226 +535,21 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// Hub form of the same legs: on skewed graphs a few hundred rows of X carry a third to a
-// half of all references (power-law in-degrees), and every one of those references costs a
-// 128-byte request on the L1/L2 path that bounds spmm_gather_kernel.  Here
-// a persistent NW-wave workgroup keeps the panel's segments of the `hub_n` most referenced
-// rows in LDS (128 B each), walks `rounds` tile rounds of the panel, and serves the entries
-// the host encoded as -1-slot from that tile: only the tail goes through the vector-memory
-// path.  Same tiles, phases, stores and epilogue as above (tile_round), same summation
-// order as spmm_gather_kernel on the same graph (the host orders hub entries first in `col`
-// too), so the two kernels are bitwise interchangeable.
-// ---------------------------------------------------------------------------------------
-template <int MODE, int NW>
-__global__ __launch_bounds__(NW * 64) void spmm_hub_kernel(const SpmmArgs p) {
-    constexpr int VEC = 4, LPR = 8, RT = 32, PW = VEC * LPR;
-    constexpr bool TILE = MODE != kPlain;
-    // [wave tiles][parts NW x PW][huge sums kHubHuge x PW][huge row ids kHubHuge][hub tile]
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    // block -> (panel, chunk of rounds); blocks equal mod 8 share an XCD, and the chunks of a
-    // panel are neighbours there, so its hub segments are fetched from HBM once per XCD
-    const int x = int(blockIdx.x & 7);
-    const int local = int(blockIdx.x >> 3);
-    const int panel = (local / p.chunks) * 8 + x;
-    const int chunk = local % p.chunks;
-    if (panel >= p.n_panels) return;
-    const int64_t c0 = int64_t(panel) * PW;
-    int r0 = chunk * p.rounds;
-    int r1 = min(r0 + p.rounds, p.row_tiles);
-    if constexpr (MODE == kSym) r1 = min(r1, int(c0 / (NW * RT)) + 1);   // rounds below the diagonal
-    if (r0 >= r1) return;
-
-    float* hub = smem + p.hub_off;
-    for (int e = threadIdx.x; e < p.hub_n * LPR; e += NW * 64) {
-        const int slot = e / LPR, qq = e % LPR;
-        const int64_t c = c0 + qq * VEC;
-        float v[VEC] = {0.f, 0.f, 0.f, 0.f};
-        if (c < p.L) vload<VEC>(v, p.X + int64_t(p.hub_ids[slot]) * p.ldx + c);
-        vstore<VEC>(hub + slot * PW + qq * VEC, v);
-    }
-    const unsigned hubq = unsigned((uintptr_t)(lds_f32*)hub) + unsigned(lane % LPR) * (VEC * 4);
-
-    // ---- the chunk's huge rows, by the whole workgroup, before the rounds: kParts waves per
-    // row (same parts and order as phase A0 of spmm_gather_kernel), NW / kParts rows at a time
-    int hn = 0;
-    if (p.has_huge) {
-        float* hpart = smem + (TILE ? NW * PW * (RT + 1) : 0);
-        float* hres = hpart + NW * PW;
-        int* hrow = reinterpret_cast<int*>(hres + kHubHuge * PW);
-        const int64_t row_lo = int64_t(r0) * NW * RT;
-        int64_t row_hi = imin(p.M, int64_t(r1) * NW * RT);
-        if constexpr (MODE == kSym) row_hi = imin(row_hi, (c0 / RT + 1) * RT);   // tiles up to the diagonal's
-        int lo = 0, hi = p.n_huge_rows;
-        while (lo < hi) {                       // first huge row >= row_lo
-            const int mid = (lo + hi) >> 1;
-            if (p.huge_rows[mid] < row_lo) lo = mid + 1; else hi = mid;
-        }
-        int end = lo;
-        while (end < p.n_huge_rows && end - lo < kHubHuge && p.huge_rows[end] < row_hi) ++end;
-        hn = end - lo;
-        if (threadIdx.x < hn) hrow[threadIdx.x] = p.huge_rows[lo + threadIdx.x];
-        __syncthreads();                        // hub tile and row list complete
-        const int g = lane / LPR, q = lane % LPR;
-        const bool col_active = c0 + q * VEC < p.L;
-        const float* __restrict__ Xc = p.X + c0 + q * VEC;
-        for (int i0 = 0; i0 < hn; i0 += NW / kParts) {
-            const int i = i0 + wave / kParts;
-            if (i < hn) {
-                const int row = hrow[i];
-                const int hs = p.rowptr[row], hl = p.rowptr[row + 1] - hs;
-                const int part_id = wave % kParts;
-                const int span = ((hl + kParts - 1) / kParts + 63) & ~63;
-                const int s = hs + part_id * span;
-                float part[VEC];
-                gather_range<VEC, LPR, true>(p, Xc, hubq, s, min(hs + hl, s + span), lane, g, col_active, false, part);
-                if (g == 0) vstore<VEC>(hpart + wave * PW + q * VEC, part);
-            }
-            __syncthreads();
-            if (i < hn && wave % kParts == 0 && g == 0) {
-                float acc[VEC], t[VEC];
-                vload<VEC>(acc, hpart + wave * PW + q * VEC);
-#pragma unroll
-                for (int w = 1; w < kParts; ++w) {
-                    vload<VEC>(t, hpart + (wave + w) * PW + q * VEC);
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[k] += t[k];
-                }
-                vstore<VEC>(hres + i * PW + q * VEC, acc);
-            }
-            __syncthreads();
-        }
-    } else {
-        __syncthreads();
-    }
-
-    unsigned changed = 0;
-    for (int rt = r0; rt < r1; ++rt)
-        tile_round<VEC, LPR, MODE, RT, NW, true>(p, smem, hubq, hn, panel, rt, lane, wave, changed);
-
-    if constexpr (MODE != kTrans) {
-        if (p.has_ep && p.prev) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) changed += __shfl_down(changed, off);
-            if (lane == 0 && changed)
-                atomicAdd(p.n_changed + ((blockIdx.x * unsigned(NW) + (threadIdx.x >> 6)) * 7u) % SIMRANK_CHANGED_SLOTS,
-                          (unsigned long long)changed);
-        }
-    }
-}
-
-constexpr int kLdsBytes = 160 * 1024;
-
-// LDS floats a hub workgroup needs besides the hub tile
-static size_t hub_fixed_floats(int mode, int nw, bool has_huge) {
-    return (mode != kPlain ? size_t(nw) * 32 * 33 : 0) +
-           (has_huge ? size_t(nw) * 32 + size_t(kHubHuge) * 32 + kHubHuge : 0);
-}
-
-// Largest hub tile every mode of an NW-wave workgroup can hold.
-int hub_capacity(int nw) {
-    return int((kLdsBytes - 1024 - sizeof(float) * hub_fixed_floats(kTrans, nw, true)) / (32 * sizeof(float)));
-}
-
-__global__ __launch_bounds__(256) void scale_ids_kernel(const int32_t* __restrict__ in,
-                                                        int32_t* __restrict__ out, int64_t n,
-                                                        int32_t mult) {
-    for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n;
-         i += int64_t(gridDim.x) * blockDim.x) {
-        const int32_t v = in[i];
-        out[i] = v >= 0 ? v * mult : v;
-    }
-}
-
-// The id lists the 16-byte kernels read: id * (ldx / 4), the row's offset in 16-byte units, so
-// a gather's address is one shift-add.  Cached per graph for the last ldx (a solver uses one
-// pitch for all its matrices).  Built on the launch stream: ordered before the launch.
-static int scaled_ids(simrank_graph* g, int64_t ldx, hipStream_t st) {
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    if (g->col_s && g->scaled_ld == ldx) return SIMRANK_OK;
-    if (g->col_s) SR_HIP(hipDeviceSynchronize());   // other streams may still read the old lists
-    const size_t bytes = std::max<size_t>(16, size_t(g->nnz) * 4);
-    if (!g->col_s) SR_HIP(hipMalloc((void**)&g->col_s, bytes));
-    if (g->hub_n && !g->col_enc_s) SR_HIP(hipMalloc((void**)&g->col_enc_s, bytes));
-    if (g->nnz) {
-        const int grid = (int)std::min<int64_t>((g->nnz + 255) / 256, 4096);
-        hipLaunchKernelGGL(scale_ids_kernel, dim3(grid), dim3(256), 0, st, g->col, g->col_s,
-                           g->nnz, (int32_t)(ldx / 4));
-        if (g->hub_n)
-            hipLaunchKernelGGL(scale_ids_kernel, dim3(grid), dim3(256), 0, st, g->col_enc,
-                               g->col_enc_s, g->nnz, (int32_t)(ldx / 4));
-        SR_HIP(hipGetLastError());
-        SR_HIP(hipStreamSynchronize(st));           // later launches may come from other streams
-    }
-    g->scaled_ld = ldx;
-    return SIMRANK_OK;
-}
-
-// Rows of at least `huge_len` entries, ascending, on the device (cached in the graph).
-static int ensure_huge_rows(simrank_graph* g, int32_t huge_len) {
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    if (g->huge_rows && g->huge_len_built == huge_len) return SIMRANK_OK;
-    std::vector<int32_t> rows;
-    for (int64_t a = 0; a < g->n_rows; ++a)
-        if (g->h_rowptr[size_t(a) + 1] - g->h_rowptr[size_t(a)] >= huge_len) rows.push_back((int32_t)a);
-    if (g->huge_rows) {
-        SR_HIP(hipDeviceSynchronize());      // a launch may still be reading the old list
-        SR_HIP(hipFree(g->huge_rows));
-        g->huge_rows = nullptr;
-    }
-    SR_HIP(hipMalloc((void**)&g->huge_rows, std::max<size_t>(16, rows.size() * 4)));
-    if (!rows.empty())
-        SR_HIP(hipMemcpy(g->huge_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
-    g->n_huge_rows = (int32_t)rows.size();
-    g->huge_len_built = huge_len;
-    return SIMRANK_OK;
-}
-
-template <int MODE, int NW>
-static int launch_hub(SpmmArgs a, hipStream_t st) {
-    constexpr int PW = 32, RT = 32;
-    a.n_panels = int((a.L + PW - 1) / PW);
-    a.row_tiles = int((a.M + int64_t(NW) * RT - 1) / (int64_t(NW) * RT));      // rounds in all
-    int64_t rounds = tuning().hub_rounds;
-    if (rounds <= 0) {
-        // enough rows per workgroup to amortise the tile (>= 4 rounds where the launch still
-        // yields ~16 workgroups per CU), never more than 16 rounds
-        rounds = std::min<int64_t>(16, std::max<int64_t>(4, int64_t(a.row_tiles) * a.n_panels / 4096));
-    }
-    rounds = std::max<int64_t>(1, std::min<int64_t>(rounds, a.row_tiles));
-    a.rounds = int(rounds);
-    a.chunks = int((a.row_tiles + rounds - 1) / rounds);
-    const size_t fixed = hub_fixed_floats(MODE, NW, a.has_huge != 0);
-    a.hub_off = int(fixed);
-    const size_t lds = sizeof(float) * (fixed + size_t(a.hub_n) * PW);
-    SR_REQUIRE(lds <= size_t(kLdsBytes), "hub tile of %d rows needs %zu bytes of LDS", a.hub_n, lds);
-    const int64_t grid = int64_t((a.n_panels + 7) / 8) * 8 * a.chunks;
-    SR_REQUIRE(grid > 0 && grid < (int64_t(1) << 31), "grid of %lld blocks", (long long)grid);
-    auto kern = spmm_hub_kernel<MODE, NW>;
-    SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, st, a);
-    SR_HIP(hipGetLastError());
-    return SIMRANK_OK;
-}
-
 template <int VEC, int LPR, int MODE, int RT>
 static int launch_spmm(SpmmArgs a, hipStream_t st) {
     constexpr int PW = VEC * LPR;
     a.n_panels = int((a.L + PW - 1) / PW);
     const int64_t rows_per_block = int64_t(kWaves) * RT;
     a.row_tiles = int((a.M + rows_per_block - 1) / rows_per_block);
+    if (RT != 32 || (MODE == kSym && !a.sym_map)) a.tile_row0 = nullptr;
+    if (a.tile_row0) a.row_tiles = (a.n_tiles + kWaves - 1) / kWaves;
     const int64_t panels_padded = a.xcd_map ? int64_t((a.n_panels + 7) / 8) * 8 : a.n_panels;
     int64_t grid = panels_padded * a.row_tiles;
     if constexpr (MODE == kSym) {
         static_assert(PW == 32 && RT == 32, "triangular block map assumes 128-row blocks, 32-col panels");
         const int64_t J = (a.n_panels + 7) / 8;      // panels per XCD
         grid = 8 * (J * J + J);                       // longest list (b = 2), others padded
+        if (a.tile_row0) grid = a.sym_blocks;
     }
     SR_REQUIRE(grid > 0 && grid < (int64_t(1) << 31), "grid of %lld blocks", (long long)grid);
     const size_t lds = sizeof(float) * ((MODE != kPlain ? size_t(kWaves) * PW * (RT + 1) : 0) +
@@ -953,12 +608,14 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const float* __restrict__
 
 // ---------------------------------------------------------------------------------------
 // top-k per row: one wave per row, k rounds of "largest element after the previous pick" in
-// the total order (value descending, column ascending).  Exact and deterministic; the row is
+// the total order (value descending, column id ascending; the id of block column c is
+// col_ids[c] when the caller works in a permuted node order, col0 + c otherwise).  Exact and deterministic; the row is
 // re-read k times from L2 (a 128 KiB row stays resident).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ S, int64_t ld,
                                                         int64_t n_rows, int64_t n_cols,
                                                         int64_t col0, int k, int exclude_diag,
+                                                        const int32_t* __restrict__ col_ids,
                                                         int32_t* idx_out, float* val_out) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (blockIdx.x * int64_t(blockDim.x) + threadIdx.x) >> 6;
@@ -973,9 +630,10 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
             int bi = 0x7fffffff;
             for (int64_t c = lane; c < n_cols; c += 64) {
                 const float v = row[c];
-                const bool after = (v < pv) || (v == pv && int(c) > pi);
-                const bool better = (v > bv) || (v == bv && int(c) < bi);
-                if (c != skip && after && better) { bv = v; bi = int(c); }
+                const int id = col_ids ? col_ids[c] : int(col0 + c);
+                const bool after = (v < pv) || (v == pv && id > pi);
+                const bool better = (v > bv) || (v == bv && id < bi);
+                if (c != skip && after && better) { bv = v; bi = id; }
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -985,7 +643,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
             }
             const bool found = bi != 0x7fffffff;
             if (lane == 0) {
-                idx_out[a * k + j] = found ? int32_t(col0 + bi) : -1;
+                idx_out[a * k + j] = found ? bi : -1;
                 val_out[a * k + j] = found ? bv : 0.f;
             }
             if (!found) {
@@ -996,6 +654,25 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
             pv = bv;
             pi = bi;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// dst[i][j] = src[row_idx[i]][col_idx[j]] (a NULL index list = identity): moves a matrix
+// between the solver's node order (rows sorted by length) and the caller's.  One workgroup
+// per destination row: the source row is read scattered (it sits in L2), written coalesced.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void permute_kernel(const T* __restrict__ src, int64_t ld_src,
+                                                      T* __restrict__ dst, int64_t ld_dst,
+                                                      int64_t n_rows, int64_t n_cols,
+                                                      const int32_t* __restrict__ row_idx,
+                                                      const int32_t* __restrict__ col_idx) {
+    for (int64_t i = blockIdx.x; i < n_rows; i += gridDim.x) {
+        const T* in = src + int64_t(row_idx ? row_idx[i] : i) * ld_src;
+        T* out = dst + i * ld_dst;
+        for (int64_t j = threadIdx.x; j < n_cols; j += blockDim.x)
+            out[j] = in[col_idx ? col_idx[j] : j];
     }
 }
 
@@ -1085,8 +762,13 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
     a.tvec = aligned16(Y) && (a.tstride ? a.tstride % 4 == 0
                                         : (a.tblock % 4 == 0 && a.tpad % 4 == 0 && g->n_rows % 4 == 0));
     a.xcd_map = (int)tuning().xcd_map;
-    // 16-byte kernels address rows by 32-bit offsets in 16-byte units
-    bool vec_ok = aligned16(X) && ldx % 4 == 0 && (g->n_cols - 1) * (ldx / 4) < (int64_t(1) << 31);
+    if (g->tile_row0 && tuning().balance) {
+        a.tile_row0 = g->tile_row0;
+        a.n_tiles = g->n_tiles;
+        a.sym_map = g->sym_map;
+        a.sym_blocks = g->sym_blocks;
+    }
+    bool vec_ok = aligned16(X) && ldx % 4 == 0;
     if (!transpose_out) vec_ok = vec_ok && aligned16(Y) && ldy % 4 == 0;
     hipStream_t st = as_stream(stream);
     if (ep) {
@@ -1125,49 +807,18 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
         return transpose_out ? launch_spmm<1, 32, kTrans, 32>(a, st)
                              : launch_spmm<1, 32, kPlain, 32>(a, st);
     }
-    {
-        const int rc = scaled_ids(const_cast<simrank_graph*>(g), ldx, st);
-        if (rc) return rc;
-        a.col = g->col_s;
-    }
 #define SR_TILE_SWITCH(LPR, TR)                                             \
     switch (tile) {                                                         \
         case 16: return launch_spmm<4, LPR, TR, 16>(a, st);                 \
         case 32: return launch_spmm<4, LPR, TR, 32>(a, st);                 \
         default: return launch_spmm<4, LPR, TR, 64>(a, st);                 \
     }
-    // hub form: graphs with a hub plan, 32-float panels, 32-row tiles
-    const bool hub = g->hub_n > 0 && tuning().hub != 0 && tile == 32 &&
-                     (want_sym || (panel == 32) || (!transpose_out && tuning().panel == 0));
-#define SR_HUB_SWITCH(MODE)                                                 \
-    switch (g->hub_waves) {                                                 \
-        case 8: return launch_hub<MODE, 8>(a, st);                          \
-        case 12: return launch_hub<MODE, 12>(a, st);                        \
-        default: return launch_hub<MODE, 16>(a, st);                        \
-    }
-    if (hub) {
-        a.col = g->col_enc_s;
-        a.hub_ids = g->hub_ids;
-        a.hub_n = g->hub_n;
-        if (a.has_huge) {
-            const int rc = ensure_huge_rows(const_cast<simrank_graph*>(g), a.huge_len);
-            if (rc) return rc;
-            a.huge_rows = g->huge_rows;
-            a.n_huge_rows = g->n_huge_rows;
-        }
-    }
     if (want_sym) {
         // upper triangle + mirror: square 32 x 32 wave tiles
         a.tblock = g->n_rows;
         a.tstride = ldy;
-        if (hub) SR_HUB_SWITCH(kSym)
         return launch_spmm<4, 8, kSym, 32>(a, st);
     }
-    if (hub) {
-        if (transpose_out) SR_HUB_SWITCH(kTrans)
-        SR_HUB_SWITCH(kPlain)
-    }
-#undef SR_HUB_SWITCH
     if (transpose_out) {
         if (panel > 64) panel = 64;  // wider panels would not leave LDS for the transpose tile
         if (panel == 64 && tile > 32) tile = 32;
@@ -1215,15 +866,39 @@ int simrank_epilogue_apply(const float* Q, int64_t ldq, float* Y, int64_t ldy, i
     return SIMRANK_OK;
 }
 
-int simrank_topk_rows(const float* S, int64_t ld, int64_t n_rows, int64_t n_cols, int64_t col0,
-                      int32_t k, int32_t exclude_diag, int32_t* idx_out, float* val_out,
-                      void* stream) {
+int simrank_topk_rows_ids(const float* S, int64_t ld, int64_t n_rows, int64_t n_cols, int64_t col0,
+                          const int32_t* col_ids, int32_t k, int32_t exclude_diag,
+                          int32_t* idx_out, float* val_out, void* stream) {
     SR_REQUIRE(S && idx_out && val_out, "NULL argument");
     SR_REQUIRE(n_rows > 0 && n_cols > 0 && ld >= n_cols && n_cols < (int64_t(1) << 31) && k > 0 &&
                    k <= 1024, "bad top-k request");
     const int grid = (int)std::min<int64_t>((n_rows + 3) / 4, 256 * 8);
     hipLaunchKernelGGL(topk_rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), S, ld, n_rows,
-                       n_cols, col0, k, exclude_diag, idx_out, val_out);
+                       n_cols, col0, k, exclude_diag, col_ids, idx_out, val_out);
+    SR_HIP(hipGetLastError());
+    return SIMRANK_OK;
+}
+
+int simrank_topk_rows(const float* S, int64_t ld, int64_t n_rows, int64_t n_cols, int64_t col0,
+                      int32_t k, int32_t exclude_diag, int32_t* idx_out, float* val_out,
+                      void* stream) {
+    return simrank_topk_rows_ids(S, ld, n_rows, n_cols, col0, nullptr, k, exclude_diag, idx_out,
+                                 val_out, stream);
+}
+
+int simrank_permute(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t n_rows,
+                    int64_t n_cols, const int32_t* row_idx, const int32_t* col_idx,
+                    int32_t elem_bytes, void* stream) {
+    SR_REQUIRE(src && dst && src != dst, "permute needs two distinct matrices");
+    SR_REQUIRE(n_rows > 0 && n_cols > 0 && ld_dst >= n_cols && ld_src > 0, "bad block shape");
+    SR_REQUIRE(elem_bytes == 1 || elem_bytes == 4, "elem_bytes must be 1 (u8) or 4 (f32)");
+    const int grid = (int)std::min<int64_t>(n_rows, 256 * 16);
+    if (elem_bytes == 4)
+        hipLaunchKernelGGL(permute_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream),
+                           (const float*)src, ld_src, (float*)dst, ld_dst, n_rows, n_cols, row_idx, col_idx);
+    else
+        hipLaunchKernelGGL(permute_kernel<uint8_t>, dim3(grid), dim3(256), 0, as_stream(stream),
+                           (const uint8_t*)src, ld_src, (uint8_t*)dst, ld_dst, n_rows, n_cols, row_idx, col_idx);
     SR_HIP(hipGetLastError());
     return SIMRANK_OK;
 }

@@ -20,11 +20,11 @@ single GPU that is available, bit-for-bit against P = 1).
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
+from dataclasses import dataclass, replace
 
 import numpy as np
 
-from .ingest import CSR, partition
+from .ingest import CSR, partition, relabel
 
 DENSE_THRESHOLD = 0.05   # density above which the MFMA GEMM legs beat the gather legs
 PAD_MIN_ROWS, PAD_MULTIPLE = 1024, 256   # when exchanged chunk rows get padded (row_pad)
@@ -375,16 +375,53 @@ def choose_mode(mode: str, csrs, world: int, symmetric: bool = True) -> str:
 # --------------------------------------------------------------------------------------
 # solvers
 # --------------------------------------------------------------------------------------
+def length_order(csr: CSR) -> np.ndarray:
+    """Rows of ``csr`` by ascending number of entries (stable)."""
+    return np.argsort(np.diff(csr.rowptr), kind="stable")
+
+
+def reorder_specs(specs):
+    """The update is equivariant under a renaming of the nodes, so the solver is free to pick
+    the order it iterates in: every node set goes by ASCENDING ROW LENGTH of its graph.
+    The rows a wave gathers together then have equal lengths (no masked gathers), and in the
+    upper-triangle form of leg 2 the long rows own the short column ranges — on a power-law
+    graph a quarter of the gathers of the natural order.
+    Returns (specs in the new order, [order of node set j]); results are handed back in the
+    caller's order by ``Solver.result`` / ``topk`` / ``evidence``."""
+    orders = [length_order(sp.csr) for sp in specs]
+    out = []
+    for j, sp in enumerate(specs):
+        cols = orders[0] if len(specs) == 1 else orders[1 - j]
+        csr = relabel(sp.csr, orders[j], cols)
+        ev = sp.evidence_from
+        if ev is sp.csr:
+            ev = csr
+        elif ev is not None and ev.n_rows == sp.csr.n_rows:
+            ev = relabel(ev, orders[j], None)          # common-neighbour counts ignore column names
+        ap = sp.apriori
+        if ap is not None and np.shape(ap) == (sp.csr.n_rows, sp.csr.n_rows):
+            ap = np.asarray(ap)[orders[j]][:, orders[j]]
+        out.append(replace(sp, csr=csr, rowscale=np.asarray(sp.rowscale)[orders[j]],
+                           evidence_from=ev, apriori=ap))
+    return out, orders
+
+
 class Solver:
     """Runs the reference loop for one or two coupled similarity matrices.
 
     ``sides``: [spec] for the directed classes (S <- f(S)); [spec1, spec2] for the bipartite
     ones (S1 <- f1(S2), then S2 <- f2(S1_new)).  ``make_ops(virtual_rank)`` returns the
-    kernel launcher of a virtual rank.
+    kernel launcher of a virtual rank.  Inside, nodes are in ``reorder_specs`` order
+    (``reorder=False`` keeps the caller's); everything handed back is in the caller's.
     """
 
-    def __init__(self, make_ops, world, specs, mode="auto"):
+    def __init__(self, make_ops, world, specs, mode="auto", reorder=True):
         self.world = world
+        self.order = [None] * len(specs)
+        if reorder:
+            specs, self.order = reorder_specs(specs)
+        self.inv = [None if o is None else np.argsort(o) for o in self.order]
+        self._index = {}
         self.specs = specs
         self.bipartite = len(specs) == 2
         self.mode = choose_mode(mode, [s.csr for s in specs], world.size,
@@ -482,10 +519,50 @@ class Solver:
             changed = self.step(eps)
         return None
 
+    def _index_vector(self, r, key, values):
+        """Device copy of an index list, made once per (rank, key)."""
+        if (r, key) not in self._index:
+            self._index[(r, key)] = self.ops[r].index_vector(values)
+        return self._index[(r, key)]
+
     def result(self, j=0):
-        """Full similarity matrix j as float64 on the host (every rank gets it)."""
-        blocks = {r: self.ops[r].download_f64(self.cur[j][r]) for r in self.world.local_ranks}
-        return self.world.gather_columns(blocks, self.n[j], self.n[j])
+        """Full similarity matrix j as float64 on the host (every rank gets it), in the
+        caller's node order."""
+        inv = self.inv[j]
+        blocks = {}
+        for r in self.world.local_ranks:
+            o, src = self.ops[r], self.cur[j][r]
+            if inv is not None and src.cols:
+                # un-permute on the device into the idle ping-pong partner: rows always, and
+                # columns too when this rank holds all of them
+                rows = self._index_vector(r, ("inv", j), inv)
+                o.permute(src, self.nxt[j][r], rows, rows if self.world.size == 1 else None)
+                src = self.nxt[j][r]
+            blocks[r] = o.download_f64(src)
+        full = self.world.gather_columns(blocks, self.n[j], self.n[j])
+        if inv is not None and self.world.size > 1:
+            full = np.ascontiguousarray(full[:, inv])
+        return full
+
+    def evidence(self, j=0):
+        """Evidence matrix of side j (1 - 0.5**count, SimRank.py:316) as float64 in the
+        caller's node order; local shards only (see estimators._lazy_evidence)."""
+        inv = self.inv[j]
+        blocks = {}
+        for r, side in self.sides[j].items():
+            o, cnt = side.ops, side.ev
+            if inv is not None and cnt.cols:
+                tmp = o.matrix(cnt.rows, cnt.cols, np.uint8)
+                rows = self._index_vector(r, ("inv", j), inv)
+                o.permute(cnt, tmp, rows, rows if self.world.size == 1 else None)
+                blocks[r] = 1 - 0.5 ** o.download(tmp).astype(np.float64)
+                tmp.free()
+            else:
+                blocks[r] = 1 - 0.5 ** o.download(cnt).astype(np.float64)
+        full = self.world.gather_columns(blocks, self.n[j], self.n[j])
+        if inv is not None and self.world.size > 1:
+            full = np.ascontiguousarray(full[:, inv])
+        return full
 
     def topk(self, j, k, exclude_diag=True):
         """k most similar columns of every row of similarity matrix j, found on the device
@@ -497,8 +574,11 @@ class Solver:
         for r in self.world.local_ranks:
             lo, hi = partition(n, self.world.size, r)
             if hi > lo:
+                ids = None
+                if self.order[j] is not None:      # report (and break ties by) the caller's ids
+                    ids = self._index_vector(r, ("ids", j), self.order[j][lo:hi])
                 per_rank[r] = self.ops[r].topk_rows(self.cur[j][r], min(k, hi - lo), col0=lo,
-                                                    exclude_diag=exclude_diag)
+                                                    exclude_diag=exclude_diag, col_ids=ids)
             else:
                 per_rank[r] = (np.full((n, 1), -1, np.int32), np.zeros((n, 1), np.float32))
         parts = self.world.gather_list(per_rank)
@@ -507,7 +587,10 @@ class Solver:
         key = np.where(idx >= 0, val, -np.inf)
         order = np.lexsort((idx, -key), axis=1)[:, :k]
         rows = np.arange(n)[:, None]
-        return idx[rows, order], np.where(idx[rows, order] >= 0, val[rows, order], 0.0)
+        idx, val = idx[rows, order], np.where(idx[rows, order] >= 0, val[rows, order], 0.0)
+        if self.inv[j] is not None:                # rows back into the caller's order
+            idx, val = idx[self.inv[j]], val[self.inv[j]]
+        return idx, val
 
     def release(self):
         """Free the work buffers; the evidence counts stay (the ``Evidence`` attributes of

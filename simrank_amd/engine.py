@@ -151,19 +151,38 @@ class HipOps:
                                               m.cols * isz, self.stream), "simrank_memcpy_d2h")
         return out
 
-    def topk_rows(self, m: Matrix, k: int, col0: int = 0, exclude_diag: bool = True):
-        """(global column ids int32 [rows, k], values float32 [rows, k]) of the k largest
-        entries of every row, computed on the device; -1 / 0 where a row has fewer."""
+    def topk_rows(self, m: Matrix, k: int, col0: int = 0, exclude_diag: bool = True,
+                  col_ids: Matrix | None = None):
+        """(column ids int32 [rows, k], values float32 [rows, k]) of the k largest entries of
+        every row, computed on the device; -1 / 0 where a row has fewer.  The id of block
+        column c is ``col0 + c`` unless ``col_ids`` (an ``index_vector``) names them."""
         k = int(k)
         idx = self.matrix(m.rows, k, np.int32, ld=k)
         val = self.matrix(m.rows, k, np.float32, ld=k)
-        check(self.lib.simrank_topk_rows(m.ptr, m.ld, m.rows, m.cols, int(col0), k,
-                                         1 if exclude_diag else 0, idx.ptr, val.ptr, self.stream),
-              "simrank_topk_rows")
+        check(self.lib.simrank_topk_rows_ids(m.ptr, m.ld, m.rows, m.cols, int(col0),
+                                             col_ids.ptr if col_ids is not None else None, k,
+                                             1 if exclude_diag else 0, idx.ptr, val.ptr,
+                                             self.stream), "simrank_topk_rows_ids")
         out = self.download(idx), self.download(val)
         idx.free()
         val.free()
         return out
+
+    def index_vector(self, values) -> Matrix:
+        """int32 index list on the device (for ``permute`` and ``topk_rows``)."""
+        v = np.ascontiguousarray(values, dtype=np.int32).reshape(1, -1)
+        m = self.matrix(1, v.shape[1], np.int32, ld=v.shape[1])
+        self.upload(m, v)
+        return m
+
+    def permute(self, src: Matrix, dst: Matrix, row_idx: Matrix | None = None,
+                col_idx: Matrix | None = None):
+        """dst[i, j] = src[row_idx[i], col_idx[j]] (None = identity); float32 or uint8."""
+        assert src.dtype == dst.dtype and src.dtype.itemsize in (1, 4)
+        check(self.lib.simrank_permute(src.ptr, src.ld, dst.ptr, dst.ld, dst.rows, dst.cols,
+                                       row_idx.ptr if row_idx is not None else None,
+                                       col_idx.ptr if col_idx is not None else None,
+                                       src.dtype.itemsize, self.stream), "simrank_permute")
 
     def download_f64(self, m: Matrix, out: np.ndarray | None = None) -> np.ndarray:
         """float32 device matrix -> float64 host array (pinned, pipelined staging)."""

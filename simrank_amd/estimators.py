@@ -96,13 +96,6 @@ def _is_symmetric(prior) -> bool:
     return a.ndim == 2 and a.shape[0] == a.shape[1] and bool(np.array_equal(a, a.T))
 
 
-def _evidence_from_counts(side):
-    """1 - 0.5**count as float64 (SimRank.py:316); counts saturate at 255 on the device,
-    and 0.5**54 already rounds 1 - x to 1.0, so saturation is exact."""
-    cnt = side.ops.download(side.ev).astype(np.float64)
-    return 1 - 0.5 ** cnt
-
-
 class SimRank(object):
     """SimRank on a directed, optionally weighted graph (SimRank.py:8-141).
 
@@ -194,7 +187,7 @@ class SimRankPP(SimRank):
         k = solver.run(iterations, eps,
                        on_iteration=(lambda i: update_progress(i / iterations)) if talk else None,
                        on_converged=announce_converged if talk else None)
-        self.Evidence = _lazy_evidence(world, solver.sides[0], csr)
+        self.Evidence = _lazy_evidence(world, solver, 0, csr)
         return self._finish(solver, k, top_k)
 
     def fit(self, data, C=0.8, weighted=False, from_node_column="from", to_node_column="to",
@@ -325,10 +318,9 @@ class BipartiteSimRankPP(SimRankPP):
         k = solver.run(iterations, eps,
                        on_iteration=(lambda i: update_progress(i / iterations)) if talk else None,
                        on_converged=announce_converged if talk else None)
-        s1, s2 = solver.sides
-        self.Evidence_N1 = _lazy_evidence(world, s1, g12)
+        self.Evidence_N1 = _lazy_evidence(world, solver, 0, g12)
         self.Evidence_N2 = ((lambda: _host_evidence(g21)) if strict_reference
-                            else _lazy_evidence(world, s2, g21))
+                            else _lazy_evidence(world, solver, 1, g21))
         return self._finish(solver, k, strict_reference, top_k)
 
     def fit(self, data, C1=0.8, C2=0.8, weighted=False, node_group1_column="user",
@@ -360,13 +352,14 @@ class BipartitleAprioriSimRank(BipartiteSimRankPP):
                              lbds=(lbd1, lbd2), top_k=top_k)
 
 
-def _lazy_evidence(world, sides, csr):
-    """Reader for an ``Evidence`` attribute.  With every shard in this process the counts
-    come back from the device; in a multi-process world a lazy read must not be a
-    collective (only some ranks may read it), so it is recomputed from the CSR."""
+def _lazy_evidence(world, solver, j, csr):
+    """Reader for an ``Evidence`` attribute: 1 - 0.5**count as float64 (SimRank.py:316; the
+    device counts saturate at 255, and 0.5**54 already rounds 1 - x to 1.0, so saturation is
+    exact).  With every shard in this process the counts come back from the device; in a
+    multi-process world a lazy read must not be a collective (only some ranks may read
+    it), so it is recomputed from the CSR."""
     if isinstance(world, LocalWorld):
-        return lambda: world.gather_columns(
-            {r: _evidence_from_counts(s) for r, s in sides.items()}, csr.n_rows, csr.n_rows)
+        return lambda: solver.evidence(j)
     return lambda: _host_evidence(csr)
 
 

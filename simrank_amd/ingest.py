@@ -45,6 +45,28 @@ class CSR:
         return CSR(self.n_rows, self.n_cols, self.rowptr, self.col, rowscale)
 
 
+def relabel(csr: CSR, row_order: np.ndarray | None, col_order: np.ndarray | None) -> CSR:
+    """The same matrix with its rows and columns taken in another order: row i of the result is
+    row ``row_order[i]`` of ``csr`` and its column j is column ``col_order[j]`` (None = as they
+    are).  Column ids stay ascending inside a row."""
+    M = csr.n_rows
+    rows = np.arange(M) if row_order is None else np.asarray(row_order, dtype=np.int64)
+    lens = np.diff(csr.rowptr)[rows]
+    rowptr = np.zeros(M + 1, dtype=np.int64)
+    np.cumsum(lens, out=rowptr[1:])
+    # positions of the entries of the selected rows, in the new row order
+    src = np.repeat(csr.rowptr[:-1][rows].astype(np.int64) - rowptr[:-1], lens) + np.arange(rowptr[-1])
+    col = csr.col[src].astype(np.int64)
+    if col_order is not None:
+        new_id = np.empty(csr.n_cols, dtype=np.int64)
+        new_id[np.asarray(col_order, dtype=np.int64)] = np.arange(csr.n_cols)
+        col = new_id[col]
+        key = np.repeat(np.arange(M, dtype=np.int64), lens) * csr.n_cols + col
+        key.sort()
+        col = key % csr.n_cols
+    return CSR(M, csr.n_cols, rowptr.astype(np.int32), col.astype(np.int32), csr.rowscale[rows])
+
+
 def _reciprocal(x) -> np.ndarray:
     """1/x with +-inf replaced by 0 (SimRank.py:49, :197-198)."""
     with np.errstate(divide="ignore"):

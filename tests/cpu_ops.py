@@ -89,16 +89,28 @@ class NumpyOps:
             return out
         return r
 
-    def topk_rows(self, m, k, col0=0, exclude_diag=True):
+    def topk_rows(self, m, k, col0=0, exclude_diag=True, col_ids=None):
         a = m.a[:, :m.cols].astype(np.float32)
+        ids = np.arange(col0, col0 + m.cols) if col_ids is None else col_ids.a[0, :m.cols]
         idx = np.full((m.rows, k), -1, dtype=np.int32)
         val = np.zeros((m.rows, k), dtype=np.float32)
         for r in range(m.rows):
             cols = [c for c in range(m.cols) if not (exclude_diag and c == r - col0)]
-            cols.sort(key=lambda c: (-a[r, c], c))
+            cols.sort(key=lambda c: (-a[r, c], ids[c]))
             for j, c in enumerate(cols[:k]):
-                idx[r, j], val[r, j] = col0 + c, a[r, c]
+                idx[r, j], val[r, j] = ids[c], a[r, c]
         return idx, val
+
+    def index_vector(self, values):
+        v = np.ascontiguousarray(values, dtype=np.int32).reshape(1, -1)
+        m = self.matrix(1, v.shape[1], np.int32, ld=v.shape[1])
+        self.upload(m, v)
+        return m
+
+    def permute(self, src, dst, row_idx=None, col_idx=None):
+        rows = np.arange(dst.rows) if row_idx is None else row_idx.a[0, :dst.rows]
+        cols = np.arange(dst.cols) if col_idx is None else col_idx.a[0, :dst.cols]
+        dst.a[:, :dst.cols] = src.a[rows][:, cols]
 
     def synchronize(self):
         pass

@@ -21,7 +21,7 @@ def ops():
     from simrank_amd.engine import HipOps
     o = HipOps(0)
     yield o
-    o.set_tuning(panel=0, xcd_map=1, hub=-1, hub_waves=8, hub_rounds=0)
+    o.set_tuning(panel=0, xcd_map=1)
 
 
 def random_csr(M, K, avg, seed, heavy=()):
@@ -376,121 +376,3 @@ def test_spmm_lds_epilogue_and_identity(ops):
     ops.b4_identity(eye_b, n)
     ops.b4_unpack(eye_b, n, n, eye)
     np.testing.assert_array_equal(ops.download(eye), np.eye(n, dtype=np.float32))
-
-
-def skewed_csr(M, K, avg, seed, heavy=()):
-    """Zipf-popular columns: a few rows of X carry most references (what the hub tile serves)."""
-    rng = np.random.default_rng(seed)
-    w = 1.0 / np.arange(1, K + 1) ** 1.1
-    w = rng.permutation(w / w.sum())
-    rows = []
-    for a in range(M):
-        d = heavy[a] if a in heavy else (0 if rng.random() < 0.05 else min(K, 1 + rng.poisson(avg)))
-        rows.append(np.sort(rng.choice(K, size=d, replace=False, p=w)))
-    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
-    col = np.concatenate(rows).astype(np.int32)
-    rs = rng.random(M) + 0.1
-    return CSR(M, K, rowptr, col, rs)
-
-
-@pytest.mark.parametrize("waves,hub,rounds", [(8, 48, 0), (8, 300, 1), (12, 64, 2), (16, 1, 3), (16, 700, 0)])
-def test_spmm_hub_kernel_all_modes(ops, waves, hub, rounds):
-    """spmm_hub_kernel (most referenced rows of X served from an LDS tile): plain, transposed
-    (pitched and blocked) and the fused epilogue, against NumPy — and bit-identical to
-    spmm_gather_kernel on the same graph object (same summation order by construction)."""
-    M, K, L = 700, 600, 100
-    heavy = {0: 580, 5: 540, 6: 512, 300: 599, 301: 70, 650: 520}
-    heavy.update({a: 515 + a - 256 for a in range(256, 267)})     # more huge rows than slots
-    ops.set_tuning(panel=0, hub=hub, hub_waves=waves, hub_rounds=rounds)
-    csr = skewed_csr(M, K, 12, seed=waves + hub, heavy=heavy)
-    g = ops.graph(csr)                                             # plan built here
-    rng = np.random.default_rng(2)
-    X = rng.random((K, L)).astype(np.float32)
-    x = put(ops, X)
-    want = dense64(csr) @ X.astype(np.float64)
-
-    def both(fn):
-        """fn() under the hub kernel and under the gather kernel; returns the two results."""
-        ops.set_tuning(hub=hub)
-        a = fn()
-        ops.set_tuning(hub=0, panel=32)
-        b = fn()
-        ops.set_tuning(hub=hub, panel=0)
-        return a, b
-
-    def plain():
-        y = ops.matrix(M, L)
-        ops.spmm(g, x, y)
-        return ops.download(y)
-
-    def trans():
-        y = ops.matrix(L, M)
-        ops.spmm(g, x, y, transpose_out=True)
-        return ops.download(y)
-
-    def blocked():
-        tb, pad = 128, 4
-        nblk = -(-M // tb)
-        y = ops.matrix(1, nblk * L * (tb + pad), ld=nblk * L * (tb + pad))
-        ops.spmm(g, x, y, transpose_out=True, t_block=tb, t_pad=pad)
-        flat = ops.download(y).ravel()
-        out = np.zeros((L, M), dtype=np.float32)
-        for h in range(nblk):
-            lo, hi = h * tb, min(M, (h + 1) * tb)
-            w = hi - lo + pad
-            out[:, lo:hi] = flat[h * L * (tb + pad): h * L * (tb + pad) + L * w].reshape(L, w)[:, :hi - lo]
-        return out
-
-    for fn, ref in ((plain, want), (trans, want.T), (blocked, want.T)):
-        a, b = both(fn)
-        np.testing.assert_allclose(a, ref, rtol=RTOL, atol=1e-30)
-        assert np.array_equal(a, b), fn.__name__
-
-    cnt = rng.integers(0, 6, size=(M, L)).astype(np.uint8)
-    prior = rng.random((M, L)).astype(np.float32)
-    prev = (rng.random((M, L)) * 40).astype(np.float32)
-    e, pr, pv = put(ops, cnt, dtype=np.uint8), put(ops, prior), put(ops, prev)
-
-    def fused():
-        y = ops.matrix(M, L)
-        ops.spmm(g, x, y, epilogue=dict(coef=0.8, diag_col0=40, previous=pv, eps=9.0, evidence=e,
-                                        apriori=pr, lbd=0.3))
-        return ops.download(y), ops.read_changed()
-
-    (a, na), (b, nb) = both(fused)
-    ref = (1 - np.float32(0.3)) * (0.8 * want * (1 - 0.5 ** cnt.astype(np.float64))) + \
-        np.float32(0.3) * prior.astype(np.float64)
-    for c in range(L):
-        ref[40 + c, c] = 1.0
-    np.testing.assert_allclose(a, ref, rtol=RTOL, atol=1e-30)
-    assert np.array_equal(a, b) and na == nb
-    assert na == int((np.abs(a.astype(np.float64) - prev.astype(np.float64)) > 9.0).sum()) and 0 < na < M * L
-
-
-@pytest.mark.parametrize("n,waves", [(200, 8), (1000, 8), (1031, 12), (1031, 16)])
-def test_spmm_hub_kernel_symmetric_leg2(ops, n, waves):
-    """Upper triangle + mirror under the hub kernel: rounds below the diagonal are skipped."""
-    ops.set_tuning(panel=0, hub=96, hub_waves=waves, hub_rounds=2)
-    csr = skewed_csr(n, n, 10, seed=n, heavy={3: min(n, 600), 40: min(n, 90)})
-    rng = np.random.default_rng(n)
-    S = rng.random((n, n)).astype(np.float32)
-    S = ((S + S.T) / 2).astype(np.float32)
-    np.fill_diagonal(S, 1)
-    cnt = rng.integers(0, 5, size=(n, n))
-    cnt = np.minimum(cnt, cnt.T).astype(np.uint8)
-    g, s_in, tt, e = ops.graph(csr), put(ops, S), ops.matrix(n, n), put(ops, cnt, dtype=np.uint8)
-    ops.spmm(g, s_in, tt, transpose_out=True)
-    outs = {}
-    for hub in (96, 0):
-        ops.set_tuning(hub=hub)
-        y = ops.matrix(n, n)
-        ops.spmm(g, tt, y, epilogue=dict(coef=0.8, evidence=e, previous=s_in, eps=0.05, diag_col0=0,
-                                         symmetric=True))
-        outs[hub] = (ops.download(y), ops.read_changed())
-    W = dense64(csr)
-    want = 0.8 * (W @ S.astype(np.float64) @ W.T) * (1 - 0.5 ** cnt.astype(np.float64))
-    np.fill_diagonal(want, 1.0)
-    np.testing.assert_allclose(outs[96][0], want, rtol=RTOL, atol=1e-30)
-    assert np.array_equal(outs[96][0], outs[0][0]) and outs[96][1] == outs[0][1]
-    assert np.array_equal(outs[96][0][:32, 32:], outs[96][0][32:, :32].T)    # mirrored tiles: same bits
-    ops.set_tuning(hub=-1, hub_waves=8, hub_rounds=0)

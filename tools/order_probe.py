@@ -53,7 +53,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="pl32768,er8192")
 args = ap.parse_args()
 ops = HipOps(0)
-ops.set_tuning(hub=0)
+pass
 for w in args.workload.split(","):
     df = synth.WORKLOADS[w][0]()
     _, csr = ingest.directed(df, False, "from", "to", "weight")

@@ -4,7 +4,6 @@ simrank_set_tuning).  Used for the profiles/sweep_r01_*.log tables.
 
     python tools/sweep.py [--workload pl32768] [--panel 32,64] [--tile 16,32,64]
                           [--xcd 1,0] [--huge 512] [--triangle 1]
-                          [--hub -1,0] [--hub-waves 8,12,16] [--hub-rounds 0]
 """
 import argparse
 import itertools
@@ -28,9 +27,6 @@ ap.add_argument("--tile", type=ints, default=[0])
 ap.add_argument("--xcd", type=ints, default=[1])
 ap.add_argument("--huge", type=ints, default=[512])
 ap.add_argument("--triangle", type=ints, default=[1])
-ap.add_argument("--hub", type=ints, default=[-1])
-ap.add_argument("--hub-waves", type=ints, default=[8])
-ap.add_argument("--hub-rounds", type=ints, default=[0])
 args = ap.parse_args()
 
 ops = HipOps(0)
@@ -38,11 +34,9 @@ for w in args.workload.split(","):
     df = synth.WORKLOADS[w][0]()
     _, csr = ingest.directed(df, False, "from", "to", "weight")
     print(f"# {w}: N={csr.n_rows} nnz={csr.nnz}", flush=True)
-    for panel, tile, xcd, huge, tri, hub, hw, hr in itertools.product(
-            args.panel, args.tile, args.xcd, args.huge, args.triangle, args.hub, args.hub_waves,
-            args.hub_rounds):
-        ops.set_tuning(panel=panel, tile=tile, xcd_map=xcd, huge=huge, triangle=tri, hub=hub,
-                       hub_waves=hw, hub_rounds=hr)
+    for panel, tile, xcd, huge, tri in itertools.product(args.panel, args.tile, args.xcd, args.huge,
+                                                         args.triangle):
+        ops.set_tuning(panel=panel, tile=tile, xcd_map=xcd, huge=huge, triangle=tri)
         s = Solver(lambda r: ops, LocalWorld(1), [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
         s.reset()
         for _ in range(2):
@@ -53,9 +47,8 @@ for w in args.workload.split(","):
         t = s.leg_times()
         l1, l2 = t["leg1.0"][0], t["leg2.0"][0]
         gb = 4e-9 * csr.nnz * csr.n_rows
-        print(f"{w} panel={panel:3d} tile={tile:2d} xcd={xcd} huge={huge} triangle={tri} "
-              f"hub={hub:4d} waves={hw:2d} rounds={hr:2d}  "
+        print(f"{w} panel={panel:3d} tile={tile:2d} xcd={xcd} huge={huge} triangle={tri}  "
               f"leg1 {l1:8.3f} ms ({gb / l1:6.2f} TB/s gathered)  leg2 {l2:8.3f} ms", flush=True)
         s.release()
         del s
-ops.set_tuning(panel=0, tile=0, xcd_map=1, huge=512, triangle=1, hub=-1, hub_waves=8, hub_rounds=0)
+ops.set_tuning(panel=0, tile=0, xcd_map=1, huge=512, triangle=1)

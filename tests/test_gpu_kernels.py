@@ -376,3 +376,69 @@ def test_spmm_lds_epilogue_and_identity(ops):
     ops.b4_identity(eye_b, n)
     ops.b4_unpack(eye_b, n, n, eye)
     np.testing.assert_array_equal(ops.download(eye), np.eye(n, dtype=np.float32))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint8])
+def test_permute(ops, dtype):
+    """dst[i, j] = src[row_idx[i], col_idx[j]], pitched operands, either index list optional."""
+    rng = np.random.default_rng(8)
+    src_h = (rng.random((70, 45)) * 200).astype(dtype)
+    src = put(ops, src_h, ld=64 if dtype == np.float32 else 48, dtype=dtype)
+    ri, ci = rng.integers(0, 70, size=33), rng.integers(0, 45, size=51)
+    rv, cv = ops.index_vector(ri), ops.index_vector(ci)
+    for rows, cols, want in ((rv, cv, src_h[ri][:, ci]), (rv, None, src_h[ri]), (None, cv, src_h[:, ci]),
+                             (None, None, src_h)):
+        dst = ops.matrix(want.shape[0], want.shape[1], dtype)
+        ops.permute(src, dst, rows, cols)
+        np.testing.assert_array_equal(ops.download(dst), want)
+
+
+def test_topk_rows_with_column_ids(ops):
+    """Ids given by the caller are what is reported and what breaks ties."""
+    rng = np.random.default_rng(2)
+    S = rng.integers(0, 4, size=(40, 30)).astype(np.float32)          # many ties
+    ids = rng.permutation(1000)[:30].astype(np.int32)
+    idx, val = ops.topk_rows(put(ops, S), 6, col0=5, exclude_diag=True, col_ids=ops.index_vector(ids))
+    for a in range(40):
+        cols = [c for c in range(30) if c != a - 5]
+        cols.sort(key=lambda c: (-S[a, c], ids[c]))
+        assert list(idx[a]) == [ids[c] for c in cols[:6]]
+        assert list(val[a]) == [S[a, c] for c in cols[:6]]
+
+
+@pytest.mark.parametrize("balance", [0, 1, 4])
+def test_balanced_tiles(ops, balance):
+    """Rows sorted by length (all the long ones in the last 32-row blocks): heavy tiles are cut
+    into halves down to single rows, workgroups run last-first, leg 2 takes its launch list
+    from the host.  Every form of the leg against NumPy, for uniform and balanced tilings."""
+    n = 700
+    rng = np.random.default_rng(balance)
+    lens = np.sort(np.minimum(n, (rng.pareto(1.2, size=n) * 6).astype(int) + (rng.random(n) < 0.9)))
+    lens[-3:] = [520, 600, 700]
+    rows = [np.sort(rng.choice(n, size=d, replace=False)) for d in lens]
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    csr = CSR(n, n, rowptr, np.concatenate(rows).astype(np.int32), rng.random(n) + 0.1)
+    ops.set_tuning(balance=balance)
+    try:
+        g = ops.graph(csr)
+    finally:
+        ops.set_tuning(balance=4)
+    S = rng.random((n, n)).astype(np.float32)
+    S = ((S + S.T) / 2).astype(np.float32)
+    np.fill_diagonal(S, 1)
+    W = dense64(csr)
+    s_in, tt, y = put(ops, S), ops.matrix(n, n), ops.matrix(n, n)
+    ops.spmm(g, s_in, y)
+    np.testing.assert_allclose(ops.download(y), W @ S.astype(np.float64), rtol=RTOL, atol=1e-30)
+    ops.spmm(g, s_in, tt, transpose_out=True)
+    np.testing.assert_allclose(ops.download(tt), (W @ S.astype(np.float64)).T, rtol=RTOL, atol=1e-30)
+    cnt = rng.integers(0, 5, size=(n, n))
+    cnt = np.minimum(cnt, cnt.T).astype(np.uint8)
+    want = 0.8 * (W @ S.astype(np.float64) @ W.T) * (1 - 0.5 ** cnt.astype(np.float64))
+    np.fill_diagonal(want, 1.0)
+    for sym in (True, False):
+        ops.spmm(g, tt, y, epilogue=dict(coef=0.8, evidence=put(ops, cnt, dtype=np.uint8), previous=s_in,
+                                         eps=0.05, diag_col0=0, symmetric=sym))
+        got = ops.download(y)
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-30)
+        assert ops.read_changed() == int((np.abs(got.astype(np.float64) - S) > 0.05).sum())

@@ -197,3 +197,72 @@ def test_stage_plan_is_a_permutation():
     p = permute_columns(csr, perm)
     d = csr.dense()
     np.testing.assert_array_equal(p.dense()[:, perm], d)
+
+
+def test_relabel_is_the_permuted_matrix():
+    rng = np.random.default_rng(5)
+    dense = (rng.random((37, 23)) < 0.2)
+    dense[4] = False                                   # an empty row
+    rows, cols = np.nonzero(dense)
+    rowptr = np.concatenate([[0], np.cumsum(dense.sum(axis=1))]).astype(np.int32)
+    csr = ingest.CSR(37, 23, rowptr, cols.astype(np.int32), rng.random(37) + 0.5)
+    ro, co = rng.permutation(37), rng.permutation(23)
+    for r, c in ((ro, co), (ro, None), (None, co), (None, None)):
+        out = ingest.relabel(csr, r, c)
+        want = csr.dense()
+        want = want if r is None else want[r]
+        want = want if c is None else want[:, c]
+        np.testing.assert_array_equal(out.dense(), want)
+        for a in range(37):                            # ids ascending inside every row
+            seg = out.col[out.rowptr[a]:out.rowptr[a + 1]]
+            assert np.all(np.diff(seg) > 0)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("name", ["SimRank_er128", "SimRankPP_quirky", "AprioriSimRank_er64_asym",
+                                  "BipartiteSimRankPP_b40", "BipartiteSimRank_b5030"])
+def test_solver_node_order_is_invisible(name, world):
+    """The solver iterates with every node set sorted by row length (driver.reorder_specs);
+    results, evidence and top-k come back in the caller's order and match a solver that
+    keeps the caller's order throughout."""
+    from simrank_amd import driver
+    g = Golden(name)
+    made = []
+    orig = driver.Solver.__init__
+    outs = {}
+    for reorder in (True, False):
+        def init(self, make_ops, w, specs, mode="auto", reorder=reorder):
+            orig(self, make_ops, w, specs, mode, reorder=reorder)
+            made.append(self)
+        driver.Solver.__init__ = init
+        try:
+            est, res, _ = run_estimator(g, _factory(), world=LocalWorld(world), mode="sparse")
+            ev = [getattr(est, a) for a in ("Evidence", "Evidence_N1", "Evidence_N2") if hasattr(est, a)]
+            outs[reorder] = (res, ev)
+        finally:
+            driver.Solver.__init__ = orig
+    assert any(s.order[0] is not None and not np.array_equal(s.order[0], np.arange(s.n[0])) for s in made)
+    a, b = outs[True], outs[False]
+    for x, y in zip(a[0] if isinstance(a[0], tuple) else (a[0],), b[0] if isinstance(b[0], tuple) else (b[0],)):
+        assert list(x.index) == list(y.index)
+        np.testing.assert_allclose(x.values, y.values, rtol=1e-6, atol=1e-30)
+    for x, y in zip(a[1], b[1]):
+        np.testing.assert_array_equal(x, y)
+    check_against_golden(g, *run_estimator(g, _factory(), world=LocalWorld(world), mode="sparse"))
+
+
+def test_top_k_ties_follow_the_callers_order():
+    """Equal similarities are ranked by position in the caller's node order even though the
+    device works in its own order (simrank_topk_rows_ids)."""
+    import simrank_amd.SimRank as SRA
+    # a star: every leaf is equally similar to every other leaf
+    df = pd.DataFrame({"from": [0] * 12, "to": list(range(1, 13))})
+    df = pd.concat([df, pd.DataFrame({"from": [3, 3, 5], "to": [0, 7, 7]})], ignore_index=True)
+    dense = SRA.SimRank().fit(df, verbose=False, _ops_factory=_factory())
+    top = SRA.SimRank().fit(df, verbose=False, top_k=4, _ops_factory=_factory(), mode="sparse")
+    labels = list(dense.index)
+    for node in labels:
+        row = dense.loc[node].drop(node)
+        order = sorted(range(len(row)), key=lambda i: (-np.float32(row.iloc[i]), labels.index(row.index[i])))
+        got = top[top.node == node].sort_values("rank")
+        assert list(got.neighbor) == [row.index[i] for i in order[:4]]

@@ -219,6 +219,17 @@ SIMRANK_API int simrank_b4_unpack(const float* S_b4, int64_t n_rows, int64_t n_c
 SIMRANK_API int simrank_b4_pack(const void* in, int64_t ld, int64_t n_rows, int64_t n_cols,
                                 int32_t elem_bytes, void* out_b4, void* stream);
 
+/* ---- block-dense part of a pattern.  When a graph is created, every aligned
+ *      block of 128 rows gets a DENSE SET: the columns referenced by at least `dense_min` of its
+ *      rows (kept only if there are `dense_cols` of them).  simrank_spmm multiplies those
+ *      entries on the matrix cores (0/1 pattern in bf16 x the operand split into three bf16
+ *      terms: exact f32 products, f32 accumulation) and gathers only the remainder; this is
+ *      the "dense S.W contraction on MFMA" of the north star, applied where W really is dense
+ *      (first and second `.dot` of SimRank.py:139 and their bipartite / PP forms).
+ *      The statistics: blocks with a dense set, total size of the sets, entries covered. */
+SIMRANK_API int simrank_graph_dense_stats(const simrank_graph* g, int64_t* n_tiles,
+                                          int64_t* dense_cols, int64_t* nnz_covered);
+
 /* ---- tuning knobs (measurement harness; defaults are the tuned values):
  *      "panel"    columns per gather panel (16, 32, 64, 128, 256; 0 = automatic)
  *      "tile"     rows per wave tile (16, 32, 64; 0 = automatic)
@@ -227,7 +238,10 @@ SIMRANK_API int simrank_b4_pack(const void* in, int64_t ld, int64_t n_rows, int6
  *      "stream_nt" 0/1 non-temporal access for streamed-once data
  *      "huge"     rows of at least this many entries are split over a workgroup's waves
  *      "balance"  32-row tiles heavier than this many times the mean tile are cut in halves
- *                 (read when a graph is created; 0 = uniform tiles) ---- */
+ *                 (read when a graph is created; 0 = uniform tiles)
+ *      "dense_min" / "dense_cols"  selection of the block-dense part (see above); read when a
+ *                 graph is created; simrank_spmm also skips the dense part while dense_min
+ *                 is 0 ---- */
 SIMRANK_API int simrank_set_tuning(const char* key, int64_t value);
 SIMRANK_API int simrank_get_tuning(const char* key, int64_t* value);
 

@@ -28,6 +28,60 @@ Tuning& tuning() {
 
 }  // namespace simrank
 
+
+namespace simrank {
+// ---- balanced tiling: 32-row blocks whose cost (entries) exceeds `balance` times the mean
+// are cut into aligned halves, down to single rows, so that no wave is left with a tile
+// many times the others' (a power-law row order sorted by length puts all long rows
+// in a few blocks).  For the upper-triangle leg 2: the (panel, workgroup) launch list.
+void build_tiles(const int32_t* rowptr, int64_t n_rows, int64_t nnz, std::vector<int32_t>& tile_row0,
+                 std::vector<int32_t>& sym_map) {
+    tile_row0.clear();
+    sym_map.clear();
+    if (tuning().balance <= 0 || nnz <= 0) return;
+    const int64_t nblk = (n_rows + 31) / 32;
+    const int64_t limit = std::max<int64_t>(tuning().balance * ((nnz + nblk - 1) / nblk), 256);
+    std::vector<std::pair<int64_t, int64_t>> stack;
+    for (int64_t b = 0; b < nblk; ++b) {
+        stack.clear();
+        stack.emplace_back(b * 32, std::min<int64_t>(n_rows, b * 32 + 32));
+        while (!stack.empty()) {
+            const auto [lo, hi] = stack.back();
+            stack.pop_back();
+            if (rowptr[hi] - rowptr[lo] <= limit || hi - lo <= 1) {
+                tile_row0.push_back((int32_t)lo);
+            } else {
+                const int64_t mid = lo + (hi - lo + 1) / 2;
+                stack.emplace_back(mid, hi);       // popped second: tiles stay in row order
+                stack.emplace_back(lo, mid);
+            }
+        }
+    }
+    tile_row0.push_back((int32_t)n_rows);
+    const int64_t n_tiles = (int64_t)tile_row0.size() - 1;
+    if (n_rows < 64) return;
+    std::vector<std::vector<int32_t>> lists(8);
+    size_t t_end = 0;                            // tiles with row0 < 32 (p + 1)
+    for (int64_t pnl = 0; pnl < nblk; ++pnl) {
+        while (t_end < (size_t)n_tiles && tile_row0[t_end] < 32 * (pnl + 1)) ++t_end;
+        const int64_t groups = ((int64_t)t_end + 3) / 4;
+        std::vector<int32_t>& l = lists[size_t(pnl & 7)];
+        for (int64_t rt = groups - 1; rt >= 0; --rt) {     // heavy (late) groups first
+            l.push_back((int32_t)pnl);
+            l.push_back((int32_t)rt);
+        }
+    }
+    size_t longest = 0;
+    for (const auto& l : lists) longest = std::max(longest, l.size() / 2);
+    sym_map.assign(longest * 8 * 2, -1);
+    for (size_t x = 0; x < 8; ++x)
+        for (size_t k = 0; k < lists[x].size() / 2; ++k) {
+            sym_map[2 * (8 * k + x)] = lists[x][2 * k];
+            sym_map[2 * (8 * k + x) + 1] = lists[x][2 * k + 1];
+        }
+}
+}  // namespace simrank
+
 using namespace simrank;
 
 extern "C" {
@@ -273,56 +327,10 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
     g->max_row_nnz = max_row;
     g->h_rowptr.assign(rowptr, rowptr + n_rows + 1);
     g->h_col.assign(col, col + nnz);
-    // ---- balanced tiling: 32-row blocks whose cost (entries) exceeds `balance` times the mean
-    // are cut into aligned halves, down to single rows, so that no wave is left with a tile
-    // many times the others' (a power-law row order sorted by length puts all long rows
-    // in a few blocks).  For the upper-triangle leg 2: the (panel, workgroup) launch list.
     std::vector<int32_t> tile_row0, sym_map;
-    if (tuning().balance > 0 && nnz > 0) {
-        const int64_t nblk = (n_rows + 31) / 32;
-        const int64_t limit = std::max<int64_t>(tuning().balance * ((nnz + nblk - 1) / nblk), 256);
-        std::vector<std::pair<int64_t, int64_t>> stack;
-        for (int64_t b = 0; b < nblk; ++b) {
-            stack.clear();
-            stack.emplace_back(b * 32, std::min<int64_t>(n_rows, b * 32 + 32));
-            while (!stack.empty()) {
-                const auto [lo, hi] = stack.back();
-                stack.pop_back();
-                if (rowptr[hi] - rowptr[lo] <= limit || hi - lo <= 1) {
-                    tile_row0.push_back((int32_t)lo);
-                } else {
-                    const int64_t mid = lo + (hi - lo + 1) / 2;
-                    stack.emplace_back(mid, hi);       // popped second: tiles stay in row order
-                    stack.emplace_back(lo, mid);
-                }
-            }
-        }
-        tile_row0.push_back((int32_t)n_rows);
-        const int64_t n_tiles = (int64_t)tile_row0.size() - 1;
-        if (n_rows >= 64) {
-            std::vector<std::vector<int32_t>> lists(8);
-            size_t t_end = 0;                            // tiles with row0 < 32 (p + 1)
-            for (int64_t pnl = 0; pnl < nblk; ++pnl) {
-                while (t_end < (size_t)n_tiles && tile_row0[t_end] < 32 * (pnl + 1)) ++t_end;
-                const int64_t groups = ((int64_t)t_end + 3) / 4;
-                std::vector<int32_t>& l = lists[size_t(pnl & 7)];
-                for (int64_t rt = groups - 1; rt >= 0; --rt) {     // heavy (late) groups first
-                    l.push_back((int32_t)pnl);
-                    l.push_back((int32_t)rt);
-                }
-            }
-            size_t longest = 0;
-            for (const auto& l : lists) longest = std::max(longest, l.size() / 2);
-            sym_map.assign(longest * 8 * 2, -1);
-            for (size_t x = 0; x < 8; ++x)
-                for (size_t k = 0; k < lists[x].size() / 2; ++k) {
-                    sym_map[2 * (8 * k + x)] = lists[x][2 * k];
-                    sym_map[2 * (8 * k + x) + 1] = lists[x][2 * k + 1];
-                }
-        }
-        g->n_tiles = (int32_t)n_tiles;
-        g->sym_blocks = (int32_t)(sym_map.size() / 2);
-    }
+    build_tiles(rowptr, n_rows, nnz, tile_row0, sym_map);
+    g->n_tiles = tile_row0.empty() ? 0 : (int32_t)tile_row0.size() - 1;
+    g->sym_blocks = (int32_t)(sym_map.size() / 2);
     auto up = [&](void** d, const void* h, size_t bytes) -> int {
         size_t alloc = std::max<size_t>(bytes, 16);
         hipError_t e = hipMalloc(d, alloc);
@@ -341,6 +349,7 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
     if (!rc) rc = up((void**)&g->t_col, t_col.data(), size_t(nnz) * 4);
     if (!rc && g->n_tiles) rc = up((void**)&g->tile_row0, tile_row0.data(), tile_row0.size() * 4);
     if (!rc && g->sym_blocks) rc = up((void**)&g->sym_map, sym_map.data(), sym_map.size() * 4);
+    if (!rc && tuning().dense_min > 0 && nnz > 0) rc = build_dense_plan(g, rowptr, col);
     if (rc) {
         simrank_graph_destroy(g);
         return rc;
@@ -359,6 +368,7 @@ int simrank_graph_destroy(simrank_graph* g) {
     (void)hipFree(g->tile_row0);
     (void)hipFree(g->sym_map);
     free_lds_plan(g->lds_plan);
+    free_dense_plan(g->dense);
     delete g;
     return SIMRANK_OK;
 }
@@ -397,6 +407,14 @@ int simrank_set_tuning(const char* key, int64_t value) {
     } else if (!strcmp(key, "balance")) {
         SR_REQUIRE(value >= 0 && value <= 1024, "balance must be 0 (uniform tiles) .. 1024");
         t.balance = value;
+    } else if (!strcmp(key, "dense_min")) {
+        SR_REQUIRE(value >= 0 && value <= 128, "dense_min must be 0 (off) .. 128");
+        t.dense_min = value;
+    } else if (!strcmp(key, "dense_sym")) {
+        t.dense_sym = value ? 1 : 0;
+    } else if (!strcmp(key, "dense_cols")) {
+        SR_REQUIRE(value >= 1 && value <= (1 << 20), "dense_cols must be >= 1");
+        t.dense_cols = value;
     } else {
         SR_REQUIRE(false, "unknown tuning key '%s'", key);
     }
@@ -413,6 +431,9 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     else if (!strcmp(key, "triangle")) *value = t.triangle;
     else if (!strcmp(key, "huge")) *value = t.huge;
     else if (!strcmp(key, "balance")) *value = t.balance;
+    else if (!strcmp(key, "dense_min")) *value = t.dense_min;
+    else if (!strcmp(key, "dense_cols")) *value = t.dense_cols;
+    else if (!strcmp(key, "dense_sym")) *value = t.dense_sym;
     else SR_REQUIRE(false, "unknown tuning key '%s'", key);
     return SIMRANK_OK;
 }

@@ -39,6 +39,10 @@ struct Tuning {
     int64_t huge = 512;   // rows of at least this many entries are split over a workgroup's waves
     int64_t triangle = 1; // allow the upper-triangle + mirror form of a symmetric leg 2
     int64_t balance = 4;  // cut 32-row tiles heavier than balance x the mean tile (0 = uniform tiles)
+    int64_t dense_min = 4;   // block-dense MFMA part: a column joins a 128-row tile's dense set when
+                             // at least this many of the tile's rows reference it (0 = off)
+    int64_t dense_cols = 128; // ... and a tile gets a dense set only with this many such columns
+    int64_t dense_sym = 0;   // use the dense part in the upper-triangle form of leg 2 as well
 };
 Tuning& tuning();
 
@@ -49,6 +53,59 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 struct simrank_lds_plan;   // lds.hip: SELL / long-row packing for the LDS-tiled kernel
 namespace simrank { void free_lds_plan(simrank_lds_plan* p); }
+
+// blockdense.hip: the part of the pattern that is dense enough for the matrix cores.  Rows go in
+// aligned blocks of 128; inside a block the columns referenced by at least `dense_min` rows form
+// the block's DENSE SET.  Those entries are multiplied on MFMA (0/1 pattern in bf16 x the operand
+// split into three bf16 terms = exact f32 products, f32 accumulation) into a partial-sum buffer;
+// the gather kernel runs on the REMAINDER pattern and adds the partial sums before its epilogue.
+struct simrank_dense_plan {
+    // A row block's dense set is cut into UNITS of at most 2048 columns (one workgroup per unit
+    // and 256 output columns); unit u writes its raw sums into slab unit_slab[u] of the partial
+    // buffer, and the slabs of a block are consecutive: block b owns slabs
+    // [block_slab0[b], block_slab0[b] + block_nslab[b]).
+    int32_t n_units = 0;            // launch order: heaviest first
+    int32_t n_slabs = 0;
+    int32_t n_blocks_dense = 0;     // 128-row blocks with a dense set
+    int64_t total_k = 0;            // sum of the dense set sizes (each unit padded to 16)
+    int64_t nnz_covered = 0;        // entries that moved to the dense part
+    int32_t* unit_row0 = nullptr;   // [n_units]   first row of the unit's block
+    int32_t* unit_slab = nullptr;   // [n_units]
+    int32_t* unit_kofs = nullptr;   // [n_units+1] offsets into dcols (multiples of 16), launch order
+    int32_t* dcols = nullptr;       // [total_k]   operand rows of the dense sets (padding: 0)
+    uint4* afrag = nullptr;         // [total_k/16][4 row blocks][64 lanes] pattern in MFMA A-operand order
+    int32_t* block_slab0 = nullptr; // [ceil(n_rows/128)] first slab of a row block
+    int32_t* block_nslab = nullptr; // [ceil(n_rows/128)] number of slabs (0 = no dense set)
+    // the remainder pattern and its balanced tiling (as simrank_graph's own)
+    int64_t r_nnz = 0;
+    int32_t r_max_row = 0;
+    int32_t* r_rowptr = nullptr;
+    int32_t* r_col = nullptr;
+    int32_t* r_tile_row0 = nullptr;
+    int32_t r_n_tiles = 0;
+    int32_t* r_sym_map = nullptr;
+    int32_t r_sym_blocks = 0;
+    // partial sums of the last launch: [n_slabs * 128][ldp] f32, grown on demand.  Calls on one
+    // graph must be stream-ordered (one solver per graph object).
+    float* part = nullptr;
+    size_t part_cap = 0;            // floats
+};
+
+namespace simrank {
+struct DenseUse {                   // what the gather kernel needs from a dense launch
+    const float* part = nullptr;
+    int64_t ldp = 0;
+    const int32_t* block_slab0 = nullptr;
+    const int32_t* block_nslab = nullptr;
+};
+void free_dense_plan(simrank_dense_plan* p);
+int build_dense_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col);
+int launch_dense_tiles(const simrank_graph* g, const float* X, int64_t ldx, int64_t L, bool tri,
+                       hipStream_t st, DenseUse* use);
+// balanced 32-row tiling of a pattern (api.hip): tile list and the upper-triangle launch list
+void build_tiles(const int32_t* rowptr, int64_t n_rows, int64_t nnz, std::vector<int32_t>& tile_row0,
+                 std::vector<int32_t>& sym_map);
+}
 
 // The graph object: device CSR of the 0/1 pattern + per-row scale, and the transposed
 // pattern (CSC) used by the evidence kernel.
@@ -71,4 +128,5 @@ struct simrank_graph {
     std::vector<int32_t> h_rowptr, h_col;
     simrank_lds_plan* lds_plan = nullptr;
     bool lds_plan_failed = false;
+    simrank_dense_plan* dense = nullptr;   // NULL: no block of the pattern is dense enough
 };

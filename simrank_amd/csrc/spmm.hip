@@ -71,6 +71,13 @@ struct SpmmArgs {
     unsigned long long* n_changed;
     int64_t diag_col0;
     int32_t set_diag;
+    // block-dense part (blockdense.hip): raw partial sums of the entries that went to the matrix
+    // cores; row a of 128-row block b has one row in each of the block's slabs,
+    // dpart[((dslab0[b] + s) * 128 + a % 128) * ldp], s < dnslab[b]; NULL = none
+    const float* dpart;
+    int64_t ldp;
+    const int32_t* dslab0;
+    const int32_t* dnslab;
 };
 
 template <int VEC>
@@ -143,7 +150,19 @@ __device__ __forceinline__ void emit_row(const SpmmArgs& p, float* tbuf_wave, in
     const float sc = p.rowscale[a] * (p.has_ep ? p.coef : 1.0f);
     float o[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) o[i] = acc[i] * sc;
+    for (int i = 0; i < VEC; ++i) o[i] = acc[i];
+    if (p.dpart) {
+        const int ns = p.dnslab[a >> 7];
+        const float* dp = p.dpart + (int64_t(p.dslab0[a >> 7]) * 128 + (a & 127)) * p.ldp + mycol;
+        for (int s = 0; s < ns; ++s, dp += 128 * p.ldp) {        // fixed order
+            float d[VEC];
+            vload_nt<VEC>(d, dp);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) o[i] += d[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] *= sc;
     if constexpr (TRANS) {
         float* t = tbuf_wave + (q * VEC) * (RT + 1) + r_local;
 #pragma unroll
@@ -762,12 +781,6 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
     a.tvec = aligned16(Y) && (a.tstride ? a.tstride % 4 == 0
                                         : (a.tblock % 4 == 0 && a.tpad % 4 == 0 && g->n_rows % 4 == 0));
     a.xcd_map = (int)tuning().xcd_map;
-    if (g->tile_row0 && tuning().balance) {
-        a.tile_row0 = g->tile_row0;
-        a.n_tiles = g->n_tiles;
-        a.sym_map = g->sym_map;
-        a.sym_blocks = g->sym_blocks;
-    }
     bool vec_ok = aligned16(X) && ldx % 4 == 0;
     if (!transpose_out) vec_ok = vec_ok && aligned16(Y) && ldy % 4 == 0;
     hipStream_t st = as_stream(stream);
@@ -803,6 +816,32 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
     a.nt = (int32_t)tuning().stream_nt;
     const bool want_sym = ep && ep->symmetric && tuning().triangle && vec_ok && !transpose_out &&
                           n_cols_x == g->n_rows && ep->diag_col0 == 0 && g->n_rows >= 64;
+    // the block-dense part goes to the matrix cores first; the gather then runs on the remainder
+    // (not for the upper-triangle form: there the long rows, which own the dense sets, compute
+    // only the few columns right of the diagonal, and the partial sums cost more than they save)
+    const simrank_dense_plan* dp = (vec_ok && tuning().dense_min > 0 && tile == 32 &&
+                                    !(want_sym && !tuning().dense_sym)) ? g->dense : nullptr;
+    if (dp) {
+        DenseUse use;
+        const int rc = launch_dense_tiles(g, X, ldx, n_cols_x, want_sym, st, &use);
+        if (rc) return rc;
+        a.dpart = use.part;
+        a.ldp = use.ldp;
+        a.dslab0 = use.block_slab0;
+        a.dnslab = use.block_nslab;
+        a.rowptr = dp->r_rowptr;
+        a.col = dp->r_col;
+        a.has_huge = dp->r_max_row >= a.huge_len ? 1 : 0;
+    }
+    if (tuning().balance) {
+        const int32_t* tr0 = dp ? dp->r_tile_row0 : g->tile_row0;
+        if (tr0) {
+            a.tile_row0 = tr0;
+            a.n_tiles = dp ? dp->r_n_tiles : g->n_tiles;
+            a.sym_map = dp ? dp->r_sym_map : g->sym_map;
+            a.sym_blocks = dp ? dp->r_sym_blocks : g->sym_blocks;
+        }
+    }
     if (!vec_ok) {
         return transpose_out ? launch_spmm<1, 32, kTrans, 32>(a, st)
                              : launch_spmm<1, 32, kPlain, 32>(a, st);

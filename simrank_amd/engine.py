@@ -294,6 +294,14 @@ class HipOps:
         check(self.lib.simrank_graph_densify(g.handle, Wd.ptr, Wd.ld, self.stream),
               "simrank_graph_densify")
 
+    def dense_stats(self, g: Graph):
+        """(row blocks with a dense set, total size of the sets, entries covered) of the
+        block-dense part of a graph (simrank_graph_dense_stats)."""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(self.lib.simrank_graph_dense_stats(g.handle, C.byref(a), C.byref(b), C.byref(c)),
+              "simrank_graph_dense_stats")
+        return a.value, b.value, c.value
+
     def evidence_counts(self, g: Graph, col0: int, out: Matrix):
         if out.cols:
             check(self.lib.simrank_evidence_counts(g.handle, col0, out.cols, out.ptr, out.ld,

@@ -442,3 +442,126 @@ def test_balanced_tiles(ops, balance):
         got = ops.download(y)
         np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-30)
         assert ops.read_changed() == int((np.abs(got.astype(np.float64) - S) > 0.05).sum())
+
+
+# ---- block-dense part on the matrix cores (blockdense.hip) ----------------------------------
+import contextlib
+
+
+@contextlib.contextmanager
+def dense_knobs(ops, dense_min=3, dense_cols=32, dense_sym=1):
+    """Selection knobs of the dense part for small test graphs (read at graph creation and at
+    launch); the tuned defaults are restored on exit."""
+    ops.set_tuning(dense_min=dense_min, dense_cols=dense_cols, dense_sym=dense_sym)
+    try:
+        yield
+    finally:
+        ops.set_tuning(dense_min=4, dense_cols=128, dense_sym=0)
+
+
+def corner_csr(M, K, seed, hubs=120, p_hub=0.35, avg=5):
+    """Sparse random pattern whose LAST rows reference the first `hubs` columns densely — the
+    corner a power-law graph sorted by row length has."""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for a in range(M):
+        c = set(rng.choice(K, size=min(K, rng.poisson(avg)), replace=False).tolist())
+        if a >= M // 2:
+            c |= set(np.flatnonzero(rng.random(min(hubs, K)) < p_hub * (a / M)).tolist())
+        rows.append(np.array(sorted(c), dtype=np.int32))
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    return CSR(M, K, rowptr, np.concatenate(rows).astype(np.int32), rng.random(M) + 0.1)
+
+
+@pytest.mark.parametrize("shape", [(520, 400, 333), (384, 384, 384), (1000, 300, 70), (130, 200, 2)])
+def test_dense_part_matches_numpy_and_the_gather_path(ops, shape):
+    """Entries of dense (row block, column) pairs go through bf16x3 MFMA, the rest is gathered:
+    same result as NumPy in f64 (1e-5) and as the all-gather path (rounding only), in the plain
+    and the transposed form, ragged widths included."""
+    M, K, L = shape
+    csr = corner_csr(M, K, seed=M + L)
+    X = (np.random.default_rng(5).random((K, L)) ** 3).astype(np.float32)
+    want = dense64(csr) @ X.astype(np.float64)
+    with dense_knobs(ops):
+        g = ops.graph(csr)
+        nt, dk, cov = ops.dense_stats(g)
+        assert nt >= 1 and dk >= 32 and 0 < cov < csr.nnz
+        x, y, yt = put(ops, X), ops.matrix(M, L), ops.matrix(L, M)
+        ops.spmm(g, x, y)
+        ops.spmm(g, x, yt, transpose_out=True)
+        got, got_t = ops.download(y), ops.download(yt)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-30)
+    np.testing.assert_allclose(got_t, want.T, rtol=RTOL, atol=1e-30)
+    with dense_knobs(ops, dense_min=0):             # same graph object, dense part switched off
+        ops.spmm(g, x, y)
+    np.testing.assert_allclose(got, ops.download(y), rtol=2e-6, atol=1e-30)
+
+
+def test_dense_part_split_is_exact(ops):
+    """One dense entry per row: the bf16 hi + mid + lo split must hand the f32 operand back
+    bit for bit (24 mantissa bits, either sign, any exponent whose low-order term is still a
+    normal bf16 number: |x| > ~1e-33)."""
+    M, K, L = 256, 64, 128
+    rows = [np.array([a % 64], dtype=np.int32) for a in range(M)]      # every column: 2 rows per block
+    csr = CSR(M, K, np.arange(M + 1, dtype=np.int32), np.concatenate(rows), np.ones(M))
+    rng = np.random.default_rng(0)
+    X = (rng.standard_normal((K, L)) * np.exp(rng.uniform(-60, 60, size=(K, L)))).astype(np.float32)
+    X[0, :8] = [0.0, 1.0, -1.0, 2.0 ** -100, 1 + 2.0 ** -23, 16777215.0, -3.0000002, 1e-30]
+    with dense_knobs(ops, dense_min=2):
+        g = ops.graph(csr)
+        assert ops.dense_stats(g) == (2, 128, M)
+        x, y = put(ops, X), ops.matrix(M, L)
+        ops.spmm(g, x, y)
+    assert np.array_equal(ops.download(y), X[np.arange(M) % 64])
+
+
+@pytest.mark.parametrize("n", [256, 700])
+def test_dense_part_in_a_whole_update(ops, n):
+    """Both legs with dense sets, fused epilogue, upper-triangle and full forms, convergence count."""
+    csr = corner_csr(n, n, seed=n, hubs=150)
+    with dense_knobs(ops):
+        _whole_update_with_dense_sets(ops, csr, n)
+
+
+def _whole_update_with_dense_sets(ops, csr, n):
+    g = ops.graph(csr)
+    assert ops.dense_stats(g)[0] >= 1
+    rng = np.random.default_rng(n)
+    S = rng.random((n, n)).astype(np.float32)
+    S = ((S + S.T) / 2).astype(np.float32)
+    np.fill_diagonal(S, 1)
+    W = dense64(csr)
+    cnt = rng.integers(0, 5, size=(n, n))
+    cnt = np.minimum(cnt, cnt.T).astype(np.uint8)
+    want = 0.8 * (W @ S.astype(np.float64) @ W.T) * (1 - 0.5 ** cnt.astype(np.float64))
+    np.fill_diagonal(want, 1.0)
+    s_in, tt, y = put(ops, S), ops.matrix(n, n), ops.matrix(n, n)
+    ops.spmm(g, s_in, tt, transpose_out=True)
+    for sym in (True, False):
+        ops.spmm(g, tt, y, epilogue=dict(coef=0.8, evidence=put(ops, cnt, dtype=np.uint8), previous=s_in,
+                                         eps=0.05, diag_col0=0, symmetric=sym))
+        got = ops.download(y)
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-30)
+        assert ops.read_changed() == int((np.abs(got.astype(np.float64) - S) > 0.05).sum())
+        if sym:                                   # mirrored tiles carry the same bits
+            assert np.array_equal(got[:32, 32:], got[32:, :32].T)
+
+
+def test_dense_part_with_a_set_cut_into_units(ops):
+    """A dense set of more than 2048 columns is cut into units with one slab of partial sums
+    each; the gather leg adds the slabs of a row block in a fixed order."""
+    M, K, L = 300, 6000, 100
+    csr = corner_csr(M, K, seed=3, hubs=5500, p_hub=0.6)
+    g = ops.graph(csr)                                       # default knobs
+    nt, dk, cov = ops.dense_stats(g)
+    assert nt >= 1 and dk > 2048 + 2048
+    X = np.random.default_rng(8).random((K, L)).astype(np.float32)
+    want = dense64(csr) @ X.astype(np.float64)
+    x, y, yt = put(ops, X), ops.matrix(M, L), ops.matrix(L, M)
+    ops.spmm(g, x, y)
+    ops.spmm(g, x, yt, transpose_out=True)
+    np.testing.assert_allclose(ops.download(y), want, rtol=RTOL, atol=1e-30)
+    np.testing.assert_allclose(ops.download(yt), want.T, rtol=RTOL, atol=1e-30)
+    first = ops.download(y)
+    ops.spmm(g, x, y)
+    assert np.array_equal(first, ops.download(y))            # reproducible

@@ -229,6 +229,11 @@ SIMRANK_API int simrank_b4_pack(const void* in, int64_t ld, int64_t n_rows, int6
  *      The statistics: blocks with a dense set, total size of the sets, entries covered. */
 SIMRANK_API int simrank_graph_dense_stats(const simrank_graph* g, int64_t* n_tiles,
                                           int64_t* dense_cols, int64_t* nnz_covered);
+/* The matrix-core part of simrank_spmm alone, into the graph's partial-sum buffer (measurement
+ * harness: its HIP-event time and 2 * 3 * 128 * dense_cols * n_cols_x bf16 flop give the MFMA
+ * rate).  X needs 8-byte alignment and an even ldx.  Fails when the graph has no dense sets. */
+SIMRANK_API int simrank_dense_part(const simrank_graph* g, const float* X, int64_t ldx,
+                                   int64_t n_cols_x, void* stream);
 
 /* ---- tuning knobs (measurement harness; defaults are the tuned values):
  *      "panel"    columns per gather panel (16, 32, 64, 128, 256; 0 = automatic)
@@ -241,7 +246,9 @@ SIMRANK_API int simrank_graph_dense_stats(const simrank_graph* g, int64_t* n_til
  *                 (read when a graph is created; 0 = uniform tiles)
  *      "dense_min" / "dense_cols"  selection of the block-dense part (see above); read when a
  *                 graph is created; simrank_spmm also skips the dense part while dense_min
- *                 is 0 ---- */
+ *                 is 0
+ *      "dense_sym" dense part in the upper-triangle form of leg 2: 1 always, 0 never, -1 when
+ *                 the dense sets hold at least half of the entries ---- */
 SIMRANK_API int simrank_set_tuning(const char* key, int64_t value);
 SIMRANK_API int simrank_get_tuning(const char* key, int64_t* value);
 

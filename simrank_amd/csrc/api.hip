@@ -411,7 +411,7 @@ int simrank_set_tuning(const char* key, int64_t value) {
         SR_REQUIRE(value >= 0 && value <= 128, "dense_min must be 0 (off) .. 128");
         t.dense_min = value;
     } else if (!strcmp(key, "dense_sym")) {
-        t.dense_sym = value ? 1 : 0;
+        t.dense_sym = value < 0 ? -1 : (value ? 1 : 0);
     } else if (!strcmp(key, "dense_cols")) {
         SR_REQUIRE(value >= 1 && value <= (1 << 20), "dense_cols must be >= 1");
         t.dense_cols = value;

@@ -339,6 +339,16 @@ using namespace simrank;
 
 extern "C" {
 
+int simrank_dense_part(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_cols_x,
+                       void* stream) {
+    SR_REQUIRE(g && X, "NULL argument");
+    SR_REQUIRE(g->dense, "the graph has no dense sets");
+    SR_REQUIRE(n_cols_x > 0 && ldx >= n_cols_x, "X: %lld columns, ld %lld", (long long)n_cols_x,
+               (long long)ldx);
+    DenseUse use;
+    return launch_dense_tiles(g, X, ldx, n_cols_x, false, as_stream(stream), &use);
+}
+
 int simrank_graph_dense_stats(const simrank_graph* g, int64_t* n_tiles, int64_t* dense_cols,
                               int64_t* nnz_covered) {
     SR_REQUIRE(g, "graph is NULL");

@@ -42,7 +42,8 @@ struct Tuning {
     int64_t dense_min = 4;   // block-dense MFMA part: a column joins a 128-row tile's dense set when
                              // at least this many of the tile's rows reference it (0 = off)
     int64_t dense_cols = 128; // ... and a tile gets a dense set only with this many such columns
-    int64_t dense_sym = 0;   // use the dense part in the upper-triangle form of leg 2 as well
+    int64_t dense_sym = -1;  // dense part in the upper-triangle form of leg 2: 1 yes, 0 no, -1 = when the
+                             // dense sets hold at least half of the pattern's entries
 };
 Tuning& tuning();
 

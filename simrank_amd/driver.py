@@ -26,7 +26,6 @@ import numpy as np
 
 from .ingest import CSR, partition, relabel
 
-DENSE_THRESHOLD = 0.05   # density above which the MFMA GEMM legs beat the gather legs
 PAD_MIN_ROWS, PAD_MULTIPLE = 1024, 256   # when exchanged chunk rows get padded (row_pad)
 STAGE_ALIGN = 32         # stage widths of a pipelined exchange are multiples of this (panels)
 
@@ -365,8 +364,11 @@ def choose_mode(mode: str, csrs, world: int, symmetric: bool = True) -> str:
     if not symmetric:
         return "sparse"       # the NT GEMM legs rely on S == S^T; the gather legs do not
     if mode == "auto":
-        dense = world == 1 and all(c.density > DENSE_THRESHOLD for c in csrs)
-        return "dense" if dense else "sparse"
+        # The gather legs serve every density since the dense blocks of a pattern go to the
+        # matrix cores inside simrank_spmm (bf16x3 MFMA, csrc/blockdense.hip): measured 2-3x
+        # faster than the f32 MFMA GEMM legs on dense graphs too (profiles/modes_r01.log).
+        # "dense" / "hybrid" remain as explicit choices.
+        return "sparse"
     if mode != "sparse" and world != 1:
         raise ValueError("dense and hybrid modes are single-rank; use mode='sparse' when sharded")
     return mode

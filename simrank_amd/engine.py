@@ -302,6 +302,11 @@ class HipOps:
               "simrank_graph_dense_stats")
         return a.value, b.value, c.value
 
+    def dense_part(self, g: Graph, X: Matrix, n_cols: int | None = None):
+        """The matrix-core part of ``spmm`` alone (measurement; see simrank_dense_part)."""
+        check(self.lib.simrank_dense_part(g.handle, X.ptr, X.ld, X.cols if n_cols is None else n_cols,
+                                          self.stream), "simrank_dense_part")
+
     def evidence_counts(self, g: Graph, col0: int, out: Matrix):
         if out.cols:
             check(self.lib.simrank_evidence_counts(g.handle, col0, out.cols, out.ptr, out.ld,

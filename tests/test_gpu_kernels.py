@@ -456,7 +456,7 @@ def dense_knobs(ops, dense_min=3, dense_cols=32, dense_sym=1):
     try:
         yield
     finally:
-        ops.set_tuning(dense_min=4, dense_cols=128, dense_sym=0)
+        ops.set_tuning(dense_min=4, dense_cols=128, dense_sym=-1)
 
 
 def corner_csr(M, K, seed, hubs=120, p_hub=0.35, avg=5):

@@ -47,9 +47,11 @@ def test_golden_vectors_in_every_mode(name, mode):
     check_against_golden(g, est, res, text, check_attrs=False)
 
 
-def test_auto_mode_dispatches_on_density():
+def test_auto_mode_is_the_gather_legs_at_every_density():
+    """mode="auto": simrank_spmm for both legs (dense blocks of the pattern go to the matrix
+    cores inside it); the f32 GEMM legs are an explicit choice."""
     est, _, _ = run_estimator(Golden("BipartiteSimRank_k10"))       # complete bipartite
-    assert est.engine_mode == "dense"
+    assert est.engine_mode == "sparse"
     est, _, _ = run_estimator(Golden("SimRank_er256"))               # 3 % dense
     assert est.engine_mode == "sparse"
 
@@ -267,7 +269,7 @@ def test_directed_edge_cases_on_gpu(cls):
         np.testing.assert_allclose(got.values, want["S"], rtol=RTOL, atol=1e-30, err_msg=name)
         assert est.converged_at == want["k"], name
         if name == "complete_40":
-            assert est.engine_mode == "dense"
+            assert est.engine_mode == "sparse"
 
 
 def test_bipartite_edge_cases_on_gpu():

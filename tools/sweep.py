@@ -27,20 +27,25 @@ ap.add_argument("--tile", type=ints, default=[0])
 ap.add_argument("--xcd", type=ints, default=[1])
 ap.add_argument("--huge", type=ints, default=[512])
 ap.add_argument("--triangle", type=ints, default=[1])
+ap.add_argument("--mode", default="sparse")
 ap.add_argument("--dense-min", type=ints, default=[4])
 ap.add_argument("--dense-cols", type=ints, default=[128])
 args = ap.parse_args()
 
 ops = HipOps(0)
 for w in args.workload.split(","):
-    df = synth.WORKLOADS[w][0]()
+    if w.startswith("er:"):                      # er:N:p  ad-hoc Erdos-Renyi graph
+        _, n_, p_ = w.split(":")
+        df = synth.er_directed(int(n_), float(p_), 1)
+    else:
+        df = synth.WORKLOADS[w][0]()
     _, csr = ingest.directed(df, False, "from", "to", "weight")
     print(f"# {w}: N={csr.n_rows} nnz={csr.nnz}", flush=True)
     for panel, tile, xcd, huge, tri, dmin, dcols in itertools.product(
             args.panel, args.tile, args.xcd, args.huge, args.triangle, args.dense_min, args.dense_cols):
         ops.set_tuning(panel=panel, tile=tile, xcd_map=xcd, huge=huge, triangle=tri, dense_min=dmin,
                        dense_cols=dcols)
-        s = Solver(lambda r: ops, LocalWorld(1), [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
+        s = Solver(lambda r: ops, LocalWorld(1), [SideSpec(csr, csr.rowscale, 0.8)], args.mode)
         s.reset()
         for _ in range(2):
             s.step(0.0)
@@ -51,7 +56,7 @@ for w in args.workload.split(","):
         l1, l2 = t["leg1.0"][0], t["leg2.0"][0]
         gb = 4e-9 * csr.nnz * csr.n_rows
         nt, dk, cov = ops.dense_stats(next(iter(s.sides[0].values())).graph)
-        print(f"{w} panel={panel:3d} tile={tile:2d} xcd={xcd} huge={huge} triangle={tri} "
+        print(f"{w} mode={s.mode} panel={panel:3d} tile={tile:2d} xcd={xcd} huge={huge} triangle={tri} "
               f"dense_min={dmin} dense_cols={dcols} [tiles {nt} cols {dk} covered {cov / max(1, csr.nnz):.3f}]  "
               f"leg1 {l1:8.3f} ms ({gb / l1:6.2f} TB/s gathered)  leg2 {l2:8.3f} ms  "
               f"total {l1 + l2:8.3f} ms", flush=True)

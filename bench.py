@@ -148,7 +148,7 @@ def main():
 
     for _ in range(args.warmup):
         solver.step(0.0)
-    solver.enable_timing()
+    solver.enable_timing(args.steps)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -256,7 +256,7 @@ def main():
             s2.reset()
             for _ in range(3):
                 s2.step(0.0)
-            s2.enable_timing()
+            s2.enable_timing(50)
             ops.synchronize()
             t0 = time.perf_counter()
             for _ in range(50):
@@ -301,7 +301,7 @@ def main():
             s3.reset()
             for _ in range(2):
                 s3.step(0.0)
-            s3.enable_timing()
+            s3.enable_timing(10)
             ops.synchronize()
             t0 = time.perf_counter()
             for _ in range(10):

@@ -129,6 +129,12 @@ typedef struct simrank_epilogue {
                                         symmetric; n_changed counts mirrored elements twice) */
 } simrank_epilogue;
 
+/* ---- the convergence count on the host: sum of the n striped counters an epilogue wrote
+ *      (`_converged`, SimRank.py:74, called once per loop index at :130).  Synchronises the
+ *      stream; the copy goes through pinned memory. */
+SIMRANK_API int simrank_read_counters(const unsigned long long* counters, int32_t n,
+                                      unsigned long long* sum, void* stream);
+
 /* ---- K2 (+K3 sparse form, K4, K5): Y = diag(rowscale).A.X with optional transposed
  *      store and fused epilogue.  X: n_cols(g) x n_cols_x, Y: n_rows(g) x n_cols_x.
  *      transpose_out = 0: Y[a*ldy + c]

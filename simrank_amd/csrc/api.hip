@@ -245,6 +245,34 @@ int simrank_download_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
     return rc;
 }
 
+int simrank_read_counters(const unsigned long long* counters, int32_t n, unsigned long long* sum,
+                          void* stream) {
+    SR_REQUIRE(counters && sum && n > 0 && n <= 65536, "bad counter read");
+    // through a pinned slab kept per device: a pageable 8 KiB read-back costs ~50 us, and the
+    // loop of SimRank.py:130 needs the count on the host after every update
+    struct Slab { unsigned long long* host = nullptr; int32_t cap = 0; };
+    static std::mutex m;
+    static Slab slabs[16];
+    std::lock_guard<std::mutex> lock(m);
+    int dev = 0;
+    SR_HIP(hipGetDevice(&dev));
+    Slab& sl = slabs[dev & 15];
+    if (n > sl.cap) {
+        if (sl.host) (void)hipHostFree(sl.host);
+        sl.host = nullptr;
+        sl.cap = 0;
+        SR_HIP(hipHostMalloc((void**)&sl.host, size_t(n) * sizeof(unsigned long long), hipHostMallocPortable));
+        sl.cap = n;
+    }
+    hipStream_t st = as_stream(stream);
+    SR_HIP(hipMemcpyAsync(sl.host, counters, size_t(n) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    SR_HIP(hipStreamSynchronize(st));
+    unsigned long long total = 0;
+    for (int32_t i = 0; i < n; ++i) total += sl.host[i];
+    *sum = total;
+    return SIMRANK_OK;
+}
+
 int simrank_stream_create(void** stream) {
     SR_REQUIRE(stream, "stream is NULL");
     hipStream_t s;

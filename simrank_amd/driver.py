@@ -456,15 +456,20 @@ class Solver:
                 lo, _ = partition(n, self.world.size, r)
                 self.ops[r].fill_identity(self.cur[j][r], lo)
 
-    def enable_timing(self):
-        """Record HIP events around every leg on the engine's stream (rank-local)."""
+    def enable_timing(self, steps: int = 0):
+        """Record HIP events around every leg on the engine's stream (rank-local).  ``steps``:
+        events for that many steps are created now, outside the region being timed."""
         self.events = []
+        self._event_pool = {r: [self.ops[r].event() for _ in range(4 * len(self.sides) * steps)]
+                            for r in self.world.local_ranks}
 
     def _timed(self, r, fn, tag):
         if self.events is None:
             return fn()
         o = self.ops[r]
-        a, b = o.event(), o.event()
+        pool = getattr(self, "_event_pool", {}).get(r, [])
+        a = pool.pop() if pool else o.event()
+        b = pool.pop() if pool else o.event()
         o.record(a)
         out = fn()
         o.record(b)

@@ -314,10 +314,10 @@ class HipOps:
 
     def read_changed(self) -> int:
         """Value of the convergence counter of the last epilogue with ``previous``."""
-        v = (C.c_ulonglong * CHANGED_SLOTS)()
-        check(self.lib.simrank_memcpy_d2h(v, self._counter, 8 * CHANGED_SLOTS, self.stream),
-              "read counter")
-        return int(sum(v))
+        total = C.c_ulonglong(0)
+        check(self.lib.simrank_read_counters(self._counter, CHANGED_SLOTS, C.byref(total),
+                                             self.stream), "simrank_read_counters")
+        return int(total.value)
 
     # ---- timing (HIP events on the engine's own stream) ----
     def event(self) -> int:

@@ -42,6 +42,7 @@ struct DenseArgs {
     const int32_t* dcols;
     const uint4* afrag;
     int32_t n_units, n_cblocks, tri;
+    int32_t wg_cols;          // columns per workgroup: 64 per wave, 4 waves or 1
 };
 
 // (x0, x1) -> packed bf16 pairs of the three terms of the truncation split
@@ -75,8 +76,8 @@ __global__ __launch_bounds__(256, 2) void dense_tiles_kernel(const DenseArgs p) 
     if (cb >= p.n_cblocks) return;
     const int row0 = p.unit_row0[t];
     // upper-triangle form of leg 2: row block rb needs the columns >= rb only
-    if (p.tri && (int64_t(cb) + 1) * kDN <= row0) return;
-    const int64_t wcol = int64_t(cb) * kDN + wave * 64;
+    if (p.tri && (int64_t(cb) + 1) * p.wg_cols <= row0) return;
+    const int64_t wcol = int64_t(cb) * p.wg_cols + wave * 64;
     if (wcol >= p.L) return;                       // no barrier in this kernel: a wave may leave
     const int64_t col = wcol + 2 * r;
     const bool col_ok = col < p.L;                 // (col + 1 may be L: inside the padded row)
@@ -320,11 +321,13 @@ int launch_dense_tiles(const simrank_graph* g, const float* X, int64_t ldx, int6
     a.unit_row0 = pl->unit_row0; a.unit_slab = pl->unit_slab; a.unit_kofs = pl->unit_kofs;
     a.dcols = pl->dcols; a.afrag = pl->afrag;
     a.n_units = pl->n_units;
-    a.n_cblocks = (int32_t)((L + kDN - 1) / kDN);
+    // narrow launches (a stage of a sharded leg): one wave per workgroup, four times the workgroups
+    a.wg_cols = ((L + kDN - 1) / kDN) * pl->n_units >= 2048 ? kDN : 64;
+    a.n_cblocks = (int32_t)((L + a.wg_cols - 1) / a.wg_cols);
     a.tri = tri ? 1 : 0;
     const int64_t grid = int64_t((a.n_cblocks + 7) / 8) * 8 * a.n_units;
     SR_REQUIRE(grid > 0 && grid < (int64_t(1) << 31), "grid of %lld blocks", (long long)grid);
-    hipLaunchKernelGGL(dense_tiles_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(dense_tiles_kernel, dim3((unsigned)grid), dim3((unsigned)a.wg_cols), 0, st, a);
     SR_HIP(hipGetLastError());
     use->part = pl->part;
     use->ldp = ldp;

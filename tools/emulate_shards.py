@@ -17,8 +17,9 @@ _, csr = ingest.directed(df, False, "from", "to", "weight")
 n = csr.n_rows
 import itertools
 huges = [int(x) for x in os.environ.get('HUGE', '512').split(',')]
-for huge, P in itertools.product(huges, (1, 8) if len(huges) > 1 else (1, 2, 4, 8)):
-    ops.set_tuning(huge=huge)
+dmins = [int(x) for x in os.environ.get('DMIN', '4').split(',')]
+for huge, dmin, P in itertools.product(huges, dmins, (1, 8) if len(huges) > 1 else (1, 2, 4, 8)):
+    ops.set_tuning(huge=huge, dense_min=dmin)
     s = Solver(lambda r: ops, LocalWorld(P), [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
     s.reset()
     s.step(0.0)
@@ -28,7 +29,7 @@ for huge, P in itertools.product(huges, (1, 8) if len(huges) > 1 else (1, 2, 4, 
     t = s.leg_times()
     l1, l2 = t["leg1.0"][0], t["leg2.0"][0]
     xfer = 4.0 * n * n / P * (P - 1) / P
-    print(f"{w} huge={huge} P={P}: per-rank leg1 {l1:.3f} ms, leg2 {l2:.3f} ms -> compute {l1 + l2:.3f} ms/iteration; "
+    print(f"{w} huge={huge} dense_min={dmin} P={P}: per-rank leg1 {l1:.3f} ms, leg2 {l2:.3f} ms -> compute {l1 + l2:.3f} ms/iteration; "
           f"all-to-all payload per rank {xfer / 2**20:.0f} MiB out + in", flush=True)
     s.release()
     del s

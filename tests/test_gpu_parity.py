@@ -360,3 +360,53 @@ def test_top_k_hand_back_on_gpu():
             np.testing.assert_allclose(got.similarity.values, want, rtol=1e-6, atol=1e-30)
             for nb, sim in zip(got.neighbor, got.similarity):
                 np.testing.assert_allclose(dense.iloc[pos[node], pos[nb]], sim, rtol=1e-6, atol=1e-30)
+
+
+# ---------------------------------------------------------------------------------------
+# graphs with a dense corner: part of every leg runs on the matrix cores (csrc/blockdense.hip)
+# ---------------------------------------------------------------------------------------
+def _dense_corner_graph():
+    from simrank_amd import ingest
+    from simrank_amd.driver import SideSpec, reorder_specs
+    from simrank_amd.engine import HipOps
+    df = synth.powerlaw_directed(4096, 32, seed=21)
+    _, csr = ingest.directed(df, False, "from", "to", "weight")
+    specs, _ = reorder_specs([SideSpec(csr, csr.rowscale, 0.8)])
+    ops = HipOps(0)
+    blocks, cols, covered = ops.dense_stats(ops.graph(specs[0].csr))
+    assert blocks >= 1 and cols >= 128 and covered > 0.1 * csr.nnz      # the path under test is live
+    return df
+
+
+@pytest.mark.parametrize("cls", ["SimRank", "SimRankPP"])
+def test_fit_with_dense_sets_against_oracle(cls):
+    df = _dense_corner_graph()
+    est = getattr(SRA, cls)()
+    got = est.fit(df, verbose=False)
+    want = (O.fit_simrank if cls == "SimRank" else O.fit_simrank_pp)(df, verbose=False)
+    assert list(got.index) == want["labels"]
+    assert_close(got.values, want["S"])
+    assert est.converged_at == want["k"]
+
+
+def test_dense_sets_shards_equal_one_shard_bit_for_bit():
+    """The dense part works per column block with a fixed summation order: P column shards give
+    the same bits as one shard (upper-triangle shortcut off for the comparison)."""
+    from simrank_amd.engine import HipOps
+    df = _dense_corner_graph()
+    knob = HipOps(0)
+    knob.set_tuning(triangle=0)
+    try:
+        one = SRA.SimRank().fit(df, iterations=4, eps=0, verbose=False, mode="sparse")
+    finally:
+        knob.set_tuning(triangle=1)
+    for world in (2, 4):
+        many = SRA.SimRank().fit(df, iterations=4, eps=0, verbose=False, mode="sparse",
+                                 world=LocalWorld(world))
+        assert np.array_equal(one.values, many.values)
+    knob.set_tuning(dense_min=0)
+    try:
+        plain = SRA.SimRank().fit(df, iterations=4, eps=0, verbose=False, mode="sparse")
+    finally:
+        knob.set_tuning(dense_min=4)
+    np.testing.assert_allclose(one.values, plain.values, rtol=2e-6, atol=1e-30)

@@ -176,7 +176,8 @@ void free_dense_plan(simrank_dense_plan* p) {
     delete p;
 }
 
-constexpr int kUnitCols = 2048;   // a dense set is cut into units of at most this many columns
+constexpr int kUnitCols = 2048;   // a dense set is cut into units of about this many columns, or more
+                                  // when there is enough work for every CU without cutting
 
 // Host side: pick the dense sets, cut them into units, lay the pattern out in A-fragment order,
 // build the remainder.
@@ -190,7 +191,7 @@ int build_dense_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
     std::vector<int32_t> block_slab0(size_t(nblk), 0), block_nslab(size_t(nblk), 0);
     std::vector<uint16_t> cnt(size_t(K), 0);
     std::vector<int32_t> touched;
-    int64_t covered = 0, total_k = 0;
+    int64_t covered = 0, total_k = 0, set_cols = 0;
     int32_t n_slabs = 0, n_blocks_dense = 0;
     for (int64_t b = 0; b < nblk; ++b) {
         const int64_t lo = b * kDM, hi = std::min<int64_t>(M, lo + kDM);
@@ -206,9 +207,17 @@ int build_dense_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
         std::sort(set.begin(), set.end());
         covered += cov;
         ++n_blocks_dense;
-        // equal units of at most kUnitCols columns
+        set_cols += (int64_t)set.size();
+    }
+    // Units: a workgroup per (unit, 256 output columns); an XCD works through a column block with
+    // 64 resident workgroups, so no unit should be longer than 1/64 of the column block's work —
+    // and none shorter than kUnitCols, because every unit costs a slab of partial sums.
+    const int64_t unit_cols = std::max<int64_t>(kUnitCols, (set_cols / 64 + 15) / 16 * 16);
+    for (int64_t b = 0; b < nblk; ++b) {
+        const std::vector<int32_t>& set = sets[size_t(b)];
+        if (set.empty()) continue;
         const int32_t n = (int32_t)set.size();
-        const int32_t nu = (n + kUnitCols - 1) / kUnitCols;
+        const int32_t nu = (int32_t)((n + unit_cols - 1) / unit_cols);
         block_slab0[size_t(b)] = n_slabs;
         block_nslab[size_t(b)] = nu;
         for (int32_t u = 0; u < nu; ++u) {
@@ -218,8 +227,8 @@ int build_dense_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
         }
         n_slabs += nu;
     }
-    // budget: the fragment image takes 256 bytes per dense column
-    if (units.empty() || total_k * 256 > (int64_t(2) << 30)) return SIMRANK_OK;
+    // budget: the fragment image takes 256 bytes per dense column (8 GiB ~ a fully dense 32768 x 32768)
+    if (units.empty() || total_k * 256 > (int64_t(8) << 30)) return SIMRANK_OK;
     std::stable_sort(units.begin(), units.end(),
                      [](const Unit& a, const Unit& b) { return a.count > b.count; });
 

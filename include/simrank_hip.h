@@ -253,6 +253,7 @@ SIMRANK_API int simrank_dense_part(const simrank_graph* g, const float* X, int64
  *      "dense_min" / "dense_cols"  selection of the block-dense part (see above); read when a
  *                 graph is created; simrank_spmm also skips the dense part while dense_min
  *                 is 0
+ *      "ids16"    0/1  stream the neighbour ids as 16-bit values (graphs with <= 65536 columns)
  *      "dense_sym" dense part in the upper-triangle form of leg 2: 1 always, 0 never, -1 when
  *                 the dense sets hold at least half of the entries ---- */
 SIMRANK_API int simrank_set_tuning(const char* key, int64_t value);

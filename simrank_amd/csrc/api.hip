@@ -372,6 +372,10 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
     };
     int rc = up((void**)&g->rowptr, rowptr, size_t(n_rows + 1) * 4);
     if (!rc) rc = up((void**)&g->col, col, size_t(nnz) * 4);
+    if (!rc && n_cols <= 65536 && nnz > 0) {
+        std::vector<uint16_t> c16(col, col + nnz);
+        rc = up((void**)&g->col16, c16.data(), size_t(nnz) * 2);
+    }
     if (!rc) rc = up((void**)&g->rowscale, rowscale, size_t(n_rows) * 4);
     if (!rc) rc = up((void**)&g->t_rowptr, t_rowptr.data(), size_t(n_cols + 1) * 4);
     if (!rc) rc = up((void**)&g->t_col, t_col.data(), size_t(nnz) * 4);
@@ -390,6 +394,7 @@ int simrank_graph_destroy(simrank_graph* g) {
     if (!g) return SIMRANK_OK;
     (void)hipFree(g->rowptr);
     (void)hipFree(g->col);
+    (void)hipFree(g->col16);
     (void)hipFree(g->rowscale);
     (void)hipFree(g->t_rowptr);
     (void)hipFree(g->t_col);
@@ -438,6 +443,8 @@ int simrank_set_tuning(const char* key, int64_t value) {
     } else if (!strcmp(key, "dense_min")) {
         SR_REQUIRE(value >= 0 && value <= 128, "dense_min must be 0 (off) .. 128");
         t.dense_min = value;
+    } else if (!strcmp(key, "ids16")) {
+        t.ids16 = value ? 1 : 0;
     } else if (!strcmp(key, "dense_sym")) {
         t.dense_sym = value < 0 ? -1 : (value ? 1 : 0);
     } else if (!strcmp(key, "dense_cols")) {
@@ -462,6 +469,7 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     else if (!strcmp(key, "dense_min")) *value = t.dense_min;
     else if (!strcmp(key, "dense_cols")) *value = t.dense_cols;
     else if (!strcmp(key, "dense_sym")) *value = t.dense_sym;
+    else if (!strcmp(key, "ids16")) *value = t.ids16;
     else SR_REQUIRE(false, "unknown tuning key '%s'", key);
     return SIMRANK_OK;
 }

@@ -171,7 +171,7 @@ void free_dense_plan(simrank_dense_plan* p) {
     (void)hipFree(p->unit_row0); (void)hipFree(p->unit_slab); (void)hipFree(p->unit_kofs);
     (void)hipFree(p->dcols); (void)hipFree(p->afrag); (void)hipFree(p->block_slab0);
     (void)hipFree(p->block_nslab); (void)hipFree(p->r_rowptr);
-    (void)hipFree(p->r_col); (void)hipFree(p->r_tile_row0); (void)hipFree(p->r_sym_map);
+    (void)hipFree(p->r_col); (void)hipFree(p->r_col16); (void)hipFree(p->r_tile_row0); (void)hipFree(p->r_sym_map);
     (void)hipFree(p->part);
     delete p;
 }
@@ -296,6 +296,10 @@ int build_dense_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
     if (!rc) rc = upload(&pl->block_nslab, block_nslab);
     if (!rc) rc = upload(&pl->r_rowptr, r_rowptr);
     if (!rc) rc = upload(&pl->r_col, r_col);
+    if (!rc && K <= 65536 && !r_col.empty()) {
+        std::vector<uint16_t> c16(r_col.begin(), r_col.end());
+        rc = upload(&pl->r_col16, c16);
+    }
     if (!rc && pl->r_n_tiles) rc = upload(&pl->r_tile_row0, r_tile_row0);
     if (!rc && pl->r_sym_blocks) rc = upload(&pl->r_sym_map, r_sym_map);
     if (rc) {

@@ -42,6 +42,7 @@ struct Tuning {
     int64_t dense_min = 4;   // block-dense MFMA part: a column joins a 128-row tile's dense set when
                              // at least this many of the tile's rows reference it (0 = off)
     int64_t dense_cols = 128; // ... and a tile gets a dense set only with this many such columns
+    int64_t ids16 = 1;       // stream neighbour ids as 16-bit values when the graph allows it
     int64_t dense_sym = -1;  // dense part in the upper-triangle form of leg 2: 1 yes, 0 no, -1 = when the
                              // dense sets hold at least half of the pattern's entries
 };
@@ -82,6 +83,7 @@ struct simrank_dense_plan {
     int32_t r_max_row = 0;
     int32_t* r_rowptr = nullptr;
     int32_t* r_col = nullptr;
+    uint16_t* r_col16 = nullptr;    // the same ids in 16 bits when n_cols <= 65536
     int32_t* r_tile_row0 = nullptr;
     int32_t r_n_tiles = 0;
     int32_t* r_sym_map = nullptr;
@@ -114,6 +116,8 @@ struct simrank_graph {
     int64_t n_rows = 0, n_cols = 0, nnz = 0;
     int32_t* rowptr = nullptr;    // [n_rows+1]
     int32_t* col = nullptr;       // [nnz]
+    uint16_t* col16 = nullptr;    // [nnz] the same ids in 16 bits when n_cols <= 65536 (what the gather
+                                  // kernel streams once per panel: half the bytes, half the L2 lines)
     float* rowscale = nullptr;    // [n_rows]
     int32_t* t_rowptr = nullptr;  // [n_cols+1]  transposed pattern
     int32_t* t_col = nullptr;     // [nnz]       row ids, ascending per column

@@ -34,6 +34,7 @@ __device__ __forceinline__ int64_t imin(int64_t a, int64_t b) { return a < b ? a
 struct SpmmArgs {
     const int32_t* rowptr;
     const int32_t* col;       // neighbour ids, ascending per row
+    const uint16_t* col16;    // the same in 16 bits (NULL when the graph has more than 65536 columns)
     int32_t nt;               // non-temporal output stores
     int32_t has_huge;         // the graph has rows of >= huge_len entries
     int32_t huge_len;         // rows this long are split over the waves of a workgroup
@@ -126,6 +127,7 @@ __device__ __forceinline__ void vstore_nt(float* p, const float (&d)[VEC]) {
 
 // neighbour ids are streamed once per panel pass; keep them from displacing X in L2
 __device__ __forceinline__ int ldidx(const SpmmArgs& p, int j) {
+    if (p.col16) return p.nt ? int(__builtin_nontemporal_load(p.col16 + j)) : int(p.col16[j]);
     return p.nt ? __builtin_nontemporal_load(p.col + j) : p.col[j];
 }
 
@@ -764,6 +766,7 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
     SpmmArgs a{};
     a.rowptr = g->rowptr;
     a.col = g->col;
+    a.col16 = tuning().ids16 ? g->col16 : nullptr;
     a.rowscale = g->rowscale;
     a.huge_len = (int32_t)std::max<int64_t>(kHeavy, tuning().huge);
     a.has_huge = g->max_row_nnz >= a.huge_len ? 1 : 0;
@@ -836,6 +839,7 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
         a.dnslab = use.block_nslab;
         a.rowptr = dp->r_rowptr;
         a.col = dp->r_col;
+        a.col16 = tuning().ids16 ? dp->r_col16 : nullptr;
         a.has_huge = dp->r_max_row >= a.huge_len ? 1 : 0;
     }
     if (tuning().balance) {

@@ -4,7 +4,7 @@ import numpy as np, pandas as pd
 from simrank_amd import ingest, synth
 from simrank_amd.driver import LocalWorld, SideSpec, Solver
 from simrank_amd.engine import HipOps
-for w in ("bts300", "er8192"):
+for w in (sys.argv[1:] or ["bts300", "er8192", "pl32768"]):
     df = synth.WORKLOADS[w][0]()
     for rep in range(2):
         t = [time.perf_counter()]

@@ -156,8 +156,42 @@ class TorchWorld:
         # (a one-rank world stages only on request: that is how the path is exercised on one GPU)
         self.stages = max(1, int(stages)) if (self.size > 1 or stage_single_rank) else 1
 
+    @property
+    def stream_ordered(self):
+        """RCCL collectives can be ordered on the engine's stream: no host synchronisation
+        between the legs and the exchange (gloo works on host tensors and needs the syncs)."""
+        return self.dist.get_backend(self.group) == "nccl"
+
+    def begin_stage(self, x, st):
+        """Stream-ordered pipeline: called right after the kernels of one stage of leg 1 were
+        queued.  The all-to-all of that stage is issued at once; RCCL's stream waits for what is
+        on the engine's stream so far (this stage) and runs beside the kernels queued next."""
+        import torch
+        if not (sum(st["in_splits"]) or sum(st["out_splits"])):
+            return
+        with torch.cuda.stream(x.ops.torch_stream()):
+            st["work"] = self.dist.all_to_all_single(
+                x.recv_t[st["recv_off"]:st["recv_off"] + sum(st["out_splits"])],
+                x.send_t[st["send_off"]:st["send_off"] + sum(st["in_splits"])],
+                st["out_splits"], st["in_splits"], group=self.group, async_op=True)
+
     def exchange(self, parts):
         (x,) = parts
+        if self.stream_ordered:
+            import torch
+            with torch.cuda.stream(x.ops.torch_stream()):
+                if x.stages is not None:
+                    for st in x.stages:               # issued by begin_stage during leg 1
+                        w = st.pop("work", None)
+                        if w is not None:
+                            w.wait()                  # the engine's stream waits, not the host
+                    return
+                span = lambda n, h: partition(n, self.size, h)[1] - partition(n, self.size, h)[0]
+                in_splits = [x.ncols * (span(x.row_dim, h) + x.pad) for h in range(self.size)]
+                out_splits = [span(x.col_dim, h) * (x.nrows + x.pad) for h in range(self.size)]
+                self.dist.all_to_all_single(x.recv_t[:sum(out_splits)], x.send_t[:sum(in_splits)],
+                                            out_splits, in_splits, group=self.group)
+            return
         if x.stages is not None:
             works = []
             for st in x.stages:
@@ -308,7 +342,10 @@ class Side:
         self.graph2 = self.ops.graph(permute_columns(self.spec.csr, perm), self.spec.rowscale)
 
     # S_in: K x Lk block of the input similarity
-    def leg1(self, S_in):
+    def leg1(self, S_in, stage_hook=None):
+        """``stage_hook(xfer, stage)``: called after the kernels of each stage of a pipelined
+        exchange were queued (a stream-ordered world issues that stage's all-to-all there);
+        without it an event marks the end of the stage for the host to wait on."""
         o = self.ops
         if self.mode == "sparse" and self.x1.stages is not None:
             for st in self.x1.stages:
@@ -316,7 +353,10 @@ class Side:
                     o.spmm(self.graph, S_in, self.send, n_cols=st["ncols"], transpose_out=True,
                            t_block=self.mb, t_pad=self.x1.pad, x_col0=st["x_col0"],
                            y_offset=st["send_off"])
-                o.record(st["event"])
+                if stage_hook is not None:
+                    stage_hook(self.x1, st)
+                else:
+                    o.record(st["event"])
         elif self.mode == "sparse":
             if self.Lk:
                 o.spmm(self.graph, S_in, self.send, n_cols=self.Lk, transpose_out=True,
@@ -480,8 +520,9 @@ class Solver:
         """One similarity update on every local virtual rank; returns the global count of
         elements that moved by more than eps."""
         sides = self.sides[side_idx]
+        hook = self.world.begin_stage if getattr(self.world, "stream_ordered", False) else None
         for r in self.world.local_ranks:
-            self._timed(r, lambda: sides[r].leg1(self.cur[in_idx][r]), f"leg1.{side_idx}")
+            self._timed(r, lambda: sides[r].leg1(self.cur[in_idx][r], hook), f"leg1.{side_idx}")
         local = self.world.local_ranks
         if self.mode == "sparse":
             self.world.exchange([sides[r].x1 for r in local])

@@ -200,6 +200,15 @@ class HipOps:
     def synchronize(self):
         check(self.lib.simrank_stream_synchronize(self.stream), "stream_synchronize")
 
+    def torch_stream(self):
+        """The engine's stream as a torch stream: a collective issued under
+        ``torch.cuda.stream(ops.torch_stream())`` is ordered after the kernels already queued on
+        the engine's stream, and ``work.wait()`` makes that stream (not the host) wait for it."""
+        import torch
+        if getattr(self, "_torch_stream", None) is None:
+            self._torch_stream = torch.cuda.ExternalStream(self.stream.value, device=self.device)
+        return self._torch_stream
+
     def collective_done(self):
         """Make the engine's stream wait for a torch.distributed collective: the collective
         was enqueued on torch's current stream, the kernels run on the engine's own."""

@@ -1,0 +1,47 @@
+"""Worker of tests/test_gpu_parity.py::test_rccl_world_values: one rank of an RCCL ("nccl") world
+on the available GPU, launched by ``python -m torch.distributed.run``.  The TorchWorld path —
+torch-owned exchange buffers, all_to_all_single issued on the engine's stream stage by stage
+(no host synchronisation), all_reduce of the convergence count — must give the values of the
+in-process world and of the golden vectors."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+    import simrank_amd.SimRank as SRA
+    from simrank_amd import synth
+    from simrank_amd.driver import LocalWorld, TorchWorld
+    from tests.conftest import Golden
+    from tests.helpers import check_against_golden, run_estimator
+    # golden vectors (labels, values, convergence iteration, stdout) through the RCCL world
+    for name, stages in (("SimRank_er128", 1), ("SimRankPP_er128", 3), ("BipartiteSimRankPP_b40", 2),
+                         ("AprioriSimRank_er64_asym", 2)):
+        g = Golden(name)
+        est, res, text = run_estimator(g, world=TorchWorld(stages=stages, stage_single_rank=True),
+                                       mode="sparse")
+        check_against_golden(g, est, res, text)
+    # a graph with dense sets and several panels per stage, against the in-process world
+    df = synth.powerlaw_directed(3000, 24, seed=5)
+    want = SRA.SimRank().fit(df, iterations=5, eps=0, verbose=False, mode="sparse", world=LocalWorld(1))
+    for stages in (1, 4):
+        got = SRA.SimRank().fit(df, iterations=5, eps=0, verbose=False, mode="sparse",
+                                world=TorchWorld(stages=stages, stage_single_rank=True))
+        np.testing.assert_allclose(got.values, want.values, rtol=2e-6, atol=1e-30)
+    dist.barrier()
+    print("RCCL WORLD ok", flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -256,6 +256,20 @@ def test_rccl_world_of_one_rank():
     assert out["n_gpus"] == 1 and out["value"] > 100 and out["converge"]["iterations"] == 5
 
 
+def test_rccl_world_values():
+    """Values, labels, convergence iteration and stdout through the RCCL world of one rank
+    (staged and unstaged stream-ordered exchange), see tests/dist_gpu_worker.py."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", "29573",
+           os.path.join(root, "tests", "dist_gpu_worker.py")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0 and "RCCL WORLD ok" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
+
+
 @pytest.mark.parametrize("cls", ["SimRank", "SimRankPP"])
 def test_directed_edge_cases_on_gpu(cls):
     """Degenerate and extreme graphs (N = 1, stars with one 899-entry row, complete graph,

@@ -213,6 +213,17 @@ class TorchWorld:
                                     out_splits, in_splits, group=self.group)
         x.ops.collective_done()
 
+    def sum_changed(self, ops, active=True):
+        """Global convergence count of the update just queued, stream-ordered: the striped
+        counters are summed and all-reduced on the engine's stream, one read-back (the only host
+        synchronisation of an update)."""
+        import torch
+        t = ops.counter_tensor()
+        with torch.cuda.stream(ops.torch_stream()):
+            s = t.sum().reshape(1) if active else torch.zeros(1, dtype=torch.int64, device=t.device)
+            self.dist.all_reduce(s, group=self.group)
+            return int(s.item())
+
     def sum_int(self, values):
         import torch
         (v,) = values
@@ -527,11 +538,14 @@ class Solver:
         if self.mode == "sparse":
             self.world.exchange([sides[r].x1 for r in local])
         fused = sides[local[0]].symmetric
+        device_sum = fused and hook is not None        # stream-ordered world: reduce on the device
         counts = []
         for r in local:
+            if device_sum:
+                self.ops[r].counter_tensor()            # (before the epilogue takes its address)
             self._timed(r, lambda: sides[r].leg2(self.cur[out_idx][r], self.nxt[out_idx][r], eps),
                         f"leg2.{side_idx}")
-            if fused:       # virtual ranks may share one device counter: read it per launch
+            if fused and not device_sum:   # virtual ranks may share one device counter: read it per launch
                 counts.append(self.ops[r].read_changed() if sides[r].Lm else 0)
         if not fused:
             if self.world.size > 1:
@@ -541,6 +555,9 @@ class Solver:
                 counts.append(self.ops[r].read_changed() if sides[r].Lm else 0)
         for r in self.world.local_ranks:
             self.cur[out_idx][r], self.nxt[out_idx][r] = self.nxt[out_idx][r], self.cur[out_idx][r]
+        if device_sum:
+            (r,) = local
+            return self.world.sum_changed(self.ops[r], bool(sides[r].Lm))
         return self.world.sum_int(counts)
 
     def step(self, eps=0.0):

@@ -209,6 +209,18 @@ class HipOps:
             self._torch_stream = torch.cuda.ExternalStream(self.stream.value, device=self.device)
         return self._torch_stream
 
+    def counter_tensor(self):
+        """The convergence counters as a torch int64 tensor (allocated by torch from then on), so
+        that a distributed world can reduce them on the device."""
+        import torch
+        if getattr(self, "_counter_t", None) is None:
+            t = torch.zeros(CHANGED_SLOTS, dtype=torch.int64, device=f"cuda:{self.device}")
+            torch.cuda.synchronize(self.device)
+            if self._counter:
+                self._free(self._counter)
+            self._counter_t, self._counter = t, t.data_ptr()
+        return self._counter_t
+
     def collective_done(self):
         """Make the engine's stream wait for a torch.distributed collective: the collective
         was enqueued on torch's current stream, the kernels run on the engine's own."""
@@ -352,8 +364,9 @@ class HipOps:
     def close(self):
         """Release the stream and the counter (matrices and graphs free themselves)."""
         if getattr(self, "_counter", 0):
-            self._free(self._counter)
-            self._counter = 0
+            if getattr(self, "_counter_t", None) is None:
+                self._free(self._counter)
+            self._counter, self._counter_t = 0, None
         if getattr(self, "_own_stream", False) and self.stream:
             self.lib.simrank_stream_destroy(self.stream)
             self.stream = None

@@ -25,7 +25,7 @@ for tag in ("pmc_l2", "pmc_busy", "pmc_ea", "pmc_tcp", "pmc_sq", "pmc_fetch", "p
     for f in glob.glob(f"$OUT/{tag}/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(lambda: [0.0, 0])
         for r in csv.DictReader(open(f)):
-            if "spmm" not in r["Kernel_Name"] and "gemm" not in r["Kernel_Name"]:
+            if not any(k in r["Kernel_Name"] for k in ("spmm", "gemm", "dense_tiles")):
                 continue
             k = (r["Kernel_Name"][:62], r["Counter_Name"])
             acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1

@@ -29,6 +29,7 @@ ap.add_argument("--huge", type=ints, default=[512])
 ap.add_argument("--triangle", type=ints, default=[1])
 ap.add_argument("--mode", default="sparse")
 ap.add_argument("--nt", type=ints, default=[1])
+ap.add_argument("--balance", type=ints, default=[4])
 ap.add_argument("--dense-min", type=ints, default=[4])
 ap.add_argument("--dense-cols", type=ints, default=[128])
 args = ap.parse_args()
@@ -42,10 +43,11 @@ for w in args.workload.split(","):
         df = synth.WORKLOADS[w][0]()
     _, csr = ingest.directed(df, False, "from", "to", "weight")
     print(f"# {w}: N={csr.n_rows} nnz={csr.nnz}", flush=True)
-    for panel, tile, xcd, huge, tri, dmin, dcols, nt_ in itertools.product(
-            args.panel, args.tile, args.xcd, args.huge, args.triangle, args.dense_min, args.dense_cols, args.nt):
+    for panel, tile, xcd, huge, tri, dmin, dcols, nt_, bal in itertools.product(
+            args.panel, args.tile, args.xcd, args.huge, args.triangle, args.dense_min, args.dense_cols, args.nt,
+            args.balance):
         ops.set_tuning(panel=panel, tile=tile, xcd_map=xcd, huge=huge, triangle=tri, dense_min=dmin,
-                       dense_cols=dcols, stream_nt=nt_)
+                       dense_cols=dcols, stream_nt=nt_, balance=bal)
         s = Solver(lambda r: ops, LocalWorld(1), [SideSpec(csr, csr.rowscale, 0.8)], args.mode)
         s.reset()
         for _ in range(2):
@@ -58,9 +60,9 @@ for w in args.workload.split(","):
         gb = 4e-9 * csr.nnz * csr.n_rows
         nt, dk, cov = ops.dense_stats(next(iter(s.sides[0].values())).graph)
         print(f"{w} mode={s.mode} panel={panel:3d} tile={tile:2d} xcd={xcd} huge={huge} triangle={tri} "
-              f"dense_min={dmin} dense_cols={dcols} nt={nt_} [tiles {nt} cols {dk} covered {cov / max(1, csr.nnz):.3f}]  "
+              f"dense_min={dmin} dense_cols={dcols} nt={nt_} balance={bal} [tiles {nt} cols {dk} covered {cov / max(1, csr.nnz):.3f}]  "
               f"leg1 {l1:8.3f} ms ({gb / l1:6.2f} TB/s gathered)  leg2 {l2:8.3f} ms  "
               f"total {l1 + l2:8.3f} ms", flush=True)
         s.release()
         del s
-ops.set_tuning(panel=0, tile=0, xcd_map=1, huge=512, triangle=1, dense_min=4, dense_cols=128, stream_nt=1)
+ops.set_tuning(panel=0, tile=0, xcd_map=1, huge=512, triangle=1, dense_min=4, dense_cols=128, stream_nt=1, balance=4)

@@ -266,3 +266,27 @@ def test_top_k_ties_follow_the_callers_order():
         order = sorted(range(len(row)), key=lambda i: (-np.float32(row.iloc[i]), labels.index(row.index[i])))
         got = top[top.node == node].sort_values("rank")
         assert list(got.neighbor) == [row.index[i] for i in order[:4]]
+
+
+def test_bf16x3_truncation_split_is_exact_in_numpy():
+    """The dense-tile kernel (csrc/blockdense.hip) feeds the matrix cores three bf16 terms per f32
+    operand: hi = top 16 bits of x, mid = top 16 bits of x - hi, lo = x - hi - mid.  The same
+    arithmetic in NumPy: every term is a bf16 number (low 16 bits zero), the three add up to x
+    bit for bit, for both signs and every exponent whose last term is still a normal number."""
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(200_000) * np.exp(rng.uniform(-70, 80, 200_000))).astype(np.float32)
+    x = x[(np.abs(x) >= 1e-33) & np.isfinite(x)]  # below ~7.7e-34 the last term would be subnormal
+    x = np.concatenate([x, np.float32([0.0, 1.0, -1.0, 1 + 2.0 ** -23, 16777215.0, -3.0000002, 1e-30])])
+
+    def trunc(v):
+        return (v.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+
+    hi = trunc(x)
+    r = x - hi                                   # exact: both share the exponent of x
+    mid = trunc(r)
+    lo = r - mid                                 # at most 8 significant bits are left
+    for t in (hi, mid, lo):
+        assert not np.any(t.view(np.uint32) & np.uint32(0xFFFF))          # representable in bf16
+    assert np.array_equal((hi + mid) + lo, x)
+    assert np.array_equal(hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64),
+                          x.astype(np.float64))

@@ -219,6 +219,22 @@ def main():
         if world_size == 1:
             rl[1]["note"] = ("single rank: leg 2 computes the tiles on/above the diagonal and stores "
                              "their mirror image (S' is symmetric); bytes are those of the full matrix")
+        # what the runtime's own device-to-device copy of S moves per second on this GPU (read +
+        # write): the practical ceiling next to the 8 TB/s spec figure used for `frac`
+        try:
+            src, dst = solver.cur[0][rank if use_dist else 0], solver.nxt[0][rank if use_dist else 0]
+            ops.copy(dst, src)
+            e0, e1 = ops.event(), ops.event()
+            ops.record(e0)
+            for _ in range(3):
+                ops.copy(dst, src)
+            ops.record(e1)
+            copy_gbs = 2 * src.nbytes / (ops.elapsed_ms(e0, e1) / 3 * 1e-3) / 1e9
+            for r in rl:
+                r["box_memcpy_GBps"] = copy_gbs
+                r["frac_of_box_memcpy"] = r["achieved"] / copy_gbs
+        except Exception:
+            pass
         rl.sort(key=lambda r: -r["ms"])
         out["roofline"], out["roofline_other"] = rl[0], rl[1]
     else:

@@ -160,6 +160,9 @@ class TorchWorld:
     def stream_ordered(self):
         """RCCL collectives can be ordered on the engine's stream: no host synchronisation
         between the legs and the exchange (gloo works on host tensors and needs the syncs)."""
+        import os
+        if os.environ.get("SIMRANK_HOST_SYNC_EXCHANGE") == "1":      # debugging aid: host-driven pipeline
+            return False
         return self.dist.get_backend(self.group) == "nccl"
 
     def begin_stage(self, x, st):

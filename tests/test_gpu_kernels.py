@@ -565,3 +565,45 @@ def test_dense_part_with_a_set_cut_into_units(ops):
     first = ops.download(y)
     ops.spmm(g, x, y)
     assert np.array_equal(first, ops.download(y))            # reproducible
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_dense_part_randomized(ops, seed):
+    """Random shapes (row counts off the 128-row block grid, ragged widths), random corner
+    densities and selection knobs, every form of the leg: the dense part + remainder must equal
+    NumPy, and the upper-triangle form must count like the full one."""
+    rng = np.random.default_rng(1000 + seed)
+    square = seed % 2 == 0
+    M = int(rng.integers(130, 900))
+    K = M if square else int(rng.integers(60, 900))
+    L = K if square else int(rng.integers(1, 700))
+    csr = corner_csr(M, K, seed=seed, hubs=int(rng.integers(40, max(41, K))), p_hub=float(rng.uniform(0.1, 0.9)),
+                     avg=int(rng.integers(1, 12)))
+    W = dense64(csr)
+    with dense_knobs(ops, dense_min=int(rng.integers(2, 5)), dense_cols=int(rng.choice([16, 32, 64]))):
+        g = ops.graph(csr)
+        if square:
+            S = rng.random((M, M)).astype(np.float32)
+            S = ((S + S.T) / 2).astype(np.float32)
+            np.fill_diagonal(S, 1)
+            cnt = rng.integers(0, 4, size=(M, M))
+            cnt = np.minimum(cnt, cnt.T).astype(np.uint8)
+            want = 0.8 * (W @ S.astype(np.float64) @ W.T) * (1 - 0.5 ** cnt.astype(np.float64))
+            np.fill_diagonal(want, 1.0)
+            s_in, tt, y = put(ops, S), ops.matrix(M, M), ops.matrix(M, M)
+            ops.spmm(g, s_in, tt, transpose_out=True)
+            np.testing.assert_allclose(ops.download(tt), (W @ S.astype(np.float64)).T, rtol=RTOL, atol=1e-30)
+            for sym in (True, False):
+                ops.spmm(g, tt, y, epilogue=dict(coef=0.8, evidence=put(ops, cnt, dtype=np.uint8),
+                                                 previous=s_in, eps=0.05, diag_col0=0, symmetric=sym))
+                got = ops.download(y)
+                np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-30)
+                assert ops.read_changed() == int((np.abs(got.astype(np.float64) - S) > 0.05).sum())
+        else:
+            X = (rng.random((K, L)) ** 2).astype(np.float32)
+            want = W @ X.astype(np.float64)
+            x, y, yt = put(ops, X), ops.matrix(M, L), ops.matrix(L, M)
+            ops.spmm(g, x, y)
+            ops.spmm(g, x, yt, transpose_out=True)
+            np.testing.assert_allclose(ops.download(y), want, rtol=RTOL, atol=1e-30)
+            np.testing.assert_allclose(ops.download(yt), want.T, rtol=RTOL, atol=1e-30)

@@ -95,8 +95,9 @@ def main():
     ap.add_argument("--panel", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--stages", type=int, default=4,
-                    help="pipeline depth of the sharded exchange (all_to_all_single calls per update)")
+    ap.add_argument("--stages", type=int, default=0,
+                    help="pipeline depth of the sharded exchange (all_to_all_single calls per update; "
+                         "0 = by the width of a rank's column block)")
     ap.add_argument("--force-dist", action="store_true",
                     help="use the torch.distributed world even with one rank (exercises RCCL)")
     args = ap.parse_args()
@@ -163,6 +164,7 @@ def main():
     legs = solver.leg_times()                 # mean ms per launch, measured by HIP events
     solver.events = None
     side = solver.sides[0][rank if use_dist else 0]
+    side_stages = side.n_stages
     out = {
         "metric": "simrank_iterations_per_sec", "value": args.steps / elapsed,
         "unit": "iterations/s", "n_gpus": world_size, "steps": args.steps,
@@ -173,7 +175,7 @@ def main():
                                f"SimRank C=0.8 fp32, eps test every iteration",
                    "N": n, "nnz": nnz, "mode": solver.mode,
                    "sharding": f"S column-sharded over {world_size} rank(s), all-to-all per update"
-                               + (f" in {world.stages} overlapped stages" if use_dist else "")},
+                               + (f" in {side_stages} overlapped stage(s)" if use_dist else "")},
     }
     if solver.mode == "sparse":
         l1 = legs["leg1.0"][0]

@@ -67,6 +67,14 @@ def row_pad(block_rows: int) -> int:
     return 32 if block_rows >= PAD_MIN_ROWS and block_rows % PAD_MULTIPLE == 0 else 0
 
 
+def auto_stages(k_dim: int, world: int) -> int:
+    """Pipeline depth of the exchange when the caller does not fix it: slices of at least 2048
+    columns, at most 4.  Narrower slices cost more in short launches than their overlap gives
+    back (pl32768, one rank's leg 1 of 4096 columns: 0.89 ms in one launch, 1.05 in two, 1.38 in
+    four — tools/stage_probe.py).  Every rank derives it from the largest block, so all agree."""
+    return int(max(1, min(4, -(-k_dim // world) // 2048)))
+
+
 def stage_widths(n_cols: int, n_stages: int):
     """Column counts of the stages a rank cuts its n_cols product columns into: equal
     pieces rounded up to 32 columns (whole gather panels), the last one shorter or empty."""
@@ -142,10 +150,11 @@ class TorchWorld:
     """One rank per process over torch.distributed (backend "nccl" = RCCL over xGMI on the
     GPU box; "gloo" in the CPU tests)."""
 
-    def __init__(self, group=None, stages: int = 4, stage_single_rank: bool = False):
+    def __init__(self, group=None, stages: int = 0, stage_single_rank: bool = False):
         """``stages``: leg 1 is cut into that many column slices, each exchanged by its own
         all_to_all_single as soon as its kernel has finished, so the transfers over xGMI overlap
-        the remaining leg-1 kernels (1 = one exchange after the whole leg)."""
+        the remaining leg-1 kernels (1 = one exchange after the whole leg; 0 = by the width of a
+        rank's column block, see ``auto_stages``)."""
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -154,7 +163,7 @@ class TorchWorld:
         self.local_ranks = [self.rank]
         self.is_root = self.rank == 0
         # (a one-rank world stages only on request: that is how the path is exercised on one GPU)
-        self.stages = max(1, int(stages)) if (self.size > 1 or stage_single_rank) else 1
+        self.stages = max(0, int(stages)) if (self.size > 1 or stage_single_rank) else 1
 
     @property
     def stream_ordered(self):
@@ -271,8 +280,10 @@ class Side:
     def __init__(self, ops, spec: SideSpec, rank: int, world: int, mode: str, torch_buffers: bool,
                  stages: int = 1):
         self.ops, self.spec, self.rank, self.world, self.mode = ops, spec, rank, world, mode
-        self.n_stages = stages if (torch_buffers and mode == "sparse") else 1
         csr = spec.csr
+        if stages == 0:
+            stages = auto_stages(csr.n_cols, world)
+        self.n_stages = stages if (torch_buffers and mode == "sparse") else 1
         self.M, self.K = csr.n_rows, csr.n_cols
         self.m_lo, self.m_hi = partition(self.M, world, rank)
         self.k_lo, self.k_hi = partition(self.K, world, rank)

@@ -179,8 +179,8 @@ class TorchWorld:
         queued.  The all-to-all of that stage is issued at once; RCCL's stream waits for what is
         on the engine's stream so far (this stage) and runs beside the kernels queued next."""
         import torch
-        if not (sum(st["in_splits"]) or sum(st["out_splits"])):
-            return
+        # every rank joins every stage's collective, also with all-zero splits (a rank that owns an
+        # empty block at small N): skipping it on local data would leave the peers waiting
         with torch.cuda.stream(x.ops.torch_stream()):
             st["work"] = self.dist.all_to_all_single(
                 x.recv_t[st["recv_off"]:st["recv_off"] + sum(st["out_splits"])],
@@ -208,11 +208,11 @@ class TorchWorld:
             works = []
             for st in x.stages:
                 x.ops.event_synchronize(st["event"])      # this slice's kernel has finished
-                if sum(st["in_splits"]) or sum(st["out_splits"]):
-                    works.append(self.dist.all_to_all_single(
-                        x.recv_t[st["recv_off"]:st["recv_off"] + sum(st["out_splits"])],
-                        x.send_t[st["send_off"]:st["send_off"] + sum(st["in_splits"])],
-                        st["out_splits"], st["in_splits"], group=self.group, async_op=True))
+                # (zero-size splits are legal; every rank must issue every stage's collective)
+                works.append(self.dist.all_to_all_single(
+                    x.recv_t[st["recv_off"]:st["recv_off"] + sum(st["out_splits"])],
+                    x.send_t[st["send_off"]:st["send_off"] + sum(st["in_splits"])],
+                    st["out_splits"], st["in_splits"], group=self.group, async_op=True))
             for w in works:
                 w.wait()
             x.ops.collective_done()
@@ -292,6 +292,7 @@ class Side:
         self.graph = ops.graph(csr, spec.rowscale)
         self.symmetric = spec.symmetric
         self.x1 = self.x2 = None
+        self.broadcast_error = None
         if mode == "sparse":
             # exchange 1: leg-1 product (M rows x my Lk of K columns) -> K x Lm
             self.x1 = self._xfer(self.Lk, self.k_lo, self.K, torch_buffers)
@@ -309,13 +310,24 @@ class Side:
             self.t = ops.matrix(self.M, self.K)
         self.ev = None
         if spec.evidence_from is not None:
-            eg = self.graph if spec.evidence_from is csr else ops.graph(spec.evidence_from)
-            if eg.n_rows != self.M:
-                # quirk Q2: the reference multiplies an n2 x n2 update by Evidence_N1
-                raise ValueError(f"operands could not be broadcast together with shapes "
-                                 f"({eg.n_rows},{eg.n_rows}) ({self.M},{self.M}) ")
+            ev = spec.evidence_from
             self.ev = ops.matrix(self.M, self.Lm, np.uint8)
-            ops.evidence_counts(eg, self.m_lo, self.ev)
+            if ev.n_rows == self.M:
+                eg = self.graph if ev is csr else ops.graph(ev)
+                ops.evidence_counts(eg, self.m_lo, self.ev)
+            elif ev.n_rows == 1:
+                # quirk Q2 with a single group-1 node: NumPy broadcasts the 1 x 1 Evidence_N1 over
+                # the n2 x n2 update (SimRank.py:423), i.e. one count gates every element
+                live = ev.rowscale[0] > 0
+                cnt = min(255, int(ev.rowptr[1] - ev.rowptr[0])) if live else 0
+                ops.upload(self.ev, np.full((self.M, self.Lm), cnt, dtype=np.uint8))
+            else:
+                # quirk Q2: the reference multiplies the n2 x n2 update by the n1 x n1 Evidence_N1 and
+                # NumPy raises when that update RUNS (not at set-up: iterations=0 or eps >= 1 return
+                # the identity matrices); `leg2` raises it at the first group-2 update
+                self.broadcast_error = ValueError(
+                    f"operands could not be broadcast together with shapes "
+                    f"({ev.n_rows},{ev.n_rows}) ({self.M},{self.M}) ")
         self.ap = None
         if spec.apriori is not None:
             a = np.asarray(spec.apriori)
@@ -400,6 +412,8 @@ class Side:
         Otherwise only the raw product, stored transposed (what W . Tt yields is the
         TRANSPOSE of the wanted block); ``finish`` applies the epilogue after exchange 2."""
         o = self.ops
+        if self.broadcast_error is not None:
+            raise self.broadcast_error
         if not self.Lm:
             return
         if self.mode != "sparse":

@@ -32,7 +32,11 @@ def main(argv):
             first = res[0] if isinstance(res, tuple) else res
             want = g.out["S1"] if isinstance(res, tuple) else g.out["S"]
             np.testing.assert_allclose(first.values, want, rtol=1e-5, atol=1e-30)
-        assert any(c[0] == "spmm" and c[1] for c in ops.calls)
+        # (a rank whose column block is empty at this N launches nothing but joins every collective)
+        from simrank_amd.ingest import partition
+        first = res[0] if isinstance(res, tuple) else res
+        lo, hi = partition(len(first), dist.get_world_size(), rank)
+        assert hi == lo or any(c[0] == "spmm" and c[1] for c in ops.calls)
     dist.barrier()
     print(f"RANK {rank} ok", flush=True)
     dist.destroy_process_group()

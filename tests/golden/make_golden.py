@@ -155,15 +155,37 @@ def cases():
         lbd1=0.4, lbd2=0.2)
     add("BipartitleAprioriSimRank_b40_asym", "BipartitleAprioriSimRank", b40,
         (rng.random((40, 40)), p2), lbd1=0.3, lbd2=0.3)
+    # round 2 (appended: the cases above keep their random streams)
+    # quirk Q2 fires only when the group-2 update RUNS: no iteration / eps >= 1 return identities,
+    # and a single group-1 node gives a 1 x 1 Evidence_N1 that NumPy broadcasts
+    add("BipartiteSimRankPP_b5030_iter0", "BipartiteSimRankPP", b5030, iterations=0)
+    add("BipartiteSimRankPP_b5030_eps1", "BipartiteSimRankPP", b5030, eps=1.0)
+    one = _pd.DataFrame({"user": [7] * 6, "item": [3, 9, 4, 12, 5, 8], "weight": [1, 2, 3, 1, 2, 5]})
+    add("BipartiteSimRankPP_one_user", "BipartiteSimRankPP", one)
+    # BASELINE.json configs[0]: BTS-flights-like directed graph (~300 airports), C = 0.8, 10 iterations
+    from simrank_amd.synth import hub_and_spoke
+    bts = hub_and_spoke(300, 300)
+    add("SimRank_bts300", "SimRank", bts, C=0.8, iterations=10)
+    add("SimRankPP_bts300", "SimRankPP", bts, C=0.8, iterations=10)
     return out
 
 
 def main():
+    """``--only a,b``: (re)generate just those cases and merge them into the manifest."""
+    only = None
+    if "--only" in sys.argv:
+        only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
     manifest = {}
-    for f in os.listdir(HERE):
-        if f.endswith(".npz"):
-            os.remove(os.path.join(HERE, f))
+    if only is not None:
+        with open(os.path.join(HERE, "manifest.json")) as f:
+            manifest = json.load(f)
+    else:
+        for f in os.listdir(HERE):
+            if f.endswith(".npz"):
+                os.remove(os.path.join(HERE, f))
     for name, cls, df, args, kw in cases():
+        if only is not None and name not in only:
+            continue
         res = run(cls, df, args, **kw)
         arrays = {f"in_{c}": df[c].to_numpy() for c in df.columns}
         for i, a in enumerate(args):

@@ -23,6 +23,19 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def test_staged_exchange_with_empty_blocks_does_not_hang():
+    """N = 5 over 4 ranks in 2 stages: rank 3 owns an empty block and still has to join every
+    stage's all_to_all_single (round-1 advisor finding: it skipped it and the peers hung)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dist_worker.py"), "2", "SimRank_toy5", "SimRankPP_toy5"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    for r in range(4):
+        assert f"RANK {r} ok" in p.stdout
+
+
 @pytest.mark.parametrize("world,stages", [(2, 1), (3, 1), (2, 3), (3, 2)])
 def test_sharded_driver_over_gloo(world, stages):
     """stages > 1: leg 1 cut into column slices, one asynchronous all_to_all_single per slice

@@ -11,7 +11,7 @@ import simrank_amd.SimRank as SRA
 from oracle import simrank_oracle as O
 from simrank_amd import ingest, synth
 from simrank_amd.driver import LocalWorld, SideSpec, Solver
-from tests.conftest import Golden, golden_names
+from tests.conftest import Golden, free_port, golden_names
 from tests.graphs import bipartite_random
 from tests.helpers import RTOL, assert_close, check_against_golden, run_estimator
 
@@ -246,7 +246,7 @@ def test_rccl_world_of_one_rank():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
-           "--master-addr", "127.0.0.1", "--master-port", "29571", os.path.join(root, "bench.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(root, "bench.py"),
            "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "er8192", "--force-dist",
            "--stages", "3", "--no-cpu-baseline"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
@@ -264,7 +264,7 @@ def test_rccl_world_values():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
-           "--master-addr", "127.0.0.1", "--master-port", "29573",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(root, "tests", "dist_gpu_worker.py")]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert p.returncode == 0 and "RCCL WORLD ok" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]

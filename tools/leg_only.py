@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""A few updates of one workload with given tuning knobs — the program rocprofv3 wraps when a
+counter pass is about ONE setting (tools/pmc_knob.sh).
+
+    python3 tools/leg_only.py [--workload pl32768] [--steps 3] [--set balance=1,dense_min=4]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from simrank_amd import ingest, synth                              # noqa: E402
+from simrank_amd.driver import LocalWorld, SideSpec, Solver        # noqa: E402
+from simrank_amd.engine import HipOps                              # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="pl32768")
+ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--set", default="")
+args = ap.parse_args()
+ops = HipOps(0)
+if args.set:
+    ops.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.set.split(","))})
+df = synth.WORKLOADS[args.workload][0]()
+_, csr = ingest.directed(df, False, "from", "to", "weight")
+s = Solver(lambda r: ops, LocalWorld(1), [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
+s.reset()
+s.enable_timing()
+for _ in range(args.steps):
+    s.step(0.0)
+ops.synchronize()
+print(args.set, {k: round(v[0], 3) for k, v in s.leg_times().items()}, flush=True)

@@ -85,6 +85,44 @@ def cpu_baseline(csr, S_host, coef, budget_s=45.0):
                       f"host cpu_count={os.cpu_count()}"}
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n):
+    """``python bench.py --gpus N`` outside torchrun: start the N ranks as a CHILD process
+    (python -m torch.distributed.run ... bench.py <same arguments>), relay rank 0's JSON line
+    and return the child's exit code.  Runs before torch or HIP is touched in this process:
+    nothing that has initialised the GPU is ever exec'ed or re-exec'ed."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    if lines:
+        print(lines[-1], flush=True)
+    else:
+        sys.stdout.write(p.stdout)
+    return p.returncode
+
+
+def workload_frame(synth, name):
+    """A named BASELINE.json workload, or an ad-hoc ``er:N:p`` / ``pl:N:deg`` graph."""
+    if name.startswith("er:"):
+        _, n, p = name.split(":")
+        return synth.er_directed(int(n), float(p), int(n)), "directed"
+    if name.startswith("pl:"):
+        _, n, d = name.split(":")
+        return synth.powerlaw_directed(int(n), float(d), int(n)), "directed"
+    factory, kind = synth.WORKLOADS[name]
+    return factory(), kind
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,43 +136,56 @@ def main():
     ap.add_argument("--stages", type=int, default=0,
                     help="pipeline depth of the sharded exchange (all_to_all_single calls per update; "
                          "0 = by the width of a rank's column block)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL on the GPUs (the measurement); gloo = CPU rehearsal of the launch "
+                         "path with the NumPy test double (tests only)")
     ap.add_argument("--force-dist", action="store_true",
                     help="use the torch.distributed world even with one rank (exercises RCCL)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))           # before anything touches torch or HIP
+
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world_size:
-        if world_size == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs: python -m torch.distributed.run --nnodes=1 "
-                     f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus}")
-        args.gpus = world_size
+    args.gpus = world_size
 
     import torch
     import torch.distributed as dist
     from simrank_amd import ingest, synth
     from simrank_amd.driver import LocalWorld, SideSpec, Solver, TorchWorld
-    from simrank_amd.engine import HipOps
 
-    torch.cuda.set_device(local_rank)
+    gpu = args.backend == "nccl"
     use_dist = world_size > 1 or args.force_dist
+    if gpu:
+        torch.cuda.set_device(local_rank)
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29555")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size,
-                                device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        if gpu:
+            dist.init_process_group("nccl", rank=rank, world_size=world_size,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
         world = TorchWorld(stages=args.stages, stage_single_rank=args.force_dist)
     else:
         world = LocalWorld(1)
 
-    ops = HipOps(local_rank)
-    if args.panel is not None:
-        ops.set_tuning(panel=args.panel)
-    factory, kind = synth.WORKLOADS[args.workload]
+    if gpu:
+        from simrank_amd.engine import HipOps
+        ops = HipOps(local_rank)
+        if args.panel is not None:
+            ops.set_tuning(panel=args.panel)
+    else:
+        # rehearsal of the multi-rank launch path on CPU (tests/test_bench_launch.py): real
+        # collectives over gloo, the kernels replaced by the NumPy test double; no number
+        # from this path is a measurement
+        from tests.cpu_ops import NumpyOps
+        ops = NumpyOps()
+    df, kind = workload_frame(synth, args.workload)
     assert kind == "directed", "bench workloads are the directed SimRank configurations"
-    df = factory()
     _, csr = ingest.directed(df, False, "from", "to", "weight")
     n, nnz = csr.n_rows, csr.nnz
     coef = 0.8
@@ -143,7 +194,8 @@ def main():
 
     def barrier():
         ops.synchronize()
-        torch.cuda.synchronize()
+        if gpu:
+            torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
 
@@ -157,7 +209,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -167,7 +219,8 @@ def main():
     side_stages = side.n_stages
     out = {
         "metric": "simrank_iterations_per_sec", "value": args.steps / elapsed,
-        "unit": "iterations/s", "n_gpus": world_size, "steps": args.steps,
+        "unit": "iterations/s", "n_gpus": world_size,
+        "rccl_ranks": (dist.get_world_size() if use_dist and gpu else 0), "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
@@ -177,7 +230,11 @@ def main():
                    "sharding": f"S column-sharded over {world_size} rank(s), all-to-all per update"
                                + (f" in {side_stages} overlapped stage(s)" if use_dist else "")},
     }
-    if solver.mode == "sparse":
+    if not gpu:
+        out["data"] = "synthetic; gloo rehearsal with the NumPy test double: NOT a measurement"
+        out["ranks"] = dist.get_world_size() if use_dist else 1
+        args.no_extras = args.no_cpu_baseline = True
+    elif solver.mode == "sparse":
         l1 = legs["leg1.0"][0]
         l2 = legs["leg2.0"][0]
         b1 = leg_bytes(side.M, side.K, side.Lk, nnz, leg2=False)

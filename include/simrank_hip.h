@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define SIMRANK_ABI_VERSION 1
+#define SIMRANK_ABI_VERSION 2
 #define SIMRANK_CHANGED_SLOTS 1024
 
 #if defined(__GNUC__)
@@ -203,27 +203,6 @@ SIMRANK_API int simrank_gemm_nt(int64_t M, int64_t N, int64_t K, const float* A,
                     const float* B, int64_t ldb, float* C, int64_t ldc,
                     const simrank_epilogue* epilogue, void* stream);
 
-/* ---- EXPERIMENTAL (not used by the Python driver yet) ----
- * ---- LDS-tiled legs for graphs with at most 8192 source rows (n_cols(g) <= 8192): the reuse
- *      of X rows is served from LDS instead of L2.  Operands are in the
- *      panel-blocked layout "B4": element (r, c) of a matrix padded to Rp x Cp (multiples of
- *      4) is at ((c >> 2) * Rp + r) * 4 + (c & 3).
- *      simrank_spmm_lds: X is n_cols(g) x n_cols_x in B4; the result is stored TRANSPOSED,
- *      Zt(c, a) = epilogue(rowscale[a] * sum_{i in row a} X(i, c)), as an n_cols_x x n_rows(g)
- *      matrix in B4; evidence (u8), prior and previous iterate are B4 matrices indexed like
- *      Zt.  With symmetric iterates the transposed result of leg 2 is the next iterate, so
- *      both legs of an update are this one call (same reference lines as simrank_spmm). */
-SIMRANK_API int simrank_lds_supported(const simrank_graph* g, int32_t* ok);
-SIMRANK_API int simrank_spmm_lds(const simrank_graph* g, const float* X_b4, int64_t n_cols_x,
-                                 float* Zt_b4, const simrank_epilogue* epilogue, void* stream);
-/* S <- identity (n x n) in B4 */
-SIMRANK_API int simrank_b4_identity(float* S_b4, int64_t n, void* stream);
-/* B4 (rows padded) -> row-major float32 */
-SIMRANK_API int simrank_b4_unpack(const float* S_b4, int64_t n_rows, int64_t n_cols, float* out,
-                                  int64_t ld, void* stream);
-/* row-major (elem_bytes 1 = uint8 counts, 4 = float32) -> B4 */
-SIMRANK_API int simrank_b4_pack(const void* in, int64_t ld, int64_t n_rows, int64_t n_cols,
-                                int32_t elem_bytes, void* out_b4, void* stream);
 
 /* ---- block-dense part of a pattern.  When a graph is created, every aligned
  *      block of 128 rows gets a DENSE SET: the columns referenced by at least `dense_min` of its

@@ -76,11 +76,6 @@ PROTOTYPES = {
     "simrank_graph_densify": [_vp, _vp, _i64, _vp],
     "simrank_gemm_nt": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64,
                         C.POINTER(Epilogue), _vp],
-    "simrank_lds_supported": [_vp, C.POINTER(_i32)],
-    "simrank_spmm_lds": [_vp, _vp, _i64, _vp, C.POINTER(Epilogue), _vp],
-    "simrank_b4_identity": [_vp, _i64, _vp],
-    "simrank_b4_unpack": [_vp, _i64, _i64, _vp, _i64, _vp],
-    "simrank_b4_pack": [_vp, _i64, _i64, _i64, _i32, _vp, _vp],
     "simrank_graph_dense_stats": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
     "simrank_dense_part": [_vp, _vp, _i64, _i64, _vp],
     "simrank_set_tuning": [C.c_char_p, _i64],
@@ -106,7 +101,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError = symbol missing from the .so
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
-    if lib.simrank_abi_version() != 1:
+    if lib.simrank_abi_version() != 2:
         raise ImportError("libsimrank_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -26,6 +26,16 @@ Tuning& tuning() {
     return t;
 }
 
+static std::mutex& tuning_mutex() {
+    static std::mutex m;
+    return m;
+}
+
+Tuning tuning_snapshot() {
+    std::lock_guard<std::mutex> lock(tuning_mutex());
+    return tuning();
+}
+
 }  // namespace simrank
 
 
@@ -34,13 +44,13 @@ namespace simrank {
 // are cut into aligned halves, down to single rows, so that no wave is left with a tile
 // many times the others' (a power-law row order sorted by length puts all long rows
 // in a few blocks).  For the upper-triangle leg 2: the (panel, workgroup) launch list.
-void build_tiles(const int32_t* rowptr, int64_t n_rows, int64_t nnz, std::vector<int32_t>& tile_row0,
-                 std::vector<int32_t>& sym_map) {
+void build_tiles(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int64_t balance,
+                 std::vector<int32_t>& tile_row0, std::vector<int32_t>& sym_map) {
     tile_row0.clear();
     sym_map.clear();
-    if (tuning().balance <= 0 || nnz <= 0) return;
+    if (balance <= 0 || nnz <= 0) return;
     const int64_t nblk = (n_rows + 31) / 32;
-    const int64_t limit = std::max<int64_t>(tuning().balance * ((nnz + nblk - 1) / nblk), 256);
+    const int64_t limit = std::max<int64_t>(balance * ((nnz + nblk - 1) / nblk), 256);
     std::vector<std::pair<int64_t, int64_t>> stack;
     for (int64_t b = 0; b < nblk; ++b) {
         stack.clear();
@@ -349,14 +359,13 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
             for (int32_t j = rowptr[a]; j < rowptr[a + 1]; ++j) t_col[cur[col[j]]++] = (int32_t)a;
     }
     simrank_graph* g = new simrank_graph;
+    g->tun = tuning_snapshot();
     g->n_rows = n_rows;
     g->n_cols = n_cols;
     g->nnz = nnz;
     g->max_row_nnz = max_row;
-    g->h_rowptr.assign(rowptr, rowptr + n_rows + 1);
-    g->h_col.assign(col, col + nnz);
     std::vector<int32_t> tile_row0, sym_map;
-    build_tiles(rowptr, n_rows, nnz, tile_row0, sym_map);
+    build_tiles(rowptr, n_rows, nnz, g->tun.balance, tile_row0, sym_map);
     g->n_tiles = tile_row0.empty() ? 0 : (int32_t)tile_row0.size() - 1;
     g->sym_blocks = (int32_t)(sym_map.size() / 2);
     auto up = [&](void** d, const void* h, size_t bytes) -> int {
@@ -381,7 +390,7 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
     if (!rc) rc = up((void**)&g->t_col, t_col.data(), size_t(nnz) * 4);
     if (!rc && g->n_tiles) rc = up((void**)&g->tile_row0, tile_row0.data(), tile_row0.size() * 4);
     if (!rc && g->sym_blocks) rc = up((void**)&g->sym_map, sym_map.data(), sym_map.size() * 4);
-    if (!rc && tuning().dense_min > 0 && nnz > 0) rc = build_dense_plan(g, rowptr, col);
+    if (!rc && g->tun.dense_min > 0 && nnz > 0) rc = build_dense_plan(g, rowptr, col);
     if (rc) {
         simrank_graph_destroy(g);
         return rc;
@@ -400,7 +409,6 @@ int simrank_graph_destroy(simrank_graph* g) {
     (void)hipFree(g->t_col);
     (void)hipFree(g->tile_row0);
     (void)hipFree(g->sym_map);
-    free_lds_plan(g->lds_plan);
     free_dense_plan(g->dense);
     delete g;
     return SIMRANK_OK;
@@ -419,6 +427,7 @@ int simrank_graph_shape(const simrank_graph* g, int64_t* n_rows, int64_t* n_cols
 // ---------------------------------------------------------------------------------------
 int simrank_set_tuning(const char* key, int64_t value) {
     SR_REQUIRE(key, "key is NULL");
+    std::lock_guard<std::mutex> lock(tuning_mutex());
     Tuning& t = tuning();
     if (!strcmp(key, "panel")) {
         SR_REQUIRE(value == 0 || value == 16 || value == 32 || value == 64 || value == 128 ||
@@ -443,6 +452,13 @@ int simrank_set_tuning(const char* key, int64_t value) {
     } else if (!strcmp(key, "dense_min")) {
         SR_REQUIRE(value >= 0 && value <= 128, "dense_min must be 0 (off) .. 128");
         t.dense_min = value;
+    } else if (!strcmp(key, "probe_mask")) {
+        t.probe_mask = value < 0 ? -1 : value;
+    } else if (!strcmp(key, "probe_flags")) {
+        t.probe_flags = value & 15;
+    } else if (!strcmp(key, "lean")) {
+        SR_REQUIRE(value >= 0 && value <= 2, "lean must be 0, 1 or 2");
+        t.lean = value;
     } else if (!strcmp(key, "ids16")) {
         t.ids16 = value ? 1 : 0;
     } else if (!strcmp(key, "dense_sym")) {
@@ -458,7 +474,7 @@ int simrank_set_tuning(const char* key, int64_t value) {
 
 int simrank_get_tuning(const char* key, int64_t* value) {
     SR_REQUIRE(key && value, "NULL argument");
-    const Tuning& t = tuning();
+    const Tuning t = tuning_snapshot();
     if (!strcmp(key, "panel")) *value = t.panel;
     else if (!strcmp(key, "xcd_map")) *value = t.xcd_map;
     else if (!strcmp(key, "stream_nt")) *value = t.stream_nt;
@@ -470,6 +486,9 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     else if (!strcmp(key, "dense_cols")) *value = t.dense_cols;
     else if (!strcmp(key, "dense_sym")) *value = t.dense_sym;
     else if (!strcmp(key, "ids16")) *value = t.ids16;
+    else if (!strcmp(key, "lean")) *value = t.lean;
+    else if (!strcmp(key, "probe_flags")) *value = t.probe_flags;
+    else if (!strcmp(key, "probe_mask")) *value = t.probe_mask;
     else SR_REQUIRE(false, "unknown tuning key '%s'", key);
     return SIMRANK_OK;
 }

@@ -187,7 +187,7 @@ constexpr int kUnitCols = 2048;   // a dense set is cut into units of about this
 // build the remainder.
 int build_dense_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col) {
     const int64_t M = g->n_rows, K = g->n_cols;
-    const int64_t min_rows = tuning().dense_min, min_cols = tuning().dense_cols;
+    const int64_t min_rows = g->tun.dense_min, min_cols = g->tun.dense_cols;
     const int64_t nblk = (M + kDM - 1) / kDM;
     struct Unit { int32_t block, slab, first, count; };        // columns [first, first+count) of the block's set
     std::vector<std::vector<int32_t>> sets(static_cast<size_t>(nblk));
@@ -279,7 +279,7 @@ int build_dense_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
         for (int32_t c : set) kpos[c] = -1;
     }
     std::vector<int32_t> r_tile_row0, r_sym_map;
-    build_tiles(r_rowptr.data(), M, (int64_t)r_col.size(), r_tile_row0, r_sym_map);
+    build_tiles(r_rowptr.data(), M, (int64_t)r_col.size(), g->tun.balance, r_tile_row0, r_sym_map);
 
     simrank_dense_plan* pl = new simrank_dense_plan;
     pl->n_units = (int32_t)nu;

@@ -42,19 +42,23 @@ struct Tuning {
     int64_t dense_min = 4;   // block-dense MFMA part: a column joins a 128-row tile's dense set when
                              // at least this many of the tile's rows reference it (0 = off)
     int64_t dense_cols = 128; // ... and a tile gets a dense set only with this many such columns
+    int64_t probe_mask = -1; // DIAGNOSTIC ONLY: gathered row ids are ANDed with this (wrong results; prices
+                             // the memory path of the gather kernel: 255 = L1-resident operand, 8191 = L2-resident)
+    int64_t probe_flags = 0; // DIAGNOSTIC ONLY (lean kernel): 1 no gathers, 2 no stores, 4 no dense partial sums, 8 no ids
+    int64_t lean = 1;        // 1: the lean gather kernel (32-float panels) where it applies, 2: also for
+                             // the plain (sharded leg 2) form, 0: the generic kernel everywhere
     int64_t ids16 = 1;       // stream neighbour ids as 16-bit values when the graph allows it
     int64_t dense_sym = -1;  // dense part in the upper-triangle form of leg 2: 1 yes, 0 no, -1 = when the
                              // dense sets hold at least half of the pattern's entries
 };
-Tuning& tuning();
+Tuning& tuning();            // the process-wide defaults: simrank_set_tuning writes them, simrank_graph_create
+Tuning tuning_snapshot();    // copies them (under a lock) into the graph it builds; launches read the copy
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace simrank
 
-struct simrank_lds_plan;   // lds.hip: SELL / long-row packing for the LDS-tiled kernel
-namespace simrank { void free_lds_plan(simrank_lds_plan* p); }
 
 // blockdense.hip: the part of the pattern that is dense enough for the matrix cores.  Rows go in
 // aligned blocks of 128; inside a block the columns referenced by at least `dense_min` rows form
@@ -106,8 +110,8 @@ int build_dense_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
 int launch_dense_tiles(const simrank_graph* g, const float* X, int64_t ldx, int64_t L, bool tri,
                        hipStream_t st, DenseUse* use);
 // balanced 32-row tiling of a pattern (api.hip): tile list and the upper-triangle launch list
-void build_tiles(const int32_t* rowptr, int64_t n_rows, int64_t nnz, std::vector<int32_t>& tile_row0,
-                 std::vector<int32_t>& sym_map);
+void build_tiles(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int64_t balance,
+                 std::vector<int32_t>& tile_row0, std::vector<int32_t>& sym_map);
 }
 
 // The graph object: device CSR of the 0/1 pattern + per-row scale, and the transposed
@@ -129,9 +133,7 @@ struct simrank_graph {
     int32_t n_tiles = 0;
     int32_t* sym_map = nullptr;
     int32_t sym_blocks = 0;
-    // host copies, kept for the lazily built LDS plan (lds.hip)
-    std::vector<int32_t> h_rowptr, h_col;
-    simrank_lds_plan* lds_plan = nullptr;
-    bool lds_plan_failed = false;
     simrank_dense_plan* dense = nullptr;   // NULL: no block of the pattern is dense enough
+    simrank::Tuning tun;                   // knobs in force when the graph was created (every launch on
+                                           // this graph uses these, whatever is set afterwards)
 };

@@ -35,6 +35,9 @@ struct SpmmArgs {
     const int32_t* rowptr;
     const int32_t* col;       // neighbour ids, ascending per row
     const uint16_t* col16;    // the same in 16 bits (NULL when the graph has more than 65536 columns)
+    int32_t idx_mask;         // diagnostic (tuning "probe_mask"): neighbour ids are ANDed with it; -1 = off
+    int32_t probe;            // diagnostic (tuning "probe_flags", lean kernel): 1 no gathers, 2 no stores of Y,
+                              // 4 no partial sums of the dense part, 8 no neighbour-id loads
     int32_t nt;               // non-temporal output stores
     int32_t has_huge;         // the graph has rows of >= huge_len entries
     int32_t huge_len;         // rows this long are split over the waves of a workgroup
@@ -246,7 +249,7 @@ __device__ __forceinline__ void gather_range(const SpmmArgs& p, const float* __r
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 const int k = k0 + u * G + g;
-                idx[u] = __shfl(myidx, k & 63);
+                idx[u] = __shfl(myidx, k & 63) & p.idx_mask;
                 if (!(col_active && k < n)) idx[u] = kSkip;
             }
 #pragma unroll
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const SpmmArgs p) {
                     int idx[JU];
 #pragma unroll
                     for (int j = 0; j < JU; ++j) {
-                        idx[j] = __shfl(iv, gbase + jb + j);
+                        idx[j] = __shfl(iv, gbase + jb + j) & p.idx_mask;
                         if (!(col_active && t0 + jb + j < len)) idx[j] = kSkip;
                     }
 #pragma unroll
@@ -580,6 +583,514 @@ static int launch_spmm(SpmmArgs a, hipStream_t st) {
         SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);
+    SR_HIP(hipGetLastError());
+    return SIMRANK_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// The lean form of the same kernel (round 2).  Counters and an ablation (every neighbour id
+// forced to one row: the gathers become L1 hits, nothing else changes) showed that the generic
+// kernel above is bound by instruction issue, not by the memory path: its ~18 instructions per
+// gather (two 64-bit multiply-adds, zero fills, an exec-masked branch per gather) and a 64-bit
+// division per piece of the transposed store cost more than the L2.  This version fixes
+// VEC = 4, LPR = 8 (32-float panels, 32-row tiles) and
+//   * addresses a neighbour row with one 24-bit multiply (row id x pitch in 16-byte units) and
+//     one 64-bit shift-add;
+//   * issues the gathers of a chunk unconditionally: slots that every row of the pass has are
+//     plain adds, the ragged rest is multiplied by a 0/1 mask (fma(v, 1, acc) == v + acc
+//     bit for bit; masked slots read row 0, which is valid memory);
+//   * skips the bitonic sort when the tile's rows already come in ascending length (the solver's
+//     node order), preloads the row scales, and computes block offsets of the transposed store
+//     per tile, not per element.
+//   * requests a row's partial sums of the matrix-core part before its gathers, four slabs at a time.
+// Same phases and the same summation order of a row's neighbours as the generic kernel (A0: huge rows
+// over the four waves; A: long rows over the 8 lane groups; B: one row per lane group); the dense
+// partial sums are added as one term (slabs summed first), so rows with a dense set may differ from
+// the generic kernel in the last bit.  Deterministic, and identical for 1 or P shards.
+// ---------------------------------------------------------------------------------------
+template <bool IDS16>
+__device__ __forceinline__ int ld_id(const SpmmArgs& p, int j) {
+    if constexpr (IDS16) return int(p.col16[j]);
+    else return p.col[j];
+}
+
+__device__ __forceinline__ float4 ld_row(const float* Xc, int idx, uint32_t pitch16) {
+    return reinterpret_cast<const float4*>(Xc)[size_t(__umul24(uint32_t(idx), pitch16))];
+}
+
+// N slots of a chunk: slot j reads the row whose id sits in lane lane0 + j * LS of `ids`.
+// MASKED: slot j counts for this lane only when j < rem.
+template <int N, int LS, bool MASKED>
+__device__ __forceinline__ void gather_slots(const float* Xc, uint32_t pitch16, int ids, int lane0,
+                                             int rem, float (&acc)[4]) {
+    float4 v[N > 0 ? N : 1];
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = ld_row(Xc, __shfl(ids, lane0 + j * LS), pitch16);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        if constexpr (MASKED) {
+            const float m = j < rem ? 1.0f : 0.0f;
+            acc[0] = fmaf(v[j].x, m, acc[0]);
+            acc[1] = fmaf(v[j].y, m, acc[1]);
+            acc[2] = fmaf(v[j].z, m, acc[2]);
+            acc[3] = fmaf(v[j].w, m, acc[3]);
+        } else {
+            acc[0] += v[j].x;
+            acc[1] += v[j].y;
+            acc[2] += v[j].z;
+            acc[3] += v[j].w;
+        }
+    }
+}
+
+// n_max (wave-uniform, 0..8) slots are needed by some lane group, n_full by all of them.  At most
+// four gathers are in flight per call (16 registers of data): the kernel's latency hiding comes
+// from eight waves per SIMD, not from long per-wave queues (64 VGPRs).
+template <int LS>
+__device__ __forceinline__ void gather_half(const float* Xc, uint32_t pitch16, int ids, int lane0,
+                                            int n_max, int n_full, int rem, float (&acc)[4]) {
+    if (n_full >= n_max) {
+        switch (n_max) {
+            case 4: gather_slots<4, LS, false>(Xc, pitch16, ids, lane0, rem, acc); break;
+            case 3: gather_slots<3, LS, false>(Xc, pitch16, ids, lane0, rem, acc); break;
+            case 2: gather_slots<2, LS, false>(Xc, pitch16, ids, lane0, rem, acc); break;
+            case 1: gather_slots<1, LS, false>(Xc, pitch16, ids, lane0, rem, acc); break;
+            default: break;
+        }
+    } else {
+        switch (n_max) {
+            case 4: gather_slots<4, LS, true>(Xc, pitch16, ids, lane0, rem, acc); break;
+            case 3: gather_slots<3, LS, true>(Xc, pitch16, ids, lane0, rem, acc); break;
+            case 2: gather_slots<2, LS, true>(Xc, pitch16, ids, lane0, rem, acc); break;
+            case 1: gather_slots<1, LS, true>(Xc, pitch16, ids, lane0, rem, acc); break;
+            default: break;
+        }
+    }
+}
+
+template <int LS>
+__device__ __forceinline__ void gather_chunk(const float* Xc, uint32_t pitch16, int ids, int lane0,
+                                             int n_max, int n_full, int rem, float (&acc)[4]) {
+    gather_half<LS>(Xc, pitch16, ids, lane0, min(n_max, 4), min(n_full, 4), rem, acc);
+    if (n_max > 4)
+        gather_half<LS>(Xc, pitch16, ids, lane0 + 4 * LS, n_max - 4, n_full - 4, rem - 4, acc);
+}
+
+// Sum of the X segments of the neighbours at CSR positions [s, e) (s, e wave-uniform): blocks of
+// 64 ids, one per lane; slot u of lane group g is neighbour 8 u + g of the block; partial sums of
+// the 8 groups combined by shuffles in a fixed order.  Every lane ends with the total.
+template <bool IDS16>
+__device__ __forceinline__ void gather_range3(const SpmmArgs& p, const float* Xc, uint32_t pitch16,
+                                              int s, int e, int lane, int g, float (&acc)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = 0.f;
+    for (int base = s; base < e; base += 64) {
+        const int n = min(64, e - base);
+        const int myid = (lane < n && !(p.probe & 8)) ? (ld_id<IDS16>(p, base + lane) & p.idx_mask) : 0;
+        if (!(p.probe & 1))
+            gather_chunk<8>(Xc, pitch16, myid, g, (n + 7) >> 3, n >> 3, (n - g + 7) >> 3, acc);
+    }
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += __shfl_xor(acc[i], off);
+}
+
+// Partial sums of the matrix-core part for row a (blockdense.hip), its slabs added in slab order.
+// Called BEFORE the row's gathers are issued, so these loads are in flight beside them instead
+// of forming a dependent chain in the epilogue (0.6 ms of leg 1 at pl32768 when they did).
+__device__ __forceinline__ void dense_partial(const SpmmArgs& p, int64_t a, int64_t mycol, bool on,
+                                              float (&dsum)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dsum[i] = 0.f;
+    if (!p.dpart || (p.probe & 4) || !on) return;
+    const int ns = p.dnslab[a >> 7];
+    const float* dp = p.dpart + (int64_t(p.dslab0[a >> 7]) * 128 + (a & 127)) * p.ldp + mycol;
+    int s = 0;
+    for (; s + 4 <= ns; s += 4, dp += 4 * 128 * p.ldp) {       // four independent loads at a time
+        float d0[4], d1[4], d2[4], d3[4];
+        vload_nt<4>(d0, dp);
+        vload_nt<4>(d1, dp + 128 * p.ldp);
+        vload_nt<4>(d2, dp + 2 * 128 * p.ldp);
+        vload_nt<4>(d3, dp + 3 * 128 * p.ldp);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dsum[i] = (((dsum[i] + d0[i]) + d1[i]) + d2[i]) + d3[i];
+    }
+    for (; s < ns; ++s, dp += 128 * p.ldp) {
+        float d[4];
+        vload_nt<4>(d, dp);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dsum[i] += d[i];
+    }
+}
+
+// emit_row of the generic kernel with the row scale and the dense partial sums handed in
+template <int MODE>
+__device__ __forceinline__ void emit_row3(const SpmmArgs& p, float* tbuf_wave, int r_local, int64_t a,
+                                          int q, int64_t mycol, float rowscale, const float (&acc)[4],
+                                          const float (&dsum)[4], unsigned& changed, bool mirror) {
+    constexpr int RT = 32;
+    const float sc = rowscale * (p.has_ep ? p.coef : 1.0f);
+    float o[4] = {acc[0] + dsum[0], acc[1] + dsum[1], acc[2] + dsum[2], acc[3] + dsum[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] *= sc;
+    if constexpr (MODE == kTrans) {
+        float* t = tbuf_wave + (q * 4) * (RT + 1) + r_local;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i * (RT + 1)] = o[i];
+    } else {
+        const int nvalid = int(imin(4, p.L - mycol));
+        if (p.has_ep) {
+            if (p.ev) {
+                const unsigned w = __builtin_nontemporal_load(
+                    reinterpret_cast<const unsigned*>(p.ev + a * p.ld_ev + mycol));
+                o[0] *= 1.0f - __builtin_ldexpf(1.0f, -int(w & 255u));
+                o[1] *= 1.0f - __builtin_ldexpf(1.0f, -int((w >> 8) & 255u));
+                o[2] *= 1.0f - __builtin_ldexpf(1.0f, -int((w >> 16) & 255u));
+                o[3] *= 1.0f - __builtin_ldexpf(1.0f, -int(w >> 24));
+            }
+            if (p.ap) {
+                float pr[4];
+                vload_nt<4>(pr, p.ap + a * p.ld_ap + mycol);
+                const float keep = 1.0f - p.lbd;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = keep * o[i] + p.lbd * pr[i];
+            }
+            if (p.set_diag) {
+                const int64_t d = a - (p.diag_col0 + mycol);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (d == i) o[i] = 1.0f;
+            }
+            if (p.prev) {
+                float old[4];
+                vload_nt<4>(old, p.prev + a * p.ld_prev + mycol);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    changed += (i < nvalid && fabs(double(o[i]) - double(old[i])) > p.eps)
+                                   ? (mirror ? 2u : 1u) : 0u;
+            }
+        }
+        if constexpr (MODE == kSym) {
+            if (mirror) {
+                float* t = tbuf_wave + (q * 4) * (RT + 1) + r_local;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i * (RT + 1)] = o[i];
+            }
+        }
+        float* y = p.Y + a * p.ldy + mycol;
+        if (p.probe & 2) {
+        } else if (nvalid == 4) {
+            if (p.nt) vstore_nt<4>(y, o); else vstore<4>(y, o);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nvalid) y[i] = o[i];
+        }
+    }
+}
+
+template <int MODE, bool IDS16>
+__global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(const SpmmArgs p) {
+    constexpr bool TRANS = MODE == kTrans;
+    constexpr bool TILE = MODE != kPlain;
+    constexpr int PW = 32, RT = 32, LPR = 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    int panel, rt;
+    if (MODE == kSym && p.sym_map) {
+        panel = p.sym_map[2 * blockIdx.x];
+        rt = p.sym_map[2 * blockIdx.x + 1];
+        if (panel < 0) return;
+    } else if constexpr (MODE == kSym) {
+        const int x = int(blockIdx.x & 7);
+        const int t = int(blockIdx.x >> 3);
+        const int b1 = x >> 2;
+        int j = int((sqrtf(float(b1 * b1 + 4 * t)) - float(b1)) * 0.5f);
+        while ((j + 1) * (j + 1) + b1 * (j + 1) <= t) ++j;
+        while (j * j + b1 * j > t) --j;
+        panel = x + 8 * j;
+        rt = t - (j * j + b1 * j);
+        if (rt > panel / 4) return;
+    } else {
+        const uint32_t bid = blockIdx.x;
+        if (p.xcd_map) {
+            const uint32_t local = bid >> 3;
+            panel = int(local / uint32_t(p.row_tiles)) * 8 + int(bid & 7);
+            rt = int(local % uint32_t(p.row_tiles));
+        } else {
+            panel = int(bid / uint32_t(p.row_tiles));
+            rt = int(bid % uint32_t(p.row_tiles));
+        }
+        if (p.tile_row0) rt = p.row_tiles - 1 - rt;
+    }
+    if (panel >= p.n_panels) return;
+
+    const int64_t c0 = int64_t(panel) * PW;
+    const int g = lane >> 3;
+    const int q = lane & 7;
+    const int gbase = lane & ~7;
+    const int64_t mycol = c0 + int64_t(q) * 4;
+    const bool col_active = mycol < p.L;
+    // lanes past the last column gather from column 0 (valid memory); nothing of theirs is stored
+    const float* __restrict__ Xc = p.X + (col_active ? mycol : 0);
+    const uint32_t pitch16 = uint32_t(p.ldx >> 2);
+    float* tbuf_wave = smem + (TILE ? wave * PW * (RT + 1) : 0);
+    unsigned changed = 0;
+
+    int row0 = (rt * kWaves + wave) * RT;
+    int nrows = int(imin(RT, p.M - row0));
+    if (p.tile_row0) {
+        const int t = rt * kWaves + wave;
+        row0 = t < p.n_tiles ? p.tile_row0[t] : int(p.M);
+        nrows = t < p.n_tiles ? p.tile_row0[t + 1] - row0 : 0;
+    }
+    bool mirror = false;
+    if constexpr (MODE == kSym) {
+        const int rb = row0 & ~(RT - 1);
+        if (rb > c0) nrows = 0;
+        mirror = rb < c0;
+    }
+
+    // ---- rows of the tile by length, longest first
+    int my_start = 0, my_len = -1;
+    float my_scale = 0.f;
+    if (lane < nrows) {
+        my_start = p.rowptr[row0 + lane];
+        my_len = p.rowptr[row0 + lane + 1] - my_start;
+        my_scale = p.rowscale[row0 + lane];
+    }
+    int s_row, s_len, s_start;
+    {
+        const int nxt = __shfl_down(my_len, 1);
+        const bool out_of_order = lane + 1 < nrows && nxt < my_len;
+        if (__ballot(out_of_order) == 0) {
+            // already ascending (the solver's node order): longest first = reversed
+            s_row = lane < nrows ? nrows - 1 - lane : lane;
+            s_len = __shfl(my_len, s_row);
+            s_start = __shfl(my_start, s_row);
+            if (lane >= nrows) s_len = -1;
+        } else {
+            int key = lane < nrows ? ((my_len << 6) | lane) : -64 + lane;
+#pragma unroll
+            for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    const int other = __shfl_xor(key, j);
+                    const bool desc = (lane & k) == 0;
+                    const bool lower = (lane & j) == 0;
+                    const bool take = (lower == desc) ? (other > key) : (other < key);
+                    key = take ? other : key;
+                }
+            }
+            s_row = key & 63;
+            s_len = key >> 6;
+            s_start = __shfl(my_start, s_row);
+        }
+    }
+    const int n_heavy = __popcll(__ballot(s_len >= kHeavy));
+
+    // ---- phase A0: huge rows, split over the four waves of the workgroup (see the generic kernel)
+    int posted = 0;
+    if (p.has_huge) {
+        int* hmeta = reinterpret_cast<int*>(smem + (TILE ? kWaves * PW * (RT + 1) : 0));
+        float* hpart = reinterpret_cast<float*>(hmeta + 64);
+        const int n_huge = __popcll(__ballot(s_len >= p.huge_len));
+        if (lane == 0) hmeta[60 + wave] = n_huge;
+        __syncthreads();
+        int slot0 = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            const int c = hmeta[60 + w];
+            slot0 += w < wave ? c : 0;
+            total += c;
+        }
+        posted = max(0, min(n_huge, kMaxHuge - slot0));
+        if (lane < posted) {
+            int* d = hmeta + 4 + 4 * (slot0 + lane);
+            d[0] = s_row; d[1] = s_start; d[2] = s_len; d[3] = wave;
+        }
+        __syncthreads();
+        const int nh = min(total, kMaxHuge);
+        for (int i = 0; i < nh; ++i) {
+            const int* d = hmeta + 4 + 4 * i;
+            const int hs = d[1], hl = d[2];
+            const int chunk = ((hl + kWaves - 1) / kWaves + 63) & ~63;
+            const int s = hs + wave * chunk;
+            const int e = min(hs + hl, s + chunk);
+            float part[4];
+            gather_range3<IDS16>(p, Xc, pitch16, s, e, lane, g, part);
+            if (g == 0) vstore<4>(hpart + (i * kWaves + wave) * PW + q * 4, part);
+        }
+        __syncthreads();
+        for (int i = 0; i < nh; ++i) {
+            const int* d = hmeta + 4 + 4 * i;
+            if (d[3] == wave) {
+                const int r = d[0];
+                const float sc = __shfl(my_scale, r);
+                if (g == 0 && col_active) {
+                    float acc[4], t[4], dsum[4];
+                    dense_partial(p, int64_t(row0) + r, mycol, true, dsum);
+                    vload<4>(acc, hpart + (i * kWaves + 0) * PW + q * 4);
+#pragma unroll
+                    for (int w = 1; w < kWaves; ++w) {
+                        vload<4>(t, hpart + (i * kWaves + w) * PW + q * 4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[k] += t[k];
+                    }
+                    emit_row3<MODE>(p, tbuf_wave, r, int64_t(row0) + r, q, mycol, sc, acc, dsum, changed, mirror);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- phase A: the other long rows, one at a time, the 8 lane groups splitting the neighbours
+    for (int h = posted; h < n_heavy; ++h) {
+        const int r = __builtin_amdgcn_readfirstlane(__shfl(s_row, h));
+        const int s = __builtin_amdgcn_readfirstlane(__shfl(s_start, h));
+        const int e = s + __builtin_amdgcn_readfirstlane(__shfl(s_len, h));
+        const float sc = __shfl(my_scale, r);
+        float acc[4], dsum[4];
+        dense_partial(p, int64_t(row0) + r, mycol, g == 0 && col_active, dsum);
+        gather_range3<IDS16>(p, Xc, pitch16, s, e, lane, g, acc);
+        if (g == 0 && col_active)
+            emit_row3<MODE>(p, tbuf_wave, r, int64_t(row0) + r, q, mycol, sc, acc, dsum, changed, mirror);
+    }
+
+    // ---- phase B: the other rows, 8 at a time, one row per lane group; the ids of the next chunk
+    // are requested before the gathers of the current one
+    if (n_heavy < nrows) {
+        int pos = n_heavy, t0 = 0;
+        int src = pos + g;
+        int r = __shfl(s_row, src & 63);
+        int st = __shfl(s_start, src & 63);
+        int len = __shfl(s_len, src & 63);
+        if (src >= nrows) len = 0;
+        float sc = __shfl(my_scale, r & 63);
+        int maxlen = __builtin_amdgcn_readfirstlane(len);           // sorted: group 0 has the longest
+        int minlen = __builtin_amdgcn_readlane(len, 63);            // ... group 7 the shortest (0: no row)
+        int iv = (q < len && !(p.probe & 8)) ? (ld_id<IDS16>(p, st + q) & p.idx_mask) : 0;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float dsum[4];
+        dense_partial(p, int64_t(row0) + r, mycol, src < nrows && col_active, dsum);
+        while (true) {
+            const bool same_pass = t0 + LPR < maxlen;
+            const int npos = same_pass ? pos : pos + 8;
+            const int nt0 = same_pass ? t0 + LPR : 0;
+            const bool more = npos < nrows;
+            int nr = r, nst = st, nlen = len, nmax = maxlen, nmin = minlen, niv = 0;
+            float nsc = sc;
+            if (!same_pass && more) {
+                const int nsrc = npos + g;
+                nr = __shfl(s_row, nsrc & 63);
+                nst = __shfl(s_start, nsrc & 63);
+                nlen = __shfl(s_len, nsrc & 63);
+                if (nsrc >= nrows) nlen = 0;
+                nsc = __shfl(my_scale, nr & 63);
+                nmax = __builtin_amdgcn_readfirstlane(nlen);
+                nmin = __builtin_amdgcn_readlane(nlen, 63);
+            }
+            if (more && nt0 + q < nlen && !(p.probe & 8)) niv = ld_id<IDS16>(p, nst + nt0 + q) & p.idx_mask;
+
+            if (!(p.probe & 1))
+                gather_chunk<1>(Xc, pitch16, iv, gbase, min(LPR, maxlen - t0), max(0, min(LPR, minlen - t0)),
+                                len - t0, acc);
+
+            if (!same_pass) {
+                if (pos + g < nrows && col_active)
+                    emit_row3<MODE>(p, tbuf_wave, r, int64_t(row0) + r, q, mycol, sc, acc, dsum, changed, mirror);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = 0.f;
+                if (more) dense_partial(p, int64_t(row0) + nr, mycol, npos + g < nrows && col_active, dsum);
+            }
+            if (!more) break;
+            pos = npos; t0 = nt0; r = nr; st = nst; len = nlen; maxlen = nmax; minlen = nmin; iv = niv; sc = nsc;
+        }
+    }
+
+    if constexpr (TILE) {
+        __syncthreads();
+        const int cols_here = int(imin(PW, p.L - c0));
+        const int rows_out = ((TRANS || mirror) && !(p.probe & 2)) ? nrows : 0;
+        if (rows_out > 0) {
+            // where the tile lands: Y^T rows are the tile's columns; block h of t_block rows is
+            // contiguous.  A tile never crosses more than one block boundary when t_block >= 32.
+            const int64_t tb = p.tblock;
+            const bool one_block = p.tstride != 0;
+            const uint32_t blk0 = one_block ? 0u : uint32_t(row0) / uint32_t(tb);
+            const int in0 = row0 - int(blk0 * uint32_t(tb));          // row0's index inside its block
+            if (MODE == kTrans && p.tvec && rows_out == RT && cols_here == PW && (one_block || tb >= RT)) {
+                // whole tile, aligned destination: 16-byte stores of 4 consecutive rows
+                const int64_t rows0 = one_block ? p.tstride : imin(tb, p.M - int64_t(blk0) * tb) + p.tpad;
+                const int64_t rows1 = one_block ? p.tstride : imin(tb, p.M - int64_t(blk0 + 1) * tb) + p.tpad;
+                float* base0 = p.Y + int64_t(blk0) * (p.L * (tb + p.tpad)) + c0 * rows0 + in0;
+                float* base1 = p.Y + int64_t(blk0 + 1) * (p.L * (tb + p.tpad)) + c0 * rows1 + (in0 - int(tb));
+#pragma unroll
+                for (int it = 0; it < PW * (RT / 4) / 64; ++it) {
+                    const int x = lane + it * 64;
+                    const int c = x >> 3;
+                    const int r4 = (x & 7) * 4;
+                    const float* t = tbuf_wave + c * (RT + 1) + r4;
+                    const float v4[4] = {t[0], t[1], t[2], t[3]};
+                    const bool second = !one_block && in0 + r4 >= tb;
+                    float* dst = second ? base1 + int64_t(c) * rows1 + r4 : base0 + int64_t(c) * rows0 + r4;
+                    if (p.nt) vstore_nt<4>(dst, v4); else vstore<4>(dst, v4);
+                }
+            } else {
+                for (int x = lane; x < PW * RT; x += 64) {
+                    const int c = x >> 5;
+                    const int r = x & 31;
+                    if (c < cols_here && r < rows_out) {
+                        const int64_t a = int64_t(row0) + r;
+                        const int64_t blk = one_block ? 0 : a / tb;
+                        const int64_t a_in = a - blk * tb;
+                        const int64_t stride = one_block ? p.tstride : imin(tb, p.M - blk * tb) + p.tpad;
+                        float* dst = p.Y + blk * (p.L * (tb + p.tpad)) + (c0 + c) * stride + a_in;
+                        if (p.nt) __builtin_nontemporal_store(tbuf_wave[c * (RT + 1) + r], dst);
+                        else *dst = tbuf_wave[c * (RT + 1) + r];
+                    }
+                }
+            }
+        }
+    }
+
+    if constexpr (!TRANS) {
+        if (p.has_ep && p.prev) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) changed += __shfl_down(changed, off);
+            if (lane == 0 && changed)
+                atomicAdd(p.n_changed + ((blockIdx.x * 4u + (threadIdx.x >> 6)) * 7u) % SIMRANK_CHANGED_SLOTS,
+                          (unsigned long long)changed);
+        }
+    }
+}
+
+template <int MODE>
+static int launch_gather3(SpmmArgs a, hipStream_t st) {
+    constexpr int PW = 32, RT = 32;
+    a.n_panels = int((a.L + PW - 1) / PW);
+    const int64_t rows_per_block = int64_t(kWaves) * RT;
+    a.row_tiles = int((a.M + rows_per_block - 1) / rows_per_block);
+    if (MODE == kSym && !a.sym_map) a.tile_row0 = nullptr;
+    if (a.tile_row0) a.row_tiles = (a.n_tiles + kWaves - 1) / kWaves;
+    const int64_t panels_padded = a.xcd_map ? int64_t((a.n_panels + 7) / 8) * 8 : a.n_panels;
+    int64_t grid = panels_padded * a.row_tiles;
+    if constexpr (MODE == kSym) {
+        const int64_t J = (a.n_panels + 7) / 8;
+        grid = 8 * (J * J + J);
+        if (a.tile_row0) grid = a.sym_blocks;
+    }
+    SR_REQUIRE(grid > 0 && grid < (int64_t(1) << 31), "grid of %lld blocks", (long long)grid);
+    const size_t lds = sizeof(float) * ((MODE != kPlain ? size_t(kWaves) * PW * (RT + 1) : 0) +
+                                        (a.has_huge ? 64 + size_t(kMaxHuge) * kWaves * PW : 0));
+    if (a.col16)
+        hipLaunchKernelGGL((gather3_kernel<MODE, true>), dim3((unsigned)grid), dim3(256), lds, st, a);
+    else
+        hipLaunchKernelGGL((gather3_kernel<MODE, false>), dim3((unsigned)grid), dim3(256), lds, st, a);
     SR_HIP(hipGetLastError());
     return SIMRANK_OK;
 }
@@ -758,6 +1269,7 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
                  const simrank_epilogue* ep, void* stream) {
     SR_REQUIRE(t_pad >= 0 && t_pad < 4096, "t_pad out of range");
     SR_REQUIRE(g && X && Y, "NULL argument");
+    const Tuning& T = g->tun;        // the knobs as they were when the graph was created
     SR_REQUIRE(n_cols_x > 0 && ldx >= n_cols_x, "X: %lld columns, ld %lld", (long long)n_cols_x,
                (long long)ldx);
     SR_REQUIRE(transpose_out || ldy >= n_cols_x, "Y: ld %lld < %lld columns", (long long)ldy,
@@ -766,9 +1278,9 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
     SpmmArgs a{};
     a.rowptr = g->rowptr;
     a.col = g->col;
-    a.col16 = tuning().ids16 ? g->col16 : nullptr;
+    a.col16 = T.ids16 ? g->col16 : nullptr;
     a.rowscale = g->rowscale;
-    a.huge_len = (int32_t)std::max<int64_t>(kHeavy, tuning().huge);
+    a.huge_len = (int32_t)std::max<int64_t>(kHeavy, T.huge);
     a.has_huge = g->max_row_nnz >= a.huge_len ? 1 : 0;
     a.X = X;
     a.ldx = ldx;
@@ -783,7 +1295,9 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
     // and inside one block (tiles are 16/32/64 rows, blocks start at multiples of t_block)
     a.tvec = aligned16(Y) && (a.tstride ? a.tstride % 4 == 0
                                         : (a.tblock % 4 == 0 && a.tpad % 4 == 0 && g->n_rows % 4 == 0));
-    a.xcd_map = (int)tuning().xcd_map;
+    a.xcd_map = (int)T.xcd_map;
+    a.idx_mask = (int32_t)T.probe_mask;
+    a.probe = (int32_t)T.probe_flags;
     bool vec_ok = aligned16(X) && ldx % 4 == 0;
     if (!transpose_out) vec_ok = vec_ok && aligned16(Y) && ldy % 4 == 0;
     hipStream_t st = as_stream(stream);
@@ -812,21 +1326,21 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
     }
     // automatic choice (profiles/ sweep_r01.log): 32 rows per wave tile; 32-float panels for
     // the transposed leg (keeps its LDS tile at 17 KiB -> 7 workgroups per CU), 64 otherwise
-    int64_t panel = tuning().panel;
+    int64_t panel = T.panel;
     if (panel == 0) panel = transpose_out ? 32 : 64;
-    int64_t tile = tuning().tile;
+    int64_t tile = T.tile;
     if (tile == 0) tile = 32;
-    a.nt = (int32_t)tuning().stream_nt;
-    const bool want_sym = ep && ep->symmetric && tuning().triangle && vec_ok && !transpose_out &&
+    a.nt = (int32_t)T.stream_nt;
+    const bool want_sym = ep && ep->symmetric && T.triangle && vec_ok && !transpose_out &&
                           n_cols_x == g->n_rows && ep->diag_col0 == 0 && g->n_rows >= 64;
     // the block-dense part goes to the matrix cores first; the gather then runs on the remainder
     // In the upper-triangle form only when the pattern is dense throughout (MovieLens-like: 87 % of
     // the entries in dense sets, leg 2 0.9 -> 0.4 ms): on a power-law pattern the long rows, which
     // own the dense sets, compute only the few columns right of the diagonal there, and the
     // partial sums cost as much as they save.
-    const simrank_dense_plan* dp = (vec_ok && tuning().dense_min > 0 && tile == 32) ? g->dense : nullptr;
+    const simrank_dense_plan* dp = (vec_ok && T.dense_min > 0 && tile == 32) ? g->dense : nullptr;
     if (dp && want_sym) {
-        const int64_t mode = tuning().dense_sym;
+        const int64_t mode = T.dense_sym;
         if (mode == 0 || (mode < 0 && 2 * dp->nnz_covered < g->nnz)) dp = nullptr;
     }
     if (dp) {
@@ -839,10 +1353,10 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
         a.dnslab = use.block_nslab;
         a.rowptr = dp->r_rowptr;
         a.col = dp->r_col;
-        a.col16 = tuning().ids16 ? dp->r_col16 : nullptr;
+        a.col16 = T.ids16 ? dp->r_col16 : nullptr;
         a.has_huge = dp->r_max_row >= a.huge_len ? 1 : 0;
     }
-    if (tuning().balance) {
+    if (T.balance) {
         const int32_t* tr0 = dp ? dp->r_tile_row0 : g->tile_row0;
         if (tr0) {
             a.tile_row0 = tr0;
@@ -855,6 +1369,19 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
         return transpose_out ? launch_spmm<1, 32, kTrans, 32>(a, st)
                              : launch_spmm<1, 32, kPlain, 32>(a, st);
     }
+    // the lean kernel: 32-float panels, 32-row tiles, row offsets (in 16-byte units) in 32 bits
+    const bool lean_ok = T.lean && tile == 32 && ldx / 4 < (int64_t(1) << 24) &&
+                         g->n_cols < (int64_t(1) << 24) && g->n_cols * (ldx / 4) < (int64_t(1) << 32) &&
+                         g->n_rows < (int64_t(1) << 30);
+    if (lean_ok && want_sym) {
+        a.tblock = g->n_rows;
+        a.tstride = ldy;
+        return launch_gather3<kSym>(a, st);
+    }
+    if (lean_ok && transpose_out && (T.panel == 0 || T.panel == 32))
+        return launch_gather3<kTrans>(a, st);
+    if (lean_ok && !transpose_out && (T.lean == 2 ? T.panel == 0 : T.panel == 32))
+        return launch_gather3<kPlain>(a, st);
 #define SR_TILE_SWITCH(LPR, TR)                                             \
     switch (tile) {                                                         \
         case 16: return launch_spmm<4, LPR, TR, 16>(a, st);                 \

@@ -150,12 +150,21 @@ class TorchWorld:
     """One rank per process over torch.distributed (backend "nccl" = RCCL over xGMI on the
     GPU box; "gloo" in the CPU tests)."""
 
-    def __init__(self, group=None, stages: int = 0, stage_single_rank: bool = False):
+    def __init__(self, group=None, stages: int = 0, stage_single_rank: bool = False,
+                 handback: str = "root"):
         """``stages``: leg 1 is cut into that many column slices, each exchanged by its own
         all_to_all_single as soon as its kernel has finished, so the transfers over xGMI overlap
         the remaining leg-1 kernels (1 = one exchange after the whole leg; 0 = by the width of a
-        rank's column block, see ``auto_stages``)."""
+        rank's column block, see ``auto_stages``).
+        ``handback``: who receives the dense result of a fit.  "root" (default): the float32
+        column blocks are gathered to rank 0 on the device, put back into the caller's node order
+        there and downloaded once; the other ranks' ``fit`` returns None.  "all": every rank gets
+        the full float64 matrix (pickled all-gather: N^2 x 8 B x P per node — small N only).
+        ``fit(top_k=k)`` hands k columns per row to every rank either way."""
         import torch.distributed as dist
+        if handback not in ("root", "all"):
+            raise ValueError("handback must be 'root' or 'all'")
+        self.handback = handback
         self.dist = dist
         self.group = group
         self.size = dist.get_world_size(group)
@@ -260,6 +269,38 @@ class TorchWorld:
         parts = [None] * self.size
         self.dist.all_gather_object(parts, blk, group=self.group)
         return np.concatenate(parts, axis=1)
+
+    def gather_to_root(self, ops, src, n, rows, col_inv):
+        """Dense hand-back to rank 0: ``src`` is this rank's n x L float32 block (solver order);
+        its rows are taken in the order ``rows`` (an index vector or None) while it is copied into
+        a padded n x ceil(n/P) send buffer; one ``gather`` of those device buffers; on the root
+        the blocks are laid side by side, the columns put into the caller's order (``col_inv``)
+        and the matrix downloaded once as float64.  Other ranks return None."""
+        import torch
+        P, mb = self.size, -(-n // self.size)
+        send = ops.exchange_buffer(n * mb)
+        if src.cols:
+            ops.permute(src, ops.matrix(n, src.cols, ld=mb, external=send), rows, None)
+        ops.synchronize()
+        big = ops.exchange_buffer(P * n * mb) if self.is_root else None
+        self.dist.gather(send, list(big.view(P, n * mb)) if self.is_root else None,
+                         dst=self.dist.get_global_rank(self.group, 0) if self.group else 0,
+                         group=self.group)
+        if not self.is_root:
+            return None
+        side = big.view(P, n, mb).permute(1, 0, 2).reshape(n, P * mb).contiguous()   # [i][h*mb + j]
+        if side.is_cuda:
+            torch.cuda.current_stream(side.device).synchronize()
+        del big
+        full = ops.matrix(n, n, ld=P * mb, external=side)
+        if col_inv is not None:
+            final = ops.matrix(n, n)
+            ops.permute(full, final, None, col_inv)
+            out = ops.download_f64(final)
+            final.free()
+        else:
+            out = ops.download_f64(full)
+        return out
 
 
 # --------------------------------------------------------------------------------------
@@ -619,9 +660,13 @@ class Solver:
         return self._index[(r, key)]
 
     def result(self, j=0):
-        """Full similarity matrix j as float64 on the host (every rank gets it), in the
-        caller's node order."""
+        """Full similarity matrix j as float64 on the host, in the caller's node order.  In a
+        multi-process world with ``handback="root"`` only rank 0 gets it (None elsewhere)."""
         inv = self.inv[j]
+        if getattr(self.world, "handback", "all") == "root" and self.world.size > 1:
+            (r,) = self.world.local_ranks
+            rows = None if inv is None else self._index_vector(r, ("inv", j), inv)
+            return self.world.gather_to_root(self.ops[r], self.cur[j][r], self.n[j], rows, rows)
         blocks = {}
         for r in self.world.local_ranks:
             o, src = self.ops[r], self.cur[j][r]

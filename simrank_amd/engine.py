@@ -280,37 +280,6 @@ class HipOps:
                                        C.byref(ep) if ep is not None else None, self.stream),
               "simrank_gemm_nt")
 
-    # ---- LDS-tiled legs (graphs with at most 8192 source rows), panel-blocked "B4" operands
-    def lds_supported(self, g: Graph) -> bool:
-        ok = C.c_int32(0)
-        check(self.lib.simrank_lds_supported(g.handle, C.byref(ok)), "simrank_lds_supported")
-        return bool(ok.value)
-
-    def b4_matrix(self, rows: int, cols: int, dtype=np.float32) -> Matrix:
-        """Rows x cols matrix in the B4 layout (both dimensions padded to multiples of 4)."""
-        rp, cp = -(-rows // 4) * 4, -(-cols // 4) * 4
-        m = Matrix(self, 1, rp * cp, dtype, ld=rp * cp)
-        m.b4_shape = (rows, cols)
-        return m
-
-    def b4_identity(self, S: Matrix, n: int):
-        check(self.lib.simrank_b4_identity(S.ptr, n, self.stream), "simrank_b4_identity")
-
-    def b4_pack(self, src: Matrix, dst: Matrix):
-        check(self.lib.simrank_b4_pack(src.ptr, src.ld, src.rows, src.cols, src.dtype.itemsize,
-                                       dst.ptr, self.stream), "simrank_b4_pack")
-
-    def b4_unpack(self, src: Matrix, n_rows: int, n_cols: int, dst: Matrix):
-        check(self.lib.simrank_b4_unpack(src.ptr, n_rows, n_cols, dst.ptr, dst.ld, self.stream),
-              "simrank_b4_unpack")
-
-    def spmm_lds(self, g: Graph, X: Matrix, n_cols: int, Zt: Matrix, epilogue: dict | None = None):
-        """Zt(c, a) = epilogue(rowscale[a] . sum_i X(i, c)), operands in B4; see simrank_spmm_lds."""
-        ep = self._epilogue(**epilogue) if epilogue is not None else None
-        check(self.lib.simrank_spmm_lds(g.handle, X.ptr, int(n_cols), Zt.ptr,
-                                        C.byref(ep) if ep is not None else None, self.stream),
-              "simrank_spmm_lds")
-
     def densify(self, g: Graph, Wd: Matrix):
         check(self.lib.simrank_graph_densify(g.handle, Wd.ptr, Wd.ld, self.stream),
               "simrank_graph_densify")

@@ -12,7 +12,8 @@ when read.
 Extra keyword-only arguments (defaults keep the reference's behaviour):
     mode              "auto" | "sparse" | "dense" | "hybrid" — which kernels run the two legs
     device            HIP device ordinal (default: LOCAL_RANK or 0)
-    world             ``driver.LocalWorld`` / ``driver.TorchWorld`` (sharded runs)
+    world             ``driver.LocalWorld`` / ``driver.TorchWorld`` (sharded runs; in a multi-process
+                      world the dense result goes to rank 0 only unless TorchWorld(handback="all"))
     top_k             return, instead of the dense matrix, a long-format frame (node, rank,
                       neighbor, similarity) with the k most similar other nodes of every node,
                       selected on the device (no N x N transfer)
@@ -130,6 +131,8 @@ class SimRank(object):
             return out
         S = solver.result(0)
         solver.release()
+        if S is None:                     # multi-process world, root-only hand-back: not the root
+            return None
         return pd.DataFrame(S, index=self._order, columns=self._order)
 
     def fit(self, data, C=0.8, weighted=False, from_node_column="from", to_node_column="to",
@@ -253,6 +256,8 @@ class BipartiteSimRank(object):
             return out
         S1, S2 = solver.result(0), solver.result(1)
         solver.release()
+        if S1 is None:                    # multi-process world, root-only hand-back: not the root
+            return None
         return (pd.DataFrame(S1, index=l1, columns=l1), pd.DataFrame(S2, index=l2, columns=l2))
 
     def fit(self, data, C1=0.8, C2=0.8, weighted=False, node_group1_column="user",

@@ -36,15 +36,31 @@ def er_directed(n: int, p: float, seed: int) -> pd.DataFrame:
     return _finish_directed(src, dst, n, rng)
 
 
-def powerlaw_directed(n: int, avg_deg: float, seed: int, exponent: float = 2.1) -> pd.DataFrame:
+def powerlaw_directed(n: int, avg_deg: float, seed: int, exponent: float = 2.1,
+                      exact: bool = False) -> pd.DataFrame:
     """Chung-Lu directed graph with power-law in- and out-degrees (config 4:
-    n=32768, avg_deg=32, seed=32768).  Expected degree of rank-i node ~ (i+1)^(-1/(g-1))."""
+    n=32768, avg_deg=32, seed=32768).  Expected degree of rank-i node ~ (i+1)^(-1/(g-1)).
+    ``exact``: n.avg_deg distinct edges (default: that many draws, duplicates dropped)."""
     rng = np.random.default_rng(seed)
     w = (np.arange(n) + 1.0) ** (-1.0 / (exponent - 1.0))
     w /= w.sum()
     m = int(n * avg_deg)
-    src = rng.permutation(n)[rng.choice(n, size=m, p=w)]
-    dst = rng.permutation(n)[rng.choice(n, size=m, p=w)]
+    ps = rng.permutation(n)                       # (draw order fixed: the round-1 graphs stay the same)
+    src = ps[rng.choice(n, size=m, p=w)]
+    pd_ = rng.permutation(n)
+    dst = pd_[rng.choice(n, size=m, p=w)]
+    if exact:
+        # Chung-Lu sampling with replacement loses the duplicates (a quarter of the draws at
+        # n = 32768, avg_deg = 32): keep drawing until m DISTINCT edges exist, so the mean degree
+        # after de-duplication is the one asked for
+        key = np.unique(src.astype(np.int64) * n + dst)
+        while key.size < m:
+            extra = int((m - key.size) * 1.5) + 1024
+            s2 = ps[rng.choice(n, size=extra, p=w)]
+            d2 = pd_[rng.choice(n, size=extra, p=w)]
+            new = np.setdiff1d(np.unique(s2.astype(np.int64) * n + d2), key)
+            key = np.concatenate([key, rng.permutation(new)[:m - key.size]])
+        src, dst = key // n, key % n
     return _finish_directed(src, dst, n, rng)
 
 
@@ -100,6 +116,9 @@ WORKLOADS = {
     "ml1m": (lambda: bipartite_zipf(6040, 3706, 1_000_209, 1), "bipartite"),
     "pl32768": (lambda: powerlaw_directed(32768, 32, 32768), "directed"),
     "pl65536": (lambda: powerlaw_directed(65536, 32, 65536), "directed"),
+    # config 4 with the stated mean degree AFTER de-duplication (1 048 576 distinct edges; the plain
+    # "pl32768" recipe of SURVEY.md §8d keeps 783 100 of its 1 048 576 draws)
+    "pl32768d32": (lambda: powerlaw_directed(32768, 32, 32768, exact=True), "directed"),
     # not a BASELINE.json configuration: same size and average degree as pl32768 without the skew
     "er32768": (lambda: er_directed(32768, 32 / 32768, 32768), "directed"),
 }

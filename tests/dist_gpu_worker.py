@@ -24,19 +24,23 @@ def main():
     from simrank_amd.driver import LocalWorld, TorchWorld
     from tests.conftest import Golden
     from tests.helpers import check_against_golden, run_estimator
+    rank = dist.get_rank()
     # golden vectors (labels, values, convergence iteration, stdout) through the RCCL world
     for name, stages in (("SimRank_er128", 1), ("SimRankPP_er128", 3), ("BipartiteSimRankPP_b40", 2),
                          ("AprioriSimRank_er64_asym", 2)):
         g = Golden(name)
         est, res, text = run_estimator(g, world=TorchWorld(stages=stages, stage_single_rank=True),
                                        mode="sparse")
-        check_against_golden(g, est, res, text)
+        if rank == 0:
+            check_against_golden(g, est, res, text)
+        else:                                   # root-only hand-back (TorchWorld default)
+            assert res is None and text == ""
     # a graph with dense sets and several panels per stage, against the in-process world
     df = synth.powerlaw_directed(3000, 24, seed=5)
     want = SRA.SimRank().fit(df, iterations=5, eps=0, verbose=False, mode="sparse", world=LocalWorld(1))
     for stages in (1, 4):
         got = SRA.SimRank().fit(df, iterations=5, eps=0, verbose=False, mode="sparse",
-                                world=TorchWorld(stages=stages, stage_single_rank=True))
+                                world=TorchWorld(stages=stages, stage_single_rank=True, handback="all"))
         np.testing.assert_allclose(got.values, want.values, rtol=2e-6, atol=1e-30)
     dist.barrier()
     print("RCCL WORLD ok", flush=True)

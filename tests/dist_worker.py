@@ -24,7 +24,18 @@ def main(argv):
     for name in names:
         g = Golden(name)
         ops = NumpyOps()
+        # hand-back to the root only (the default): the other ranks get None
         est, res, text = run_estimator(g, lambda r: ops, world=TorchWorld(stages=stages), mode="sparse")
+        if rank == 0:
+            check_against_golden(g, est, res, text)
+            n = len(res[0] if isinstance(res, tuple) else res)
+        else:
+            assert text == "" and res is None
+            n = None
+        # hand-back to every rank
+        ops = NumpyOps()
+        est, res, text = run_estimator(g, lambda r: ops, world=TorchWorld(stages=stages, handback="all"),
+                                       mode="sparse")
         if rank == 0:
             check_against_golden(g, est, res, text)
         else:                        # other ranks are silent but hold the same result

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_string():
     lib = _lib.load()
-    assert lib.simrank_abi_version() == 1
+    assert lib.simrank_abi_version() == 2
     rc = lib.simrank_set_tuning(b"no_such_knob", 1)
     assert rc == -1 and b"no_such_knob" in lib.simrank_last_error()
     assert lib.simrank_set_tuning(b"panel", 48) == -1

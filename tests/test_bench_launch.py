@@ -1,0 +1,35 @@
+"""``python bench.py --gpus N`` must launch its own ranks (the driver calls it exactly like that
+when it is not already under torchrun).  Rehearsed here on CPU: same launch path
+(child ``python -m torch.distributed.run``), real collectives over gloo, NumPy test double for the
+kernels; the JSON line of rank 0 is relayed and the exit code is the child's."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *extra],
+                          capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+
+
+def test_bench_launches_its_own_ranks_over_gloo():
+    p = _run("--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+             "--workload", "er:96:0.06")
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1                       # rank 0's line, relayed once
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["steps"] == 2
+    assert out["metric"] == "simrank_iterations_per_sec" and out["value"] > 0
+    assert out["scaling"] == "strong" and "NOT a measurement" in out["data"]
+
+
+def test_bench_child_failure_is_reported():
+    p = _run("--gpus", "2", "--backend", "gloo", "--workload", "no-such-workload")
+    assert p.returncode != 0

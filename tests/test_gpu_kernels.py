@@ -274,12 +274,19 @@ def test_symmetric_leg2_upper_triangle_and_mirror(ops, n):
     assert np.array_equal(mirrored[:32, 32:], mirrored[32:, :32].T)       # mirrored tiles: same bits
     assert outs[True][1] == int((np.abs(mirrored.astype(np.float64) - S) > 0.05).sum())
     assert outs[False][1] == int((np.abs(full.astype(np.float64) - S) > 0.05).sum())
+    # the knobs are copied into a graph when it is created: an existing graph keeps its own
     ops.set_tuning(triangle=0)
-    y = ops.matrix(n, n)
-    ops.spmm(g, tt, y, epilogue=dict(coef=0.8, evidence=put(ops, cnt, dtype=np.uint8), previous=s_in,
-                                     eps=0.05, diag_col0=0, symmetric=True))
-    ops.set_tuning(triangle=1)
-    assert np.array_equal(ops.download(y), full)                  # knob off -> plain path
+    try:
+        y = ops.matrix(n, n)
+        ep = dict(coef=0.8, evidence=put(ops, cnt, dtype=np.uint8), previous=s_in, eps=0.05,
+                  diag_col0=0, symmetric=True)
+        ops.spmm(g, tt, y, epilogue=ep)
+        assert np.array_equal(ops.download(y), mirrored)          # g was created with triangle = 1
+        g0 = ops.graph(csr)
+        ops.spmm(g0, tt, y, epilogue=ep)
+    finally:
+        ops.set_tuning(triangle=1)
+    assert np.array_equal(ops.download(y), full)                  # knob off at creation -> plain path
 
 
 @pytest.mark.parametrize("panel", [0, 32, 128])
@@ -320,62 +327,6 @@ def test_topk_rows(ops, shape, k, c0):
         assert list(idx[r, :len(want)]) == [c0 + c for c in want]
         assert (idx[r, len(want):] == -1).all()
         np.testing.assert_array_equal(val[r, :len(want)], h[r, want])
-
-
-@pytest.mark.parametrize("shape", [(300, 257, 100), (64, 64, 64), (1000, 777, 37), (5, 5, 5),
-                                   (2500, 8192, 64), (9000, 500, 12)])
-def test_spmm_lds_against_numpy(ops, shape):
-    """LDS-tiled leg (B4 operands, transposed store): short rows one per lane in SELL order,
-    long rows one per wave, several row blocks, ragged sizes."""
-    M, K, L = shape
-    heavy = {1: min(K, 200), 3: min(K, 70), 4: min(K, 65), 7: min(K, 1025), 9: min(K, 3000)} if M > 9 else {}
-    csr = random_csr(M, K, 9, seed=M + L, heavy=heavy)
-    X = np.random.default_rng(1).random((K, L)).astype(np.float32)
-    g = ops.graph(csr)
-    assert ops.lds_supported(g)
-    xb = ops.b4_matrix(K, L)
-    ops.b4_pack(put(ops, X), xb)
-    zt = ops.b4_matrix(L, M)
-    ops.spmm_lds(g, xb, L, zt)
-    out = ops.matrix(L, M)
-    ops.b4_unpack(zt, L, M, out)
-    want = (dense64(csr) @ X.astype(np.float64)).T
-    np.testing.assert_allclose(ops.download(out), want, rtol=RTOL, atol=1e-30)
-
-
-def test_spmm_lds_epilogue_and_identity(ops):
-    n = 203
-    csr = random_csr(n, n, 8, seed=3, heavy={2: 150})
-    rng = np.random.default_rng(5)
-    S = rng.random((n, n)).astype(np.float32)
-    S = ((S + S.T) / 2).astype(np.float32)
-    cnt = rng.integers(0, 5, size=(n, n))
-    cnt = np.minimum(cnt, cnt.T).astype(np.uint8)
-    prior = rng.random((n, n)).astype(np.float32)
-    prior = ((prior + prior.T) / 2).astype(np.float32)
-    g = ops.graph(csr)
-    sb, tt, out_b = ops.b4_matrix(n, n), ops.b4_matrix(n, n), ops.b4_matrix(n, n)
-    evb, apb = ops.b4_matrix(n, n, np.uint8), ops.b4_matrix(n, n)
-    ops.b4_pack(put(ops, S), sb)
-    ops.b4_pack(put(ops, cnt, dtype=np.uint8), evb)
-    ops.b4_pack(put(ops, prior), apb)
-    ops.spmm_lds(g, sb, n, tt)                                       # leg 1: Tt = (W.S)^T
-    ops.spmm_lds(g, tt, n, out_b, epilogue=dict(coef=0.8, evidence=evb, apriori=apb, lbd=0.25,
-                                                 previous=sb, eps=0.05, diag_col0=0))
-    got_m = ops.matrix(n, n)
-    ops.b4_unpack(out_b, n, n, got_m)
-    got = ops.download(got_m)
-    W = dense64(csr)
-    want = 0.8 * (W @ S.astype(np.float64) @ W.T.toarray()) * (1 - 0.5 ** cnt.astype(np.float64))
-    want = 0.75 * want + 0.25 * prior
-    np.fill_diagonal(want, 1)
-    np.testing.assert_allclose(got, want.T, rtol=RTOL, atol=1e-30)   # transposed convention
-    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-30)     # = itself up to rounding
-    assert ops.read_changed() == int((np.abs(got.astype(np.float64) - S.T) > 0.05).sum())
-    eye_b, eye = ops.b4_matrix(n, n), ops.matrix(n, n)
-    ops.b4_identity(eye_b, n)
-    ops.b4_unpack(eye_b, n, n, eye)
-    np.testing.assert_array_equal(ops.download(eye), np.eye(n, dtype=np.float32))
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.uint8])
@@ -450,8 +401,8 @@ import contextlib
 
 @contextlib.contextmanager
 def dense_knobs(ops, dense_min=3, dense_cols=32, dense_sym=1):
-    """Selection knobs of the dense part for small test graphs (read at graph creation and at
-    launch); the tuned defaults are restored on exit."""
+    """Selection knobs of the dense part for small test graphs (copied into a graph when it is
+    created); the tuned defaults are restored on exit."""
     ops.set_tuning(dense_min=dense_min, dense_cols=dense_cols, dense_sym=dense_sym)
     try:
         yield
@@ -492,8 +443,10 @@ def test_dense_part_matches_numpy_and_the_gather_path(ops, shape):
         got, got_t = ops.download(y), ops.download(yt)
     np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-30)
     np.testing.assert_allclose(got_t, want.T, rtol=RTOL, atol=1e-30)
-    with dense_knobs(ops, dense_min=0):             # same graph object, dense part switched off
-        ops.spmm(g, x, y)
+    with dense_knobs(ops, dense_min=0):             # the same pattern without a dense part
+        g0 = ops.graph(csr)
+        assert ops.dense_stats(g0)[0] == 0
+        ops.spmm(g0, x, y)
     np.testing.assert_allclose(got, ops.download(y), rtol=2e-6, atol=1e-30)
 
 

@@ -181,6 +181,88 @@ def test_full_size_properties(ops, workload, iters):
     solver.release()
 
 
+def test_config5_pl65536_simrank_pp_properties(ops):
+    """BASELINE.json configs[4] shape: N = 65536 power-law graph, SimRank++ with evidence
+    (SimRank.py:351-362, evidence :311-320), f32, on one GPU.  The dense f64 oracle would need
+    100 GB and hours, so: rows of one more update recomputed on the host in float64 from the
+    device's S_k — evidence factor 1 - 2^-|common in-neighbours| included — plus the
+    size-independent properties (unit diagonal, range, symmetry, support inside supp(E),
+    identity rows of nodes without in-edges)."""
+    df = synth.WORKLOADS["pl65536"][0]()
+    nodes, csr = ingest.directed(df, False, "from", "to", "weight")
+    n = csr.n_rows
+    assert n == 65536
+    scale = ingest.spread(csr) * csr.rowscale                      # _cal_Weight, SimRank.py:322-337
+    solver = Solver(lambda r: ops, LocalWorld(1),
+                    [SideSpec(csr, scale, 0.8, evidence_from=csr)], "sparse")
+    csr = solver.specs[0].csr                                      # the solver's own node order
+    rs = np.asarray(solver.specs[0].rowscale, dtype=np.float32).astype(np.float64)
+    solver.reset()
+    for _ in range(3):
+        solver.step(0.0)
+    rows = [0, 5, n // 2, n - 2, n - 1]                            # short rows ... the longest rows
+    need = sorted(set(np.concatenate([csr.col[csr.rowptr[a]:csr.rowptr[a + 1]] for a in rows])))
+    pos = {int(i): p for p, i in enumerate(need)}
+    part = ops.download_rows(solver.cur[0][0], need).astype(np.float64)
+    Pat = sp.csr_matrix((np.ones(csr.col.size), csr.col, csr.rowptr), shape=(n, n))
+    W = sp.diags(rs) @ Pat
+    live = sp.diags((rs > 0).astype(np.float64)) @ Pat            # evidence counts ignore dead rows
+    t_rows = {a: rs[a] * part[[pos[int(i)] for i in csr.col[csr.rowptr[a]:csr.rowptr[a + 1]]]].sum(axis=0)
+              for a in rows}
+    solver.step(0.0)
+    got = ops.download_rows(solver.cur[0][0], rows).astype(np.float64)
+    for k, a in enumerate(rows):
+        cnt = np.asarray((live[a] @ live.T).todense()).ravel()
+        want = 0.8 * (W @ t_rows[a]) * (1.0 - 0.5 ** cnt)
+        want[a] = 1.0
+        np.testing.assert_allclose(got[k], want, rtol=RTOL, atol=1e-30)
+        outside = cnt == 0                                         # S stays inside supp(E), quirk Q6
+        outside[a] = False
+        assert np.all(got[k][outside] == 0.0)
+        assert got[k].min() >= 0.0 and got[k].max() <= 1.0 and got[k][a] == 1.0
+    # symmetry between two far-apart row blocks (both triangles come from different tiles)
+    lo, hi = list(range(0, 256)), list(range(n - 256, n))
+    A = ops.download_rows(solver.cur[0][0], lo)[:, hi]
+    B = ops.download_rows(solver.cur[0][0], hi)[:, lo]
+    np.testing.assert_allclose(A, B.T, rtol=RTOL, atol=1e-30)
+    lonely = np.flatnonzero(np.diff(csr.rowptr) == 0)[:3]
+    if lonely.size:
+        L = ops.download_rows(solver.cur[0][0], lonely)
+        assert np.all(L.sum(axis=1) == 1.0)
+    solver.release()
+
+
+def test_config4_pl32768_eight_shards_bitwise(ops):
+    """BASELINE.json configs[3] in its stated form — S sharded 8 ways — at full size: eight
+    virtual ranks on the one GPU (all-to-all by device copies) against one rank without the
+    upper-triangle shortcut; sampled rows must carry the same bits."""
+    df = synth.WORKLOADS["pl32768"][0]()
+    nodes, csr = ingest.directed(df, False, "from", "to", "weight")
+    n = csr.n_rows
+    rows = [0, 1, n // 3, n // 2 + 7, n - 129, n - 1]
+    ops.set_tuning(triangle=0)
+    try:
+        one = Solver(lambda r: ops, LocalWorld(1), [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
+        one.reset()
+        for _ in range(3):
+            one.step(0.0)
+        want = ops.download_rows(one.cur[0][0], rows)
+        one.release()
+        del one
+    finally:
+        ops.set_tuning(triangle=1)
+    world = LocalWorld(8)
+    many = Solver(lambda r: ops, world, [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
+    many.reset()
+    for _ in range(3):
+        many.step(0.0)
+    got = np.concatenate([ops.download_rows(many.cur[0][r], rows) for r in world.local_ranks], axis=1)
+    many.release()
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+    assert np.all(want[np.arange(len(rows)), rows] == 1.0)
+
+
 def test_config3_movielens_shaped_bipartite_pp(ops):
     """6040 x 3706, ~1.0 M ratings: runs only with the corrected
     Evidence_N2 (the reference raises, quirk Q2); checked through sampled rows of one update
@@ -268,6 +350,24 @@ def test_rccl_world_values():
            os.path.join(root, "tests", "dist_gpu_worker.py")]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert p.returncode == 0 and "RCCL WORLD ok" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
+
+
+def test_rccl_world_of_two_ranks():
+    """The same worker on two GPUs (real all-to-all over xGMI, root-only hand-back); skipped on
+    the one-GPU box this suite usually runs on."""
+    import os
+    import subprocess
+    import sys
+    from simrank_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(root, "tests", "dist_gpu_worker.py")]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert p.returncode == 0 and p.stdout.count("RCCL WORLD ok") == 2, p.stdout[-3000:] + p.stderr[-3000:]
 
 
 @pytest.mark.parametrize("cls", ["SimRank", "SimRankPP"])

@@ -24,10 +24,17 @@ ap.add_argument("--L", type=int, default=32768)
 ap.add_argument("--deg", type=str, default="24")
 ap.add_argument("--K", type=str, default="2048,4096,8192,16384,32768")
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--ld", type=int, default=0, help="leading dimension of the operand (0 = pitched L): a narrow "
+                                                  "operand (L = 256: one panel per XCD) with ld = 256 keeps "
+                                                  "a panel slice inside 32 MB of addresses, with ld = 32800 "
+                                                  "it is spread over 4 GB like the real matrix")
+ap.add_argument("--set", default="")
 args = ap.parse_args()
 
 ops = HipOps(0)
 ops.set_tuning(dense_min=0)
+if args.set:
+    ops.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.set.split(","))})
 rng = np.random.default_rng(1)
 M, L = args.M, args.L
 for deg in [int(v) for v in args.deg.split(",")]:
@@ -38,7 +45,7 @@ for deg in [int(v) for v in args.deg.split(",")]:
         rowptr = (np.arange(M + 1, dtype=np.int64) * deg).astype(np.int32)
         csr = CSR(M, K, rowptr, col, np.full(M, 1.0 / deg))
         g = ops.graph(csr)
-        X = ops.matrix(K, L)
+        X = ops.matrix(K, L, ld=args.ld or None)
         Yt = ops.matrix(L, M)
         Y = ops.matrix(M, L)
         ops.fill_identity(X, 0)
@@ -56,7 +63,7 @@ for deg in [int(v) for v in args.deg.split(",")]:
             gb = 4e-9 * M * deg * L
             res.append(f"{'trans' if trans else 'plain'} {ms:7.3f} ms {gb / ms:6.2f} TB/s gathered "
                        f"({gb / ms / 256 * 1000:5.1f} GB/s per CU)")
-        print(f"M={M} K={K:6d} deg={deg:3d} L={L}: slice {K * 128 / 2**20:4.2f} MiB | " + " | ".join(res),
+        print(f"M={M} K={K:6d} deg={deg:3d} L={L} ld={X.ld}: slice {K * 128 / 2**20:4.2f} MiB | " + " | ".join(res),
               flush=True)
         for m in (X, Yt, Y):
             m.free()

@@ -136,6 +136,11 @@ def main():
     ap.add_argument("--stages", type=int, default=0,
                     help="pipeline depth of the sharded exchange (all_to_all_single calls per update; "
                          "0 = by the width of a rank's column block)")
+    ap.add_argument("--pp", action="store_true",
+                    help="SimRank++ (evidence-gated update, spread weights: SimRank.py:351-362) instead of SimRank")
+    ap.add_argument("--dense-precision", default="f32", choices=["f32", "fp16"],
+                    help="operand precision of the matrix-core part: f32 = exact (three bf16 terms), fp16 = one "
+                         "fp16 term (BASELINE.json config 5's reduced-precision dense leg; outside the parity bar)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL on the GPUs (the measurement); gloo = CPU rehearsal of the launch "
                          "path with the NumPy test double (tests only)")
@@ -189,7 +194,17 @@ def main():
     _, csr = ingest.directed(df, False, "from", "to", "weight")
     n, nnz = csr.n_rows, csr.nnz
     coef = 0.8
-    solver = Solver(lambda r: ops, world, [SideSpec(csr, csr.rowscale, coef)], args.mode)
+
+    def make_spec(c, pp):
+        if not pp:
+            return SideSpec(c, c.rowscale, coef)
+        return SideSpec(c, ingest.spread(c) * c.rowscale, coef, evidence_from=c)   # SimRank.py:322-337, :311-320
+
+    if gpu and args.dense_precision == "fp16":
+        ops.set_tuning(dense_terms=1)
+    solver = Solver(lambda r: ops, world, [make_spec(csr, args.pp)], args.mode)
+    if gpu:
+        ops.set_tuning(dense_terms=3)
     solver.reset()
 
     def barrier():
@@ -225,7 +240,9 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: synthetic directed graph N={n} nnz={nnz} "
-                               f"SimRank C=0.8 fp32, eps test every iteration",
+                               f"{'SimRank++ (evidence + spread)' if args.pp else 'SimRank'} C=0.8 fp32"
+                               f"{' with fp16 dense blocks' if args.dense_precision == 'fp16' else ''}, "
+                               f"eps test every iteration",
                    "N": n, "nnz": nnz, "mode": solver.mode,
                    "sharding": f"S column-sharded over {world_size} rank(s), all-to-all per update"
                                + (f" in {side_stages} overlapped stage(s)" if use_dist else "")},
@@ -238,7 +255,7 @@ def main():
         l1 = legs["leg1.0"][0]
         l2 = legs["leg2.0"][0]
         b1 = leg_bytes(side.M, side.K, side.Lk, nnz, leg2=False)
-        b2 = leg_bytes(side.M, side.K, side.Lm, nnz, leg2=True)
+        b2 = leg_bytes(side.M, side.K, side.Lm, nnz, leg2=True, has_evidence=args.pp)
         # the matrix-core part of leg 1 alone (same operand, same stream), outside the timed region
         nt, dk, cov = ops.dense_stats(side.graph)
         dense_ms = None
@@ -394,6 +411,58 @@ def main():
             del s3
         except Exception as e:
             out["bipartite_pp"] = {"error": f"{type(e).__name__}: {e}"}
+
+    if not args.no_extras and world_size == 1 and args.workload == "pl32768" and not args.pp:
+        # BASELINE.json configs[4]: N = 65536 SimRank++ with evidence weights, once with the exact
+        # dense blocks (three bf16 terms) and once with its "fp16 MFMA dense leg" (one fp16 term);
+        # the reduced-precision run is priced by its error against the exact one on sampled rows
+        try:
+            df5 = synth.WORKLOADS["pl65536"][0]()
+            _, csr5 = ingest.directed(df5, False, "from", "to", "weight")
+            rows5 = [0, 11, csr5.n_rows // 2, csr5.n_rows - 300, csr5.n_rows - 2, csr5.n_rows - 1]
+            res5, sample = {}, {}
+            for prec, terms in (("f32", 3), ("fp16", 1)):
+                ops.set_tuning(dense_terms=terms)
+                t0 = time.perf_counter()
+                s5 = Solver(lambda r: ops, world, [make_spec(csr5, True)], args.mode)
+                ops.set_tuning(dense_terms=3)
+                ops.synchronize()
+                setup_s = time.perf_counter() - t0
+                s5.reset()
+                for _ in range(2):
+                    s5.step(0.0)
+                s5.enable_timing(6)
+                ops.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(6):
+                    s5.step(0.0)
+                ops.synchronize()
+                dt = (time.perf_counter() - t0) / 6
+                lt = s5.leg_times()
+                sample[prec] = ops.download_rows(s5.cur[0][0], rows5).astype(np.float64)
+                nt5, dk5, cov5 = ops.dense_stats(next(iter(s5.sides[0].values())).graph)
+                res5[prec] = {"value": 1.0 / dt, "unit": "iterations/s", "ms_per_step": dt * 1e3,
+                              "leg1_ms": lt["leg1.0"][0], "leg2_ms": lt["leg2.0"][0],
+                              "setup_s_graph_and_evidence": setup_s}
+                s5.release()
+                del s5
+            ref, low = sample["f32"], sample["fp16"]
+            pos = ref > 0
+            rel = np.abs(low[pos] - ref[pos]) / ref[pos]
+            out["config5"] = {
+                "workload": f"pl65536: synthetic directed graph N={csr5.n_rows} nnz={csr5.nnz} SimRank++ "
+                            f"(evidence counts in the epilogue, spread weights) C=0.8, one GPU, 8 iterations",
+                "entries_in_dense_blocks_frac": cov5 / max(1, csr5.nnz),
+                "f32_exact_dense_blocks": res5["f32"], "fp16_dense_blocks": res5["fp16"],
+                "fp16_vs_f32_error": {"rows_sampled": len(rows5), "elements": int(pos.sum()),
+                                      "max_rel": float(rel.max()), "median_rel": float(np.median(rel)),
+                                      "p99_rel": float(np.quantile(rel, 0.99)),
+                                      "max_abs": float(np.abs(low - ref).max())},
+                "note": "fp16 applies to the operand of the matrix-core part only (the blocks of W dense enough "
+                        "for MFMA); the gathered remainder stays f32.  A full dense f16 GEMM of W (2N^3 = 5.6e14 "
+                        "flop) would take >= 225 ms per leg at the 2.5 PFLOP/s peak against these timings."}
+        except Exception as e:
+            out["config5"] = {"error": f"{type(e).__name__}: {e}"}
 
     if not args.no_extras and world_size == 1 and solver.mode == "sparse" and n <= 32768:
         # BASELINE.json's literal recipe — sparse leg 1, dense f32 MFMA GEMM for leg 2 —

@@ -19,7 +19,8 @@ class Epilogue(C.Structure):                   # struct simrank_epilogue
                 ("apriori", vp), ("ld_apriori", i64),
                 ("previous", vp), ("ld_previous", i64),
                 ("eps", C.c_double), ("n_changed", vp),
-                ("diag_col0", i64), ("set_diag", C.c_int32), ("symmetric", C.c_int32)]
+                ("diag_col0", i64), ("set_diag", C.c_int32), ("symmetric", C.c_int32),
+                ("restrict_support", C.c_int32), ("reserved_", C.c_int32)]
 
 
 def _ok(rc):

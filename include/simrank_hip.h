@@ -127,6 +127,13 @@ typedef struct simrank_epilogue {
                                         kernel may compute the upper triangle only and store
                                         its mirror image (off-diagonal tiles come out exactly
                                         symmetric; n_changed counts mirrored elements twice) */
+    int32_t restrict_support;        /* 1 (with evidence): the gathers of a row's 32-column segment
+                                        are skipped when all its evidence counts are zero — the
+                                        product is multiplied by E = 0 there (SimRank.py:315-316,
+                                        :361: S stays inside supp(E)); same bits, fewer gathers.
+                                        Worth it when few segments are live
+                                        (simrank_evidence_live_segments) */
+    int32_t reserved_;
 } simrank_epilogue;
 
 /* ---- the convergence count on the host: sum of the n striped counters an epilogue wrote
@@ -192,6 +199,14 @@ SIMRANK_API int simrank_permute(const void* src, int64_t ld_src, void* dst, int6
  *      SimRank.py:315; E = 1 - 2^-count is applied in the epilogue (:316). */
 SIMRANK_API int simrank_evidence_counts(const simrank_graph* g, int64_t col0, int64_t n_cols,
                             uint8_t* counts, int64_t ld, void* stream);
+
+/* ---- how many aligned 32-column segments of a u8 count block hold a nonzero count (`live`) out
+ *      of `total` = n_rows * ceil(n_cols / 32): the support density of the evidence matrix
+ *      E = 1 - 2^-count (SimRank.py:315-316) at the granularity simrank_spmm can skip.
+ *      Synchronises the stream. */
+SIMRANK_API int simrank_evidence_live_segments(const uint8_t* counts, int64_t ld, int64_t n_rows,
+                                               int64_t n_cols, int64_t* live, int64_t* total,
+                                               void* stream);
 
 /* ---- dense MFMA path (second `.dot(G.T)` of SimRank.py:139 when W really is dense) -- */
 /* Wd[a*ld + i] = rowscale[a] where (a,i) is stored, 0 elsewhere */

@@ -33,6 +33,8 @@ class Epilogue(C.Structure):
         ("diag_col0", C.c_int64),
         ("set_diag", C.c_int32),
         ("symmetric", C.c_int32),
+        ("restrict_support", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
 
@@ -72,6 +74,7 @@ PROTOTYPES = {
     "simrank_topk_rows": [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp],
     "simrank_topk_rows_ids": [_vp, _i64, _i64, _i64, _i64, _vp, _i32, _i32, _vp, _vp, _vp],
     "simrank_permute": [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i32, _vp],
+    "simrank_evidence_live_segments": [_vp, _i64, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64), _vp],
     "simrank_evidence_counts": [_vp, _i64, _i64, _vp, _i64, _vp],
     "simrank_graph_densify": [_vp, _vp, _i64, _vp],
     "simrank_gemm_nt": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64,

@@ -176,8 +176,8 @@ int simrank_download_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
     if (n_rows == 0 || n_cols == 0) return SIMRANK_OK;
     SR_REQUIRE(dst && src, "NULL pointer");
     // staged through pinned slabs so the PCIe copy of slab k+1 overlaps the f32->f64
-    // widening of slab k on the host.  The two slabs (and their events) are kept for the
-    // life of the process: allocating 64 MB of pinned memory costs more than a small download.
+    // widening of slab k on the host.  The two slabs (128 MB each at most, and their events) are
+    // kept for the life of the process: allocating pinned memory costs more than a small download.
     struct PinCache {
         float* pin[2] = {nullptr, nullptr};
         hipEvent_t done[2];
@@ -195,9 +195,9 @@ int simrank_download_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
     size_t& pin_cap = pc.cap;
     bool& have_events = pc.have_events;
     const int64_t row_bytes = n_cols * 4;
-    const int64_t slab_rows = std::max<int64_t>(1, std::min<int64_t>(n_rows, (int64_t(32) << 20) / row_bytes));
+    const int64_t slab_rows = std::max<int64_t>(1, std::min<int64_t>(n_rows, (int64_t(128) << 20) / row_bytes));
     const size_t need = size_t(slab_rows) * row_bytes;
-    const int64_t n_threads = std::max<unsigned>(1, std::min<unsigned>(16, std::thread::hardware_concurrency()));
+    const int64_t n_threads = std::max<unsigned>(1, std::min<unsigned>(32, std::thread::hardware_concurrency()));
     if (!have_events) {
         for (int i = 0; i < 2; ++i) SR_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
         have_events = true;
@@ -454,6 +454,9 @@ int simrank_set_tuning(const char* key, int64_t value) {
         t.dense_min = value;
     } else if (!strcmp(key, "probe_mask")) {
         t.probe_mask = value < 0 ? -1 : value;
+    } else if (!strcmp(key, "dense_terms")) {
+        SR_REQUIRE(value == 1 || value == 3, "dense_terms must be 3 (exact) or 1 (fp16 operand)");
+        t.dense_terms = value;
     } else if (!strcmp(key, "probe_flags")) {
         t.probe_flags = value & 15;
     } else if (!strcmp(key, "lean")) {
@@ -488,6 +491,7 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     else if (!strcmp(key, "ids16")) *value = t.ids16;
     else if (!strcmp(key, "lean")) *value = t.lean;
     else if (!strcmp(key, "probe_flags")) *value = t.probe_flags;
+    else if (!strcmp(key, "dense_terms")) *value = t.dense_terms;
     else if (!strcmp(key, "probe_mask")) *value = t.probe_mask;
     else SR_REQUIRE(false, "unknown tuning key '%s'", key);
     return SIMRANK_OK;

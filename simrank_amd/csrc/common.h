@@ -42,6 +42,8 @@ struct Tuning {
     int64_t dense_min = 4;   // block-dense MFMA part: a column joins a 128-row tile's dense set when
                              // at least this many of the tile's rows reference it (0 = off)
     int64_t dense_cols = 128; // ... and a tile gets a dense set only with this many such columns
+    int64_t dense_terms = 3; // operand terms of the matrix-core part: 3 = bf16 hi+mid+lo (exact f32 products),
+                             // 1 = one fp16 term (reduced precision: config 5's "fp16 MFMA dense leg")
     int64_t probe_mask = -1; // DIAGNOSTIC ONLY: gathered row ids are ANDed with this (wrong results; prices
                              // the memory path of the gather kernel: 255 = L1-resident operand, 8191 = L2-resident)
     int64_t probe_flags = 0; // DIAGNOSTIC ONLY (lean kernel): 1 no gathers, 2 no stores, 4 no dense partial sums, 8 no ids

@@ -75,6 +75,8 @@ struct SpmmArgs {
     unsigned long long* n_changed;
     int64_t diag_col0;
     int32_t set_diag;
+    int32_t restrict_support; // lean kernel, evidence given: skip the gathers of 32-column segments whose
+                              // evidence counts are all zero (their result is exactly 0: S inside supp(E))
     // block-dense part (blockdense.hip): raw partial sums of the entries that went to the matrix
     // cores; row a of 128-row block b has one row in each of the block's slabs,
     // dpart[((dslab0[b] + s) * 128 + a % 128) * ldp], s < dnslab[b]; NULL = none
@@ -790,7 +792,9 @@ __device__ __forceinline__ void emit_row3(const SpmmArgs& p, float* tbuf_wave, i
     }
 }
 
-template <int MODE, bool IDS16>
+// RESTRICT (leg 2 of SimRank++, SimRank.py:315-316, :361): a separate instantiation, so the plain
+// legs keep their register budget; chosen by the driver when few segments of E are live.
+template <int MODE, bool IDS16, bool RESTRICT>
 __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(const SpmmArgs p) {
     constexpr bool TRANS = MODE == kTrans;
     constexpr bool TILE = MODE != kPlain;
@@ -956,7 +960,18 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
         const float sc = __shfl(my_scale, r);
         float acc[4], dsum[4];
         dense_partial(p, int64_t(row0) + r, mycol, g == 0 && col_active, dsum);
-        gather_range3<IDS16>(p, Xc, pitch16, s, e, lane, g, acc);
+        bool live = true;
+        if constexpr (RESTRICT) {
+            const unsigned w = col_active ? *reinterpret_cast<const unsigned*>(
+                                                p.ev + (int64_t(row0) + r) * p.ld_ev + mycol) : 0u;
+            live = __ballot(w != 0u) != 0;                           // uniform: the row's 32 columns
+        }
+        if (live) {
+            gather_range3<IDS16>(p, Xc, pitch16, s, e, lane, g, acc);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = 0.f;
+        }
         if (g == 0 && col_active)
             emit_row3<MODE>(p, tbuf_wave, r, int64_t(row0) + r, q, mycol, sc, acc, dsum, changed, mirror);
     }
@@ -977,6 +992,14 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         float dsum[4];
         dense_partial(p, int64_t(row0) + r, mycol, src < nrows && col_active, dsum);
+        // RESTRICT: a lane group whose 32 evidence counts are all zero issues no gathers
+        auto group_live = [&](int row, bool on) -> bool {
+            if constexpr (!RESTRICT) return true;
+            const unsigned w = on ? *reinterpret_cast<const unsigned*>(
+                                        p.ev + (int64_t(row0) + row) * p.ld_ev + mycol) : 0u;
+            return ((__ballot(w != 0u) >> gbase) & 0xFFull) != 0;
+        };
+        bool glive = group_live(r, src < nrows && col_active);
         while (true) {
             const bool same_pass = t0 + LPR < maxlen;
             const int npos = same_pass ? pos : pos + 8;
@@ -996,7 +1019,7 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
             }
             if (more && nt0 + q < nlen && !(p.probe & 8)) niv = ld_id<IDS16>(p, nst + nt0 + q) & p.idx_mask;
 
-            if (!(p.probe & 1))
+            if (!(p.probe & 1) && glive)
                 gather_chunk<1>(Xc, pitch16, iv, gbase, min(LPR, maxlen - t0), max(0, min(LPR, minlen - t0)),
                                 len - t0, acc);
 
@@ -1005,7 +1028,10 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
                     emit_row3<MODE>(p, tbuf_wave, r, int64_t(row0) + r, q, mycol, sc, acc, dsum, changed, mirror);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] = 0.f;
-                if (more) dense_partial(p, int64_t(row0) + nr, mycol, npos + g < nrows && col_active, dsum);
+                if (more) {
+                    dense_partial(p, int64_t(row0) + nr, mycol, npos + g < nrows && col_active, dsum);
+                    glive = group_live(nr, npos + g < nrows && col_active);
+                }
             }
             if (!more) break;
             pos = npos; t0 = nt0; r = nr; st = nst; len = nlen; maxlen = nmax; minlen = nmin; iv = niv; sc = nsc;
@@ -1087,10 +1113,21 @@ static int launch_gather3(SpmmArgs a, hipStream_t st) {
     SR_REQUIRE(grid > 0 && grid < (int64_t(1) << 31), "grid of %lld blocks", (long long)grid);
     const size_t lds = sizeof(float) * ((MODE != kPlain ? size_t(kWaves) * PW * (RT + 1) : 0) +
                                         (a.has_huge ? 64 + size_t(kMaxHuge) * kWaves * PW : 0));
+    const bool restricted = MODE != kTrans && a.has_ep && a.ev && a.restrict_support;
+    if constexpr (MODE != kTrans) {
+        if (restricted) {
+            if (a.col16)
+                hipLaunchKernelGGL((gather3_kernel<MODE, true, true>), dim3((unsigned)grid), dim3(256), lds, st, a);
+            else
+                hipLaunchKernelGGL((gather3_kernel<MODE, false, true>), dim3((unsigned)grid), dim3(256), lds, st, a);
+            SR_HIP(hipGetLastError());
+            return SIMRANK_OK;
+        }
+    }
     if (a.col16)
-        hipLaunchKernelGGL((gather3_kernel<MODE, true>), dim3((unsigned)grid), dim3(256), lds, st, a);
+        hipLaunchKernelGGL((gather3_kernel<MODE, true, false>), dim3((unsigned)grid), dim3(256), lds, st, a);
     else
-        hipLaunchKernelGGL((gather3_kernel<MODE, false>), dim3((unsigned)grid), dim3(256), lds, st, a);
+        hipLaunchKernelGGL((gather3_kernel<MODE, false, false>), dim3((unsigned)grid), dim3(256), lds, st, a);
     SR_HIP(hipGetLastError());
     return SIMRANK_OK;
 }
@@ -1247,11 +1284,56 @@ __global__ __launch_bounds__(256) void evidence_counts_kernel(
     }
 }
 
+// 32-column segments (aligned to 32) of a u8 count block that hold a nonzero count
+__global__ __launch_bounds__(256) void live_segments_kernel(const uint8_t* __restrict__ cnt, int64_t ld,
+                                                            int64_t n_rows, int64_t n_cols,
+                                                            unsigned long long* live) {
+    const int64_t segs = (n_cols + 31) / 32;
+    const int64_t total = n_rows * segs;
+    unsigned mine = 0;
+    for (int64_t t = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; t < total;
+         t += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t a = t / segs, sgm = t - a * segs;
+        const uint8_t* row = cnt + a * ld + sgm * 32;
+        const int n = int(imin(32, n_cols - sgm * 32));
+        unsigned any = 0;
+        for (int c = 0; c < n; ++c) any |= row[c];
+        mine += any ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(live, (unsigned long long)mine);
+}
+
 }  // namespace simrank
 
 using namespace simrank;
 
 extern "C" {
+
+int simrank_evidence_live_segments(const uint8_t* counts, int64_t ld, int64_t n_rows, int64_t n_cols,
+                                   int64_t* live, int64_t* total, void* stream) {
+    SR_REQUIRE(counts && live && total && n_rows > 0 && n_cols > 0 && ld >= n_cols, "bad evidence block");
+    unsigned long long* d = nullptr;
+    SR_HIP(hipMalloc((void**)&d, sizeof(unsigned long long)));
+    hipStream_t st = as_stream(stream);
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(unsigned long long), st);
+    unsigned long long h = 0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(live_segments_kernel, dim3(256 * 8), dim3(256), 0, st, counts, ld, n_rows, n_cols, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (e != hipSuccess) {
+        set_error("simrank_evidence_live_segments: %s", hipGetErrorString(e));
+        return SIMRANK_ERR_HIP;
+    }
+    *live = (int64_t)h;
+    *total = n_rows * ((n_cols + 31) / 32);
+    return SIMRANK_OK;
+}
 
 int simrank_fill_identity(float* S, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t col0,
                           void* stream) {
@@ -1315,6 +1397,7 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
         a.n_changed = ep->n_changed;
         a.diag_col0 = ep->diag_col0;
         a.set_diag = ep->set_diag;
+        a.restrict_support = ep->restrict_support;
         SR_REQUIRE(!a.ev || a.ld_ev >= n_cols_x, "evidence ld too small");
         SR_REQUIRE(!a.ap || a.ld_ap >= n_cols_x, "apriori ld too small");
         SR_REQUIRE(!a.prev || (a.ld_prev >= n_cols_x && a.n_changed),
@@ -1380,7 +1463,8 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
     }
     if (lean_ok && transpose_out && (T.panel == 0 || T.panel == 32))
         return launch_gather3<kTrans>(a, st);
-    if (lean_ok && !transpose_out && (T.lean == 2 ? T.panel == 0 : T.panel == 32))
+    if (lean_ok && !transpose_out &&
+        ((T.lean == 2 || (a.has_ep && a.ev && a.restrict_support)) ? (T.panel == 0 || T.panel == 32) : T.panel == 32))
         return launch_gather3<kPlain>(a, st);
 #define SR_TILE_SWITCH(LPR, TR)                                             \
     switch (tile) {                                                         \

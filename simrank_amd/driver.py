@@ -27,6 +27,8 @@ import numpy as np
 from .ingest import CSR, partition, relabel
 
 PAD_MIN_ROWS, PAD_MULTIPLE = 1024, 256   # when exchanged chunk rows get padded (row_pad)
+RESTRICT_BELOW = 0.5     # SimRank++: leg 2 skips evidence-dead 32-column segments when fewer than this
+                         # fraction of them is live (ER N=8192: 0.24 live; the power-law graphs: 0.9)
 STAGE_ALIGN = 32         # stage widths of a pipelined exchange are multiples of this (panels)
 
 
@@ -334,6 +336,7 @@ class Side:
         self.symmetric = spec.symmetric
         self.x1 = self.x2 = None
         self.broadcast_error = None
+        self.ev_live, self.restrict = 1.0, False
         if mode == "sparse":
             # exchange 1: leg-1 product (M rows x my Lk of K columns) -> K x Lm
             self.x1 = self._xfer(self.Lk, self.k_lo, self.K, torch_buffers)
@@ -356,6 +359,9 @@ class Side:
             if ev.n_rows == self.M:
                 eg = self.graph if ev is csr else ops.graph(ev)
                 ops.evidence_counts(eg, self.m_lo, self.ev)
+                # support density of E decides between the two instantiations of leg 2
+                self.ev_live = ops.evidence_live_fraction(self.ev)
+                self.restrict = self.ev_live < RESTRICT_BELOW
             elif ev.n_rows == 1:
                 # quirk Q2 with a single group-1 node: NumPy broadcasts the 1 x 1 Evidence_N1 over
                 # the n2 x n2 update (SimRank.py:423), i.e. one count gates every element
@@ -446,7 +452,8 @@ class Side:
 
     def _ep(self, S_prev, eps):
         return dict(coef=self.spec.coef, evidence=self.ev, apriori=self.ap, lbd=self.spec.lbd,
-                    previous=S_prev, eps=eps, diag_col0=self.m_lo, set_diag=True)
+                    previous=S_prev, eps=eps, diag_col0=self.m_lo, set_diag=True,
+                    restrict_support=self.restrict)
 
     def leg2(self, S_prev, S_out, eps):
         """Symmetric iterates: S_out = W . Tt with the fused epilogue.

@@ -237,7 +237,7 @@ class HipOps:
                   "simrank_fill_identity")
 
     def _epilogue(self, coef, evidence=None, apriori=None, lbd=0.0, previous=None, eps=0.0,
-                  diag_col0=0, set_diag=True, symmetric=False) -> Epilogue:
+                  diag_col0=0, set_diag=True, symmetric=False, restrict_support=False) -> Epilogue:
         ep = Epilogue()
         ep.coef = float(coef)
         ep.lbd = float(lbd)
@@ -252,6 +252,7 @@ class HipOps:
         ep.diag_col0 = int(diag_col0)
         ep.set_diag = 1 if set_diag else 0
         ep.symmetric = 1 if symmetric else 0
+        ep.restrict_support = 1 if (restrict_support and evidence is not None) else 0
         return ep
 
     def spmm(self, g: Graph, X: Matrix, Y: Matrix, n_cols: int | None = None,
@@ -301,6 +302,17 @@ class HipOps:
         if out.cols:
             check(self.lib.simrank_evidence_counts(g.handle, col0, out.cols, out.ptr, out.ld,
                                                    self.stream), "simrank_evidence_counts")
+
+    def evidence_live_fraction(self, counts: Matrix) -> float:
+        """Fraction of the aligned 32-column segments of a count block that hold a nonzero count:
+        what a support-restricted SimRank++ update (epilogue ``restrict_support``) still gathers."""
+        if not counts.cols:
+            return 1.0
+        live, total = C.c_int64(0), C.c_int64(0)
+        check(self.lib.simrank_evidence_live_segments(counts.ptr, counts.ld, counts.rows, counts.cols,
+                                                      C.byref(live), C.byref(total), self.stream),
+              "simrank_evidence_live_segments")
+        return live.value / max(1, total.value)
 
     def read_changed(self) -> int:
         """Value of the convergence counter of the last epilogue with ``previous``."""

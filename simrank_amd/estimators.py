@@ -17,12 +17,15 @@ Extra keyword-only arguments (defaults keep the reference's behaviour):
     top_k             return, instead of the dense matrix, a long-format frame (node, rank,
                       neighbor, similarity) with the k most similar other nodes of every node,
                       selected on the device (no N x N transfer)
+    dense_precision   "f32" (default) | "fp16": operand precision of the matrix-core part of the legs;
+                      "fp16" is BASELINE.json config 5's reduced-precision dense leg, outside the parity bar
     strict_reference  bipartite classes only; True keeps quirks Q1 (set-order labels on
                       sorted-order data) and Q2 (Evidence_N1 on the group-2 update, a
                       ValueError when n1 != n2); False labels correctly and uses Evidence_N2
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import time
 
@@ -32,6 +35,39 @@ import pandas as pd
 from . import ingest
 from .driver import LocalWorld, SideSpec, Solver
 from .progress import announce_converged, update_progress
+
+
+_DENSE_TERMS = {"f32": 3, "fp16": 1}
+_precision_now = ["f32"]
+
+
+@contextlib.contextmanager
+def _precision(dense_precision):
+    """``fit(dense_precision=...)``: "f32" (default) keeps the matrix-core part of the legs exact
+    (operand split into three bf16 terms); "fp16" rounds its operand to one fp16 term — BASELINE.json
+    config 5's reduced-precision dense leg: faster, NOT within the 1e-5 parity bar."""
+    if dense_precision not in _DENSE_TERMS:
+        raise ValueError(f"dense_precision must be one of {sorted(_DENSE_TERMS)}, not {dense_precision!r}")
+    _precision_now.append(dense_precision)
+    try:
+        yield
+    finally:
+        _precision_now.pop()
+
+
+def _make_solver(ops_factory, device, world, specs, mode):
+    """The solver with the graphs created under the precision asked for (the knobs are copied
+    into a graph when it is created, csrc/common.h)."""
+    factory = ops_factory or _default_ops_factory(device)
+    terms = _DENSE_TERMS[_precision_now[-1]]
+    if terms == 3:
+        return Solver(factory, world, specs, mode)
+    knob = factory(world.local_ranks[0])
+    knob.set_tuning(dense_terms=terms)
+    try:
+        return Solver(factory, world, specs, mode)
+    finally:
+        knob.set_tuning(dense_terms=3)
 
 
 def _default_ops_factory(device):
@@ -44,7 +80,7 @@ def _default_ops_factory(device):
 
 def _solve(specs, iterations, eps, verbose, mode, device, world, ops_factory=None):
     world = world or LocalWorld(1)
-    solver = Solver(ops_factory or _default_ops_factory(device), world, specs, mode)
+    solver = _make_solver(ops_factory, device, world, specs, mode)
     talk = verbose and world.is_root
     if talk:
         print("Start iterating...")
@@ -137,11 +173,13 @@ class SimRank(object):
 
     def fit(self, data, C=0.8, weighted=False, from_node_column="from", to_node_column="to",
             weight_column="weight", iterations=100, eps=1e-4, verbose=True, *,
-            mode="auto", device=None, world=None, top_k=None, _ops_factory=None):
-        csr = self._create_graph(data, weighted, from_node_column, to_node_column, weight_column)
-        solver, k = _solve([self._side(csr, C)], iterations, eps, verbose, mode, device, world,
-                           _ops_factory)
-        return self._finish(solver, k, top_k)
+            mode="auto", device=None, world=None, top_k=None, dense_precision="f32",
+            _ops_factory=None):
+        with _precision(dense_precision):
+            csr = self._create_graph(data, weighted, from_node_column, to_node_column, weight_column)
+            solver, k = _solve([self._side(csr, C)], iterations, eps, verbose, mode, device, world,
+                               _ops_factory)
+            return self._finish(solver, k, top_k)
 
 
 class SimRankPP(SimRank):
@@ -181,7 +219,7 @@ class SimRankPP(SimRank):
         start = time.time()
         # the counts are produced on the device while the solver is set up
         world = world or LocalWorld(1)
-        solver = Solver(ops_factory or _default_ops_factory(device), world, [spec], mode)
+        solver = _make_solver(ops_factory, device, world, [spec], mode)
         for o in solver.ops.values():
             o.synchronize()
         if talk:
@@ -195,10 +233,12 @@ class SimRankPP(SimRank):
 
     def fit(self, data, C=0.8, weighted=False, from_node_column="from", to_node_column="to",
             weight_column="weight", iterations=100, eps=1e-4, verbose=True, *,
-            mode="auto", device=None, world=None, top_k=None, _ops_factory=None):
-        return self._fit_pp(data, C, weighted, from_node_column, to_node_column, weight_column,
-                            iterations, eps, verbose, mode, device, world, _ops_factory,
-                            top_k=top_k)
+            mode="auto", device=None, world=None, top_k=None, dense_precision="f32",
+            _ops_factory=None):
+        with _precision(dense_precision):
+            return self._fit_pp(data, C, weighted, from_node_column, to_node_column, weight_column,
+                                iterations, eps, verbose, mode, device, world, _ops_factory,
+                                top_k=top_k)
 
 
 class AprioriSimRank(SimRankPP):
@@ -210,13 +250,14 @@ class AprioriSimRank(SimRankPP):
     def fit(self, data, AprioriSim, C=0.8, lbd=0.5, weighted=False, from_node_column="from",
             to_node_column="to", weight_column="weight", iterations=100, eps=1e-4,
             verbose=True, *, mode="auto", device=None, world=None, top_k=None,
-            _ops_factory=None):
-        if not isinstance(AprioriSim, np.ndarray):
-            # the reference fails at np.fill_diagonal for anything but an ndarray
-            raise AttributeError(f"'{type(AprioriSim).__name__}' object has no attribute 'flat'")
-        return self._fit_pp(data, C, weighted, from_node_column, to_node_column, weight_column,
-                            iterations, eps, verbose, mode, device, world, _ops_factory,
-                            apriori=AprioriSim, lbd=lbd, top_k=top_k)
+            dense_precision="f32", _ops_factory=None):
+        with _precision(dense_precision):
+            if not isinstance(AprioriSim, np.ndarray):
+                # the reference fails at np.fill_diagonal for anything but an ndarray
+                raise AttributeError(f"'{type(AprioriSim).__name__}' object has no attribute 'flat'")
+            return self._fit_pp(data, C, weighted, from_node_column, to_node_column, weight_column,
+                                iterations, eps, verbose, mode, device, world, _ops_factory,
+                                apriori=AprioriSim, lbd=lbd, top_k=top_k)
 
 
 # ----------------------------------------------------------------------------------------
@@ -263,12 +304,13 @@ class BipartiteSimRank(object):
     def fit(self, data, C1=0.8, C2=0.8, weighted=False, node_group1_column="user",
             node_group2_column="item", weight_column="weight", iterations=100, eps=1e-4,
             verbose=True, *, mode="auto", device=None, world=None, strict_reference=True,
-            top_k=None, _ops_factory=None):
-        g12, g21 = self._create_graph(data, weighted, node_group1_column, node_group2_column,
-                                      weight_column)
-        specs = [SideSpec(g12, g12.rowscale, C1), SideSpec(g21, g21.rowscale, C2)]
-        solver, k = _solve(specs, iterations, eps, verbose, mode, device, world, _ops_factory)
-        return self._finish(solver, k, strict_reference, top_k)
+            top_k=None, dense_precision="f32", _ops_factory=None):
+        with _precision(dense_precision):
+            g12, g21 = self._create_graph(data, weighted, node_group1_column, node_group2_column,
+                                          weight_column)
+            specs = [SideSpec(g12, g12.rowscale, C1), SideSpec(g21, g21.rowscale, C2)]
+            solver, k = _solve(specs, iterations, eps, verbose, mode, device, world, _ops_factory)
+            return self._finish(solver, k, strict_reference, top_k)
 
 
 class BipartiteSimRankPP(SimRankPP):
@@ -312,7 +354,7 @@ class BipartiteSimRankPP(SimRankPP):
         if talk:
             print("Initializing Evidence matrix...")
         start = time.time()
-        solver = Solver(ops_factory or _default_ops_factory(device), world, specs, mode)
+        solver = _make_solver(ops_factory, device, world, specs, mode)
         for o in solver.ops.values():
             o.synchronize()
         if talk:
@@ -331,10 +373,11 @@ class BipartiteSimRankPP(SimRankPP):
     def fit(self, data, C1=0.8, C2=0.8, weighted=False, node_group1_column="user",
             node_group2_column="item", weight_column="weight", iterations=100, eps=1e-4,
             verbose=True, *, mode="auto", device=None, world=None, strict_reference=True,
-            top_k=None, _ops_factory=None):
-        return self._fit_bpp(data, C1, C2, weighted, node_group1_column, node_group2_column,
-                             weight_column, iterations, eps, verbose, mode, device, world,
-                             strict_reference, _ops_factory, top_k=top_k)
+            top_k=None, dense_precision="f32", _ops_factory=None):
+        with _precision(dense_precision):
+            return self._fit_bpp(data, C1, C2, weighted, node_group1_column, node_group2_column,
+                                 weight_column, iterations, eps, verbose, mode, device, world,
+                                 strict_reference, _ops_factory, top_k=top_k)
 
 
 class BipartitleAprioriSimRank(BipartiteSimRankPP):
@@ -347,14 +390,16 @@ class BipartitleAprioriSimRank(BipartiteSimRankPP):
     def fit(self, data, AprioriSim1, AprioriSim2, C1=0.8, C2=0.8, lbd1=0.5, lbd2=0.5,
             weighted=False, node_group1_column="user", node_group2_column="item",
             weight_column="weight", iterations=100, eps=1e-4, verbose=True, *, mode="auto",
-            device=None, world=None, strict_reference=True, top_k=None, _ops_factory=None):
-        for a in (AprioriSim1, AprioriSim2):
-            if not isinstance(a, np.ndarray):
-                raise AttributeError(f"'{type(a).__name__}' object has no attribute 'flat'")
-        return self._fit_bpp(data, C1, C2, weighted, node_group1_column, node_group2_column,
-                             weight_column, iterations, eps, verbose, mode, device, world,
-                             strict_reference, _ops_factory, priors=(AprioriSim1, AprioriSim2),
-                             lbds=(lbd1, lbd2), top_k=top_k)
+            device=None, world=None, strict_reference=True, top_k=None, dense_precision="f32",
+            _ops_factory=None):
+        with _precision(dense_precision):
+            for a in (AprioriSim1, AprioriSim2):
+                if not isinstance(a, np.ndarray):
+                    raise AttributeError(f"'{type(a).__name__}' object has no attribute 'flat'")
+            return self._fit_bpp(data, C1, C2, weighted, node_group1_column, node_group2_column,
+                                 weight_column, iterations, eps, verbose, mode, device, world,
+                                 strict_reference, _ops_factory, priors=(AprioriSim1, AprioriSim2),
+                                 lbds=(lbd1, lbd2), top_k=top_k)
 
 
 def _lazy_evidence(world, solver, j, csr):

@@ -192,6 +192,12 @@ class NumpyOps:
         cnt = (live @ live.T).toarray()
         out.a[:, :out.cols] = np.minimum(cnt[:, col0:col0 + out.cols], 255).astype(np.uint8)
 
+    def evidence_live_fraction(self, counts):
+        a = counts.a[:, :counts.cols]
+        segs = -(-counts.cols // 32)
+        live = sum(int((a[:, 32 * k:32 * k + 32] != 0).any(axis=1).sum()) for k in range(segs))
+        return live / max(1, counts.rows * segs)
+
     def read_changed(self):
         return self._changed
 

@@ -503,6 +503,54 @@ def test_fit_with_dense_sets_against_oracle(cls):
     assert est.converged_at == want["k"]
 
 
+@pytest.mark.parametrize("world", [1, 3])
+def test_support_restricted_simrank_pp_is_bit_equal(world, monkeypatch):
+    """SimRank++ keeps S inside supp(E) (SimRank.py:315-316, :361).  The restricted instantiation
+    of leg 2 skips the gathers of 32-column segments whose evidence counts are all zero; it must
+    give the bits of the unrestricted one (single rank: upper-triangle form; sharded: plain form),
+    on a sparse-evidence graph (where the driver picks it by itself) and on one with dense sets."""
+    import simrank_amd.driver as drv
+    from simrank_amd.engine import HipOps
+    for df in (synth.er_directed(4096, 0.001, seed=11), _dense_corner_graph()):
+        out = {}
+        for name, below in (("never", 0.0), ("always", 2.0), ("auto", drv.RESTRICT_BELOW)):
+            monkeypatch.setattr(drv, "RESTRICT_BELOW", below)
+            est = SRA.SimRankPP()
+            S = est.fit(df, verbose=False, world=LocalWorld(world), mode="sparse")
+            out[name] = (S.values, est.converged_at)
+        assert np.array_equal(out["never"][0], out["always"][0])
+        assert np.array_equal(out["never"][0], out["auto"][0])
+        assert out["never"][1] == out["always"][1] == out["auto"][1]
+    # the sparse-evidence graph is the case the driver restricts by itself
+    _, csr = ingest.directed(synth.er_directed(4096, 0.001, seed=11), False, "from", "to", "weight")
+    ops = HipOps(0)
+    cnt = ops.matrix(csr.n_rows, csr.n_rows, np.uint8)
+    ops.evidence_counts(ops.graph(csr), 0, cnt)
+    frac = ops.evidence_live_fraction(cnt)
+    c = ops.download(cnt)
+    segs = c.reshape(csr.n_rows, -1, 32).any(axis=2)
+    assert abs(frac - segs.mean()) < 1e-12 and frac < drv.RESTRICT_BELOW
+
+
+def test_fp16_dense_blocks_are_an_explicit_reduced_precision_choice():
+    """fit(dense_precision="fp16"): BASELINE.json config 5's reduced-precision dense leg — the
+    operand of the matrix-core part rounded to one fp16 term.  Close to the oracle (fp16 has 11
+    significant bits; sums average the rounding), but NOT within the 1e-5 bar, and never the
+    default."""
+    df = _dense_corner_graph()
+    want = O.fit_simrank(df, iterations=6, eps=0, verbose=False)["S"]
+    exact = SRA.SimRank().fit(df, iterations=6, eps=0, verbose=False)
+    low = SRA.SimRank().fit(df, iterations=6, eps=0, verbose=False, dense_precision="fp16")
+    assert_close(exact.values, want)
+    pos = want > 0
+    rel = np.abs(low.values[pos] - want[pos]) / want[pos]
+    assert 1e-6 < rel.max() < 5e-3, rel.max()
+    again = SRA.SimRank().fit(df, iterations=6, eps=0, verbose=False)          # the knob does not stick
+    assert np.array_equal(again.values, exact.values)
+    with pytest.raises(ValueError, match="dense_precision"):
+        SRA.SimRank().fit(df, verbose=False, dense_precision="fp8")
+
+
 def test_dense_sets_shards_equal_one_shard_bit_for_bit():
     """The dense part works per column block with a fixed summation order: P column shards give
     the same bits as one shard (upper-triangle shortcut off for the comparison)."""

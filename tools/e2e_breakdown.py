@@ -6,7 +6,9 @@ from simrank_amd.driver import LocalWorld, SideSpec, Solver
 from simrank_amd.engine import HipOps
 for w in (sys.argv[1:] or ["bts300", "er8192", "pl32768"]):
     df = synth.WORKLOADS[w][0]()
+    out = S = None
     for rep in range(2):
+        del out, S                       # (freeing the previous 8 GiB result is not part of a fit)
         t = [time.perf_counter()]
         nodes, csr = ingest.directed(df, False, "from", "to", "weight"); t.append(time.perf_counter())
         ops = HipOps(0); t.append(time.perf_counter())

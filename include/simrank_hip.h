@@ -204,9 +204,43 @@ SIMRANK_API int simrank_evidence_counts(const simrank_graph* g, int64_t col0, in
  *      of `total` = n_rows * ceil(n_cols / 32): the support density of the evidence matrix
  *      E = 1 - 2^-count (SimRank.py:315-316) at the granularity simrank_spmm can skip.
  *      Synchronises the stream. */
-SIMRANK_API int simrank_evidence_live_segments(const uint8_t* counts, int64_t ld, int64_t n_rows,
-                                               int64_t n_cols, int64_t* live, int64_t* total,
+SIMRANK_API int simrank_evidence_live_segments(const uint8_t* counts, int64_t ld, int64_t rows_pad,
+                                               int64_t n_rows, int64_t n_cols, int64_t* live,
+                                               int64_t* total, void* stream);
+/* (rows_pad > 0: the counts are panel-blocked, see below; ld is then ignored) */
+
+/* ---- PANEL-BLOCKED operands.  A matrix of R rows x C columns is stored as ceil(C/32) panels of
+ *      rows_pad >= R rows x 32 elements; element (r, c) sits at
+ *          ((c >> 5) * rows_pad + r) * 32 + (c & 31)          (floats; bytes for the u8 counts).
+ *      What the gather legs read per 32-column panel — one 128-byte segment of every source row —
+ *      is then ONE contiguous slice (4 MiB at N = 32768) instead of N segments 128 KiB apart: the
+ *      gathers stop missing the TLB (measured on one XCD, K = 32768: 3.3 vs 1.7 TB/s) and every
+ *      tile a leg stores is a contiguous 4 KiB.  The single-rank solver keeps S, the transposed
+ *      product, the evidence counts and the prior in this layout; results leave it through
+ *      simrank_permute_layout.  Same reference lines as the row-major entry points. */
+SIMRANK_API int simrank_fill_identity_blocked(float* S, int64_t n_rows, int64_t n_cols,
+                                              int64_t rows_pad, int64_t col0, void* stream);
+/* X: n_cols(g) rows (x_rows_pad per panel) x n_cols_x columns.  transpose_out = 0: Y is n_rows(g)
+ * rows x n_cols_x columns and the epilogue operands share its layout (their ld_* are ignored);
+ * transpose_out = 1: Y is n_cols_x rows x n_rows(g) columns.  y_rows_pad = padded rows of Y. */
+SIMRANK_API int simrank_spmm_blocked(const simrank_graph* g, const float* X, int64_t x_rows_pad,
+                                     int64_t n_cols_x, float* Y, int64_t y_rows_pad,
+                                     int32_t transpose_out, const simrank_epilogue* epilogue,
+                                     void* stream);
+SIMRANK_API int simrank_epilogue_apply_blocked(const float* Q, float* Y, int64_t n_rows, int64_t n_cols,
+                                               int64_t rows_pad, const simrank_epilogue* epilogue,
                                                void* stream);
+SIMRANK_API int simrank_topk_rows_blocked(const float* S, int64_t rows_pad, int64_t n_rows,
+                                          int64_t n_cols, int64_t col0, const int32_t* col_ids,
+                                          int32_t k, int32_t exclude_diag, int32_t* idx_out,
+                                          float* val_out, void* stream);
+SIMRANK_API int simrank_evidence_counts_blocked(const simrank_graph* g, int64_t col0, int64_t n_cols,
+                                                uint8_t* counts, int64_t rows_pad, void* stream);
+/* simrank_permute with a layout per side: *_rows_pad = 0 row-major (ld_* used), > 0 panel-blocked */
+SIMRANK_API int simrank_permute_layout(const void* src, int64_t ld_src, int64_t src_rows_pad,
+                                       void* dst, int64_t ld_dst, int64_t dst_rows_pad,
+                                       int64_t n_rows, int64_t n_cols, const int32_t* row_idx,
+                                       const int32_t* col_idx, int32_t elem_bytes, void* stream);
 
 /* ---- dense MFMA path (second `.dot(G.T)` of SimRank.py:139 when W really is dense) -- */
 /* Wd[a*ld + i] = rowscale[a] where (a,i) is stored, 0 elsewhere */

@@ -74,7 +74,13 @@ PROTOTYPES = {
     "simrank_topk_rows": [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp],
     "simrank_topk_rows_ids": [_vp, _i64, _i64, _i64, _i64, _vp, _i32, _i32, _vp, _vp, _vp],
     "simrank_permute": [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i32, _vp],
-    "simrank_evidence_live_segments": [_vp, _i64, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64), _vp],
+    "simrank_evidence_live_segments": [_vp, _i64, _i64, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64), _vp],
+    "simrank_fill_identity_blocked": [_vp, _i64, _i64, _i64, _i64, _vp],
+    "simrank_spmm_blocked": [_vp, _vp, _i64, _i64, _vp, _i64, _i32, C.POINTER(Epilogue), _vp],
+    "simrank_epilogue_apply_blocked": [_vp, _vp, _i64, _i64, _i64, C.POINTER(Epilogue), _vp],
+    "simrank_topk_rows_blocked": [_vp, _i64, _i64, _i64, _i64, _vp, _i32, _i32, _vp, _vp, _vp],
+    "simrank_evidence_counts_blocked": [_vp, _i64, _i64, _vp, _i64, _vp],
+    "simrank_permute_layout": [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i32, _vp],
     "simrank_evidence_counts": [_vp, _i64, _i64, _vp, _i64, _vp],
     "simrank_graph_densify": [_vp, _vp, _i64, _vp],
     "simrank_gemm_nt": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64,

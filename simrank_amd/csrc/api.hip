@@ -460,7 +460,7 @@ int simrank_set_tuning(const char* key, int64_t value) {
     } else if (!strcmp(key, "probe_flags")) {
         t.probe_flags = value & 15;
     } else if (!strcmp(key, "lean")) {
-        SR_REQUIRE(value >= 0 && value <= 2, "lean must be 0, 1 or 2");
+        SR_REQUIRE(value == 0 || value == 1, "lean must be 0 or 1");
         t.lean = value;
     } else if (!strcmp(key, "ids16")) {
         t.ids16 = value ? 1 : 0;

@@ -39,6 +39,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct DenseArgs {
     const float* X;
     int64_t ldx, L;
+    int64_t xpad;             // > 0: X is panel-blocked with this many rows per panel (ldx = 32)
     float* P;
     int64_t ldp;
     const int32_t* unit_row0;
@@ -98,7 +99,9 @@ __global__ __launch_bounds__(256, 2) void dense_tiles_kernel(const DenseArgs p) 
     if (wcol >= p.L) return;                       // no barrier in this kernel: a wave may leave
     const int64_t col = wcol + 2 * r;
     const bool col_ok = col < p.L;                 // (col + 1 may be L: inside the padded row)
-    const float* __restrict__ Xc = p.X + (col_ok ? col : 0);
+    // row-major X: element (i, c) at i * ldx + c; panel-blocked (xpad > 0): ((c >> 5) * xpad + i) * 32 + (c & 31)
+    const int64_t cc = col_ok ? col : 0;
+    const float* __restrict__ Xc = p.xpad ? p.X + ((cc >> 5) * p.xpad) * 32 + (cc & 31) : p.X + cc;
     const int k0 = p.unit_kofs[t], k1 = p.unit_kofs[t + 1];
 
     f32x16 acc[4][2];
@@ -356,6 +359,7 @@ int launch_dense_tiles(const simrank_graph* g, const float* X, int64_t ldx, int6
                        hipStream_t st, DenseUse* use) {
     simrank_dense_plan* pl = g->dense;
     SR_REQUIRE(pl && pl->n_units > 0, "graph has no dense plan");
+    // (ldx < 0: X is panel-blocked with -ldx rows per panel)
     SR_REQUIRE((reinterpret_cast<uintptr_t>(X) & 7u) == 0 && ldx % 2 == 0,
                "dense tiles need an 8-byte aligned operand");
     const int64_t ldp = (L + 63) / 64 * 64;
@@ -371,7 +375,8 @@ int launch_dense_tiles(const simrank_graph* g, const float* X, int64_t ldx, int6
         pl->part_cap = need;
     }
     DenseArgs a{};
-    a.X = X; a.ldx = ldx; a.L = L;
+    a.X = X; a.ldx = ldx < 0 ? 32 : ldx; a.L = L;
+    a.xpad = ldx < 0 ? -ldx : 0;
     a.P = pl->part; a.ldp = ldp;
     a.unit_row0 = pl->unit_row0; a.unit_slab = pl->unit_slab; a.unit_kofs = pl->unit_kofs;
     a.dcols = pl->dcols; a.afrag = pl->afrag;
@@ -404,8 +409,9 @@ int simrank_dense_part(const simrank_graph* g, const float* X, int64_t ldx, int6
                        void* stream) {
     SR_REQUIRE(g && X, "NULL argument");
     SR_REQUIRE(g->dense, "the graph has no dense sets");
-    SR_REQUIRE(n_cols_x > 0 && ldx >= n_cols_x, "X: %lld columns, ld %lld", (long long)n_cols_x,
-               (long long)ldx);
+    // (ldx < 0: X is panel-blocked with -ldx rows per panel)
+    SR_REQUIRE(n_cols_x > 0 && (ldx >= n_cols_x || -ldx >= g->n_cols), "X: %lld columns, ld %lld",
+               (long long)n_cols_x, (long long)ldx);
     DenseUse use;
     return launch_dense_tiles(g, X, ldx, n_cols_x, false, as_stream(stream), &use);
 }

@@ -47,8 +47,8 @@ struct Tuning {
     int64_t probe_mask = -1; // DIAGNOSTIC ONLY: gathered row ids are ANDed with this (wrong results; prices
                              // the memory path of the gather kernel: 255 = L1-resident operand, 8191 = L2-resident)
     int64_t probe_flags = 0; // DIAGNOSTIC ONLY (lean kernel): 1 no gathers, 2 no stores, 4 no dense partial sums, 8 no ids
-    int64_t lean = 1;        // 1: the lean gather kernel (32-float panels) where it applies, 2: also for
-                             // the plain (sharded leg 2) form, 0: the generic kernel everywhere
+    int64_t lean = 1;        // 1: the lean gather kernel (32-float panels, 32-row tiles) wherever it applies,
+                             // 0: the generic kernel everywhere (row-major operands only)
     int64_t ids16 = 1;       // stream neighbour ids as 16-bit values when the graph allows it
     int64_t dense_sym = -1;  // dense part in the upper-triangle form of leg 2: 1 yes, 0 no, -1 = when the
                              // dense sets hold at least half of the pattern's entries

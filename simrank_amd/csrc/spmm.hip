@@ -31,10 +31,22 @@ namespace simrank {
 
 __device__ __forceinline__ int64_t imin(int64_t a, int64_t b) { return a < b ? a : b; }
 
+// element (r, c) of a matrix: row-major with leading dimension ld (rows_pad == 0), or panel-blocked
+// (32-column panels of rows_pad rows: see SpmmArgs::blocked)
+__device__ __forceinline__ int64_t elem_at(int64_t r, int64_t c, int64_t ld, int64_t rows_pad) {
+    return rows_pad ? ((c >> 5) * rows_pad + r) * 32 + (c & 31) : r * ld + c;
+}
+
 struct SpmmArgs {
     const int32_t* rowptr;
     const int32_t* col;       // neighbour ids, ascending per row
     const uint16_t* col16;    // the same in 16 bits (NULL when the graph has more than 65536 columns)
+    // panel-blocked operands (lean kernel only): a matrix of R rows x C columns is stored as
+    // ceil(C/32) panels of rows_pad x 32 floats (u8 counts: 32 bytes), element (r, c) at
+    // ((c >> 5) * rows_pad + r) * 32 + (c & 31).  A panel's slice is then contiguous (4 MiB at
+    // N = 32768) instead of 32768 segments spread over 4 GB: the gathers stop missing the TLB.
+    int32_t blocked;
+    int64_t x_rows_pad, y_rows_pad;   // X; Y and the epilogue operands (and Y^T of a transposed store)
     int32_t idx_mask;         // diagnostic (tuning "probe_mask"): neighbour ids are ANDed with it; -1 = off
     int32_t probe;            // diagnostic (tuning "probe_flags", lean kernel): 1 no gathers, 2 no stores of Y,
                               // 4 no partial sums of the dense part, 8 no neighbour-id loads
@@ -159,14 +171,21 @@ __device__ __forceinline__ void emit_row(const SpmmArgs& p, float* tbuf_wave, in
 #pragma unroll
     for (int i = 0; i < VEC; ++i) o[i] = acc[i];
     if (p.dpart) {
+        // the slabs are summed first (in slab order) and added as ONE term, as the lean kernel does:
+        // both kernels then give the same bits
         const int ns = p.dnslab[a >> 7];
         const float* dp = p.dpart + (int64_t(p.dslab0[a >> 7]) * 128 + (a & 127)) * p.ldp + mycol;
+        float dsum[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) dsum[i] = 0.f;
         for (int s = 0; s < ns; ++s, dp += 128 * p.ldp) {        // fixed order
             float d[VEC];
             vload_nt<VEC>(d, dp);
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) o[i] += d[i];
+            for (int i = 0; i < VEC; ++i) dsum[i] += d[i];
         }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o[i] += dsum[i];
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) o[i] *= sc;
@@ -607,8 +626,8 @@ static int launch_spmm(SpmmArgs a, hipStream_t st) {
 //   * requests a row's partial sums of the matrix-core part before its gathers, four slabs at a time.
 // Same phases and the same summation order of a row's neighbours as the generic kernel (A0: huge rows
 // over the four waves; A: long rows over the 8 lane groups; B: one row per lane group); the dense
-// partial sums are added as one term (slabs summed first), so rows with a dense set may differ from
-// the generic kernel in the last bit.  Deterministic, and identical for 1 or P shards.
+// partial sums are added as one term (slabs summed first) in both kernels: same bits from either.
+// Deterministic, and identical for 1 or P shards.
 // ---------------------------------------------------------------------------------------
 template <bool IDS16>
 __device__ __forceinline__ int ld_id(const SpmmArgs& p, int j) {
@@ -729,8 +748,11 @@ __device__ __forceinline__ void dense_partial(const SpmmArgs& p, int64_t a, int6
 // emit_row of the generic kernel with the row scale and the dense partial sums handed in
 template <int MODE>
 __device__ __forceinline__ void emit_row3(const SpmmArgs& p, float* tbuf_wave, int r_local, int64_t a,
-                                          int q, int64_t mycol, float rowscale, const float (&acc)[4],
-                                          const float (&dsum)[4], unsigned& changed, bool mirror) {
+                                          int q, int64_t mycol, int64_t colofs, float rowscale,
+                                          const float (&acc)[4], const float (&dsum)[4], unsigned& changed,
+                                          bool mirror) {
+    // colofs: where this lane's 4 columns start inside a row of Y / prev / prior / evidence
+    // (row-major: the column; panel-blocked: the panel's base + 4 q, rows then 32 apart)
     constexpr int RT = 32;
     const float sc = rowscale * (p.has_ep ? p.coef : 1.0f);
     float o[4] = {acc[0] + dsum[0], acc[1] + dsum[1], acc[2] + dsum[2], acc[3] + dsum[3]};
@@ -745,7 +767,7 @@ __device__ __forceinline__ void emit_row3(const SpmmArgs& p, float* tbuf_wave, i
         if (p.has_ep) {
             if (p.ev) {
                 const unsigned w = __builtin_nontemporal_load(
-                    reinterpret_cast<const unsigned*>(p.ev + a * p.ld_ev + mycol));
+                    reinterpret_cast<const unsigned*>(p.ev + a * p.ld_ev + colofs));
                 o[0] *= 1.0f - __builtin_ldexpf(1.0f, -int(w & 255u));
                 o[1] *= 1.0f - __builtin_ldexpf(1.0f, -int((w >> 8) & 255u));
                 o[2] *= 1.0f - __builtin_ldexpf(1.0f, -int((w >> 16) & 255u));
@@ -753,7 +775,7 @@ __device__ __forceinline__ void emit_row3(const SpmmArgs& p, float* tbuf_wave, i
             }
             if (p.ap) {
                 float pr[4];
-                vload_nt<4>(pr, p.ap + a * p.ld_ap + mycol);
+                vload_nt<4>(pr, p.ap + a * p.ld_ap + colofs);
                 const float keep = 1.0f - p.lbd;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = keep * o[i] + p.lbd * pr[i];
@@ -766,7 +788,7 @@ __device__ __forceinline__ void emit_row3(const SpmmArgs& p, float* tbuf_wave, i
             }
             if (p.prev) {
                 float old[4];
-                vload_nt<4>(old, p.prev + a * p.ld_prev + mycol);
+                vload_nt<4>(old, p.prev + a * p.ld_prev + colofs);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     changed += (i < nvalid && fabs(double(o[i]) - double(old[i])) > p.eps)
@@ -780,7 +802,7 @@ __device__ __forceinline__ void emit_row3(const SpmmArgs& p, float* tbuf_wave, i
                 for (int i = 0; i < 4; ++i) t[i * (RT + 1)] = o[i];
             }
         }
-        float* y = p.Y + a * p.ldy + mycol;
+        float* y = p.Y + a * p.ldy + colofs;
         if (p.probe & 2) {
         } else if (nvalid == 4) {
             if (p.nt) vstore_nt<4>(y, o); else vstore<4>(y, o);
@@ -840,8 +862,10 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
     const int64_t mycol = c0 + int64_t(q) * 4;
     const bool col_active = mycol < p.L;
     // lanes past the last column gather from column 0 (valid memory); nothing of theirs is stored
-    const float* __restrict__ Xc = p.X + (col_active ? mycol : 0);
-    const uint32_t pitch16 = uint32_t(p.ldx >> 2);
+    const float* __restrict__ Xc = p.blocked ? p.X + (int64_t(panel) * p.x_rows_pad) * 32 + q * 4
+                                             : p.X + (col_active ? mycol : 0);
+    const uint32_t pitch16 = uint32_t(p.ldx >> 2);            // (blocked: ldx = 32)
+    const int64_t colofs = p.blocked ? (int64_t(panel) * p.y_rows_pad) * 32 + q * 4 : mycol;
     float* tbuf_wave = smem + (TILE ? wave * PW * (RT + 1) : 0);
     unsigned changed = 0;
 
@@ -945,7 +969,7 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
 #pragma unroll
                         for (int k = 0; k < 4; ++k) acc[k] += t[k];
                     }
-                    emit_row3<MODE>(p, tbuf_wave, r, int64_t(row0) + r, q, mycol, sc, acc, dsum, changed, mirror);
+                    emit_row3<MODE>(p, tbuf_wave, r, int64_t(row0) + r, q, mycol, colofs, sc, acc, dsum, changed, mirror);
                 }
             }
         }
@@ -963,7 +987,7 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
         bool live = true;
         if constexpr (RESTRICT) {
             const unsigned w = col_active ? *reinterpret_cast<const unsigned*>(
-                                                p.ev + (int64_t(row0) + r) * p.ld_ev + mycol) : 0u;
+                                                p.ev + (int64_t(row0) + r) * p.ld_ev + colofs) : 0u;
             live = __ballot(w != 0u) != 0;                           // uniform: the row's 32 columns
         }
         if (live) {
@@ -973,7 +997,7 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
             for (int i = 0; i < 4; ++i) acc[i] = 0.f;
         }
         if (g == 0 && col_active)
-            emit_row3<MODE>(p, tbuf_wave, r, int64_t(row0) + r, q, mycol, sc, acc, dsum, changed, mirror);
+            emit_row3<MODE>(p, tbuf_wave, r, int64_t(row0) + r, q, mycol, colofs, sc, acc, dsum, changed, mirror);
     }
 
     // ---- phase B: the other rows, 8 at a time, one row per lane group; the ids of the next chunk
@@ -996,7 +1020,7 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
         auto group_live = [&](int row, bool on) -> bool {
             if constexpr (!RESTRICT) return true;
             const unsigned w = on ? *reinterpret_cast<const unsigned*>(
-                                        p.ev + (int64_t(row0) + row) * p.ld_ev + mycol) : 0u;
+                                        p.ev + (int64_t(row0) + row) * p.ld_ev + colofs) : 0u;
             return ((__ballot(w != 0u) >> gbase) & 0xFFull) != 0;
         };
         bool glive = group_live(r, src < nrows && col_active);
@@ -1025,7 +1049,7 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
 
             if (!same_pass) {
                 if (pos + g < nrows && col_active)
-                    emit_row3<MODE>(p, tbuf_wave, r, int64_t(row0) + r, q, mycol, sc, acc, dsum, changed, mirror);
+                    emit_row3<MODE>(p, tbuf_wave, r, int64_t(row0) + r, q, mycol, colofs, sc, acc, dsum, changed, mirror);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] = 0.f;
                 if (more) {
@@ -1042,7 +1066,28 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
         __syncthreads();
         const int cols_here = int(imin(PW, p.L - c0));
         const int rows_out = ((TRANS || mirror) && !(p.probe & 2)) ? nrows : 0;
-        if (rows_out > 0) {
+        if (rows_out > 0 && p.blocked) {
+            // panel-blocked Y^T: the tile's 32 c-rows are consecutive 128-byte lines of panel row0 / 32
+            float* base = p.Y + ((int64_t(row0 >> 5) * p.y_rows_pad) + c0) * 32 + (row0 & 31);
+            if (rows_out == RT && cols_here == PW) {
+#pragma unroll
+                for (int it = 0; it < PW * (RT / 4) / 64; ++it) {
+                    const int x = lane + it * 64;
+                    const int c = x >> 3;
+                    const int r4 = (x & 7) * 4;
+                    const float* t = tbuf_wave + c * (RT + 1) + r4;
+                    const float v4[4] = {t[0], t[1], t[2], t[3]};
+                    float* dst = base + c * 32 + r4;
+                    if (p.nt) vstore_nt<4>(dst, v4); else vstore<4>(dst, v4);
+                }
+            } else {
+                for (int x = lane; x < PW * RT; x += 64) {
+                    const int c = x >> 5;
+                    const int r = x & 31;
+                    if (c < cols_here && r < rows_out) base[c * 32 + r] = tbuf_wave[c * (RT + 1) + r];
+                }
+            }
+        } else if (rows_out > 0) {
             // where the tile lands: Y^T rows are the tile's columns; block h of t_block rows is
             // contiguous.  A tile never crosses more than one block boundary when t_block >= 32.
             const int64_t tb = p.tblock;
@@ -1147,24 +1192,44 @@ __global__ __launch_bounds__(256) void fill_identity_kernel(float* S, int64_t n_
     }
 }
 
+// panel-blocked: the buffer is zeroed by a memset, this sets the ones
+__global__ __launch_bounds__(256) void set_diagonal_blocked_kernel(float* S, int64_t n_rows, int64_t n_cols,
+                                                                   int64_t rows_pad, int64_t col0) {
+    for (int64_t c = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; c < n_cols;
+         c += int64_t(gridDim.x) * blockDim.x)
+        if (col0 + c < n_rows) S[elem_at(col0 + c, c, 0, rows_pad)] = 1.0f;
+}
+
 // ---------------------------------------------------------------------------------------
 // K4/K5 stand-alone: element-wise epilogue over a block (asymmetric-prior path)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void epilogue_kernel(const float* __restrict__ Q, int64_t ldq,
                                                        float* Y, int64_t ldy, int64_t n_rows,
                                                        int64_t n_cols, const SpmmArgs p) {
-    const int64_t total = n_rows * n_cols;
+    // (p.y_rows_pad > 0: every operand is panel-blocked with that many rows per panel; a thread
+    // then walks (panel, row, column in panel) so that consecutive threads touch consecutive floats)
+    const int64_t rp = p.y_rows_pad;
+    const int64_t width = rp ? ((n_cols + 31) >> 5) * 32 : n_cols;
+    const int64_t total = n_rows * width;
     unsigned changed = 0;
     for (int64_t t = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; t < total;
          t += int64_t(gridDim.x) * blockDim.x) {
-        const int64_t a = t / n_cols;
-        const int64_t c = t - a * n_cols;
-        float v = Q[a * ldq + c] * p.coef;
-        if (p.ev) v *= 1.0f - __builtin_ldexpf(1.0f, -int(p.ev[a * p.ld_ev + c]));
-        if (p.ap) v = (1.0f - p.lbd) * v + p.lbd * p.ap[a * p.ld_ap + c];
+        int64_t a, c;
+        if (rp) {
+            const int64_t pn = t / (n_rows * 32), rest = t - pn * (n_rows * 32);
+            a = rest >> 5;
+            c = pn * 32 + (rest & 31);
+            if (c >= n_cols) continue;
+        } else {
+            a = t / n_cols;
+            c = t - a * n_cols;
+        }
+        float v = Q[elem_at(a, c, ldq, rp)] * p.coef;
+        if (p.ev) v *= 1.0f - __builtin_ldexpf(1.0f, -int(p.ev[elem_at(a, c, p.ld_ev, rp)]));
+        if (p.ap) v = (1.0f - p.lbd) * v + p.lbd * p.ap[elem_at(a, c, p.ld_ap, rp)];
         if (p.set_diag && a == p.diag_col0 + c) v = 1.0f;
-        if (p.prev) changed += fabs(double(v) - double(p.prev[a * p.ld_prev + c])) > p.eps ? 1u : 0u;
-        Y[a * ldy + c] = v;
+        if (p.prev) changed += fabs(double(v) - double(p.prev[elem_at(a, c, p.ld_prev, rp)])) > p.eps ? 1u : 0u;
+        Y[elem_at(a, c, ldy, rp)] = v;
     }
     if (p.prev) {
 #pragma unroll
@@ -1182,7 +1247,7 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const float* __restrict__
 // re-read k times from L2 (a 128 KiB row stays resident).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ S, int64_t ld,
-                                                        int64_t n_rows, int64_t n_cols,
+                                                        int64_t rows_pad, int64_t n_rows, int64_t n_cols,
                                                         int64_t col0, int k, int exclude_diag,
                                                         const int32_t* __restrict__ col_ids,
                                                         int32_t* idx_out, float* val_out) {
@@ -1190,7 +1255,6 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
     const int64_t wave = (blockIdx.x * int64_t(blockDim.x) + threadIdx.x) >> 6;
     const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
     for (int64_t a = wave; a < n_rows; a += nwaves) {
-        const float* row = S + a * ld;
         const int64_t skip = exclude_diag ? a - col0 : -1;
         float pv = __builtin_inff();   // previous pick: everything is "after" (+inf, -1)
         int pi = -1;
@@ -1198,7 +1262,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
             float bv = -__builtin_inff();
             int bi = 0x7fffffff;
             for (int64_t c = lane; c < n_cols; c += 64) {
-                const float v = row[c];
+                const float v = S[elem_at(a, c, ld, rows_pad)];
                 const int id = col_ids ? col_ids[c] : int(col0 + c);
                 const bool after = (v < pv) || (v == pv && id > pi);
                 const bool better = (v > bv) || (v == bv && id < bi);
@@ -1233,15 +1297,17 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void permute_kernel(const T* __restrict__ src, int64_t ld_src,
-                                                      T* __restrict__ dst, int64_t ld_dst,
-                                                      int64_t n_rows, int64_t n_cols,
+                                                      int64_t pad_src, T* __restrict__ dst,
+                                                      int64_t ld_dst, int64_t pad_dst, int64_t n_rows,
+                                                      int64_t n_cols,
                                                       const int32_t* __restrict__ row_idx,
                                                       const int32_t* __restrict__ col_idx) {
+    // pad_* > 0: that side is panel-blocked with so many rows per panel (this is also how a
+    // matrix moves between the two layouts)
     for (int64_t i = blockIdx.x; i < n_rows; i += gridDim.x) {
-        const T* in = src + int64_t(row_idx ? row_idx[i] : i) * ld_src;
-        T* out = dst + i * ld_dst;
+        const int64_t ri = row_idx ? row_idx[i] : i;
         for (int64_t j = threadIdx.x; j < n_cols; j += blockDim.x)
-            out[j] = in[col_idx ? col_idx[j] : j];
+            dst[elem_at(i, j, ld_dst, pad_dst)] = src[elem_at(ri, col_idx ? col_idx[j] : j, ld_src, pad_src)];
     }
 }
 
@@ -1255,7 +1321,7 @@ __global__ __launch_bounds__(256) void evidence_counts_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ rowscale, const int32_t* __restrict__ t_rowptr,
     const int32_t* __restrict__ t_col, int64_t M, int64_t col0, int n_cols, uint8_t* out,
-    int64_t ld) {
+    int64_t ld, int64_t rows_pad, int64_t out_col0) {
     extern __shared__ unsigned cnt[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1276,9 +1342,8 @@ __global__ __launch_bounds__(256) void evidence_counts_kernel(
             }
         }
         __syncthreads();
-        uint8_t* o = out + a * ld;
         for (int c = tid; c < n_cols; c += 256) {
-            o[c] = (uint8_t)min(cnt[c], 255u);
+            out[elem_at(a, out_col0 + c, ld, rows_pad)] = (uint8_t)min(cnt[c], 255u);
             cnt[c] = 0;
         }
     }
@@ -1286,7 +1351,7 @@ __global__ __launch_bounds__(256) void evidence_counts_kernel(
 
 // 32-column segments (aligned to 32) of a u8 count block that hold a nonzero count
 __global__ __launch_bounds__(256) void live_segments_kernel(const uint8_t* __restrict__ cnt, int64_t ld,
-                                                            int64_t n_rows, int64_t n_cols,
+                                                            int64_t rows_pad, int64_t n_rows, int64_t n_cols,
                                                             unsigned long long* live) {
     const int64_t segs = (n_cols + 31) / 32;
     const int64_t total = n_rows * segs;
@@ -1294,7 +1359,7 @@ __global__ __launch_bounds__(256) void live_segments_kernel(const uint8_t* __res
     for (int64_t t = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; t < total;
          t += int64_t(gridDim.x) * blockDim.x) {
         const int64_t a = t / segs, sgm = t - a * segs;
-        const uint8_t* row = cnt + a * ld + sgm * 32;
+        const uint8_t* row = cnt + elem_at(a, sgm * 32, ld, rows_pad);
         const int n = int(imin(32, n_cols - sgm * 32));
         unsigned any = 0;
         for (int c = 0; c < n; ++c) any |= row[c];
@@ -1311,16 +1376,18 @@ using namespace simrank;
 
 extern "C" {
 
-int simrank_evidence_live_segments(const uint8_t* counts, int64_t ld, int64_t n_rows, int64_t n_cols,
-                                   int64_t* live, int64_t* total, void* stream) {
-    SR_REQUIRE(counts && live && total && n_rows > 0 && n_cols > 0 && ld >= n_cols, "bad evidence block");
+int simrank_evidence_live_segments(const uint8_t* counts, int64_t ld, int64_t rows_pad, int64_t n_rows,
+                                   int64_t n_cols, int64_t* live, int64_t* total, void* stream) {
+    SR_REQUIRE(counts && live && total && n_rows > 0 && n_cols > 0 &&
+                   (rows_pad ? rows_pad >= n_rows : ld >= n_cols), "bad evidence block");
     unsigned long long* d = nullptr;
     SR_HIP(hipMalloc((void**)&d, sizeof(unsigned long long)));
     hipStream_t st = as_stream(stream);
     hipError_t e = hipMemsetAsync(d, 0, sizeof(unsigned long long), st);
     unsigned long long h = 0;
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(live_segments_kernel, dim3(256 * 8), dim3(256), 0, st, counts, ld, n_rows, n_cols, d);
+        hipLaunchKernelGGL(live_segments_kernel, dim3(256 * 8), dim3(256), 0, st, counts, ld, rows_pad, n_rows,
+                           n_cols, d);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, st);
@@ -1346,18 +1413,18 @@ int simrank_fill_identity(float* S, int64_t n_rows, int64_t n_cols, int64_t ld, 
     return SIMRANK_OK;
 }
 
-int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_cols_x,
-                 float* Y, int64_t ldy, int32_t transpose_out, int64_t t_block, int64_t t_pad,
-                 const simrank_epilogue* ep, void* stream) {
+static int spmm_impl(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_cols_x,
+                     float* Y, int64_t ldy, int32_t transpose_out, int64_t t_block, int64_t t_pad,
+                     const simrank_epilogue* ep, void* stream, bool blocked, int64_t x_rows_pad,
+                     int64_t y_rows_pad) {
     SR_REQUIRE(t_pad >= 0 && t_pad < 4096, "t_pad out of range");
     SR_REQUIRE(g && X && Y, "NULL argument");
     const Tuning& T = g->tun;        // the knobs as they were when the graph was created
-    SR_REQUIRE(n_cols_x > 0 && ldx >= n_cols_x, "X: %lld columns, ld %lld", (long long)n_cols_x,
-               (long long)ldx);
-    SR_REQUIRE(transpose_out || ldy >= n_cols_x, "Y: ld %lld < %lld columns", (long long)ldy,
-               (long long)n_cols_x);
     SR_REQUIRE(!(transpose_out && ep), "an epilogue needs transpose_out = 0");
     SpmmArgs a{};
+    a.blocked = blocked ? 1 : 0;
+    a.x_rows_pad = x_rows_pad;
+    a.y_rows_pad = y_rows_pad;
     a.rowptr = g->rowptr;
     a.col = g->col;
     a.col16 = T.ids16 ? g->col16 : nullptr;
@@ -1398,9 +1465,10 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
         a.diag_col0 = ep->diag_col0;
         a.set_diag = ep->set_diag;
         a.restrict_support = ep->restrict_support;
-        SR_REQUIRE(!a.ev || a.ld_ev >= n_cols_x, "evidence ld too small");
-        SR_REQUIRE(!a.ap || a.ld_ap >= n_cols_x, "apriori ld too small");
-        SR_REQUIRE(!a.prev || (a.ld_prev >= n_cols_x && a.n_changed),
+        if (blocked) a.ld_ev = a.ld_ap = a.ld_prev = 32;      // rows of a panel are 32 elements apart
+        SR_REQUIRE(!a.ev || a.ld_ev >= n_cols_x || blocked, "evidence ld too small");
+        SR_REQUIRE(!a.ap || a.ld_ap >= n_cols_x || blocked, "apriori ld too small");
+        SR_REQUIRE(!a.prev || ((a.ld_prev >= n_cols_x || blocked) && a.n_changed),
                    "previous needs ld >= columns and a counter");
         if (a.ev) vec_ok = vec_ok && (reinterpret_cast<uintptr_t>(a.ev) % 4 == 0) && a.ld_ev % 4 == 0;
         if (a.ap) vec_ok = vec_ok && aligned16(a.ap) && a.ld_ap % 4 == 0;
@@ -1428,7 +1496,7 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
     }
     if (dp) {
         DenseUse use;
-        const int rc = launch_dense_tiles(g, X, ldx, n_cols_x, want_sym, st, &use);
+        const int rc = launch_dense_tiles(g, X, blocked ? -x_rows_pad : ldx, n_cols_x, want_sym, st, &use);
         if (rc) return rc;
         a.dpart = use.part;
         a.ldp = use.ldp;
@@ -1449,6 +1517,7 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
         }
     }
     if (!vec_ok) {
+        SR_REQUIRE(!blocked, "panel-blocked operands must be 16-byte aligned");
         return transpose_out ? launch_spmm<1, 32, kTrans, 32>(a, st)
                              : launch_spmm<1, 32, kPlain, 32>(a, st);
     }
@@ -1456,6 +1525,12 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
     const bool lean_ok = T.lean && tile == 32 && ldx / 4 < (int64_t(1) << 24) &&
                          g->n_cols < (int64_t(1) << 24) && g->n_cols * (ldx / 4) < (int64_t(1) << 32) &&
                          g->n_rows < (int64_t(1) << 30);
+    if (blocked) {
+        SR_REQUIRE(lean_ok && (T.panel == 0 || T.panel == 32),
+                   "panel-blocked operands need the lean kernel (tile 32, panel 32, < 2^24 rows)");
+        if (want_sym) return launch_gather3<kSym>(a, st);
+        return transpose_out ? launch_gather3<kTrans>(a, st) : launch_gather3<kPlain>(a, st);
+    }
     if (lean_ok && want_sym) {
         a.tblock = g->n_rows;
         a.tstride = ldy;
@@ -1463,8 +1538,7 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
     }
     if (lean_ok && transpose_out && (T.panel == 0 || T.panel == 32))
         return launch_gather3<kTrans>(a, st);
-    if (lean_ok && !transpose_out &&
-        ((T.lean == 2 || (a.has_ep && a.ev && a.restrict_support)) ? (T.panel == 0 || T.panel == 32) : T.panel == 32))
+    if (lean_ok && !transpose_out && (T.panel == 0 || T.panel == 32))
         return launch_gather3<kPlain>(a, st);
 #define SR_TILE_SWITCH(LPR, TR)                                             \
     switch (tile) {                                                         \
@@ -1497,11 +1571,44 @@ int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_
 #undef SR_TILE_SWITCH
 }
 
-int simrank_epilogue_apply(const float* Q, int64_t ldq, float* Y, int64_t ldy, int64_t n_rows,
-                           int64_t n_cols, const simrank_epilogue* ep, void* stream) {
+int simrank_fill_identity_blocked(float* S, int64_t n_rows, int64_t n_cols, int64_t rows_pad,
+                                  int64_t col0, void* stream) {
+    SR_REQUIRE(S && n_rows > 0 && n_cols > 0 && rows_pad >= n_rows, "bad identity block");
+    const size_t bytes = size_t((n_cols + 31) / 32) * size_t(rows_pad) * 32 * sizeof(float);
+    SR_HIP(hipMemsetAsync(S, 0, bytes, as_stream(stream)));
+    const int grid = (int)std::min<int64_t>((n_cols + 255) / 256, 256 * 4);
+    hipLaunchKernelGGL(set_diagonal_blocked_kernel, dim3(grid), dim3(256), 0, as_stream(stream), S, n_rows,
+                       n_cols, rows_pad, col0);
+    SR_HIP(hipGetLastError());
+    return SIMRANK_OK;
+}
+
+int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx, int64_t n_cols_x,
+                 float* Y, int64_t ldy, int32_t transpose_out, int64_t t_block, int64_t t_pad,
+                 const simrank_epilogue* ep, void* stream) {
+    SR_REQUIRE(n_cols_x > 0 && ldx >= n_cols_x, "X: %lld columns, ld %lld", (long long)n_cols_x,
+               (long long)ldx);
+    SR_REQUIRE(transpose_out || ldy >= n_cols_x, "Y: ld %lld < %lld columns", (long long)ldy,
+               (long long)n_cols_x);
+    return spmm_impl(g, X, ldx, n_cols_x, Y, ldy, transpose_out, t_block, t_pad, ep, stream, false, 0, 0);
+}
+
+int simrank_spmm_blocked(const simrank_graph* g, const float* X, int64_t x_rows_pad, int64_t n_cols_x,
+                         float* Y, int64_t y_rows_pad, int32_t transpose_out,
+                         const simrank_epilogue* ep, void* stream) {
+    SR_REQUIRE(g && n_cols_x > 0, "bad arguments");
+    SR_REQUIRE(x_rows_pad >= g->n_cols && y_rows_pad >= (transpose_out ? n_cols_x : g->n_rows),
+               "padded row counts %lld / %lld too small", (long long)x_rows_pad, (long long)y_rows_pad);
+    return spmm_impl(g, X, 32, n_cols_x, Y, 32, transpose_out, 0, 0, ep, stream, true, x_rows_pad, y_rows_pad);
+}
+
+static int epilogue_apply_impl(const float* Q, int64_t ldq, float* Y, int64_t ldy, int64_t n_rows,
+                               int64_t n_cols, const simrank_epilogue* ep, void* stream, int64_t rows_pad) {
     SR_REQUIRE(Q && Y && ep, "NULL argument");
-    SR_REQUIRE(n_rows > 0 && n_cols > 0 && ldq >= n_cols && ldy >= n_cols, "bad block shape");
+    SR_REQUIRE(n_rows > 0 && n_cols > 0 && (rows_pad ? rows_pad >= n_rows : (ldq >= n_cols && ldy >= n_cols)),
+               "bad block shape");
     SpmmArgs a{};
+    a.y_rows_pad = rows_pad;
     a.has_ep = 1;
     a.coef = ep->coef;
     a.lbd = ep->lbd;
@@ -1525,17 +1632,40 @@ int simrank_epilogue_apply(const float* Q, int64_t ldq, float* Y, int64_t ldy, i
     return SIMRANK_OK;
 }
 
+int simrank_epilogue_apply(const float* Q, int64_t ldq, float* Y, int64_t ldy, int64_t n_rows,
+                           int64_t n_cols, const simrank_epilogue* ep, void* stream) {
+    return epilogue_apply_impl(Q, ldq, Y, ldy, n_rows, n_cols, ep, stream, 0);
+}
+
+int simrank_epilogue_apply_blocked(const float* Q, float* Y, int64_t n_rows, int64_t n_cols,
+                                   int64_t rows_pad, const simrank_epilogue* ep, void* stream) {
+    return epilogue_apply_impl(Q, 32, Y, 32, n_rows, n_cols, ep, stream, rows_pad);
+}
+
+static int topk_impl(const float* S, int64_t ld, int64_t rows_pad, int64_t n_rows, int64_t n_cols,
+                     int64_t col0, const int32_t* col_ids, int32_t k, int32_t exclude_diag,
+                     int32_t* idx_out, float* val_out, void* stream) {
+    SR_REQUIRE(S && idx_out && val_out, "NULL argument");
+    SR_REQUIRE(n_rows > 0 && n_cols > 0 && (rows_pad ? rows_pad >= n_rows : ld >= n_cols) &&
+                   n_cols < (int64_t(1) << 31) && k > 0 && k <= 1024, "bad top-k request");
+    const int grid = (int)std::min<int64_t>((n_rows + 3) / 4, 256 * 8);
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), S, ld, rows_pad,
+                       n_rows, n_cols, col0, k, exclude_diag, col_ids, idx_out, val_out);
+    SR_HIP(hipGetLastError());
+    return SIMRANK_OK;
+}
+
 int simrank_topk_rows_ids(const float* S, int64_t ld, int64_t n_rows, int64_t n_cols, int64_t col0,
                           const int32_t* col_ids, int32_t k, int32_t exclude_diag,
                           int32_t* idx_out, float* val_out, void* stream) {
-    SR_REQUIRE(S && idx_out && val_out, "NULL argument");
-    SR_REQUIRE(n_rows > 0 && n_cols > 0 && ld >= n_cols && n_cols < (int64_t(1) << 31) && k > 0 &&
-                   k <= 1024, "bad top-k request");
-    const int grid = (int)std::min<int64_t>((n_rows + 3) / 4, 256 * 8);
-    hipLaunchKernelGGL(topk_rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), S, ld, n_rows,
-                       n_cols, col0, k, exclude_diag, col_ids, idx_out, val_out);
-    SR_HIP(hipGetLastError());
-    return SIMRANK_OK;
+    return topk_impl(S, ld, 0, n_rows, n_cols, col0, col_ids, k, exclude_diag, idx_out, val_out, stream);
+}
+
+int simrank_topk_rows_blocked(const float* S, int64_t rows_pad, int64_t n_rows, int64_t n_cols,
+                              int64_t col0, const int32_t* col_ids, int32_t k, int32_t exclude_diag,
+                              int32_t* idx_out, float* val_out, void* stream) {
+    return topk_impl(S, 32, rows_pad, n_rows, n_cols, col0, col_ids, k, exclude_diag, idx_out, val_out,
+                     stream);
 }
 
 int simrank_topk_rows(const float* S, int64_t ld, int64_t n_rows, int64_t n_cols, int64_t col0,
@@ -1545,27 +1675,39 @@ int simrank_topk_rows(const float* S, int64_t ld, int64_t n_rows, int64_t n_cols
                                  val_out, stream);
 }
 
-int simrank_permute(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t n_rows,
-                    int64_t n_cols, const int32_t* row_idx, const int32_t* col_idx,
-                    int32_t elem_bytes, void* stream) {
+int simrank_permute_layout(const void* src, int64_t ld_src, int64_t src_rows_pad, void* dst,
+                           int64_t ld_dst, int64_t dst_rows_pad, int64_t n_rows, int64_t n_cols,
+                           const int32_t* row_idx, const int32_t* col_idx, int32_t elem_bytes,
+                           void* stream) {
     SR_REQUIRE(src && dst && src != dst, "permute needs two distinct matrices");
-    SR_REQUIRE(n_rows > 0 && n_cols > 0 && ld_dst >= n_cols && ld_src > 0, "bad block shape");
+    SR_REQUIRE(n_rows > 0 && n_cols > 0 && (dst_rows_pad ? dst_rows_pad >= n_rows : ld_dst >= n_cols) &&
+                   (src_rows_pad > 0 || ld_src > 0), "bad block shape");
     SR_REQUIRE(elem_bytes == 1 || elem_bytes == 4, "elem_bytes must be 1 (u8) or 4 (f32)");
     const int grid = (int)std::min<int64_t>(n_rows, 256 * 16);
     if (elem_bytes == 4)
         hipLaunchKernelGGL(permute_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream),
-                           (const float*)src, ld_src, (float*)dst, ld_dst, n_rows, n_cols, row_idx, col_idx);
+                           (const float*)src, ld_src, src_rows_pad, (float*)dst, ld_dst, dst_rows_pad,
+                           n_rows, n_cols, row_idx, col_idx);
     else
         hipLaunchKernelGGL(permute_kernel<uint8_t>, dim3(grid), dim3(256), 0, as_stream(stream),
-                           (const uint8_t*)src, ld_src, (uint8_t*)dst, ld_dst, n_rows, n_cols, row_idx, col_idx);
+                           (const uint8_t*)src, ld_src, src_rows_pad, (uint8_t*)dst, ld_dst, dst_rows_pad,
+                           n_rows, n_cols, row_idx, col_idx);
     SR_HIP(hipGetLastError());
     return SIMRANK_OK;
 }
 
-int simrank_evidence_counts(const simrank_graph* g, int64_t col0, int64_t n_cols,
-                            uint8_t* counts, int64_t ld, void* stream) {
+int simrank_permute(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t n_rows,
+                    int64_t n_cols, const int32_t* row_idx, const int32_t* col_idx,
+                    int32_t elem_bytes, void* stream) {
+    return simrank_permute_layout(src, ld_src, 0, dst, ld_dst, 0, n_rows, n_cols, row_idx, col_idx,
+                                  elem_bytes, stream);
+}
+
+static int evidence_counts_impl(const simrank_graph* g, int64_t col0, int64_t n_cols, uint8_t* counts,
+                                int64_t ld, int64_t rows_pad, void* stream) {
     SR_REQUIRE(g && counts, "NULL argument");
-    SR_REQUIRE(col0 >= 0 && n_cols > 0 && col0 + n_cols <= g->n_rows && ld >= n_cols,
+    SR_REQUIRE(col0 >= 0 && n_cols > 0 && col0 + n_cols <= g->n_rows &&
+                   (rows_pad ? rows_pad >= g->n_rows : ld >= n_cols),
                "evidence block [%lld, %lld) of %lld, ld %lld", (long long)col0,
                (long long)(col0 + n_cols), (long long)g->n_rows, (long long)ld);
     const int grid = (int)std::min<int64_t>(g->n_rows, 256 * 2);
@@ -1573,10 +1715,20 @@ int simrank_evidence_counts(const simrank_graph* g, int64_t col0, int64_t n_cols
         const int nc = (int)std::min<int64_t>(kEvChunk, n_cols - c);
         hipLaunchKernelGGL(evidence_counts_kernel, dim3(grid), dim3(256), size_t(nc) * 4,
                            as_stream(stream), g->rowptr, g->col, g->rowscale, g->t_rowptr,
-                           g->t_col, g->n_rows, col0 + c, nc, counts + c, ld);
+                           g->t_col, g->n_rows, col0 + c, nc, counts, ld, rows_pad, c);
         SR_HIP(hipGetLastError());
     }
     return SIMRANK_OK;
+}
+
+int simrank_evidence_counts(const simrank_graph* g, int64_t col0, int64_t n_cols,
+                            uint8_t* counts, int64_t ld, void* stream) {
+    return evidence_counts_impl(g, col0, n_cols, counts, ld, 0, stream);
+}
+
+int simrank_evidence_counts_blocked(const simrank_graph* g, int64_t col0, int64_t n_cols,
+                                    uint8_t* counts, int64_t rows_pad, void* stream) {
+    return evidence_counts_impl(g, col0, n_cols, counts, 32, rows_pad, stream);
 }
 
 }  // extern "C"

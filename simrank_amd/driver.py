@@ -321,8 +321,9 @@ class SideSpec:
 
 class Side:
     def __init__(self, ops, spec: SideSpec, rank: int, world: int, mode: str, torch_buffers: bool,
-                 stages: int = 1):
+                 stages: int = 1, blocked: bool = False):
         self.ops, self.spec, self.rank, self.world, self.mode = ops, spec, rank, world, mode
+        self.blocked = blocked         # single rank, gather legs: every matrix panel-blocked
         csr = spec.csr
         if stages == 0:
             stages = auto_stages(csr.n_cols, world)
@@ -355,7 +356,8 @@ class Side:
         self.ev = None
         if spec.evidence_from is not None:
             ev = spec.evidence_from
-            self.ev = ops.matrix(self.M, self.Lm, np.uint8)
+            self.ev = (ops.matrix(self.M, self.Lm, np.uint8, blocked=True) if self.blocked
+                       else ops.matrix(self.M, self.Lm, np.uint8))
             if ev.n_rows == self.M:
                 eg = self.graph if ev is csr else ops.graph(ev)
                 ops.evidence_counts(eg, self.m_lo, self.ev)
@@ -381,14 +383,16 @@ class Side:
             if a.shape != (self.M, self.M):
                 raise ValueError(f"operands could not be broadcast together with shapes "
                                  f"({self.M},{self.M}) {a.shape} ")
-            self.ap = ops.matrix(self.M, self.Lm)
+            self.ap = ops.matrix(self.M, self.Lm, blocked=True) if self.blocked else ops.matrix(self.M, self.Lm)
             ops.upload(self.ap, a[:, self.m_lo:self.m_hi].astype(np.float32))
 
     def _xfer(self, ncols, col_lo, col_dim, torch_buffers) -> Xfer:
         o = self.ops
         x = Xfer(o, self.rank, None, None, ncols, col_lo, col_dim, self.M, self.mb, self.Lm)
         if self.world == 1 and not torch_buffers:
-            x.send = x.recv = o.matrix(col_dim, self.M)          # pitched; recv aliases send
+            # one rank: recv aliases send (pitched rows, or panel-blocked with the solver's matrices)
+            x.send = x.recv = (o.matrix(col_dim, self.M, blocked=True) if self.blocked
+                               else o.matrix(col_dim, self.M))
             return x
         x.pad = row_pad(self.mb)
         send_ld = self.M + self.world * x.pad                    # floats per column, all chunks
@@ -557,8 +561,14 @@ class Solver:
                                 all(s.symmetric for s in specs))
         torch_buffers = isinstance(world, TorchWorld)
         self.ops = {r: make_ops(r) for r in world.local_ranks}
+        # One rank running the gather legs keeps S, the transposed product, evidence and prior
+        # PANEL-BLOCKED (engine.Matrix): a panel's slice of the operand is then contiguous instead of
+        # one 128-byte segment every 128 KiB, which is what the gathers need at N >= 16384 (TLB reach;
+        # DESIGN.md §4.9).  Sharded ranks hold N x N/P blocks whose rows are close together already.
+        self.blocked = (world.size == 1 and not torch_buffers and self.mode == "sparse" and
+                        all(getattr(o, "supports_blocked", False) for o in self.ops.values()))
         self.sides = [{r: Side(self.ops[r], sp, r, world.size, self.mode, torch_buffers,
-                               getattr(world, "stages", 1))
+                               getattr(world, "stages", 1), self.blocked)
                        for r in world.local_ranks} for sp in specs]
         # similarity matrices: index j -> size n_j; S_j is n_j x (block of n_j), ping-pong
         if self.bipartite:
@@ -570,8 +580,9 @@ class Solver:
             c, x = {}, {}
             for r in world.local_ranks:
                 lo, hi = partition(n, world.size, r)
-                c[r] = self.ops[r].matrix(n, hi - lo)
-                x[r] = self.ops[r].matrix(n, hi - lo)
+                kw = dict(blocked=True) if self.blocked else {}
+                c[r] = self.ops[r].matrix(n, hi - lo, **kw)
+                x[r] = self.ops[r].matrix(n, hi - lo, **kw)
             self.cur.append(c)
             self.nxt.append(x)
         self.events = None
@@ -677,13 +688,22 @@ class Solver:
         blocks = {}
         for r in self.world.local_ranks:
             o, src = self.ops[r], self.cur[j][r]
-            if inv is not None and src.cols:
+            tmp = None
+            if self.blocked:
+                # out of the panel-blocked layout and the solver's node order in one pass
+                rows = None if inv is None else self._index_vector(r, ("inv", j), inv)
+                tmp = o.matrix(src.rows, src.cols)
+                o.permute(src, tmp, rows, rows)
+                src = tmp
+            elif inv is not None and src.cols:
                 # un-permute on the device into the idle ping-pong partner: rows always, and
                 # columns too when this rank holds all of them
                 rows = self._index_vector(r, ("inv", j), inv)
                 o.permute(src, self.nxt[j][r], rows, rows if self.world.size == 1 else None)
                 src = self.nxt[j][r]
             blocks[r] = o.download_f64(src)
+            if tmp is not None:
+                tmp.free()
         full = self.world.gather_columns(blocks, self.n[j], self.n[j])
         if inv is not None and self.world.size > 1:
             full = np.ascontiguousarray(full[:, inv])
@@ -696,9 +716,9 @@ class Solver:
         blocks = {}
         for r, side in self.sides[j].items():
             o, cnt = side.ops, side.ev
-            if inv is not None and cnt.cols:
+            if (inv is not None or self.blocked) and cnt.cols:
                 tmp = o.matrix(cnt.rows, cnt.cols, np.uint8)
-                rows = self._index_vector(r, ("inv", j), inv)
+                rows = None if inv is None else self._index_vector(r, ("inv", j), inv)
                 o.permute(cnt, tmp, rows, rows if self.world.size == 1 else None)
                 blocks[r] = 1 - 0.5 ** o.download(tmp).astype(np.float64)
                 tmp.free()

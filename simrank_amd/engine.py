@@ -19,19 +19,34 @@ CHANGED_SLOTS = 1024      # SIMRANK_CHANGED_SLOTS of include/simrank_hip.h
 
 
 class Matrix:
-    """Row-major device matrix (float32 or uint8) with a leading dimension."""
+    """Device matrix (float32, uint8 or int32): row-major with a leading dimension, or
+    PANEL-BLOCKED (``blocked=True``): 32-column panels of ``rows_pad`` rows, element (r, c) at
+    ((c >> 5) * rows_pad + r) * 32 + (c & 31) — the layout the single-rank solver iterates in
+    (include/simrank_hip.h, "PANEL-BLOCKED operands")."""
 
     def __init__(self, ops, rows: int, cols: int, dtype, ld: int | None = None,
-                 external=None):
+                 external=None, blocked: bool = False):
         """``external``: an object with ``data_ptr()`` (a torch tensor) whose memory is
         used instead of allocating; it is kept alive with the matrix."""
         self.ops = ops
         self.rows, self.cols = int(rows), int(cols)
         self.dtype = np.dtype(dtype)
-        self.ld = int(ld if ld is not None else ops.pitch(cols, self.dtype))
-        self.nbytes = max(1, self.rows) * self.ld * self.dtype.itemsize
+        self.blocked = bool(blocked)
+        if self.blocked:
+            assert external is None and ld is None
+            # (+8 rows: panels are not a power of two apart, and every panel starts 16-byte aligned)
+            self.rows_pad = -(-max(1, self.rows) // 8) * 8 + 8
+            self.panels = -(-max(1, self.cols) // 32)
+            self.ld = 32
+            self.nbytes = self.panels * self.rows_pad * 32 * self.dtype.itemsize
+        else:
+            self.rows_pad = 0
+            self.ld = int(ld if ld is not None else ops.pitch(cols, self.dtype))
+            self.nbytes = max(1, self.rows) * self.ld * self.dtype.itemsize
         self.external = external
         self.ptr = external.data_ptr() if external is not None else ops._malloc(self.nbytes)
+        if self.blocked:                   # padding rows / columns are read by nobody but stay defined
+            check(ops.lib.simrank_memset(C.c_void_p(self.ptr), 0, self.nbytes, ops.stream), "simrank_memset")
 
     def free(self):
         if self.ptr and self.external is None:
@@ -78,6 +93,7 @@ class HipOps:
     a panel's row segments from landing on one L2/HBM channel)."""
 
     name = "hip"
+    supports_blocked = True      # the solver may keep its matrices panel-blocked (Matrix.blocked)
 
     def __init__(self, device: int | None = None, stream: int | None = None):
         self.lib = _lib.load()
@@ -114,8 +130,8 @@ class HipOps:
             ld += self.pitch_pad
         return ld
 
-    def matrix(self, rows, cols, dtype=np.float32, ld=None, external=None) -> Matrix:
-        return Matrix(self, rows, cols, dtype, ld, external)
+    def matrix(self, rows, cols, dtype=np.float32, ld=None, external=None, blocked=False) -> Matrix:
+        return Matrix(self, rows, cols, dtype, ld, external, blocked)
 
     def exchange_buffer(self, n_floats: int):
         """Flat float32 buffer usable by torch.distributed collectives on this device."""
@@ -130,6 +146,13 @@ class HipOps:
     def upload(self, m: Matrix, host: np.ndarray):
         host = np.asarray(host)
         assert host.shape == (m.rows, m.cols), (host.shape, m.rows, m.cols)
+        if m.blocked:                       # through a row-major copy on the device
+            tmp = self.matrix(m.rows, m.cols, m.dtype)
+            self.upload(tmp, host)
+            self.permute(tmp, m)
+            self.synchronize()
+            tmp.free()
+            return
         buf = np.zeros((m.rows, m.ld), dtype=m.dtype)
         buf[:, :m.cols] = host
         check(self.lib.simrank_memcpy_h2d(m.ptr, buf.ctypes.data, buf.nbytes, self.stream),
@@ -137,6 +160,12 @@ class HipOps:
 
     def download(self, m: Matrix) -> np.ndarray:
         """Device matrix -> host array of its own dtype."""
+        if m.blocked:
+            tmp = self.matrix(m.rows, m.cols, m.dtype)
+            self.permute(m, tmp)
+            out = self.download(tmp)
+            tmp.free()
+            return out
         buf = np.empty((m.rows, m.ld), dtype=m.dtype)
         check(self.lib.simrank_memcpy_d2h(buf.ctypes.data, m.ptr, buf.nbytes, self.stream),
               "simrank_memcpy_d2h")
@@ -144,6 +173,14 @@ class HipOps:
 
     def download_rows(self, m: Matrix, rows) -> np.ndarray:
         """Selected rows of a device matrix (partial hand-back: no N x N host copy)."""
+        if m.blocked:
+            idx = self.index_vector(rows)
+            tmp = self.matrix(len(rows), m.cols, m.dtype)
+            self.permute(m, tmp, row_idx=idx)
+            out = self.download(tmp)
+            tmp.free()
+            idx.free()
+            return out
         out = np.empty((len(rows), m.cols), dtype=m.dtype)
         isz = m.dtype.itemsize
         for i, r in enumerate(rows):
@@ -159,10 +196,15 @@ class HipOps:
         k = int(k)
         idx = self.matrix(m.rows, k, np.int32, ld=k)
         val = self.matrix(m.rows, k, np.float32, ld=k)
-        check(self.lib.simrank_topk_rows_ids(m.ptr, m.ld, m.rows, m.cols, int(col0),
-                                             col_ids.ptr if col_ids is not None else None, k,
-                                             1 if exclude_diag else 0, idx.ptr, val.ptr,
-                                             self.stream), "simrank_topk_rows_ids")
+        ids = col_ids.ptr if col_ids is not None else None
+        if m.blocked:
+            check(self.lib.simrank_topk_rows_blocked(m.ptr, m.rows_pad, m.rows, m.cols, int(col0), ids, k,
+                                                     1 if exclude_diag else 0, idx.ptr, val.ptr,
+                                                     self.stream), "simrank_topk_rows_blocked")
+        else:
+            check(self.lib.simrank_topk_rows_ids(m.ptr, m.ld, m.rows, m.cols, int(col0), ids, k,
+                                                 1 if exclude_diag else 0, idx.ptr, val.ptr,
+                                                 self.stream), "simrank_topk_rows_ids")
         out = self.download(idx), self.download(val)
         idx.free()
         val.free()
@@ -177,18 +219,20 @@ class HipOps:
 
     def permute(self, src: Matrix, dst: Matrix, row_idx: Matrix | None = None,
                 col_idx: Matrix | None = None):
-        """dst[i, j] = src[row_idx[i], col_idx[j]] (None = identity); float32 or uint8."""
+        """dst[i, j] = src[row_idx[i], col_idx[j]] (None = identity); float32 / int32 or uint8;
+        either side may be panel-blocked (this is also how a matrix changes layout)."""
         assert src.dtype == dst.dtype and src.dtype.itemsize in (1, 4)
-        check(self.lib.simrank_permute(src.ptr, src.ld, dst.ptr, dst.ld, dst.rows, dst.cols,
-                                       row_idx.ptr if row_idx is not None else None,
-                                       col_idx.ptr if col_idx is not None else None,
-                                       src.dtype.itemsize, self.stream), "simrank_permute")
+        check(self.lib.simrank_permute_layout(src.ptr, src.ld, src.rows_pad, dst.ptr, dst.ld, dst.rows_pad,
+                                              dst.rows, dst.cols,
+                                              row_idx.ptr if row_idx is not None else None,
+                                              col_idx.ptr if col_idx is not None else None,
+                                              src.dtype.itemsize, self.stream), "simrank_permute_layout")
 
     def download_f64(self, m: Matrix, out: np.ndarray | None = None) -> np.ndarray:
         """float32 device matrix -> float64 host array (pinned, pipelined staging)."""
         if out is None:
             out = np.empty((m.rows, m.cols), dtype=np.float64)
-        assert out.dtype == np.float64 and out.flags.c_contiguous
+        assert out.dtype == np.float64 and out.flags.c_contiguous and not m.blocked
         check(self.lib.simrank_download_f64(out.ctypes.data, out.shape[1], m.ptr, m.ld, m.rows,
                                             m.cols, self.stream), "simrank_download_f64")
         return out
@@ -232,7 +276,10 @@ class HipOps:
         return Graph(self, csr, rowscale)
 
     def fill_identity(self, S: Matrix, col0: int):
-        if S.rows and S.cols:
+        if S.rows and S.cols and S.blocked:
+            check(self.lib.simrank_fill_identity_blocked(S.ptr, S.rows, S.cols, S.rows_pad, col0,
+                                                         self.stream), "simrank_fill_identity_blocked")
+        elif S.rows and S.cols:
             check(self.lib.simrank_fill_identity(S.ptr, S.rows, S.cols, S.ld, col0, self.stream),
                   "simrank_fill_identity")
 
@@ -262,6 +309,16 @@ class HipOps:
         column sub-block of X (first column), ``y_offset`` an element offset into Y."""
         n_cols = X.cols if n_cols is None else n_cols
         ep = self._epilogue(**epilogue) if epilogue is not None else None
+        if X.blocked:
+            assert Y.blocked and not x_col0 and not y_offset and n_cols == X.cols
+            for name in ("evidence", "apriori", "previous"):
+                m = (epilogue or {}).get(name)
+                assert m is None or (m.blocked and m.rows_pad == Y.rows_pad), name
+            check(self.lib.simrank_spmm_blocked(g.handle, X.ptr, X.rows_pad, n_cols, Y.ptr, Y.rows_pad,
+                                                1 if transpose_out else 0,
+                                                C.byref(ep) if ep is not None else None, self.stream),
+                  "simrank_spmm_blocked")
+            return
         check(self.lib.simrank_spmm(g.handle, X.ptr + 4 * int(x_col0), X.ld, n_cols,
                                     Y.ptr + 4 * int(y_offset), Y.ld,
                                     1 if transpose_out else 0, int(t_block), int(t_pad),
@@ -271,6 +328,12 @@ class HipOps:
     def epilogue_apply(self, Q: Matrix, Y: Matrix, n_rows: int, n_cols: int, epilogue: dict):
         """Y = epilogue(Q) element-wise; see simrank_epilogue_apply."""
         ep = self._epilogue(**epilogue)
+        if Q.blocked:
+            assert Y.blocked and Y.rows_pad == Q.rows_pad
+            check(self.lib.simrank_epilogue_apply_blocked(Q.ptr, Y.ptr, n_rows, n_cols, Q.rows_pad,
+                                                          C.byref(ep), self.stream),
+                  "simrank_epilogue_apply_blocked")
+            return
         check(self.lib.simrank_epilogue_apply(Q.ptr, Q.ld, Y.ptr, Y.ld, n_rows, n_cols,
                                               C.byref(ep), self.stream), "simrank_epilogue_apply")
 
@@ -295,11 +358,15 @@ class HipOps:
 
     def dense_part(self, g: Graph, X: Matrix, n_cols: int | None = None):
         """The matrix-core part of ``spmm`` alone (measurement; see simrank_dense_part)."""
-        check(self.lib.simrank_dense_part(g.handle, X.ptr, X.ld, X.cols if n_cols is None else n_cols,
-                                          self.stream), "simrank_dense_part")
+        check(self.lib.simrank_dense_part(g.handle, X.ptr, -X.rows_pad if X.blocked else X.ld,
+                                          X.cols if n_cols is None else n_cols, self.stream),
+              "simrank_dense_part")
 
     def evidence_counts(self, g: Graph, col0: int, out: Matrix):
-        if out.cols:
+        if out.cols and out.blocked:
+            check(self.lib.simrank_evidence_counts_blocked(g.handle, col0, out.cols, out.ptr, out.rows_pad,
+                                                           self.stream), "simrank_evidence_counts_blocked")
+        elif out.cols:
             check(self.lib.simrank_evidence_counts(g.handle, col0, out.cols, out.ptr, out.ld,
                                                    self.stream), "simrank_evidence_counts")
 
@@ -309,8 +376,8 @@ class HipOps:
         if not counts.cols:
             return 1.0
         live, total = C.c_int64(0), C.c_int64(0)
-        check(self.lib.simrank_evidence_live_segments(counts.ptr, counts.ld, counts.rows, counts.cols,
-                                                      C.byref(live), C.byref(total), self.stream),
+        check(self.lib.simrank_evidence_live_segments(counts.ptr, counts.ld, counts.rows_pad, counts.rows,
+                                                      counts.cols, C.byref(live), C.byref(total), self.stream),
               "simrank_evidence_live_segments")
         return live.value / max(1, total.value)
 

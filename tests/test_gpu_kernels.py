@@ -329,6 +329,61 @@ def test_topk_rows(ops, shape, k, c0):
         np.testing.assert_array_equal(val[r, :len(want)], h[r, want])
 
 
+@pytest.mark.parametrize("n,L", [(200, 200), (1031, 1031), (96, 64), (700, 333)])
+def test_panel_blocked_operands_give_the_row_major_bits(ops, n, L):
+    """The single-rank solver keeps its matrices panel-blocked (32-column panels of rows_pad rows);
+    the lean kernel reads and writes either layout.  Same bits as row-major for the transposed
+    leg, the plain leg with the whole epilogue, and (square case) the upper-triangle form."""
+    csr = random_csr(n, n, 9, seed=n + L, heavy={3: min(n, 260), 50: min(n, 80)})
+    rng = np.random.default_rng(n)
+    X = rng.random((n, L)).astype(np.float32)
+    cnt = rng.integers(0, 4, size=(n, L)).astype(np.uint8)
+    prior = rng.random((n, L)).astype(np.float32)
+    prev = rng.random((n, L)).astype(np.float32)
+    if n == L:
+        X = ((X + X.T) / 2).astype(np.float32)
+        cnt = np.minimum(cnt, cnt.T)
+        prior = ((prior + prior.T) / 2).astype(np.float32)
+        prev = ((prev + prev.T) / 2).astype(np.float32)
+    g = ops.graph(csr)
+
+    def put_as(a, blocked, dtype=np.float32):
+        m = ops.matrix(a.shape[0], a.shape[1], dtype, blocked=blocked)
+        ops.upload(m, a)
+        return m
+
+    assert np.array_equal(ops.download(put_as(X, True)), X)            # layout round trip
+    assert np.array_equal(ops.download(put_as(cnt, True, np.uint8)), cnt)
+    out = {}
+    for blocked in (False, True):
+        x = put_as(X, blocked)
+        yt = ops.matrix(L, n, blocked=blocked)
+        ops.spmm(g, x, yt, transpose_out=True)
+        res = [ops.download(yt)]
+        for sym in ((False, True) if n == L else (False,)):
+            ops.set_tuning(panel=32)                                     # plain form on the lean kernel too
+            try:
+                g32 = ops.graph(csr)
+            finally:
+                ops.set_tuning(panel=0)
+            y = ops.matrix(n, L, blocked=blocked)
+            ep = dict(coef=0.7, evidence=put_as(cnt, blocked, np.uint8), apriori=put_as(prior, blocked),
+                      lbd=0.25, previous=put_as(prev, blocked), eps=0.3, diag_col0=0, symmetric=sym)
+            ops.spmm(g32, x, y, epilogue=ep)
+            res += [ops.download(y), ops.read_changed()]
+        out[blocked] = res
+    for a, b in zip(out[False], out[True]):
+        assert np.array_equal(a, b)
+    want = (dense64(csr) @ X.astype(np.float64)).T
+    np.testing.assert_allclose(out[True][0], want, rtol=RTOL, atol=1e-30)
+    # top-k and row hand-back straight from the blocked layout
+    xb = put_as(X, True)
+    idx, val = ops.topk_rows(xb, 5, exclude_diag=False)
+    idx0, val0 = ops.topk_rows(put_as(X, False), 5, exclude_diag=False)
+    assert np.array_equal(idx, idx0) and np.array_equal(val, val0)
+    assert np.array_equal(ops.download_rows(xb, [0, n // 2, n - 1]), X[[0, n // 2, n - 1]])
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.uint8])
 def test_permute(ops, dtype):
     """dst[i, j] = src[row_idx[i], col_idx[j]], pitched operands, either index list optional."""

@@ -17,13 +17,13 @@ import csv, glob, collections
 print("== $TAG: $SET ($WL)")
 for f in glob.glob("$OUT/stats/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if any(k in r["Name"] for k in ("spmm", "dense_tiles")):
+        if any(k in r["Name"] for k in ("spmm", "gather3", "dense_tiles")):
             print("  %-70s calls %s avg %.3f ms" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e6))
 acc = collections.defaultdict(lambda: [0.0, 0])
 for tag in ("l2", "ea"):
     for f in glob.glob(f"$OUT/{tag}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if not any(k in r["Kernel_Name"] for k in ("spmm", "dense_tiles")):
+            if not any(k in r["Kernel_Name"] for k in ("spmm", "gather3", "dense_tiles")):
                 continue
             k = (r["Kernel_Name"][:60], r["Counter_Name"])
             acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1

@@ -38,15 +38,19 @@ MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
 MFMA_BF16_PEAK_TF = 2500.0     # v_mfma_f32_32x32x16_bf16 dense peak
 
 
-def leg_bytes(n_rows, n_cols_in, n_cols_x, nnz, leg2, has_evidence=False):
+def leg_bytes(n_rows, n_cols_in, n_cols_x, nnz, leg2, has_evidence=False, triangle=False):
     """Algorithmic HBM bytes of one gather-leg launch:
     read X once, write Y once, CSR (col + rowptr) once per launch; leg 2 also reads the
-    previous iterate for the convergence count (and 1 B/elt of evidence counts)."""
+    previous iterate for the convergence count (and 1 B/elt of evidence counts).
+    ``triangle``: the single-rank form of leg 2 computes the tiles on/above the diagonal and
+    stores their mirror image — it still writes all of Y and gathers from all of X, but reads
+    only half of the previous iterate and of the evidence counts."""
     b = 4 * n_cols_in * n_cols_x + 4 * n_rows * n_cols_x + 8 * nnz + 4 * (n_rows + 1)
     if leg2:
-        b += 4 * n_rows * n_cols_x
+        half = 2 if triangle else 1
+        b += 4 * n_rows * n_cols_x // half
         if has_evidence:
-            b += n_rows * n_cols_x
+            b += n_rows * n_cols_x // half
     return b
 
 
@@ -244,6 +248,7 @@ def main():
                                f"{' with fp16 dense blocks' if args.dense_precision == 'fp16' else ''}, "
                                f"eps test every iteration",
                    "N": n, "nnz": nnz, "mode": solver.mode,
+                   "layout": "panel-blocked (32-column panels)" if getattr(solver, "blocked", False) else "row-major",
                    "sharding": f"S column-sharded over {world_size} rank(s), all-to-all per update"
                                + (f" in {side_stages} overlapped stage(s)" if use_dist else "")},
     }
@@ -255,7 +260,9 @@ def main():
         l1 = legs["leg1.0"][0]
         l2 = legs["leg2.0"][0]
         b1 = leg_bytes(side.M, side.K, side.Lk, nnz, leg2=False)
-        b2 = leg_bytes(side.M, side.K, side.Lm, nnz, leg2=True, has_evidence=args.pp)
+        tri = world_size == 1 and not use_dist          # upper-triangle + mirror form of leg 2
+        b2 = leg_bytes(side.M, side.K, side.Lm, nnz, leg2=True, has_evidence=args.pp, triangle=tri)
+        b2_full = leg_bytes(side.M, side.K, side.Lm, nnz, leg2=True, has_evidence=args.pp)
         # the matrix-core part of leg 1 alone (same operand, same stream), outside the timed region
         nt, dk, cov = ops.dense_stats(side.graph)
         dense_ms = None
@@ -292,9 +299,11 @@ def main():
             rl[0]["gathered_bytes"] = 4 * (nnz - cov) * side.Lk
             rl[0]["gather_kernel_alone"] = {"achieved": b1 / ((l1 - dense_ms) * 1e-3) / 1e9, "unit": "GB/s",
                                             "frac": b1 / ((l1 - dense_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        if world_size == 1:
-            rl[1]["note"] = ("single rank: leg 2 computes the tiles on/above the diagonal and stores "
-                             "their mirror image (S' is symmetric); bytes are those of the full matrix")
+        if tri:
+            rl[1]["algorithmic_bytes_full_form"] = b2_full
+            rl[1]["note"] = ("single rank: leg 2 computes the tiles on/above the diagonal and stores their "
+                             "mirror image (S' is symmetric); `algorithmic_bytes` are those of this form (all of "
+                             "Tt read, all of S' written, half of the previous iterate read), not of the full form")
         # what the runtime's own device-to-device copy of S moves per second on this GPU (read +
         # write): the practical ceiling next to the 8 TB/s spec figure used for `frac`
         try:
@@ -338,6 +347,38 @@ def main():
         k = solver.run(100, 1e-4)
         barrier()
         out["converge"] = {"eps": 1e-4, "iterations": k, "seconds": time.perf_counter() - t0}
+
+    if not args.no_extras and world_size == 1 and args.workload == "pl32768" and not args.pp:
+        # the same configuration with the stated mean degree AFTER de-duplication: 1 048 576 distinct
+        # edges (the SURVEY.md recipe behind the headline keeps 783 100 of its 1 048 576 draws)
+        try:
+            dfd = synth.WORKLOADS["pl32768d32"][0]()
+            _, csrd = ingest.directed(dfd, False, "from", "to", "weight")
+            sd = Solver(lambda r: ops, world, [make_spec(csrd, False)], args.mode)
+            sd.reset()
+            for _ in range(3):
+                sd.step(0.0)
+            sd.enable_timing(10)
+            ops.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                sd.step(0.0)
+            ops.synchronize()
+            dt = (time.perf_counter() - t0) / 10
+            lt = sd.leg_times()
+            ntd, dkd, covd = ops.dense_stats(next(iter(sd.sides[0].values())).graph)
+            out["headline_mean_degree_32"] = {
+                "workload": f"pl32768d32: synthetic directed graph N={csrd.n_rows} nnz={csrd.nnz} (mean degree "
+                            f"{csrd.nnz / csrd.n_rows:.1f} after de-duplication) SimRank C=0.8 fp32",
+                "value": 1.0 / dt, "unit": "iterations/s", "ms_per_step": dt * 1e3,
+                "leg1_ms": lt["leg1.0"][0], "leg2_ms": lt["leg2.0"][0],
+                "leg1_algorithmic_GBps": leg_bytes(csrd.n_rows, csrd.n_rows, csrd.n_rows, csrd.nnz, False)
+                / (lt["leg1.0"][0] * 1e-3) / 1e9,
+                "entries_in_dense_blocks_frac": covd / max(1, csrd.nnz)}
+            sd.release()
+            del sd
+        except Exception as e:
+            out["headline_mean_degree_32"] = {"error": f"{type(e).__name__}: {e}"}
 
     if not args.no_extras and world_size == 1 and args.workload != "er8192":
         # BASELINE.json configs[1] (ER N=8192, p=0.001) next to the headline configuration

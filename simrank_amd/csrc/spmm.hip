@@ -854,6 +854,7 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
         if (p.tile_row0) rt = p.row_tiles - 1 - rt;
     }
     if (panel >= p.n_panels) return;
+    if ((p.probe & 16) && (blockIdx.x & 7) != 0) return;      // diagnostic: one XCD's share of the launch only
 
     const int64_t c0 = int64_t(panel) * PW;
     const int g = lane >> 3;

@@ -25,10 +25,11 @@ for tag in ("pmc_l2", "pmc_busy", "pmc_ea", "pmc_tcp", "pmc_sq", "pmc_fetch", "p
     for f in glob.glob(f"$OUT/{tag}/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(lambda: [0.0, 0])
         for r in csv.DictReader(open(f)):
-            if not any(k in r["Kernel_Name"] for k in ("spmm", "gemm", "dense_tiles")):
+            if not any(k in r["Kernel_Name"] for k in ("spmm", "gather3", "gemm", "dense_tiles")):
                 continue
             k = (r["Kernel_Name"][:62], r["Counter_Name"])
             acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
         for k, (v, n) in sorted(acc.items()):
             print(tag, k, "mean per dispatch", v / n, "n", n)
 PY
+python3 $PWD/tools/make_pmc_traffic.py $OUT ${PMC_KEY:-pl32768:1} || true

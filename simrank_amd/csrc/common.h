@@ -38,7 +38,8 @@ struct Tuning {
     int64_t tile = 0;     // rows per wave tile (16, 32, 64; 0 = automatic)
     int64_t huge = 512;   // rows of at least this many entries are split over a workgroup's waves
     int64_t triangle = 1; // allow the upper-triangle + mirror form of a symmetric leg 2
-    int64_t balance = 4;  // cut 32-row tiles heavier than balance x the mean tile (0 = uniform tiles)
+    int64_t balance = 2;  // cut 32-row tiles heavier than balance x the mean tile (0 = uniform tiles); 2 keeps an
+                          // XCD on one panel at a time: L2 fills 17.9 -> 10.7 GB per leg 1 at pl32768
     int64_t dense_min = 4;   // block-dense MFMA part: a column joins a 128-row tile's dense set when
                              // at least this many of the tile's rows reference it (0 = off)
     int64_t dense_cols = 128; // ... and a tile gets a dense set only with this many such columns

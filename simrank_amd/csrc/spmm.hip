@@ -1070,16 +1070,19 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
         if (rows_out > 0 && p.blocked) {
             // panel-blocked Y^T: the tile's 32 c-rows are consecutive 128-byte lines of panel row0 / 32
             float* base = p.Y + ((int64_t(row0 >> 5) * p.y_rows_pad) + c0) * 32 + (row0 & 31);
-            if (rows_out == RT && cols_here == PW) {
+            if (cols_here == PW && (rows_out & 3) == 0 && (row0 & 3) == 0) {
+                // whole tile, or an aligned piece of a cut tile (16, 8, 4 rows): 16-byte stores
 #pragma unroll
                 for (int it = 0; it < PW * (RT / 4) / 64; ++it) {
                     const int x = lane + it * 64;
                     const int c = x >> 3;
                     const int r4 = (x & 7) * 4;
-                    const float* t = tbuf_wave + c * (RT + 1) + r4;
-                    const float v4[4] = {t[0], t[1], t[2], t[3]};
-                    float* dst = base + c * 32 + r4;
-                    if (p.nt) vstore_nt<4>(dst, v4); else vstore<4>(dst, v4);
+                    if (r4 < rows_out) {
+                        const float* t = tbuf_wave + c * (RT + 1) + r4;
+                        const float v4[4] = {t[0], t[1], t[2], t[3]};
+                        float* dst = base + c * 32 + r4;
+                        if (p.nt) vstore_nt<4>(dst, v4); else vstore<4>(dst, v4);
+                    }
                 }
             } else {
                 for (int x = lane; x < PW * RT; x += 64) {

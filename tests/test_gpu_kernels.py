@@ -428,7 +428,7 @@ def test_balanced_tiles(ops, balance):
     try:
         g = ops.graph(csr)
     finally:
-        ops.set_tuning(balance=4)
+        ops.set_tuning(balance=2)
     S = rng.random((n, n)).astype(np.float32)
     S = ((S + S.T) / 2).astype(np.float32)
     np.fill_diagonal(S, 1)

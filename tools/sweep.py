@@ -65,4 +65,4 @@ for w in args.workload.split(","):
               f"total {l1 + l2:8.3f} ms", flush=True)
         s.release()
         del s
-ops.set_tuning(panel=0, tile=0, xcd_map=1, huge=512, triangle=1, dense_min=4, dense_cols=128, stream_nt=1, balance=4)
+ops.set_tuning(panel=0, tile=0, xcd_map=1, huge=512, triangle=1, dense_min=4, dense_cols=128, stream_nt=1, balance=2)

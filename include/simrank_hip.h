@@ -269,21 +269,29 @@ SIMRANK_API int simrank_graph_dense_stats(const simrank_graph* g, int64_t* n_til
 SIMRANK_API int simrank_dense_part(const simrank_graph* g, const float* X, int64_t ldx,
                                    int64_t n_cols_x, void* stream);
 
-/* ---- tuning knobs (measurement harness; defaults are the tuned values):
- *      "panel"    columns per gather panel (16, 32, 64, 128, 256; 0 = automatic)
- *      "tile"     rows per wave tile (16, 32, 64; 0 = automatic)
+/* ---- tuning knobs (measurement harness; defaults are the tuned values).  simrank_set_tuning
+ *      changes the process-wide DEFAULTS; simrank_graph_create copies them into the graph it
+ *      builds (under a lock), and every launch on that graph uses its copy — a knob set later does
+ *      not reach graphs that already exist.
+ *      "panel"    columns per gather panel (16, 32, 64, 128, 256; 0 = automatic = 32)
+ *      "tile"     rows per wave tile (16, 32, 64; 0 = automatic = 32)
+ *      "lean"     0/1  the lean gather kernel (32-column panels, 32-row tiles) wherever it applies;
+ *                 0 = the generic kernel (row-major operands only)
  *      "xcd_map"  0/1  panel -> XCD affinity
  *      "triangle" 0/1  allow the upper-triangle + mirror form when epilogue.symmetric
  *      "stream_nt" 0/1 non-temporal access for streamed-once data
  *      "huge"     rows of at least this many entries are split over a workgroup's waves
  *      "balance"  32-row tiles heavier than this many times the mean tile are cut in halves
- *                 (read when a graph is created; 0 = uniform tiles)
- *      "dense_min" / "dense_cols"  selection of the block-dense part (see above); read when a
- *                 graph is created; simrank_spmm also skips the dense part while dense_min
- *                 is 0
+ *                 (0 = uniform tiles; default 2)
+ *      "dense_min" / "dense_cols"  selection of the block-dense part (see above); dense_min 0 = off
+ *      "dense_terms" operand terms of the block-dense part: 3 = bf16 hi+mid+lo (exact f32
+ *                 products, default), 1 = one fp16 term (reduced precision, BASELINE config 5)
  *      "ids16"    0/1  stream the neighbour ids as 16-bit values (graphs with <= 65536 columns)
  *      "dense_sym" dense part in the upper-triangle form of leg 2: 1 always, 0 never, -1 when
- *                 the dense sets hold at least half of the entries ---- */
+ *                 the dense sets hold at least half of the entries
+ *      "probe_mask", "probe_flags"  DIAGNOSTIC ONLY (wrong results): price parts of the gather
+ *                 kernel — ids ANDed with a mask; 1 no gathers, 2 no stores, 4 no dense partial
+ *                 sums, 8 no id loads, 16 one XCD's share of the launch only ---- */
 SIMRANK_API int simrank_set_tuning(const char* key, int64_t value);
 SIMRANK_API int simrank_get_tuning(const char* key, int64_t* value);
 

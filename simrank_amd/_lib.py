@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsimrank_hip.so")
+# (SIMRANK_LIB: an experiment build of the same ABI, tools/build_variant.sh; never set in production)
+LIB_PATH = os.environ.get("SIMRANK_LIB") or os.path.join(_HERE, "libsimrank_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "simrank_hip.h")
 
 

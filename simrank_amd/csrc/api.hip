@@ -458,7 +458,7 @@ int simrank_set_tuning(const char* key, int64_t value) {
         SR_REQUIRE(value == 1 || value == 3, "dense_terms must be 3 (exact) or 1 (fp16 operand)");
         t.dense_terms = value;
     } else if (!strcmp(key, "probe_flags")) {
-        t.probe_flags = value & 31;
+        t.probe_flags = value & 63;
     } else if (!strcmp(key, "lean")) {
         SR_REQUIRE(value == 0 || value == 1, "lean must be 0 or 1");
         t.lean = value;

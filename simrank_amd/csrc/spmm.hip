@@ -720,10 +720,12 @@ __device__ __forceinline__ void gather_range3(const SpmmArgs& p, const float* Xc
 // Partial sums of the matrix-core part for row a (blockdense.hip), its slabs added in slab order.
 // Called BEFORE the row's gathers are issued, so these loads are in flight beside them instead
 // of forming a dependent chain in the epilogue (0.6 ms of leg 1 at pl32768 when they did).
+template <bool DENSE>
 __device__ __forceinline__ void dense_partial(const SpmmArgs& p, int64_t a, int64_t mycol, bool on,
                                               float (&dsum)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) dsum[i] = 0.f;
+    if constexpr (!DENSE) return;
     if (!p.dpart || (p.probe & 4) || !on) return;
     const int ns = p.dnslab[a >> 7];
     const float* dp = p.dpart + (int64_t(p.dslab0[a >> 7]) * 128 + (a & 127)) * p.ldp + mycol;
@@ -816,15 +818,47 @@ __device__ __forceinline__ void emit_row3(const SpmmArgs& p, float* tbuf_wave, i
 
 // RESTRICT (leg 2 of SimRank++, SimRank.py:315-316, :361): a separate instantiation, so the plain
 // legs keep their register budget; chosen by the driver when few segments of E are live.
-template <int MODE, bool IDS16, bool RESTRICT>
-__global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(const SpmmArgs p) {
+#ifdef SIMRANK_STAMPS
+// Diagnostic build only (bash tools/build_variant.sh stamps -DSIMRANK_STAMPS; tools/stamps.py): where
+// a wave's cycles go.  s_memtime at the phase boundaries; lane 0 of every wave adds the differences
+// to g_stamps[phase] (a __device__ array nothing else reads; simrank_read_stamps copies it out).
+// Never in the product build.
+__device__ unsigned long long g_stamps[16];
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define STAMP(i)                                                          \
+    do {                                                                  \
+        const unsigned long long now_ = stamp_now();                      \
+        if (lane == 0) atomicAdd(&g_stamps[i], now_ - stamp_prev);        \
+        stamp_prev = now_;                                                \
+    } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
+// DENSE: the launch adds partial sums of the matrix-core part; launches without them (no dense plan,
+// or the upper-triangle leg of a power-law graph) run an instantiation that does not carry the four
+// registers of those sums: 60 instead of 68 VGPRs for the transposed leg (8 waves per SIMD), 79
+// instead of 89 for the others (6 instead of 5): leg 2 -5...7 %.
+template <int MODE, bool IDS16, bool RESTRICT, bool DENSE>
+__global__ __launch_bounds__(256, MODE == kTrans ? (DENSE ? 7 : 8) : (DENSE ? 5 : 6))
+void gather3_kernel(const SpmmArgs p) {
     constexpr bool TRANS = MODE == kTrans;
     constexpr bool TILE = MODE != kPlain;
     constexpr int PW = 32, RT = 32, LPR = 8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (p.probe & 32) return;                                    // diagnostic: the price of the bare launch
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef SIMRANK_STAMPS
+    unsigned long long stamp_prev = stamp_now();
+#endif
 
     int panel, rt;
     if (MODE == kSym && p.sym_map) {
@@ -921,6 +955,7 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
         }
     }
     const int n_heavy = __popcll(__ballot(s_len >= kHeavy));
+    STAMP(0);      // prologue: arguments, tile lookup, row pointers, order
 
     // ---- phase A0: huge rows, split over the four waves of the workgroup (see the generic kernel)
     int posted = 0;
@@ -962,7 +997,7 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
                 const float sc = __shfl(my_scale, r);
                 if (g == 0 && col_active) {
                     float acc[4], t[4], dsum[4];
-                    dense_partial(p, int64_t(row0) + r, mycol, true, dsum);
+                    dense_partial<DENSE>(p, int64_t(row0) + r, mycol, true, dsum);
                     vload<4>(acc, hpart + (i * kWaves + 0) * PW + q * 4);
 #pragma unroll
                     for (int w = 1; w < kWaves; ++w) {
@@ -977,6 +1012,7 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
         __syncthreads();
     }
 
+    STAMP(1);      // phase A0
     // ---- phase A: the other long rows, one at a time, the 8 lane groups splitting the neighbours
     for (int h = posted; h < n_heavy; ++h) {
         const int r = __builtin_amdgcn_readfirstlane(__shfl(s_row, h));
@@ -984,7 +1020,7 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
         const int e = s + __builtin_amdgcn_readfirstlane(__shfl(s_len, h));
         const float sc = __shfl(my_scale, r);
         float acc[4], dsum[4];
-        dense_partial(p, int64_t(row0) + r, mycol, g == 0 && col_active, dsum);
+        dense_partial<DENSE>(p, int64_t(row0) + r, mycol, g == 0 && col_active, dsum);
         bool live = true;
         if constexpr (RESTRICT) {
             const unsigned w = col_active ? *reinterpret_cast<const unsigned*>(
@@ -1001,6 +1037,7 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
             emit_row3<MODE>(p, tbuf_wave, r, int64_t(row0) + r, q, mycol, colofs, sc, acc, dsum, changed, mirror);
     }
 
+    STAMP(2);      // phase A
     // ---- phase B: the other rows, 8 at a time, one row per lane group; the ids of the next chunk
     // are requested before the gathers of the current one
     if (n_heavy < nrows) {
@@ -1016,7 +1053,7 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
         int iv = (q < len && !(p.probe & 8)) ? (ld_id<IDS16>(p, st + q) & p.idx_mask) : 0;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         float dsum[4];
-        dense_partial(p, int64_t(row0) + r, mycol, src < nrows && col_active, dsum);
+        dense_partial<DENSE>(p, int64_t(row0) + r, mycol, src < nrows && col_active, dsum);
         // RESTRICT: a lane group whose 32 evidence counts are all zero issues no gathers
         auto group_live = [&](int row, bool on) -> bool {
             if constexpr (!RESTRICT) return true;
@@ -1054,7 +1091,7 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] = 0.f;
                 if (more) {
-                    dense_partial(p, int64_t(row0) + nr, mycol, npos + g < nrows && col_active, dsum);
+                    dense_partial<DENSE>(p, int64_t(row0) + nr, mycol, npos + g < nrows && col_active, dsum);
                     glive = group_live(nr, npos + g < nrows && col_active);
                 }
             }
@@ -1063,8 +1100,10 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
         }
     }
 
+    STAMP(3);          // phase B
     if constexpr (TILE) {
         __syncthreads();
+        STAMP(4);      // waiting for the other waves of the workgroup
         const int cols_here = int(imin(PW, p.L - c0));
         const int rows_out = ((TRANS || mirror) && !(p.probe & 2)) ? nrows : 0;
         if (rows_out > 0 && p.blocked) {
@@ -1133,6 +1172,7 @@ __global__ __launch_bounds__(256, MODE == kTrans ? 7 : 5) void gather3_kernel(co
         }
     }
 
+    STAMP(5);          // tile store issued
     if constexpr (!TRANS) {
         if (p.has_ep && p.prev) {
 #pragma unroll
@@ -1163,20 +1203,22 @@ static int launch_gather3(SpmmArgs a, hipStream_t st) {
     const size_t lds = sizeof(float) * ((MODE != kPlain ? size_t(kWaves) * PW * (RT + 1) : 0) +
                                         (a.has_huge ? 64 + size_t(kMaxHuge) * kWaves * PW : 0));
     const bool restricted = MODE != kTrans && a.has_ep && a.ev && a.restrict_support;
+    const bool dense = a.dpart != nullptr;
+    const dim3 gr((unsigned)grid), bl(256);
+#define SR_LAUNCH3(IDS, RES, DEN) \
+    hipLaunchKernelGGL((gather3_kernel<MODE, IDS, RES, DEN>), gr, bl, lds, st, a)
+#define SR_LAUNCH3_IDS(RES, DEN) \
+    do { if (a.col16) SR_LAUNCH3(true, RES, DEN); else SR_LAUNCH3(false, RES, DEN); } while (0)
     if constexpr (MODE != kTrans) {
         if (restricted) {
-            if (a.col16)
-                hipLaunchKernelGGL((gather3_kernel<MODE, true, true>), dim3((unsigned)grid), dim3(256), lds, st, a);
-            else
-                hipLaunchKernelGGL((gather3_kernel<MODE, false, true>), dim3((unsigned)grid), dim3(256), lds, st, a);
+            if (dense) SR_LAUNCH3_IDS(true, true); else SR_LAUNCH3_IDS(true, false);
             SR_HIP(hipGetLastError());
             return SIMRANK_OK;
         }
     }
-    if (a.col16)
-        hipLaunchKernelGGL((gather3_kernel<MODE, true, false>), dim3((unsigned)grid), dim3(256), lds, st, a);
-    else
-        hipLaunchKernelGGL((gather3_kernel<MODE, false, false>), dim3((unsigned)grid), dim3(256), lds, st, a);
+    if (dense) SR_LAUNCH3_IDS(false, true); else SR_LAUNCH3_IDS(false, false);
+#undef SR_LAUNCH3_IDS
+#undef SR_LAUNCH3
     SR_HIP(hipGetLastError());
     return SIMRANK_OK;
 }
@@ -1574,6 +1616,18 @@ static int spmm_impl(const simrank_graph* g, const float* X, int64_t ldx, int64_
     }
 #undef SR_TILE_SWITCH
 }
+
+#ifdef SIMRANK_STAMPS
+__attribute__((visibility("default"))) int simrank_read_stamps(unsigned long long* out16, int32_t reset) {
+    SR_HIP(hipDeviceSynchronize());
+    SR_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(simrank::g_stamps), 16 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        SR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(simrank::g_stamps), z, sizeof(z)));
+    }
+    return SIMRANK_OK;
+}
+#endif
 
 int simrank_fill_identity_blocked(float* S, int64_t n_rows, int64_t n_cols, int64_t rows_pad,
                                   int64_t col0, void* stream) {

@@ -742,8 +742,17 @@ class Solver:
                 ids = None
                 if self.order[j] is not None:      # report (and break ties by) the caller's ids
                     ids = self._index_vector(r, ("ids", j), self.order[j][lo:hi])
-                per_rank[r] = self.ops[r].topk_rows(self.cur[j][r], min(k, hi - lo), col0=lo,
+                src, tmp = self.cur[j][r], None
+                if getattr(src, "blocked", False):
+                    # a row of a panel-blocked matrix is 128-byte pieces 4 MiB apart: the k selection
+                    # rounds re-read it, so they run on a row-major copy (one pass)
+                    tmp = self.ops[r].matrix(src.rows, src.cols)
+                    self.ops[r].permute(src, tmp)
+                    src = tmp
+                per_rank[r] = self.ops[r].topk_rows(src, min(k, hi - lo), col0=lo,
                                                     exclude_diag=exclude_diag, col_ids=ids)
+                if tmp is not None:
+                    tmp.free()
             else:
                 per_rank[r] = (np.full((n, 1), -1, np.int32), np.zeros((n, 1), np.float32))
         parts = self.world.gather_list(per_rank)

@@ -459,6 +459,8 @@ int simrank_set_tuning(const char* key, int64_t value) {
         t.dense_terms = value;
     } else if (!strcmp(key, "probe_flags")) {
         t.probe_flags = value & 63;
+    } else if (!strcmp(key, "addr32")) {
+        t.addr32 = value ? 1 : 0;
     } else if (!strcmp(key, "lean")) {
         SR_REQUIRE(value == 0 || value == 1, "lean must be 0 or 1");
         t.lean = value;
@@ -490,6 +492,7 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     else if (!strcmp(key, "dense_sym")) *value = t.dense_sym;
     else if (!strcmp(key, "ids16")) *value = t.ids16;
     else if (!strcmp(key, "lean")) *value = t.lean;
+    else if (!strcmp(key, "addr32")) *value = t.addr32;
     else if (!strcmp(key, "probe_flags")) *value = t.probe_flags;
     else if (!strcmp(key, "dense_terms")) *value = t.dense_terms;
     else if (!strcmp(key, "probe_mask")) *value = t.probe_mask;

@@ -48,6 +48,7 @@ struct Tuning {
     int64_t probe_mask = -1; // DIAGNOSTIC ONLY: gathered row ids are ANDed with this (wrong results; prices
                              // the memory path of the gather kernel: 255 = L1-resident operand, 8191 = L2-resident)
     int64_t probe_flags = 0; // DIAGNOSTIC ONLY (lean kernel): 1 no gathers, 2 no stores, 4 no dense partial sums, 8 no ids
+    int64_t addr32 = 1;      // lean kernel: 32-bit buffer addressing of the operand where its rows span < 2 GiB
     int64_t lean = 1;        // 1: the lean gather kernel (32-float panels, 32-row tiles) wherever it applies,
                              // 0: the generic kernel everywhere (row-major operands only)
     int64_t ids16 = 1;       // stream neighbour ids as 16-bit values when the graph allows it

@@ -24,6 +24,7 @@
 //     single rank it computes only the tiles on/above the diagonal of the symmetric result
 //     and stores their mirror image (kSym).
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -47,6 +48,9 @@ struct SpmmArgs {
     // N = 32768) instead of 32768 segments spread over 4 GB: the gathers stop missing the TLB.
     int32_t blocked;
     int64_t x_rows_pad, y_rows_pad;   // X; Y and the epilogue operands (and Y^T of a transposed store)
+    int64_t x_span_bytes;     // A32: bytes from X (blocked: from a panel's start) to the end of what a gather may touch
+    int32_t x_sentinel;       // A32: a row id whose offset is past that span (loads zeros)
+    int32_t addr32;           // tuning "addr32": allow the 32-bit buffer addressing
     int32_t idx_mask;         // diagnostic (tuning "probe_mask"): neighbour ids are ANDed with it; -1 = off
     int32_t probe;            // diagnostic (tuning "probe_flags", lean kernel): 1 no gathers, 2 no stores of Y,
                               // 4 no partial sums of the dense part, 8 no neighbour-id loads
@@ -60,6 +64,7 @@ struct SpmmArgs {
     float* Y;
     int64_t ldy;
     int64_t M;       // rows of the graph = rows of Y
+    int64_t K;       // columns of the graph = rows of X
     int64_t tblock;  // rows per transposed block (TRANS only)
     int64_t tstride; // TRANS, single block: row stride of Y^T (0 = rows in block)
     int64_t tpad;    // TRANS, blocked: padding floats per row of a block
@@ -635,21 +640,48 @@ __device__ __forceinline__ int ld_id(const SpmmArgs& p, int j) {
     else return p.col[j];
 }
 
-__device__ __forceinline__ float4 ld_row(const float* Xc, int idx, uint32_t pitch16) {
-    return reinterpret_cast<const float4*>(Xc)[size_t(__umul24(uint32_t(idx), pitch16))];
+// Where a lane gathers from.  Two addressing forms:
+//  * Src64: a 64-bit per-lane base + row id x pitch (24-bit multiply, 64-bit shift-add).  Slots a row
+//    does not have read row 0 and are multiplied by a 0/1 mask.
+//  * Src32 (whenever the operand rows a panel can touch span < 2 GiB: always for panel-blocked
+//    operands, and for the N x N/P blocks of sharded ranks): a buffer descriptor over the panel's
+//    slice + a 32-bit byte offset = ONE VALU instruction per gather (v_mad_u32_u24), and the
+//    hardware range check does the masking: slots a row does not have carry the id `sent`, whose
+//    offset lies past the descriptor's end, so they load zeros and every add is unmasked.
+struct Src64 {
+    const float* Xc;
+    uint32_t pitch16;
+    static constexpr bool kRangeChecked = false;
+    __device__ int sent() const { return 0; }
+};
+struct Src32 {
+    __amdgpu_buffer_rsrc_t srd;
+    uint32_t pitch;          // bytes between operand rows
+    uint32_t qoff;           // this lane's byte offset inside a row segment
+    int sentinel;            // row id whose offset is out of range
+    static constexpr bool kRangeChecked = true;
+    __device__ int sent() const { return sentinel; }
+};
+
+__device__ __forceinline__ float4 ld_row(const Src64& s, int idx) {
+    return reinterpret_cast<const float4*>(s.Xc)[size_t(uint32_t(__umul24(uint32_t(idx), s.pitch16)))];
+}
+__device__ __forceinline__ float4 ld_row(const Src32& s, int idx) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(s.srd, int(__umul24(uint32_t(idx), s.pitch) + s.qoff), 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
 // N slots of a chunk: slot j reads the row whose id sits in lane lane0 + j * LS of `ids`.
-// MASKED: slot j counts for this lane only when j < rem.
-template <int N, int LS, bool MASKED>
-__device__ __forceinline__ void gather_slots(const float* Xc, uint32_t pitch16, int ids, int lane0,
-                                             int rem, float (&acc)[4]) {
+// MASKED (Src64 only): slot j counts for this lane only when j < rem.
+template <int N, int LS, bool MASKED, typename SRC>
+__device__ __forceinline__ void gather_slots(const SRC& src, int ids, int lane0, int rem, float (&acc)[4]) {
     float4 v[N > 0 ? N : 1];
 #pragma unroll
-    for (int j = 0; j < N; ++j) v[j] = ld_row(Xc, __shfl(ids, lane0 + j * LS), pitch16);
+    for (int j = 0; j < N; ++j) v[j] = ld_row(src, __shfl(ids, lane0 + j * LS));
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-        if constexpr (MASKED) {
+        if constexpr (MASKED && !SRC::kRangeChecked) {
             const float m = j < rem ? 1.0f : 0.0f;
             acc[0] = fmaf(v[j].x, m, acc[0]);
             acc[1] = fmaf(v[j].y, m, acc[1]);
@@ -666,50 +698,61 @@ __device__ __forceinline__ void gather_slots(const float* Xc, uint32_t pitch16, 
 
 // n_max (wave-uniform, 0..8) slots are needed by some lane group, n_full by all of them.  At most
 // four gathers are in flight per call (16 registers of data): the kernel's latency hiding comes
-// from eight waves per SIMD, not from long per-wave queues (64 VGPRs).
-template <int LS>
-__device__ __forceinline__ void gather_half(const float* Xc, uint32_t pitch16, int ids, int lane0,
-                                            int n_max, int n_full, int rem, float (&acc)[4]) {
-    if (n_full >= n_max) {
+// from 7-8 waves per SIMD, not from long per-wave queues.
+template <int LS, typename SRC>
+__device__ __forceinline__ void gather_half(const SRC& src, int ids, int lane0, int n_max, int n_full,
+                                            int rem, float (&acc)[4]) {
+    if (SRC::kRangeChecked || n_full >= n_max) {
         switch (n_max) {
-            case 4: gather_slots<4, LS, false>(Xc, pitch16, ids, lane0, rem, acc); break;
-            case 3: gather_slots<3, LS, false>(Xc, pitch16, ids, lane0, rem, acc); break;
-            case 2: gather_slots<2, LS, false>(Xc, pitch16, ids, lane0, rem, acc); break;
-            case 1: gather_slots<1, LS, false>(Xc, pitch16, ids, lane0, rem, acc); break;
+            case 4: gather_slots<4, LS, false>(src, ids, lane0, rem, acc); break;
+            case 3: gather_slots<3, LS, false>(src, ids, lane0, rem, acc); break;
+            case 2: gather_slots<2, LS, false>(src, ids, lane0, rem, acc); break;
+            case 1: gather_slots<1, LS, false>(src, ids, lane0, rem, acc); break;
             default: break;
         }
     } else {
         switch (n_max) {
-            case 4: gather_slots<4, LS, true>(Xc, pitch16, ids, lane0, rem, acc); break;
-            case 3: gather_slots<3, LS, true>(Xc, pitch16, ids, lane0, rem, acc); break;
-            case 2: gather_slots<2, LS, true>(Xc, pitch16, ids, lane0, rem, acc); break;
-            case 1: gather_slots<1, LS, true>(Xc, pitch16, ids, lane0, rem, acc); break;
+            case 4: gather_slots<4, LS, true>(src, ids, lane0, rem, acc); break;
+            case 3: gather_slots<3, LS, true>(src, ids, lane0, rem, acc); break;
+            case 2: gather_slots<2, LS, true>(src, ids, lane0, rem, acc); break;
+            case 1: gather_slots<1, LS, true>(src, ids, lane0, rem, acc); break;
             default: break;
         }
     }
 }
 
-template <int LS>
-__device__ __forceinline__ void gather_chunk(const float* Xc, uint32_t pitch16, int ids, int lane0,
-                                             int n_max, int n_full, int rem, float (&acc)[4]) {
-    gather_half<LS>(Xc, pitch16, ids, lane0, min(n_max, 4), min(n_full, 4), rem, acc);
-    if (n_max > 4)
-        gather_half<LS>(Xc, pitch16, ids, lane0 + 4 * LS, n_max - 4, n_full - 4, rem - 4, acc);
+template <int LS, typename SRC>
+__device__ __forceinline__ void gather_chunk(const SRC& src, int ids, int lane0, int n_max, int n_full,
+                                             int rem, float (&acc)[4]) {
+#ifdef SIMRANK_DEPTH8
+    // experiment build (tools/build_variant.sh): chunks of 5..8 slots issue all their gathers together
+    if (SRC::kRangeChecked && n_max > 4) {
+        switch (n_max) {
+            case 8: gather_slots<8, LS, false>(src, ids, lane0, rem, acc); break;
+            case 7: gather_slots<7, LS, false>(src, ids, lane0, rem, acc); break;
+            case 6: gather_slots<6, LS, false>(src, ids, lane0, rem, acc); break;
+            default: gather_slots<5, LS, false>(src, ids, lane0, rem, acc); break;
+        }
+        return;
+    }
+#endif
+    gather_half<LS>(src, ids, lane0, min(n_max, 4), min(n_full, 4), rem, acc);
+    if (n_max > 4) gather_half<LS>(src, ids, lane0 + 4 * LS, n_max - 4, n_full - 4, rem - 4, acc);
 }
 
 // Sum of the X segments of the neighbours at CSR positions [s, e) (s, e wave-uniform): blocks of
 // 64 ids, one per lane; slot u of lane group g is neighbour 8 u + g of the block; partial sums of
 // the 8 groups combined by shuffles in a fixed order.  Every lane ends with the total.
-template <bool IDS16>
-__device__ __forceinline__ void gather_range3(const SpmmArgs& p, const float* Xc, uint32_t pitch16,
-                                              int s, int e, int lane, int g, float (&acc)[4]) {
+template <bool IDS16, typename SRC>
+__device__ __forceinline__ void gather_range3(const SpmmArgs& p, const SRC& src, int s, int e, int lane,
+                                              int g, float (&acc)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = 0.f;
     for (int base = s; base < e; base += 64) {
         const int n = min(64, e - base);
-        const int myid = (lane < n && !(p.probe & 8)) ? (ld_id<IDS16>(p, base + lane) & p.idx_mask) : 0;
+        const int myid = (lane < n && !(p.probe & 8)) ? (ld_id<IDS16>(p, base + lane) & p.idx_mask) : src.sent();
         if (!(p.probe & 1))
-            gather_chunk<8>(Xc, pitch16, myid, g, (n + 7) >> 3, n >> 3, (n - g + 7) >> 3, acc);
+            gather_chunk<8>(src, myid, g, (n + 7) >> 3, n >> 3, (n - g + 7) >> 3, acc);
     }
 #pragma unroll
     for (int off = 8; off < 64; off <<= 1)
@@ -845,8 +888,12 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 // or the upper-triangle leg of a power-law graph) run an instantiation that does not carry the four
 // registers of those sums: 60 instead of 68 VGPRs for the transposed leg (8 waves per SIMD), 79
 // instead of 89 for the others (6 instead of 5): leg 2 -5...7 %.
-template <int MODE, bool IDS16, bool RESTRICT, bool DENSE>
-__global__ __launch_bounds__(256, MODE == kTrans ? (DENSE ? 7 : 8) : (DENSE ? 5 : 6))
+// A32: Src32 addressing (see above).
+template <int MODE, bool IDS16, bool RESTRICT, bool DENSE, bool A32>
+#ifndef SIMRANK_LB_DELTA
+#define SIMRANK_LB_DELTA 0      // experiment builds lower the occupancy bounds by this much
+#endif
+__global__ __launch_bounds__(256, (MODE == kTrans ? ((DENSE && !A32) ? 7 : 8) : (DENSE ? 5 : 6)) - SIMRANK_LB_DELTA)
 void gather3_kernel(const SpmmArgs p) {
     constexpr bool TRANS = MODE == kTrans;
     constexpr bool TILE = MODE != kPlain;
@@ -897,9 +944,22 @@ void gather3_kernel(const SpmmArgs p) {
     const int64_t mycol = c0 + int64_t(q) * 4;
     const bool col_active = mycol < p.L;
     // lanes past the last column gather from column 0 (valid memory); nothing of theirs is stored
-    const float* __restrict__ Xc = p.blocked ? p.X + (int64_t(panel) * p.x_rows_pad) * 32 + q * 4
-                                             : p.X + (col_active ? mycol : 0);
-    const uint32_t pitch16 = uint32_t(p.ldx >> 2);            // (blocked: ldx = 32)
+    using SRC = typename std::conditional<A32, Src32, Src64>::type;
+    SRC xs;
+    if constexpr (A32) {
+        // descriptor over everything this panel can touch: the panel's slice (blocked), or from its
+        // first column to the end of the matrix (row-major; the padding of a row is readable)
+        const float* base = p.blocked ? p.X + (int64_t(panel) * p.x_rows_pad) * 32 : p.X + c0;
+        xs.srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, int(p.x_span_bytes - (p.blocked ? 0 : c0 * 4)),
+                                                    0x00020000);
+        xs.pitch = uint32_t(p.ldx) * 4u;
+        xs.qoff = uint32_t(q) * 16u;
+        xs.sentinel = p.x_sentinel;
+    } else {
+        xs.Xc = p.blocked ? p.X + (int64_t(panel) * p.x_rows_pad) * 32 + q * 4
+                           : p.X + (col_active ? mycol : 0);
+        xs.pitch16 = uint32_t(p.ldx >> 2);                       // (blocked: ldx = 32)
+    }
     const int64_t colofs = p.blocked ? (int64_t(panel) * p.y_rows_pad) * 32 + q * 4 : mycol;
     float* tbuf_wave = smem + (TILE ? wave * PW * (RT + 1) : 0);
     unsigned changed = 0;
@@ -986,7 +1046,7 @@ void gather3_kernel(const SpmmArgs p) {
             const int s = hs + wave * chunk;
             const int e = min(hs + hl, s + chunk);
             float part[4];
-            gather_range3<IDS16>(p, Xc, pitch16, s, e, lane, g, part);
+            gather_range3<IDS16>(p, xs, s, e, lane, g, part);
             if (g == 0) vstore<4>(hpart + (i * kWaves + wave) * PW + q * 4, part);
         }
         __syncthreads();
@@ -1028,7 +1088,7 @@ void gather3_kernel(const SpmmArgs p) {
             live = __ballot(w != 0u) != 0;                           // uniform: the row's 32 columns
         }
         if (live) {
-            gather_range3<IDS16>(p, Xc, pitch16, s, e, lane, g, acc);
+            gather_range3<IDS16>(p, xs, s, e, lane, g, acc);
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = 0.f;
@@ -1050,7 +1110,7 @@ void gather3_kernel(const SpmmArgs p) {
         float sc = __shfl(my_scale, r & 63);
         int maxlen = __builtin_amdgcn_readfirstlane(len);           // sorted: group 0 has the longest
         int minlen = __builtin_amdgcn_readlane(len, 63);            // ... group 7 the shortest (0: no row)
-        int iv = (q < len && !(p.probe & 8)) ? (ld_id<IDS16>(p, st + q) & p.idx_mask) : 0;
+        int iv = (q < len && !(p.probe & 8)) ? (ld_id<IDS16>(p, st + q) & p.idx_mask) : xs.sent();
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         float dsum[4];
         dense_partial<DENSE>(p, int64_t(row0) + r, mycol, src < nrows && col_active, dsum);
@@ -1067,7 +1127,7 @@ void gather3_kernel(const SpmmArgs p) {
             const int npos = same_pass ? pos : pos + 8;
             const int nt0 = same_pass ? t0 + LPR : 0;
             const bool more = npos < nrows;
-            int nr = r, nst = st, nlen = len, nmax = maxlen, nmin = minlen, niv = 0;
+            int nr = r, nst = st, nlen = len, nmax = maxlen, nmin = minlen, niv = xs.sent();
             float nsc = sc;
             if (!same_pass && more) {
                 const int nsrc = npos + g;
@@ -1082,7 +1142,7 @@ void gather3_kernel(const SpmmArgs p) {
             if (more && nt0 + q < nlen && !(p.probe & 8)) niv = ld_id<IDS16>(p, nst + nt0 + q) & p.idx_mask;
 
             if (!(p.probe & 1) && glive)
-                gather_chunk<1>(Xc, pitch16, iv, gbase, min(LPR, maxlen - t0), max(0, min(LPR, minlen - t0)),
+                gather_chunk<1>(xs, iv, gbase, min(LPR, maxlen - t0), max(0, min(LPR, minlen - t0)),
                                 len - t0, acc);
 
             if (!same_pass) {
@@ -1205,8 +1265,16 @@ static int launch_gather3(SpmmArgs a, hipStream_t st) {
     const bool restricted = MODE != kTrans && a.has_ep && a.ev && a.restrict_support;
     const bool dense = a.dpart != nullptr;
     const dim3 gr((unsigned)grid), bl(256);
+    // 32-bit buffer addressing when one more row than the operand has still fits under 2 GiB
+    const int64_t x_rows = a.blocked ? a.x_rows_pad : a.K;
+    const int64_t span = a.blocked ? a.x_rows_pad * 128 : ((x_rows - 1) * a.ldx + a.ldx) * 4;
+    const bool a32 = a.addr32 && (x_rows + 1) * a.ldx * 4 + 256 < (int64_t(1) << 31) &&
+                     a.ldx * 4 < (int64_t(1) << 24) && x_rows < (int64_t(1) << 24) - 1;
+    a.x_span_bytes = span;
+    a.x_sentinel = (int32_t)x_rows;
 #define SR_LAUNCH3(IDS, RES, DEN) \
-    hipLaunchKernelGGL((gather3_kernel<MODE, IDS, RES, DEN>), gr, bl, lds, st, a)
+    do { if (a32) hipLaunchKernelGGL((gather3_kernel<MODE, IDS, RES, DEN, true>), gr, bl, lds, st, a); \
+         else hipLaunchKernelGGL((gather3_kernel<MODE, IDS, RES, DEN, false>), gr, bl, lds, st, a); } while (0)
 #define SR_LAUNCH3_IDS(RES, DEN) \
     do { if (a.col16) SR_LAUNCH3(true, RES, DEN); else SR_LAUNCH3(false, RES, DEN); } while (0)
     if constexpr (MODE != kTrans) {
@@ -1483,6 +1551,7 @@ static int spmm_impl(const simrank_graph* g, const float* X, int64_t ldx, int64_
     a.Y = Y;
     a.ldy = ldy;
     a.M = g->n_rows;
+    a.K = g->n_cols;
     a.tblock = (t_block <= 0 || t_block > g->n_rows) ? g->n_rows : t_block;
     a.tstride = (transpose_out && a.tblock == g->n_rows && ldy >= g->n_rows) ? ldy : 0;
     a.tpad = a.tstride ? 0 : t_pad;
@@ -1492,6 +1561,7 @@ static int spmm_impl(const simrank_graph* g, const float* X, int64_t ldx, int64_
                                         : (a.tblock % 4 == 0 && a.tpad % 4 == 0 && g->n_rows % 4 == 0));
     a.xcd_map = (int)T.xcd_map;
     a.idx_mask = (int32_t)T.probe_mask;
+    a.addr32 = (int32_t)T.addr32;
     a.probe = (int32_t)T.probe_flags;
     bool vec_ok = aligned16(X) && ldx % 4 == 0;
     if (!transpose_out) vec_ok = vec_ok && aligned16(Y) && ldy % 4 == 0;

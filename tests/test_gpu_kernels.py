@@ -355,25 +355,26 @@ def test_panel_blocked_operands_give_the_row_major_bits(ops, n, L):
     assert np.array_equal(ops.download(put_as(X, True)), X)            # layout round trip
     assert np.array_equal(ops.download(put_as(cnt, True, np.uint8)), cnt)
     out = {}
-    for blocked in (False, True):
-        x = put_as(X, blocked)
-        yt = ops.matrix(L, n, blocked=blocked)
+    for blocked in (False, True, "addr64"):
+        if blocked == "addr64":              # the 64-bit addressing form (masked slots) on blocked operands
+            ops.set_tuning(addr32=0)
+            g = ops.graph(csr)
+            ops.set_tuning(addr32=1)
+        x = put_as(X, bool(blocked))
+        yt = ops.matrix(L, n, blocked=bool(blocked))
         ops.spmm(g, x, yt, transpose_out=True)
         res = [ops.download(yt)]
         for sym in ((False, True) if n == L else (False,)):
-            ops.set_tuning(panel=32)                                     # plain form on the lean kernel too
-            try:
-                g32 = ops.graph(csr)
-            finally:
-                ops.set_tuning(panel=0)
-            y = ops.matrix(n, L, blocked=blocked)
-            ep = dict(coef=0.7, evidence=put_as(cnt, blocked, np.uint8), apriori=put_as(prior, blocked),
-                      lbd=0.25, previous=put_as(prev, blocked), eps=0.3, diag_col0=0, symmetric=sym)
-            ops.spmm(g32, x, y, epilogue=ep)
+            b = bool(blocked)
+            y = ops.matrix(n, L, blocked=b)
+            ep = dict(coef=0.7, evidence=put_as(cnt, b, np.uint8), apriori=put_as(prior, b),
+                      lbd=0.25, previous=put_as(prev, b), eps=0.3, diag_col0=0, symmetric=sym)
+            ops.spmm(g, x, y, epilogue=ep)
             res += [ops.download(y), ops.read_changed()]
         out[blocked] = res
-    for a, b in zip(out[False], out[True]):
-        assert np.array_equal(a, b)
+    for other in (True, "addr64"):
+        for a, b in zip(out[False], out[other]):
+            assert np.array_equal(a, b)
     want = (dense64(csr) @ X.astype(np.float64)).T
     np.testing.assert_allclose(out[True][0], want, rtol=RTOL, atol=1e-30)
     # top-k and row hand-back straight from the blocked layout

@@ -159,6 +159,22 @@ SIMRANK_API int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx
                  float* Y, int64_t ldy, int32_t transpose_out, int64_t t_block, int64_t t_pad,
                  const simrank_epilogue* epilogue, void* stream);
 
+/* ---- leg 2 of ONE RANK of a sharded symmetric update, half the gathers.  The graph has
+ *      n_rows = world * mb rows, mb a multiple of 32; the rank owns columns [rank*mb, (rank+1)*mb)
+ *      (epilogue->diag_col0 = rank*mb); X is the n_cols(g) x mb operand, Y the n_rows x mb block.
+ *      For the 32-row tile i of shard h and the rank's column tile j only i <= j is computed; for
+ *      i < j the transposed tile is also stored — inside Y when h == rank, else packed into
+ *      send[h*chunk_floats + (j(j-1)/2 + i)*1024 ...] (32 x 32 floats, row = the rank's column).
+ *      After an all-to-all of the chunks, simrank_shard_unpack puts what rank h sent at rows
+ *      (h, j) x columns (rank, i) of Y.  The node order must make every shard an equal mix of short
+ *      and long rows (driver.dealt_order) for the work to halve evenly.  n_changed counts mirrored
+ *      elements twice.  Same reference lines as simrank_spmm with an epilogue. */
+SIMRANK_API int simrank_spmm_shard(const simrank_graph* g, const float* X, int64_t ldx, float* Y,
+                                   int64_t ldy, const simrank_epilogue* epilogue, int32_t rank,
+                                   int32_t world, float* send, int64_t chunk_floats, void* stream);
+SIMRANK_API int simrank_shard_unpack(float* Y, int64_t ldy, const float* recv, int64_t chunk_floats,
+                                     int32_t rank, int32_t world, int64_t n_rows, void* stream);
+
 /* ---- K4/K5 alone: Y = epilogue(Q), element-wise over an n_rows x n_cols block (Q and Y may be
  *      the same buffer).  Used when an update cannot fuse its epilogue into leg 2: a prior
  *      that is not symmetric makes S asymmetric, and leg 2 must then store its product

@@ -51,6 +51,9 @@ struct SpmmArgs {
     int64_t x_span_bytes;     // A32: bytes from X (blocked: from a panel's start) to the end of what a gather may touch
     int32_t x_sentinel;       // A32: a row id whose offset is past that span (loads zeros)
     int32_t addr32;           // tuning "addr32": allow the 32-bit buffer addressing
+    int32_t sh_rank, sh_mb;   // kShard: this rank's shard, rows (= columns) per shard (multiple of 32)
+    float* sh_send;           // kShard: packed mirrored tiles for the other ranks
+    int64_t sh_chunk;         // kShard: floats per destination rank in sh_send
     int32_t idx_mask;         // diagnostic (tuning "probe_mask"): neighbour ids are ANDed with it; -1 = off
     int32_t probe;            // diagnostic (tuning "probe_flags", lean kernel): 1 no gathers, 2 no stores of Y,
                               // 4 no partial sums of the dense part, 8 no neighbour-id loads
@@ -165,6 +168,15 @@ constexpr int kSkip = INT32_MIN;  // "no neighbour in this slot"  // rows with a
 //           ALSO stored mirrored (through the LDS tile); tiles below the diagonal are
 //           never computed.  Halves the gathers of leg 2 on a single rank.
 constexpr int kPlain = 0, kTrans = 1, kSym = 2;
+// kShard (lean kernel only): leg 2 of one rank of a SHARDED symmetric update.  The rank owns the
+// columns of shard g (sh_mb columns); node positions are dealt so that every shard holds an equal mix
+// of short and long rows, ascending inside the shard.  For the row tile i of shard h and its own column
+// tile j the rank computes S'[rows (h,i), cols (g,j)] only when i <= j; for i < j it also stores the
+// transposed tile — into its own block when h == g, else into a send buffer (packed 32 x 32 tiles,
+// slot j(j-1)/2 + i of the chunk for rank h), which a second all-to-all delivers to the rank that
+// owns columns (h,i) (simrank_shard_unpack puts it at rows (g,j)).  Halves the gathers of a sharded
+// leg 2 the way kSym does on one rank.
+constexpr int kShard = 3;
 
 template <int VEC, int LPR, int MODE, int RT>
 __device__ __forceinline__ void emit_row(const SpmmArgs& p, float* tbuf_wave, int r_local,
@@ -840,7 +852,7 @@ __device__ __forceinline__ void emit_row3(const SpmmArgs& p, float* tbuf_wave, i
                                    ? (mirror ? 2u : 1u) : 0u;
             }
         }
-        if constexpr (MODE == kSym) {
+        if constexpr (MODE == kSym || MODE == kShard) {
             if (mirror) {
                 float* t = tbuf_wave + (q * 4) * (RT + 1) + r_local;
 #pragma unroll
@@ -936,6 +948,20 @@ void gather3_kernel(const SpmmArgs p) {
     }
     if (panel >= p.n_panels) return;
     if ((p.probe & 16) && (blockIdx.x & 7) != 0) return;      // diagnostic: one XCD's share of the launch only
+    if constexpr (MODE == kShard) {
+        // column tile j works on the row tiles i <= j of every shard: the late panels are the heavy
+        // ones and go first (a panel stays on one XCD: n_panels is a multiple of 8 or the tail is short)
+        panel = p.n_panels - 1 - panel;
+        // the workgroup's first tile has its smallest row: if even that lies in a tile i > j, nothing to do
+        const int t0 = rt * kWaves;
+        const int first = p.tile_row0 ? (t0 < p.n_tiles ? p.tile_row0[t0] : int(p.M)) : t0 * RT;
+        if (first >= p.M) return;
+        const int h0 = int(uint32_t(first) / uint32_t(p.sh_mb));
+        // (a workgroup's tiles may straddle two shards: then the later tiles start again at i = 0)
+        const int last = p.tile_row0 ? (t0 + kWaves < p.n_tiles ? p.tile_row0[t0 + kWaves] : int(p.M))
+                                     : min(int(p.M), (t0 + kWaves) * RT);
+        if (int(uint32_t(last - 1) / uint32_t(p.sh_mb)) == h0 && ((first - h0 * p.sh_mb) >> 5) > panel) return;
+    }
 
     const int64_t c0 = int64_t(panel) * PW;
     const int g = lane >> 3;
@@ -976,6 +1002,13 @@ void gather3_kernel(const SpmmArgs p) {
         const int rb = row0 & ~(RT - 1);
         if (rb > c0) nrows = 0;
         mirror = rb < c0;
+    }
+    int shard_h = 0, tile_i = 0;
+    if constexpr (MODE == kShard) {
+        shard_h = int(uint32_t(row0) / uint32_t(p.sh_mb));
+        tile_i = (row0 - shard_h * p.sh_mb) >> 5;
+        if (tile_i > panel) nrows = 0;          // the rank that owns columns (h, i) computes the mirror image
+        mirror = tile_i < panel;
     }
 
     // ---- rows of the tile by length, longest first
@@ -1166,7 +1199,39 @@ void gather3_kernel(const SpmmArgs p) {
         STAMP(4);      // waiting for the other waves of the workgroup
         const int cols_here = int(imin(PW, p.L - c0));
         const int rows_out = ((TRANS || mirror) && !(p.probe & 2)) ? nrows : 0;
-        if (rows_out > 0 && p.blocked) {
+        if (MODE == kShard && rows_out > 0) {
+            // the transposed tile: element (c, r) is S'[global row of my column c0 + c][column (h, i) * 32 + r]
+            const int in32 = row0 & 31;
+            float* base;
+            int64_t rstride;
+            if (shard_h == p.sh_rank) {
+                base = p.Y + (p.diag_col0 + c0) * p.ldy + (tile_i * 32 + in32);
+                rstride = p.ldy;
+            } else {
+                const int64_t slot = int64_t(panel) * (panel - 1) / 2 + tile_i;
+                base = p.sh_send + int64_t(shard_h) * p.sh_chunk + slot * 1024 + in32;
+                rstride = 32;
+            }
+            if ((rows_out & 3) == 0 && (row0 & 3) == 0) {
+#pragma unroll
+                for (int it = 0; it < PW * (RT / 4) / 64; ++it) {
+                    const int x = lane + it * 64;
+                    const int c = x >> 3;
+                    const int r4 = (x & 7) * 4;
+                    if (r4 < rows_out) {
+                        const float* t = tbuf_wave + c * (RT + 1) + r4;
+                        const float v4[4] = {t[0], t[1], t[2], t[3]};
+                        vstore<4>(base + c * rstride + r4, v4);
+                    }
+                }
+            } else {
+                for (int x = lane; x < PW * RT; x += 64) {
+                    const int c = x >> 5;
+                    const int r = x & 31;
+                    if (r < rows_out) base[c * rstride + r] = tbuf_wave[c * (RT + 1) + r];
+                }
+            }
+        } else if (rows_out > 0 && p.blocked) {
             // panel-blocked Y^T: the tile's 32 c-rows are consecutive 128-byte lines of panel row0 / 32
             float* base = p.Y + ((int64_t(row0 >> 5) * p.y_rows_pad) + c0) * 32 + (row0 & 31);
             if (cols_here == PW && (rows_out & 3) == 0 && (row0 & 3) == 0) {
@@ -1484,6 +1549,29 @@ __global__ __launch_bounds__(256) void live_segments_kernel(const uint8_t* __res
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(live, (unsigned long long)mine);
 }
 
+// kShard: the mirrored tiles a rank received (packed 32 x 32 tiles, slot j(j-1)/2 + i of the chunk of
+// source rank h) go to rows (h, j) x columns (mine, i) of its block.  One workgroup per tile.
+__global__ __launch_bounds__(256) void shard_unpack_kernel(float* Y, int64_t ldy, const float* recv,
+                                                           int64_t chunk, int rank, int mb, int tiles) {
+    const int64_t per_src = int64_t(tiles) * (tiles - 1) / 2;
+    for (int64_t w = blockIdx.x; w < per_src * gridDim.y; w += gridDim.x) {
+        const int h = blockIdx.y;
+        if (h == rank) return;
+        const int64_t slot = w % per_src;
+        // slot = j (j - 1) / 2 + i, i < j
+        int j = int((1.0 + sqrt(1.0 + 8.0 * double(slot))) * 0.5);
+        while (int64_t(j) * (j - 1) / 2 > slot) --j;
+        while (int64_t(j + 1) * j / 2 <= slot) ++j;
+        const int i = int(slot - int64_t(j) * (j - 1) / 2);
+        const float* src = recv + int64_t(h) * chunk + slot * 1024;
+        float* dst = Y + (int64_t(h) * mb + 32 * j) * ldy + 32 * i;
+        const int c = threadIdx.x >> 3, r4 = (threadIdx.x & 7) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(src + c * 32 + r4);
+        *reinterpret_cast<float4*>(dst + c * ldy + r4) = v;
+        if (gridDim.x >= per_src) return;
+    }
+}
+
 }  // namespace simrank
 
 using namespace simrank;
@@ -1756,6 +1844,72 @@ static int epilogue_apply_impl(const float* Q, int64_t ldq, float* Y, int64_t ld
         SR_HIP(hipMemsetAsync(a.n_changed, 0, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS, st));
     const int grid = (int)std::min<int64_t>((n_rows * n_cols + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(epilogue_kernel, dim3(grid), dim3(256), 0, st, Q, ldq, Y, ldy, n_rows, n_cols, a);
+    SR_HIP(hipGetLastError());
+    return SIMRANK_OK;
+}
+
+int simrank_spmm_shard(const simrank_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy,
+                       const simrank_epilogue* ep, int32_t rank, int32_t world, float* send,
+                       int64_t chunk_floats, void* stream) {
+    SR_REQUIRE(g && X && Y && ep && send, "NULL argument");
+    SR_REQUIRE(world > 1 && rank >= 0 && rank < world && g->n_rows % (int64_t(world) * 32) == 0,
+               "a symmetric sharded leg needs n_rows (%lld) divisible by 32 x world (%d)",
+               (long long)g->n_rows, world);
+    const int64_t mb = g->n_rows / world, tiles = mb / 32;
+    SR_REQUIRE(chunk_floats >= tiles * (tiles - 1) / 2 * 1024, "send chunk too small");
+    SR_REQUIRE(ep->diag_col0 == int64_t(rank) * mb && ldx >= mb && ldy >= mb && aligned16(X) && aligned16(Y) &&
+                   aligned16(send) && ldx % 4 == 0 && ldy % 4 == 0, "bad shard operands");
+    const Tuning& T = g->tun;
+    SR_REQUIRE(T.lean && (T.tile == 0 || T.tile == 32) && (T.panel == 0 || T.panel == 32) &&
+                   g->n_cols < (int64_t(1) << 24) && ldx / 4 < (int64_t(1) << 24) &&
+                   g->n_cols * (ldx / 4) < (int64_t(1) << 32), "the symmetric sharded leg needs the lean kernel");
+    SpmmArgs a{};
+    a.rowptr = g->rowptr;
+    a.col = g->col;
+    a.col16 = T.ids16 ? g->col16 : nullptr;
+    a.rowscale = g->rowscale;
+    a.huge_len = (int32_t)std::max<int64_t>(kHeavy, T.huge);
+    a.has_huge = g->max_row_nnz >= a.huge_len ? 1 : 0;
+    a.X = X; a.ldx = ldx; a.L = mb; a.Y = Y; a.ldy = ldy;
+    a.M = g->n_rows; a.K = g->n_cols;
+    a.tblock = g->n_rows;
+    a.xcd_map = (int)T.xcd_map;
+    a.idx_mask = (int32_t)T.probe_mask;
+    a.addr32 = (int32_t)T.addr32;
+    a.probe = (int32_t)T.probe_flags;
+    a.nt = 0;
+    a.has_ep = 1;
+    a.coef = ep->coef; a.lbd = ep->lbd;
+    a.ev = ep->evidence; a.ld_ev = ep->ld_evidence;
+    a.ap = ep->apriori; a.ld_ap = ep->ld_apriori;
+    a.prev = ep->previous; a.ld_prev = ep->ld_previous;
+    a.eps = ep->eps; a.n_changed = ep->n_changed;
+    a.diag_col0 = ep->diag_col0; a.set_diag = ep->set_diag;
+    a.restrict_support = ep->restrict_support;
+    SR_REQUIRE(!a.prev || a.n_changed, "previous needs a counter");
+    SR_REQUIRE((!a.ev || (a.ld_ev % 4 == 0 && reinterpret_cast<uintptr_t>(a.ev) % 4 == 0)) &&
+                   (!a.ap || (aligned16(a.ap) && a.ld_ap % 4 == 0)) &&
+                   (!a.prev || (aligned16(a.prev) && a.ld_prev % 4 == 0)), "unaligned epilogue operand");
+    a.sh_rank = rank; a.sh_mb = (int32_t)mb; a.sh_send = send; a.sh_chunk = chunk_floats;
+    hipStream_t st = as_stream(stream);
+    if (a.prev) SR_HIP(hipMemsetAsync(a.n_changed, 0, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS, st));
+    if (T.balance && g->tile_row0) {
+        a.tile_row0 = g->tile_row0;
+        a.n_tiles = g->n_tiles;
+    }
+    return launch_gather3<kShard>(a, st);
+}
+
+int simrank_shard_unpack(float* Y, int64_t ldy, const float* recv, int64_t chunk_floats, int32_t rank,
+                         int32_t world, int64_t n_rows, void* stream) {
+    SR_REQUIRE(Y && recv && world > 1 && rank >= 0 && rank < world && n_rows % (int64_t(world) * 32) == 0,
+               "bad shard unpack");
+    const int mb = int(n_rows / world), tiles = mb / 32;
+    const int64_t per_src = int64_t(tiles) * (tiles - 1) / 2;
+    if (per_src == 0) return SIMRANK_OK;
+    SR_REQUIRE(per_src < (int64_t(1) << 31), "too many tiles");
+    hipLaunchKernelGGL(shard_unpack_kernel, dim3((unsigned)per_src, (unsigned)world), dim3(256), 0,
+                       as_stream(stream), Y, ldy, recv, chunk_floats, (int)rank, mb, tiles);
     SR_HIP(hipGetLastError());
     return SIMRANK_OK;
 }

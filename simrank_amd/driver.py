@@ -114,11 +114,15 @@ def permute_columns(csr: CSR, perm: np.ndarray) -> CSR:
 class LocalWorld:
     """P virtual ranks inside this process (P = 1 is the ordinary single-GPU case)."""
 
-    def __init__(self, size: int = 1):
+    def __init__(self, size: int = 1, symmetric_shards: bool = True):
+        """``symmetric_shards``: sharded symmetric updates run leg 2 in its half form when the node
+        count allows it (``Side.shard_sym``); False keeps the full form, whose results are bit-equal
+        to a single rank's full form."""
         self.size = int(size)
         self.local_ranks = list(range(self.size))
         self.is_root = True
         self.stages = 1
+        self.symmetric_shards = bool(symmetric_shards)
 
     def exchange(self, parts):
         """All-to-all of the transposed tiles between the virtual ranks (device copies)."""
@@ -131,6 +135,14 @@ class LocalWorld:
                 src.ops.copy_bytes(dst.recv.ptr + 4 * src.col_lo * w,
                                    src.send.ptr + 4 * dst.rank * src.ncols * (src.mb + src.pad),
                                    4 * n)
+
+    def exchange_mirrors(self, sides):
+        """All-to-all of the packed mirrored tiles of a half-form leg 2 (equal chunks)."""
+        for src in sides:
+            for dst in sides:
+                if src is not dst:
+                    n = 4 * src.sh_chunk
+                    src.ops.copy_bytes(dst.sh_recv.ptr + n * src.rank, src.sh_send.ptr + n * dst.rank, n)
 
     def sum_int(self, values):
         return int(sum(values))
@@ -153,7 +165,7 @@ class TorchWorld:
     GPU box; "gloo" in the CPU tests)."""
 
     def __init__(self, group=None, stages: int = 0, stage_single_rank: bool = False,
-                 handback: str = "root"):
+                 handback: str = "root", symmetric_shards: bool = True):
         """``stages``: leg 1 is cut into that many column slices, each exchanged by its own
         all_to_all_single as soon as its kernel has finished, so the transfers over xGMI overlap
         the remaining leg-1 kernels (1 = one exchange after the whole leg; 0 = by the width of a
@@ -162,11 +174,13 @@ class TorchWorld:
         column blocks are gathered to rank 0 on the device, put back into the caller's node order
         there and downloaded once; the other ranks' ``fit`` returns None.  "all": every rank gets
         the full float64 matrix (pickled all-gather: N^2 x 8 B x P per node — small N only).
-        ``fit(top_k=k)`` hands k columns per row to every rank either way."""
+        ``fit(top_k=k)`` hands k columns per row to every rank either way.
+        ``symmetric_shards``: as for ``LocalWorld``."""
         import torch.distributed as dist
         if handback not in ("root", "all"):
             raise ValueError("handback must be 'root' or 'all'")
         self.handback = handback
+        self.symmetric_shards = bool(symmetric_shards)
         self.dist = dist
         self.group = group
         self.size = dist.get_world_size(group)
@@ -235,6 +249,19 @@ class TorchWorld:
         self.dist.all_to_all_single(x.recv_t[:sum(out_splits)], x.send_t[:sum(in_splits)],
                                     out_splits, in_splits, group=self.group)
         x.ops.collective_done()
+
+    def exchange_mirrors(self, sides):
+        """All-to-all of the packed mirrored tiles of a half-form leg 2: equal chunks, the one a
+        rank addresses to itself is empty on purpose (its own mirrors were stored in place)."""
+        (sd,) = sides
+        if self.stream_ordered:
+            import torch
+            with torch.cuda.stream(sd.ops.torch_stream()):
+                self.dist.all_to_all_single(sd.sh_recv_t, sd.sh_send_t, group=self.group)
+            return
+        sd.ops.synchronize()
+        self.dist.all_to_all_single(sd.sh_recv_t, sd.sh_send_t, group=self.group)
+        sd.ops.collective_done()
 
     def sum_changed(self, ops, active=True):
         """Global convergence count of the update just queued, stream-ordered: the striped
@@ -321,7 +348,7 @@ class SideSpec:
 
 class Side:
     def __init__(self, ops, spec: SideSpec, rank: int, world: int, mode: str, torch_buffers: bool,
-                 stages: int = 1, blocked: bool = False):
+                 stages: int = 1, blocked: bool = False, shard_symmetric: bool = True):
         self.ops, self.spec, self.rank, self.world, self.mode = ops, spec, rank, world, mode
         self.blocked = blocked         # single rank, gather legs: every matrix panel-blocked
         csr = spec.csr
@@ -353,6 +380,23 @@ class Side:
             self.wd = ops.matrix(self.M, self.K)
             ops.densify(self.graph, self.wd)
             self.t = ops.matrix(self.M, self.K)
+        # Half-form leg 2 of a sharded symmetric update (simrank_spmm_shard): of the 32 x 32 tiles
+        # (shard h, tile i) x (my column tile j) only i <= j is computed, the transposed tiles i < j go to
+        # the ranks that own them in a second, half-size all-to-all.  Needs equal shards of whole tiles.
+        self.shard_sym = (mode == "sparse" and world > 1 and self.symmetric and shard_symmetric and
+                          self.M % (32 * world) == 0 and getattr(ops, "supports_shard_symmetric", False))
+        if self.shard_sym:
+            t = self.mb // 32
+            self.sh_chunk = max(1, t * (t - 1) // 2 * 1024)
+            self.sh_send_t = self.sh_recv_t = None
+            if torch_buffers:
+                self.sh_send_t = ops.exchange_buffer(world * self.sh_chunk)
+                self.sh_recv_t = ops.exchange_buffer(world * self.sh_chunk)
+                self.sh_send = ops.matrix(world, self.sh_chunk, ld=self.sh_chunk, external=self.sh_send_t)
+                self.sh_recv = ops.matrix(world, self.sh_chunk, ld=self.sh_chunk, external=self.sh_recv_t)
+            else:
+                self.sh_send = ops.matrix(world, self.sh_chunk, ld=self.sh_chunk)
+                self.sh_recv = ops.matrix(world, self.sh_chunk, ld=self.sh_chunk)
         self.ev = None
         if spec.evidence_from is not None:
             ev = spec.evidence_from
@@ -470,6 +514,9 @@ class Side:
             return
         if self.mode != "sparse":
             o.gemm_nt(self.t, self.wd, S_out, self.M, self.M, self.K, epilogue=self._ep(S_prev, eps))
+        elif self.shard_sym:
+            o.spmm_shard(self.graph2, self.recv, S_out, self._ep(S_prev, eps), self.rank, self.world,
+                         self.sh_send, self.sh_chunk)
         elif self.symmetric:
             ep = self._ep(S_prev, eps)
             # one rank holds the whole symmetric matrix: upper triangle + mirror image
@@ -480,6 +527,10 @@ class Side:
         else:
             o.spmm(self.graph2, self.recv, self.x2.send, n_cols=self.Lm, transpose_out=True,
                    t_block=self.mb, t_pad=self.x2.pad)
+
+    def unpack(self, S_out):
+        """Half-form leg 2, after the exchange of the mirrored tiles: put the received ones in place."""
+        self.ops.shard_unpack(S_out, self.sh_recv, self.sh_chunk, self.rank, self.world, self.M)
 
     def finish(self, S_prev, S_out, eps):
         """Second half of an update with asymmetric iterates: the stand-alone epilogue."""
@@ -513,7 +564,19 @@ def length_order(csr: CSR) -> np.ndarray:
     return np.argsort(np.diff(csr.rowptr), kind="stable")
 
 
-def reorder_specs(specs):
+def dealt_order(order: np.ndarray, world: int) -> np.ndarray:
+    """Ascending-length order dealt to ``world`` shards in tiles of 32 nodes: tile t goes to shard
+    t mod world, so every shard holds the same mix of short and long rows, ascending inside.  That is
+    what makes the half-form sharded leg 2 (``Side.shard_sym``) — tile i of any shard against column
+    tile j of mine only when i <= j — cut every rank's gathers the way the triangle does on one
+    rank, and balances leg 1 over the ranks as well.  Unchanged when the tiles do not divide evenly."""
+    n = order.size
+    if world <= 1 or n % (32 * world):
+        return order
+    return order.reshape(n // (32 * world), world, 32).transpose(1, 0, 2).reshape(-1)
+
+
+def reorder_specs(specs, deal: int = 1):
     """The update is equivariant under a renaming of the nodes, so the solver is free to pick
     the order it iterates in: every node set goes by ASCENDING ROW LENGTH of its graph.
     The rows a wave gathers together then have equal lengths (no masked gathers), and in the
@@ -521,7 +584,7 @@ def reorder_specs(specs):
     graph a quarter of the gathers of the natural order.
     Returns (specs in the new order, [order of node set j]); results are handed back in the
     caller's order by ``Solver.result`` / ``topk`` / ``evidence``."""
-    orders = [length_order(sp.csr) for sp in specs]
+    orders = [dealt_order(length_order(sp.csr), deal) for sp in specs]
     out = []
     for j, sp in enumerate(specs):
         cols = orders[0] if len(specs) == 1 else orders[1 - j]
@@ -552,7 +615,8 @@ class Solver:
         self.world = world
         self.order = [None] * len(specs)
         if reorder:
-            specs, self.order = reorder_specs(specs)
+            sym = getattr(world, "symmetric_shards", True) and all(s.symmetric for s in specs)
+            specs, self.order = reorder_specs(specs, world.size if sym else 1)
         self.inv = [None if o is None else np.argsort(o) for o in self.order]
         self._index = {}
         self.specs = specs
@@ -568,7 +632,8 @@ class Solver:
         self.blocked = (world.size == 1 and not torch_buffers and self.mode == "sparse" and
                         all(getattr(o, "supports_blocked", False) for o in self.ops.values()))
         self.sides = [{r: Side(self.ops[r], sp, r, world.size, self.mode, torch_buffers,
-                               getattr(world, "stages", 1), self.blocked)
+                               getattr(world, "stages", 1), self.blocked,
+                               getattr(world, "symmetric_shards", True))
                        for r in world.local_ranks} for sp in specs]
         # similarity matrices: index j -> size n_j; S_j is n_j x (block of n_j), ping-pong
         if self.bipartite:
@@ -598,7 +663,7 @@ class Solver:
         """Record HIP events around every leg on the engine's stream (rank-local).  ``steps``:
         events for that many steps are created now, outside the region being timed."""
         self.events = []
-        self._event_pool = {r: [self.ops[r].event() for _ in range(4 * len(self.sides) * steps)]
+        self._event_pool = {r: [self.ops[r].event() for _ in range(6 * len(self.sides) * steps)]
                             for r in self.world.local_ranks}
 
     def _timed(self, r, fn, tag):
@@ -634,6 +699,12 @@ class Solver:
                         f"leg2.{side_idx}")
             if fused and not device_sum:   # virtual ranks may share one device counter: read it per launch
                 counts.append(self.ops[r].read_changed() if sides[r].Lm else 0)
+        if sides[local[0]].shard_sym:
+            # (the convergence counters were read above / are reduced below: the mirrored tiles were
+            # counted by the rank that computed them)
+            self.world.exchange_mirrors([sides[r] for r in local])
+            for r in local:
+                self._timed(r, lambda: sides[r].unpack(self.nxt[out_idx][r]), f"unpack.{side_idx}")
         if not fused:
             if self.world.size > 1:
                 self.world.exchange([sides[r].x2 for r in local])
@@ -775,10 +846,11 @@ class Solver:
                     m.free()
         for sides in self.sides:
             for s in sides.values():
-                for name in ("wd", "t", "ap"):
+                for name in ("wd", "t", "ap", "sh_send", "sh_recv"):
                     m = getattr(s, name, None)
                     if m is not None:
                         m.free()
+                s.sh_send_t = s.sh_recv_t = None
                 for x in (s.x1, s.x2):
                     if x is not None:
                         x.send.free()

@@ -94,6 +94,7 @@ class HipOps:
 
     name = "hip"
     supports_blocked = True      # the solver may keep its matrices panel-blocked (Matrix.blocked)
+    supports_shard_symmetric = True   # sharded leg 2 in its half form (spmm_shard / shard_unpack)
 
     def __init__(self, device: int | None = None, stream: int | None = None):
         self.lib = _lib.load()
@@ -324,6 +325,23 @@ class HipOps:
                                     1 if transpose_out else 0, int(t_block), int(t_pad),
                                     C.byref(ep) if ep is not None else None, self.stream),
               "simrank_spmm")
+
+    def spmm_shard(self, g: Graph, X: Matrix, Y: Matrix, epilogue: dict, rank: int, world: int,
+                   send: Matrix, chunk_floats: int):
+        """Leg 2 of one rank of a sharded symmetric update in its half form: tiles (h, i) x (rank, j)
+        with i <= j into Y, the transposed tiles i < j into Y (h == rank) or ``send`` (packed, one
+        chunk per destination rank); see simrank_spmm_shard."""
+        ep = self._epilogue(**epilogue)
+        check(self.lib.simrank_spmm_shard(g.handle, X.ptr, X.ld, Y.ptr, Y.ld, C.byref(ep), int(rank),
+                                          int(world), send.ptr, int(chunk_floats), self.stream),
+              "simrank_spmm_shard")
+
+    def shard_unpack(self, Y: Matrix, recv: Matrix, chunk_floats: int, rank: int, world: int,
+                     n_rows: int):
+        """The mirrored tiles received from the other ranks go to their places in Y."""
+        check(self.lib.simrank_shard_unpack(Y.ptr, Y.ld, recv.ptr, int(chunk_floats), int(rank),
+                                            int(world), int(n_rows), self.stream),
+              "simrank_shard_unpack")
 
     def epilogue_apply(self, Q: Matrix, Y: Matrix, n_rows: int, n_cols: int, epilogue: dict):
         """Y = epilogue(Q) element-wise; see simrank_epilogue_apply."""

@@ -48,6 +48,7 @@ class NpGraph:
 
 class NumpyOps:
     name = "numpy-test-double"
+    supports_shard_symmetric = True
 
     def __init__(self):
         self._buffers = {}
@@ -151,6 +152,53 @@ class NumpyOps:
         if epilogue:
             v = self._epilogue(v, epilogue, M, L)
         Y.a[:M, :L] = v
+
+    def spmm_shard(self, g, X, Y, epilogue, rank, world, send, chunk_floats):
+        """simrank_spmm_shard: only tiles i <= j are computed; what is not written keeps its junk."""
+        self.calls.append(("spmm_shard",))
+        M = g.n_rows
+        mb = M // world
+        T = mb // 32
+        assert mb * world == M and T * 32 == mb and epilogue["diag_col0"] == rank * mb
+        assert chunk_floats >= T * (T - 1) // 2 * 1024
+        x = X.a[:g.n_cols, :mb]
+        v = (g.pattern @ x) * (g.rowscale * np.float32(epilogue["coef"]))[:, None]
+        old_changed = self._changed
+        v = self._epilogue(v, dict(epilogue, previous=None), M, mb)
+        prev, eps = epilogue.get("previous"), epilogue.get("eps", 0.0)
+        moved = (np.abs(v.astype(np.float64) - prev.a[:M, :mb].astype(np.float64)) > eps
+                 if prev is not None else np.zeros((M, mb), bool))
+        changed = 0
+        for h in range(world):
+            chunk = send.flat[h * chunk_floats:(h + 1) * chunk_floats]
+            for i in range(T):
+                rows = slice(h * mb + 32 * i, h * mb + 32 * i + 32)
+                for j in range(i, T):
+                    cols = slice(32 * j, 32 * j + 32)
+                    Y.a[rows, cols] = v[rows, cols]
+                    changed += int(moved[rows, cols].sum()) * (2 if i < j else 1)
+                    if i == j:
+                        continue
+                    if h == rank:
+                        Y.a[rank * mb + 32 * j: rank * mb + 32 * j + 32, 32 * i:32 * i + 32] = v[rows, cols].T
+                    else:
+                        slot = j * (j - 1) // 2 + i
+                        chunk[slot * 1024:(slot + 1) * 1024] = v[rows, cols].T.reshape(-1)
+        self._changed = changed if prev is not None else old_changed
+
+    def shard_unpack(self, Y, recv, chunk_floats, rank, world, n_rows):
+        self.calls.append(("shard_unpack",))
+        mb = n_rows // world
+        T = mb // 32
+        for h in range(world):
+            if h == rank:
+                continue
+            chunk = recv.flat[h * chunk_floats:(h + 1) * chunk_floats]
+            for j in range(T):
+                for i in range(j):
+                    slot = j * (j - 1) // 2 + i
+                    Y.a[h * mb + 32 * j: h * mb + 32 * j + 32, 32 * i:32 * i + 32] = \
+                        chunk[slot * 1024:(slot + 1) * 1024].reshape(32, 32)
 
     def _epilogue(self, v, ep, M, L):
         v = v.astype(np.float32)

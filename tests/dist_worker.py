@@ -21,6 +21,24 @@ def main(argv):
     from tests.conftest import Golden
     from tests.cpu_ops import NumpyOps
     from tests.helpers import check_against_golden, run_estimator
+    for name in [n for n in names if n.startswith("half:")]:
+        # half-form leg 2 (driver.Side.shard_sym): N divisible by 32 x world, second all-to-all real
+        import simrank_amd.SimRank as SRA
+        from simrank_amd import synth
+        from simrank_amd.driver import LocalWorld
+        cls = name.split(":")[1]
+        frame = synth.powerlaw_directed(64 * dist.get_world_size(), 5, 3)
+        kw = dict(weighted=True) if cls.endswith("PP") else {}
+        one = NumpyOps()
+        want = getattr(SRA, cls)().fit(frame, verbose=False, world=LocalWorld(1), mode="sparse",
+                                       _ops_factory=lambda r: one, **kw)
+        ops = NumpyOps()
+        got = getattr(SRA, cls)().fit(frame, verbose=False, mode="sparse", _ops_factory=lambda r: ops,
+                                      world=TorchWorld(stages=stages, handback="all"), **kw)
+        assert any(c[0] == "spmm_shard" for c in ops.calls) and any(c[0] == "shard_unpack" for c in ops.calls)
+        assert list(got.index) == list(want.index)
+        np.testing.assert_allclose(got.values, want.values, rtol=2e-5, atol=1e-30)
+    names = [n for n in names if not n.startswith("half:")]
     for name in names:
         g = Golden(name)
         ops = NumpyOps()

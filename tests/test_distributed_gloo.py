@@ -49,3 +49,18 @@ def test_sharded_driver_over_gloo(world, stages):
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     for r in range(world):
         assert f"RANK {r} ok" in p.stdout
+
+
+@pytest.mark.parametrize("world,stages", [(2, 1), (3, 2)])
+def test_half_form_leg2_over_gloo(world, stages):
+    """N = 64 x world: every rank runs leg 2 in its half form and the mirrored tiles travel in a
+    second (real) all_to_all_single; the result equals the one-rank result."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"),
+           str(stages), "half:SimRank", "half:SimRankPP"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    for r in range(world):
+        assert f"RANK {r} ok" in p.stdout

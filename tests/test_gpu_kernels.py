@@ -412,6 +412,74 @@ def test_topk_rows_with_column_ids(ops):
         assert list(idx[a]) == [ids[c] for c in cols[:6]]
         assert list(val[a]) == [S[a, c] for c in cols[:6]]
 
+@pytest.mark.parametrize("world,mb,balance", [(2, 64, 2), (4, 128, 2), (3, 96, 0), (8, 32, 2)])
+def test_half_form_shard_leg2(ops, world, mb, balance):
+    """simrank_spmm_shard: for every shard h, row tile i and column tile j of the rank, i <= j is
+    computed with the bits of the full form, i < j is also stored transposed — in place for the
+    rank's own shard, else packed in the send chunk of rank h; i > j is left alone.  The counter
+    counts a mirrored element twice.  simrank_shard_unpack puts received chunks in place."""
+    n, T = world * mb, mb // 32
+    rng = np.random.default_rng(world * 1000 + mb)
+    lens = np.minimum(n, (rng.pareto(1.1, size=n) * 5).astype(int) + (rng.random(n) < 0.9))
+    lens[rng.choice(n, 3, replace=False)] = [n, n // 2, 300 % n]
+    # ascending inside every shard, like the solver's dealt order
+    lens = np.concatenate([np.sort(lens[h * mb:(h + 1) * mb]) for h in range(world)])
+    rows = [np.sort(rng.choice(n, size=d, replace=False)) for d in lens]
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    csr = CSR(n, n, rowptr, np.concatenate(rows).astype(np.int32), rng.random(n) + 0.1)
+    ops.set_tuning(balance=balance, dense_min=0)
+    try:
+        g = ops.graph(csr)
+    finally:
+        ops.set_tuning(balance=2, dense_min=4)
+    chunk = max(1, T * (T - 1) // 2 * 1024)
+    for rank in (0, world - 1):
+        X = rng.random((n, mb)).astype(np.float32)
+        prev = rng.random((n, mb)).astype(np.float32)
+        cnt = rng.integers(0, 4, size=(n, mb)).astype(np.uint8)
+        x, pv, ev = put(ops, X), put(ops, prev), put(ops, cnt, dtype=np.uint8)
+        ep = dict(coef=0.8, evidence=ev, previous=pv, eps=0.3, diag_col0=rank * mb)
+        full_m = ops.matrix(n, mb)
+        ops.spmm(g, x, full_m, epilogue=dict(ep))
+        full, full_changed = ops.download(full_m), ops.read_changed()
+        junk = np.full((n, mb), -7.0, np.float32)
+        y, send = put(ops, junk), put(ops, np.full((world, chunk), -7.0, np.float32))
+        ops.spmm_shard(g, x, y, dict(ep), rank, world, send, chunk)
+        got, changed, sent = ops.download(y), ops.read_changed(), ops.download(send)
+        moved = np.abs(full.astype(np.float64) - prev) > 0.3
+        assert int(moved.sum()) == full_changed
+        want, want_changed = junk.copy(), 0
+        want_send = np.full((world, chunk), -7.0, np.float32)
+        for h in range(world):
+            for i in range(T):
+                r = slice(h * mb + 32 * i, h * mb + 32 * i + 32)
+                for j in range(i, T):
+                    c = slice(32 * j, 32 * j + 32)
+                    want[r, c] = full[r, c]
+                    want_changed += int(moved[r, c].sum()) * (2 if i < j else 1)
+                    if i < j and h == rank:
+                        want[rank * mb + 32 * j:rank * mb + 32 * j + 32, 32 * i:32 * i + 32] = full[r, c].T
+                    elif i < j:
+                        slot = j * (j - 1) // 2 + i
+                        want_send[h, slot * 1024:(slot + 1) * 1024] = full[r, c].T.reshape(-1)
+        assert np.array_equal(got, want)
+        assert np.array_equal(sent, want_send)
+        assert changed == want_changed
+        # unpack: chunk h of the receive buffer holds what rank h sent to this rank
+        recv_h = rng.random((world, chunk)).astype(np.float32)
+        y2 = put(ops, junk)
+        ops.shard_unpack(y2, put(ops, recv_h), chunk, rank, world, n)
+        want2 = junk.copy()
+        for h in range(world):
+            if h == rank:
+                continue
+            for j in range(T):
+                for i in range(j):
+                    slot = j * (j - 1) // 2 + i
+                    want2[h * mb + 32 * j:h * mb + 32 * j + 32, 32 * i:32 * i + 32] = \
+                        recv_h[h, slot * 1024:(slot + 1) * 1024].reshape(32, 32)
+        assert np.array_equal(ops.download(y2), want2)
+
 
 @pytest.mark.parametrize("balance", [0, 1, 4])
 def test_balanced_tiles(ops, balance):

@@ -83,8 +83,15 @@ def test_logical_shards_are_bitwise_equal_to_one_shard():
     np.testing.assert_allclose(tri.values, one.values, rtol=1e-6, atol=1e-30)
     for world in (2, 4, 8):
         many = SRA.SimRank().fit(df, iterations=6, eps=0, verbose=False, mode="sparse",
-                                 world=LocalWorld(world))
+                                 world=LocalWorld(world, symmetric_shards=False))
         assert np.array_equal(one.values, many.values)
+        # N = 1024 is a multiple of 32 x P: by default leg 2 runs in its half form (nodes dealt to
+        # the shards, tiles i <= j, mirrored tiles exchanged) — other summation order, same values
+        half = SRA.SimRank().fit(df, iterations=6, eps=0, verbose=False, mode="sparse",
+                                 world=LocalWorld(world))
+        np.testing.assert_allclose(half.values, one.values, rtol=1e-6, atol=1e-30)
+        # (tiles i == j of two different shards are computed on both sides: 1/4 of them at P = 8)
+        assert (half.values == half.values.T).mean() > 0.7
 
 
 def test_runs_are_bitwise_reproducible():
@@ -248,10 +255,11 @@ def test_config4_pl32768_eight_shards_bitwise(ops):
             one.step(0.0)
         want = ops.download_rows(one.cur[0][0], rows)
         one.release()
-        del one
     finally:
         ops.set_tuning(triangle=1)
-    world = LocalWorld(8)
+    inv_one = one.inv[0]
+    del one
+    world = LocalWorld(8, symmetric_shards=False)
     many = Solver(lambda r: ops, world, [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
     many.reset()
     for _ in range(3):
@@ -261,6 +269,20 @@ def test_config4_pl32768_eight_shards_bitwise(ops):
     assert got.shape == want.shape
     assert np.array_equal(got, want)
     assert np.all(want[np.arange(len(rows)), rows] == 1.0)
+    # the same with leg 2 in its half form (tiles i <= j + a second, half-size exchange of the mirrored
+    # tiles; nodes dealt to the shards in tiles of 32): same values up to float32 summation order
+    world = LocalWorld(8)
+    half = Solver(lambda r: ops, world, [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
+    assert all(sd.shard_sym for sd in half.sides[0].values())
+    half.reset()
+    for _ in range(3):
+        half.step(0.0)
+    nodes_ = np.argsort(inv_one)[rows]                # the caller's ids of the sampled rows
+    hrows = [int(half.inv[0][a]) for a in nodes_]
+    got = np.concatenate([ops.download_rows(half.cur[0][r], hrows) for r in world.local_ranks], axis=1)
+    half.release()
+    got = got[:, half.inv[0]][:, np.argsort(inv_one)]   # columns: dealt order -> caller's -> ascending
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-30)
 
 
 def test_config3_movielens_shaped_bipartite_pp(ops):
@@ -564,7 +586,7 @@ def test_dense_sets_shards_equal_one_shard_bit_for_bit():
         knob.set_tuning(triangle=1)
     for world in (2, 4):
         many = SRA.SimRank().fit(df, iterations=4, eps=0, verbose=False, mode="sparse",
-                                 world=LocalWorld(world))
+                                 world=LocalWorld(world, symmetric_shards=False))
         assert np.array_equal(one.values, many.values)
     knob.set_tuning(dense_min=0)
     try:

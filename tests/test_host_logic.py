@@ -290,3 +290,56 @@ def test_bf16x3_truncation_split_is_exact_in_numpy():
     assert np.array_equal((hi + mid) + lo, x)
     assert np.array_equal(hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64),
                           x.astype(np.float64))
+
+
+def _fit_all(cls_name, frame, world, **kw):
+    import simrank_amd.SimRank as SRA
+    ops = NumpyOps()                 # the virtual ranks of a LocalWorld share one "device"
+    est = getattr(SRA, cls_name)()
+    res = est.fit(frame, verbose=False, world=world, mode="sparse", _ops_factory=lambda r: ops, **kw)
+    return est, (res if isinstance(res, tuple) else (res,)), [ops]
+
+
+@pytest.mark.parametrize("cls_name,world", [("SimRank", 2), ("SimRank", 4), ("SimRankPP", 2),
+                                            ("AprioriSimRank", 4), ("BipartiteSimRank", 2),
+                                            ("BipartiteSimRankPP", 2)])
+def test_half_form_sharded_leg2(cls_name, world):
+    """Node counts divisible by 32 x P: leg 2 of every rank computes only the tiles i <= j and
+    the mirrored ones travel in a second all-to-all (driver.Side.shard_sym).  The result is the
+    one-rank result up to float32 summation order; with ``symmetric_shards=False`` the full
+    form runs instead."""
+    from simrank_amd import synth
+    if cls_name.startswith("Bipart"):
+        # (the ++ class only runs with equally large groups: quirk Q2)
+        frame = synth.bipartite_zipf(128, 128 if cls_name.endswith("PP") else 192, 1500, 7)
+        kw = dict(node_group1_column="user", node_group2_column="item")
+    else:
+        frame = synth.powerlaw_directed(256, 6, 11)
+        kw = dict(from_node_column="from", to_node_column="to")
+    if cls_name == "AprioriSimRank":
+        rng = np.random.default_rng(5)
+        a = rng.random((256, 256))
+        kw["AprioriSim"] = (a + a.T) / 2                   # symmetric prior: fused path
+    if cls_name.endswith("PP"):
+        kw["weighted"] = True
+    _, one, _ = _fit_all(cls_name, frame, LocalWorld(1), **kw)
+    _, half, ops = _fit_all(cls_name, frame, LocalWorld(world), **kw)
+    assert any(c[0] == "spmm_shard" for o in ops for c in o.calls)
+    assert any(c[0] == "shard_unpack" for o in ops for c in o.calls)
+    for x, y in zip(one, half):
+        assert list(x.index) == list(y.index)
+        np.testing.assert_allclose(y.values, x.values, rtol=2e-5, atol=1e-30)
+    _, full, ops = _fit_all(cls_name, frame, LocalWorld(world, symmetric_shards=False), **kw)
+    assert not any(c[0] == "spmm_shard" for o in ops for c in o.calls)
+    for x, y in zip(one, full):
+        np.testing.assert_allclose(y.values, x.values, rtol=2e-5, atol=1e-30)
+
+
+def test_dealt_order():
+    from simrank_amd.driver import dealt_order
+    o = np.arange(256)
+    d = dealt_order(o, 4)
+    assert sorted(d) == list(o)
+    assert list(d[:32]) == list(range(32)) and list(d[32:64]) == list(range(128, 160))
+    assert list(d[64:96]) == list(range(32, 64))          # shard 1 starts with tile 1
+    assert dealt_order(np.arange(100), 4) is not None and list(dealt_order(np.arange(100), 4)) == list(range(100))

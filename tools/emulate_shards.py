@@ -19,17 +19,25 @@ import itertools
 huges = [int(x) for x in os.environ.get('HUGE', '512').split(',')]
 dmins = [int(x) for x in os.environ.get('DMIN', '4').split(',')]
 for huge, dmin, P in itertools.product(huges, dmins, (1, 8) if len(huges) > 1 else (1, 2, 4, 8)):
-    ops.set_tuning(huge=huge, dense_min=dmin)
-    s = Solver(lambda r: ops, LocalWorld(P), [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
-    s.reset()
-    s.step(0.0)
-    s.enable_timing()
-    for _ in range(3):
+    for half in ((False,) if P == 1 else (False, True)):
+        ops.set_tuning(huge=huge, dense_min=dmin)
+        s = Solver(lambda r: ops, LocalWorld(P, symmetric_shards=half),
+                   [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
+        s.reset()
         s.step(0.0)
-    t = s.leg_times()
-    l1, l2 = t["leg1.0"][0], t["leg2.0"][0]
-    xfer = 4.0 * n * n / P * (P - 1) / P
-    print(f"{w} huge={huge} dense_min={dmin} P={P}: per-rank leg1 {l1:.3f} ms, leg2 {l2:.3f} ms -> compute {l1 + l2:.3f} ms/iteration; "
-          f"all-to-all payload per rank {xfer / 2**20:.0f} MiB out + in", flush=True)
-    s.release()
-    del s
+        s.enable_timing()
+        for _ in range(3):
+            s.step(0.0)
+        t = s.leg_times()
+        l1, l2 = t["leg1.0"][0], t["leg2.0"][0]
+        un = t.get("unpack.0", (0.0, 0))[0]
+        xfer = 4.0 * n * n / P * (P - 1) / P
+        form = "full form"
+        if half and s.sides[0][0].shard_sym:
+            form = "half form"
+            xfer += 4.0 * s.sides[0][0].sh_chunk * (P - 1)
+        print(f"{w} huge={huge} dense_min={dmin} P={P} leg 2 in its {form}: per-rank leg1 {l1:.3f} ms, "
+              f"leg2 {l2:.3f} ms, unpack {un:.3f} ms -> compute {l1 + l2 + un:.3f} ms/iteration; "
+              f"all-to-all payload per rank {xfer / 2**20:.0f} MiB out + in", flush=True)
+        s.release()
+        del s

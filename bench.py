@@ -250,7 +250,9 @@ def main():
                    "N": n, "nnz": nnz, "mode": solver.mode,
                    "layout": "panel-blocked (32-column panels)" if getattr(solver, "blocked", False) else "row-major",
                    "sharding": f"S column-sharded over {world_size} rank(s), all-to-all per update"
-                               + (f" in {side_stages} overlapped stage(s)" if use_dist else "")},
+                               + (f" in {side_stages} overlapped stage(s)" if use_dist else "")
+                               + ("; leg 2 in its half form (tiles i <= j per rank, mirrored tiles in a second "
+                                  "half-size all-to-all)" if getattr(side, "shard_sym", False) else "")},
     }
     if not gpu:
         out["data"] = "synthetic; gloo rehearsal with the NumPy test double: NOT a measurement"
@@ -261,7 +263,8 @@ def main():
         l2 = legs["leg2.0"][0]
         b1 = leg_bytes(side.M, side.K, side.Lk, nnz, leg2=False)
         tri = world_size == 1 and not use_dist          # upper-triangle + mirror form of leg 2
-        b2 = leg_bytes(side.M, side.K, side.Lm, nnz, leg2=True, has_evidence=args.pp, triangle=tri)
+        half = bool(getattr(side, "shard_sym", False))   # sharded: tiles i <= j + exchanged mirror images
+        b2 = leg_bytes(side.M, side.K, side.Lm, nnz, leg2=True, has_evidence=args.pp, triangle=tri or half)
         b2_full = leg_bytes(side.M, side.K, side.Lm, nnz, leg2=True, has_evidence=args.pp)
         # the matrix-core part of leg 1 alone (same operand, same stream), outside the timed region
         nt, dk, cov = ops.dense_stats(side.graph)
@@ -288,7 +291,8 @@ def main():
                         "rate is a third of this"}
         rl = []
         for name, ms, b in (("leg 1 = dense_tiles + spmm_gather (transposed store)", l1, b1),
-                            ("leg 2 = spmm_gather (upper triangle, fused epilogue)", l2, b2)):
+                            ("leg 2 = spmm_gather (" + ("upper triangle" if tri else "half form" if half else
+                                                        "full form") + ", fused epilogue)", l2, b2)):
             gbs = b / (ms * 1e-3) / 1e9
             rl.append({"kernel": name, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
@@ -299,6 +303,8 @@ def main():
             rl[0]["gathered_bytes"] = 4 * (nnz - cov) * side.Lk
             rl[0]["gather_kernel_alone"] = {"achieved": b1 / ((l1 - dense_ms) * 1e-3) / 1e9, "unit": "GB/s",
                                             "frac": b1 / ((l1 - dense_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if half and "unpack.0" in legs:
+            rl[1]["unpack_ms"] = legs["unpack.0"][0]
         if tri:
             rl[1]["algorithmic_bytes_full_form"] = b2_full
             rl[1]["note"] = ("single rank: leg 2 computes the tiles on/above the diagonal and stores their "

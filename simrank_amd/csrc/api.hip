@@ -44,11 +44,26 @@ namespace simrank {
 // are cut into aligned halves, down to single rows, so that no wave is left with a tile
 // many times the others' (a power-law row order sorted by length puts all long rows
 // in a few blocks).  For the upper-triangle leg 2: the (panel, workgroup) launch list.
-void build_tiles(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int64_t balance,
-                 std::vector<int32_t>& tile_row0, std::vector<int32_t>& sym_map) {
+// Appends the launch order of the plain legs to tile_row0 (after its n_tiles + 1 entries): the groups
+// of four tiles a workgroup takes, most entries first.  In ascending row-length order that is the
+// reverse order; when the nodes were dealt to shards the long rows sit at the end of every shard.
+static void append_group_order(const int32_t* rowptr, std::vector<int32_t>& tile_row0, int64_t n_tiles) {
+    const int64_t groups = (n_tiles + 3) / 4;
+    std::vector<std::pair<int64_t, int32_t>> key((size_t)groups);
+    for (int64_t gidx = 0; gidx < groups; ++gidx) {
+        const int64_t lo = tile_row0[(size_t)(4 * gidx)];
+        const int64_t hi = tile_row0[(size_t)std::min<int64_t>(4 * gidx + 4, n_tiles)];
+        key[(size_t)gidx] = {-(int64_t)(rowptr[hi] - rowptr[lo]), (int32_t)(groups - 1 - gidx)};
+    }
+    std::sort(key.begin(), key.end());
+    for (const auto& k : key) tile_row0.push_back((int32_t)(groups - 1 - k.second));
+}
+
+int64_t build_tiles(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int64_t balance,
+                    std::vector<int32_t>& tile_row0, std::vector<int32_t>& sym_map) {
     tile_row0.clear();
     sym_map.clear();
-    if (balance <= 0 || nnz <= 0) return;
+    if (balance <= 0 || nnz <= 0) return 0;
     const int64_t nblk = (n_rows + 31) / 32;
     const int64_t limit = std::max<int64_t>(balance * ((nnz + nblk - 1) / nblk), 256);
     std::vector<std::pair<int64_t, int64_t>> stack;
@@ -69,7 +84,8 @@ void build_tiles(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int64_t bal
     }
     tile_row0.push_back((int32_t)n_rows);
     const int64_t n_tiles = (int64_t)tile_row0.size() - 1;
-    if (n_rows < 64) return;
+    append_group_order(rowptr, tile_row0, n_tiles);
+    if (n_rows < 64) return n_tiles;
     std::vector<std::vector<int32_t>> lists(8);
     size_t t_end = 0;                            // tiles with row0 < 32 (p + 1)
     for (int64_t pnl = 0; pnl < nblk; ++pnl) {
@@ -89,6 +105,7 @@ void build_tiles(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int64_t bal
             sym_map[2 * (8 * k + x)] = lists[x][2 * k];
             sym_map[2 * (8 * k + x) + 1] = lists[x][2 * k + 1];
         }
+    return n_tiles;
 }
 }  // namespace simrank
 
@@ -365,8 +382,7 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
     g->nnz = nnz;
     g->max_row_nnz = max_row;
     std::vector<int32_t> tile_row0, sym_map;
-    build_tiles(rowptr, n_rows, nnz, g->tun.balance, tile_row0, sym_map);
-    g->n_tiles = tile_row0.empty() ? 0 : (int32_t)tile_row0.size() - 1;
+    g->n_tiles = (int32_t)build_tiles(rowptr, n_rows, nnz, g->tun.balance, tile_row0, sym_map);
     g->sym_blocks = (int32_t)(sym_map.size() / 2);
     auto up = [&](void** d, const void* h, size_t bytes) -> int {
         size_t alloc = std::max<size_t>(bytes, 16);

@@ -320,7 +320,8 @@ int build_dense_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
         for (int32_t c : set) kpos[c] = -1;
     }
     std::vector<int32_t> r_tile_row0, r_sym_map;
-    build_tiles(r_rowptr.data(), M, (int64_t)r_col.size(), g->tun.balance, r_tile_row0, r_sym_map);
+    const int64_t r_n_tiles = build_tiles(r_rowptr.data(), M, (int64_t)r_col.size(), g->tun.balance,
+                                          r_tile_row0, r_sym_map);
 
     simrank_dense_plan* pl = new simrank_dense_plan;
     pl->n_units = (int32_t)nu;
@@ -330,7 +331,7 @@ int build_dense_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
     pl->nnz_covered = covered;
     pl->r_nnz = (int64_t)r_col.size();
     pl->r_max_row = r_max;
-    pl->r_n_tiles = r_tile_row0.empty() ? 0 : (int32_t)r_tile_row0.size() - 1;
+    pl->r_n_tiles = (int32_t)r_n_tiles;
     pl->r_sym_blocks = (int32_t)(r_sym_map.size() / 2);
     int rc = upload(&pl->unit_row0, unit_row0);
     if (!rc) rc = upload(&pl->unit_slab, unit_slab);

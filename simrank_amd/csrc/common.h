@@ -114,8 +114,10 @@ int build_dense_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
 int launch_dense_tiles(const simrank_graph* g, const float* X, int64_t ldx, int64_t L, bool tri,
                        hipStream_t st, DenseUse* use);
 // balanced 32-row tiling of a pattern (api.hip): tile list and the upper-triangle launch list
-void build_tiles(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int64_t balance,
-                 std::vector<int32_t>& tile_row0, std::vector<int32_t>& sym_map);
+// returns the number of tiles; tile_row0 = n_tiles + 1 row offsets, then the launch order of the
+// ceil(n_tiles / 4) workgroup groups (most entries first)
+int64_t build_tiles(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int64_t balance,
+                    std::vector<int32_t>& tile_row0, std::vector<int32_t>& sym_map);
 }
 
 // The graph object: device CSR of the 0/1 pattern + per-row scale, and the transposed

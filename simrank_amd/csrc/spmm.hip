@@ -944,7 +944,7 @@ void gather3_kernel(const SpmmArgs p) {
             panel = int(bid / uint32_t(p.row_tiles));
             rt = int(bid % uint32_t(p.row_tiles));
         }
-        if (p.tile_row0) rt = p.row_tiles - 1 - rt;
+        if (p.tile_row0) rt = p.tile_row0[p.n_tiles + 1 + rt];     // groups of tiles, most entries first
     }
     if (panel >= p.n_panels) return;
     if ((p.probe & 16) && (blockIdx.x & 7) != 0) return;      // diagnostic: one XCD's share of the launch only

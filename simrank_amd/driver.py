@@ -29,6 +29,7 @@ from .ingest import CSR, partition, relabel
 PAD_MIN_ROWS, PAD_MULTIPLE = 1024, 256   # when exchanged chunk rows get padded (row_pad)
 RESTRICT_BELOW = 0.5     # SimRank++: leg 2 skips evidence-dead 32-column segments when fewer than this
                          # fraction of them is live (ER N=8192: 0.24 live; the power-law graphs: 0.9)
+DEAL_UNIT = 128         # nodes are dealt to the shards in runs of this many (dealt_order)
 STAGE_ALIGN = 32         # stage widths of a pipelined exchange are multiples of this (panels)
 
 
@@ -573,7 +574,10 @@ def dealt_order(order: np.ndarray, world: int) -> np.ndarray:
     n = order.size
     if world <= 1 or n % (32 * world):
         return order
-    return order.reshape(n // (32 * world), world, 32).transpose(1, 0, 2).reshape(-1)
+    # (whole 128-row blocks when they divide evenly: a block of the matrix-core part then holds
+    # consecutive rows of the ascending order, as on one rank — leg 1 at P = 8: 0.96 -> 0.90 ms)
+    unit = DEAL_UNIT if n % (DEAL_UNIT * world) == 0 else 32
+    return order.reshape(n // (unit * world), world, unit).transpose(1, 0, 2).reshape(-1)
 
 
 def reorder_specs(specs, deal: int = 1):

@@ -336,9 +336,14 @@ def test_half_form_sharded_leg2(cls_name, world):
 
 
 def test_dealt_order():
+    from simrank_amd import driver
     from simrank_amd.driver import dealt_order
+    o = np.arange(1024)
+    d = dealt_order(o, 4)                 # runs of 128: 0..127 -> shard 0, 128..255 -> shard 1, ...
+    assert sorted(d) == list(o) and list(d[:128]) == list(range(128))
+    assert list(d[128:256]) == list(range(512, 640)) and list(d[256:384]) == list(range(128, 256))
     o = np.arange(256)
-    d = dealt_order(o, 4)
+    d = dealt_order(o, 4)                 # too few nodes for runs of 128: tiles of 32
     assert sorted(d) == list(o)
     assert list(d[:32]) == list(range(32)) and list(d[32:64]) == list(range(128, 160))
     assert list(d[64:96]) == list(range(32, 64))          # shard 1 starts with tile 1

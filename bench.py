@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--stages", type=int, default=0,
                     help="pipeline depth of the sharded exchange (all_to_all_single calls per update; "
                          "0 = by the width of a rank's column block)")
+    ap.add_argument("--shard-form", choices=["auto", "half", "full"], default="auto",
+                    help="leg 2 of a sharded run: half = tiles i <= j per rank + a second all-to-all of the "
+                         "mirrored tiles, full = every tile; auto = half from 8 ranks on (DESIGN.md §5)")
     ap.add_argument("--pp", action="store_true",
                     help="SimRank++ (evidence-gated update, spread weights: SimRank.py:351-362) instead of SimRank")
     ap.add_argument("--dense-precision", default="f32", choices=["f32", "fp16"],
@@ -178,7 +181,8 @@ def main():
                                     device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world_size)
-        world = TorchWorld(stages=args.stages, stage_single_rank=args.force_dist)
+        form = {"auto": "auto", "half": True, "full": False}[args.shard_form]
+        world = TorchWorld(stages=args.stages, stage_single_rank=args.force_dist, symmetric_shards=form)
     else:
         world = LocalWorld(1)
 

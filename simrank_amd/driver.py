@@ -29,6 +29,7 @@ from .ingest import CSR, partition, relabel
 PAD_MIN_ROWS, PAD_MULTIPLE = 1024, 256   # when exchanged chunk rows get padded (row_pad)
 RESTRICT_BELOW = 0.5     # SimRank++: leg 2 skips evidence-dead 32-column segments when fewer than this
                          # fraction of them is live (ER N=8192: 0.24 live; the power-law graphs: 0.9)
+HALF_FORM_FROM = 8      # TorchWorld(symmetric_shards="auto"): half-form leg 2 from this many ranks on
 DEAL_UNIT = 128         # nodes are dealt to the shards in runs of this many (dealt_order)
 STAGE_ALIGN = 32         # stage widths of a pipelined exchange are multiples of this (panels)
 
@@ -166,7 +167,7 @@ class TorchWorld:
     GPU box; "gloo" in the CPU tests)."""
 
     def __init__(self, group=None, stages: int = 0, stage_single_rank: bool = False,
-                 handback: str = "root", symmetric_shards: bool = True):
+                 handback: str = "root", symmetric_shards="auto"):
         """``stages``: leg 1 is cut into that many column slices, each exchanged by its own
         all_to_all_single as soon as its kernel has finished, so the transfers over xGMI overlap
         the remaining leg-1 kernels (1 = one exchange after the whole leg; 0 = by the width of a
@@ -176,15 +177,18 @@ class TorchWorld:
         there and downloaded once; the other ranks' ``fit`` returns None.  "all": every rank gets
         the full float64 matrix (pickled all-gather: N^2 x 8 B x P per node — small N only).
         ``fit(top_k=k)`` hands k columns per row to every rank either way.
-        ``symmetric_shards``: as for ``LocalWorld``."""
+        ``symmetric_shards``: as for ``LocalWorld``; "auto" (default) = from ``HALF_FORM_FROM`` ranks
+        on — the half form trades 50 % more bytes on the links for 30-35 % less compute per rank,
+        which pays once a rank spreads its exchange over seven xGMI links."""
         import torch.distributed as dist
         if handback not in ("root", "all"):
             raise ValueError("handback must be 'root' or 'all'")
         self.handback = handback
-        self.symmetric_shards = bool(symmetric_shards)
         self.dist = dist
         self.group = group
         self.size = dist.get_world_size(group)
+        self.symmetric_shards = (self.size >= HALF_FORM_FROM if symmetric_shards == "auto"
+                                 else bool(symmetric_shards))
         self.rank = dist.get_rank(group)
         self.local_ranks = [self.rank]
         self.is_root = self.rank == 0

@@ -34,7 +34,8 @@ def main(argv):
                                        _ops_factory=lambda r: one, **kw)
         ops = NumpyOps()
         got = getattr(SRA, cls)().fit(frame, verbose=False, mode="sparse", _ops_factory=lambda r: ops,
-                                      world=TorchWorld(stages=stages, handback="all"), **kw)
+                                      world=TorchWorld(stages=stages, handback="all", symmetric_shards=True),
+                                      **kw)
         assert any(c[0] == "spmm_shard" for c in ops.calls) and any(c[0] == "shard_unpack" for c in ops.calls)
         assert list(got.index) == list(want.index)
         np.testing.assert_allclose(got.values, want.values, rtol=2e-5, atol=1e-30)

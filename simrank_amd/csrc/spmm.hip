@@ -1852,7 +1852,7 @@ int simrank_spmm_shard(const simrank_graph* g, const float* X, int64_t ldx, floa
                        const simrank_epilogue* ep, int32_t rank, int32_t world, float* send,
                        int64_t chunk_floats, void* stream) {
     SR_REQUIRE(g && X && Y && ep && send, "NULL argument");
-    SR_REQUIRE(world > 1 && rank >= 0 && rank < world && g->n_rows % (int64_t(world) * 32) == 0,
+    SR_REQUIRE(world >= 1 && rank >= 0 && rank < world && g->n_rows % (int64_t(world) * 32) == 0,
                "a symmetric sharded leg needs n_rows (%lld) divisible by 32 x world (%d)",
                (long long)g->n_rows, world);
     const int64_t mb = g->n_rows / world, tiles = mb / 32;
@@ -1902,11 +1902,11 @@ int simrank_spmm_shard(const simrank_graph* g, const float* X, int64_t ldx, floa
 
 int simrank_shard_unpack(float* Y, int64_t ldy, const float* recv, int64_t chunk_floats, int32_t rank,
                          int32_t world, int64_t n_rows, void* stream) {
-    SR_REQUIRE(Y && recv && world > 1 && rank >= 0 && rank < world && n_rows % (int64_t(world) * 32) == 0,
+    SR_REQUIRE(Y && recv && world >= 1 && rank >= 0 && rank < world && n_rows % (int64_t(world) * 32) == 0,
                "bad shard unpack");
     const int mb = int(n_rows / world), tiles = mb / 32;
     const int64_t per_src = int64_t(tiles) * (tiles - 1) / 2;
-    if (per_src == 0) return SIMRANK_OK;
+    if (per_src == 0 || world == 1) return SIMRANK_OK;
     SR_REQUIRE(per_src < (int64_t(1) << 31), "too many tiles");
     hipLaunchKernelGGL(shard_unpack_kernel, dim3((unsigned)per_src, (unsigned)world), dim3(256), 0,
                        as_stream(stream), Y, ldy, recv, chunk_floats, (int)rank, mb, tiles);

@@ -187,8 +187,10 @@ class TorchWorld:
         self.dist = dist
         self.group = group
         self.size = dist.get_world_size(group)
+        # ("force": also in a one-rank world — how the half-form path, RCCL call included, is
+        # exercised on a single GPU)
         self.symmetric_shards = (self.size >= HALF_FORM_FROM if symmetric_shards == "auto"
-                                 else bool(symmetric_shards))
+                                 else "force" if symmetric_shards == "force" else bool(symmetric_shards))
         self.rank = dist.get_rank(group)
         self.local_ranks = [self.rank]
         self.is_root = self.rank == 0
@@ -388,7 +390,8 @@ class Side:
         # Half-form leg 2 of a sharded symmetric update (simrank_spmm_shard): of the 32 x 32 tiles
         # (shard h, tile i) x (my column tile j) only i <= j is computed, the transposed tiles i < j go to
         # the ranks that own them in a second, half-size all-to-all.  Needs equal shards of whole tiles.
-        self.shard_sym = (mode == "sparse" and world > 1 and self.symmetric and shard_symmetric and
+        self.shard_sym = (mode == "sparse" and (world > 1 or shard_symmetric == "force") and
+                          self.symmetric and bool(shard_symmetric) and
                           self.M % (32 * world) == 0 and getattr(ops, "supports_shard_symmetric", False))
         if self.shard_sym:
             t = self.mb // 32

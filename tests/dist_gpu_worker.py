@@ -42,6 +42,27 @@ def main():
         got = SRA.SimRank().fit(df, iterations=5, eps=0, verbose=False, mode="sparse",
                                 world=TorchWorld(stages=stages, stage_single_rank=True, handback="all"))
         np.testing.assert_allclose(got.values, want.values, rtol=2e-6, atol=1e-30)
+    # leg 2 in its half form (simrank_spmm_shard, the second all_to_all_single on the engine's stream,
+    # simrank_shard_unpack); N must be a multiple of 32 x ranks.  "force" takes it in a one-rank world too
+    import simrank_amd.driver as drv
+    made = []
+    orig = drv.Solver.__init__
+
+    def spy(self, *a, **k):
+        orig(self, *a, **k)
+        made.append(self)
+    drv.Solver.__init__ = spy
+    try:
+        df = synth.powerlaw_directed(2048 * dist.get_world_size(), 16, seed=9)
+        want = SRA.SimRankPP().fit(df, iterations=4, eps=0, verbose=False, mode="sparse", world=LocalWorld(1))
+        for stages in (1, 2):
+            got = SRA.SimRankPP().fit(df, iterations=4, eps=0, verbose=False, mode="sparse",
+                                      world=TorchWorld(stages=stages, stage_single_rank=True, handback="all",
+                                                       symmetric_shards="force"))
+            assert all(sd.shard_sym for sd in made[-1].sides[0].values())
+            np.testing.assert_allclose(got.values, want.values, rtol=2e-6, atol=1e-30)
+    finally:
+        drv.Solver.__init__ = orig
     dist.barrier()
     print("RCCL WORLD ok", flush=True)
     dist.destroy_process_group()

@@ -188,6 +188,45 @@ def test_full_size_properties(ops, workload, iters):
     solver.release()
 
 
+def test_n98304_beyond_16_bit_ids_and_32_bit_element_offsets(ops):
+    """N = 98 304: more than 65 536 nodes (neighbour ids no longer fit the 16-bit id stream) and
+    N^2 = 9.7e9 elements per matrix (element offsets beyond 2^32; at N = 65 536 they still fit).
+    Three updates, then rows of one more update recomputed on the host in float64 from the device's
+    S_k, the unit diagonal and symmetry on sampled rows/columns."""
+    n = 98304
+    df = synth.er_directed(n, 8.0 / n, seed=98304)
+    nodes, csr = ingest.directed(df, False, "from", "to", "weight")
+    assert csr.n_rows == n
+    solver = Solver(lambda r: ops, LocalWorld(1), [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
+    assert solver.blocked
+    csr = solver.specs[0].csr
+    solver.reset()
+    for _ in range(3):
+        solver.step(0.0)
+    rows = [0, 1, 40000, 65535, 65536, 70001, n - 2, n - 1]
+    need = sorted(set(np.concatenate([csr.col[csr.rowptr[a]:csr.rowptr[a + 1]] for a in rows])))
+    pos = {int(i): p for p, i in enumerate(need)}
+    part = ops.download_rows(solver.cur[0][0], need).astype(np.float64)
+    rs = csr.rowscale.astype(np.float32).astype(np.float64)
+    W = sp.diags(rs) @ sp.csr_matrix((np.ones(csr.col.size), csr.col, csr.rowptr), shape=(n, n))
+    t_rows = {a: rs[a] * part[[pos[int(i)] for i in csr.col[csr.rowptr[a]:csr.rowptr[a + 1]]]].sum(axis=0)
+              for a in rows}
+    changed = solver.step(0.0)
+    got = ops.download_rows(solver.cur[0][0], rows)
+    for k, a in enumerate(rows):
+        want = 0.8 * (W @ t_rows[a])
+        want[a] = 1.0
+        np.testing.assert_allclose(got[k], want, rtol=RTOL, atol=1e-30)
+        assert got[k][a] == 1.0
+    assert 0 < changed <= n * n
+    # symmetry across the 2^32-element line: column a of the sampled rows against row a
+    sub = got[:, rows]
+    np.testing.assert_allclose(sub, sub.T, rtol=RTOL, atol=1e-30)
+    top = solver.topk(0, 3)
+    assert top[0].shape == (n, 3)
+    solver.release()
+
+
 def test_config5_pl65536_simrank_pp_properties(ops):
     """BASELINE.json configs[4] shape: N = 65536 power-law graph, SimRank++ with evidence
     (SimRank.py:351-362, evidence :311-320), f32, on one GPU.  The dense f64 oracle would need

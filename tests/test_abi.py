@@ -54,3 +54,37 @@ def test_product_path_fails_loudly_without_gpu():
     from simrank_amd._lib import SimRankHipError
     with pytest.raises(SimRankHipError, match="no CPU fallback"):
         SRA.SimRank().fit(pd.DataFrame({"from": [1, 2], "to": [2, 1]}), verbose=False)
+
+
+def test_header_is_plain_c_and_a_c_program_links(tmp_path):
+    """The boundary is a C ABI: the header compiles as C99 with no other include path, and a C
+    program linked against the shared library can call it (argument checks only: no device)."""
+    import os
+    inc = os.path.dirname(_lib.HEADER_PATH)
+    src = tmp_path / "use_abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "simrank_hip.h"
+int main(void) {
+    simrank_graph* g = NULL;
+    simrank_epilogue ep;
+    memset(&ep, 0, sizeof ep);
+    ep.coef = 0.8f;
+    if (simrank_abi_version() != 2) return 1;
+    if (simrank_graph_create(0, 4, 0, NULL, NULL, NULL, &g) != SIMRANK_ERR_INVALID) return 2;
+    if (simrank_spmm_shard(NULL, NULL, 0, NULL, 0, &ep, 0, 2, NULL, 0, NULL) != SIMRANK_ERR_INVALID) return 3;
+    if (simrank_shard_unpack(NULL, 0, NULL, 0, 0, 2, 64, NULL) != SIMRANK_ERR_INVALID) return 4;
+    if (!strlen(simrank_last_error())) return 5;
+    printf("abi %d ok\n", simrank_abi_version());
+    return 0;
+}
+''')
+    exe = tmp_path / "use_abi"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cc = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", f"-I{inc}", str(src),
+                         "-o", str(exe), f"-L{libdir}", "-lsimrank_hip", f"-Wl,-rpath,{libdir}"],
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert run.returncode == 0 and "abi 2 ok" in run.stdout, (run.returncode, run.stdout, run.stderr)

@@ -500,6 +500,59 @@ def test_randomized_against_oracle(seed):
         assert_close(got.values, want["S"])
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_randomized_half_form_against_oracle(seed, monkeypatch):
+    """Node counts that are multiples of 32 x P, so that leg 2 of every virtual rank runs in its half
+    form (simrank_spmm_shard + the exchange of the mirrored tiles + simrank_shard_unpack): random P,
+    size, density and class — bipartite, evidence (also support-restricted), symmetric prior —
+    against the oracle; the convergence iteration must match too (the counter counts mirrored
+    elements twice)."""
+    import simrank_amd.driver as drv
+    rng = np.random.default_rng(7000 + seed)
+    P = int(rng.choice([2, 3, 4, 8]))
+    n = 32 * P * int(rng.integers(1, 7 if P < 8 else 4))
+    made = []
+    orig = drv.Solver.__init__
+
+    def spy(self, *a, **k):
+        orig(self, *a, **k)
+        made.append(self)
+    monkeypatch.setattr(drv.Solver, "__init__", spy)
+    if seed % 3 == 2:
+        monkeypatch.setattr(drv, "RESTRICT_BELOW", 2.0)          # always the support-restricted leg 2
+    world = LocalWorld(P)
+    weighted = bool(rng.integers(0, 2))
+    if seed % 5 == 4:
+        n2 = 32 * P * int(rng.integers(1, 4))
+        pp = bool(rng.integers(0, 2)) and n2 == n                 # (the ++ class needs equal groups: Q2)
+        df = bipartite_random(n, n2, float(rng.uniform(0.02, 0.2)), seed=seed)
+        est = (SRA.BipartiteSimRankPP if pp else SRA.BipartiteSimRank)()
+        kw = dict(weighted=weighted, verbose=False, C1=0.7, C2=0.85)
+        s1, s2 = est.fit(df, world=world, mode="sparse", **kw)
+        want = (O.fit_bipartite_pp if pp else O.fit_bipartite)(df, **kw)
+        assert_close(s1.values, want["S1"])
+        assert_close(s2.values, want["S2"])
+        assert est.converged_at == want["k"]
+    else:
+        df = (synth.er_directed(n, float(rng.uniform(0.01, 0.15)), seed) if seed % 2
+              else synth.powerlaw_directed(n, float(rng.uniform(3, 30)), seed))
+        cls = ["SimRank", "SimRankPP", "AprioriSimRank"][seed % 3]
+        kw = dict(weighted=weighted, verbose=False, C=float(rng.uniform(0.5, 0.9)))
+        if cls == "AprioriSimRank":
+            prior = rng.random((n, n))
+            prior = (prior + prior.T) / 2                         # symmetric: the fused path
+            got = SRA.AprioriSimRank().fit(df, prior, lbd=0.3, world=world, mode="sparse", **kw)
+            want = O.fit_simrank_pp(df, apriori=prior, lbd=0.3, **kw)
+        else:
+            est = getattr(SRA, cls)()
+            got = est.fit(df, world=world, mode="sparse", **kw)
+            want = (O.fit_simrank if cls == "SimRank" else O.fit_simrank_pp)(df, **kw)
+            assert est.converged_at == want["k"]
+        assert list(got.index) == want["labels"]
+        assert_close(got.values, want["S"])
+    assert made and all(sd.shard_sym for side in made[-1].sides for sd in side.values())
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_logical_shards_with_padded_chunks(world, monkeypatch):
     """The padded chunk layout (t_pad) through the real kernels, forced on at small size and

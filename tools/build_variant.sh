@@ -1,7 +1,7 @@
 #!/bin/bash
 # Experiment build of the library with extra -D flags next to the product one (same ABI):
-#   bash tools/build_variant.sh d8 -DSIMRANK_DEPTH8     ->  build/variants/libsimrank_hip_d8.so
-# run with  SIMRANK_LIB=$PWD/build/variants/libsimrank_hip_d8.so python tools/leg_only.py ...
+#   bash tools/build_variant.sh d8 -DSIMRANK_DEPTH8     ->  gpurun_variants/libsimrank_hip_d8.so
+# run with  SIMRANK_LIB=$PWD/gpurun_variants/libsimrank_hip_d8.so python tools/leg_only.py ...
 set -e
 TAG=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)

@@ -1552,24 +1552,18 @@ __global__ __launch_bounds__(256) void live_segments_kernel(const uint8_t* __res
 // kShard: the mirrored tiles a rank received (packed 32 x 32 tiles, slot j(j-1)/2 + i of the chunk of
 // source rank h) go to rows (h, j) x columns (mine, i) of its block.  One workgroup per tile.
 __global__ __launch_bounds__(256) void shard_unpack_kernel(float* Y, int64_t ldy, const float* recv,
-                                                           int64_t chunk, int rank, int mb, int tiles) {
-    const int64_t per_src = int64_t(tiles) * (tiles - 1) / 2;
-    for (int64_t w = blockIdx.x; w < per_src * gridDim.y; w += gridDim.x) {
-        const int h = blockIdx.y;
-        if (h == rank) return;
-        const int64_t slot = w % per_src;
-        // slot = j (j - 1) / 2 + i, i < j
-        int j = int((1.0 + sqrt(1.0 + 8.0 * double(slot))) * 0.5);
-        while (int64_t(j) * (j - 1) / 2 > slot) --j;
-        while (int64_t(j + 1) * j / 2 <= slot) ++j;
-        const int i = int(slot - int64_t(j) * (j - 1) / 2);
-        const float* src = recv + int64_t(h) * chunk + slot * 1024;
-        float* dst = Y + (int64_t(h) * mb + 32 * j) * ldy + 32 * i;
-        const int c = threadIdx.x >> 3, r4 = (threadIdx.x & 7) * 4;
-        const float4 v = *reinterpret_cast<const float4*>(src + c * 32 + r4);
-        *reinterpret_cast<float4*>(dst + c * ldy + r4) = v;
-        if (gridDim.x >= per_src) return;
-    }
+                                                           int64_t chunk, int rank, int mb) {
+    const int h = blockIdx.y;                                   // source rank
+    if (h == rank) return;
+    const int64_t slot = blockIdx.x;                            // = j (j - 1) / 2 + i, i < j
+    int j = int((1.0 + sqrt(1.0 + 8.0 * double(slot))) * 0.5);
+    while (int64_t(j) * (j - 1) / 2 > slot) --j;
+    while (int64_t(j + 1) * j / 2 <= slot) ++j;
+    const int i = int(slot - int64_t(j) * (j - 1) / 2);
+    const float* src = recv + int64_t(h) * chunk + slot * 1024;
+    float* dst = Y + (int64_t(h) * mb + 32 * j) * ldy + 32 * i;
+    const int c = threadIdx.x >> 3, r4 = (threadIdx.x & 7) * 4;
+    *reinterpret_cast<float4*>(dst + c * ldy + r4) = *reinterpret_cast<const float4*>(src + c * 32 + r4);
 }
 
 }  // namespace simrank
@@ -1856,7 +1850,8 @@ int simrank_spmm_shard(const simrank_graph* g, const float* X, int64_t ldx, floa
                "a symmetric sharded leg needs n_rows (%lld) divisible by 32 x world (%d)",
                (long long)g->n_rows, world);
     const int64_t mb = g->n_rows / world, tiles = mb / 32;
-    SR_REQUIRE(chunk_floats >= tiles * (tiles - 1) / 2 * 1024, "send chunk too small");
+    SR_REQUIRE(chunk_floats >= tiles * (tiles - 1) / 2 * 1024 && (tiles < 2 || chunk_floats % 4 == 0),
+               "send chunk too small or not a multiple of 4 floats");
     SR_REQUIRE(ep->diag_col0 == int64_t(rank) * mb && ldx >= mb && ldy >= mb && aligned16(X) && aligned16(Y) &&
                    aligned16(send) && ldx % 4 == 0 && ldy % 4 == 0, "bad shard operands");
     const Tuning& T = g->tun;
@@ -1908,8 +1903,10 @@ int simrank_shard_unpack(float* Y, int64_t ldy, const float* recv, int64_t chunk
     const int64_t per_src = int64_t(tiles) * (tiles - 1) / 2;
     if (per_src == 0 || world == 1) return SIMRANK_OK;
     SR_REQUIRE(per_src < (int64_t(1) << 31), "too many tiles");
+    SR_REQUIRE(ldy >= mb && ldy % 4 == 0 && aligned16(Y) && aligned16(recv) && chunk_floats % 4 == 0 &&
+                   chunk_floats >= per_src * 1024, "bad shard unpack operands");
     hipLaunchKernelGGL(shard_unpack_kernel, dim3((unsigned)per_src, (unsigned)world), dim3(256), 0,
-                       as_stream(stream), Y, ldy, recv, chunk_floats, (int)rank, mb, tiles);
+                       as_stream(stream), Y, ldy, recv, chunk_floats, (int)rank, mb);
     SR_HIP(hipGetLastError());
     return SIMRANK_OK;
 }

@@ -168,7 +168,9 @@ SIMRANK_API int simrank_spmm(const simrank_graph* g, const float* X, int64_t ldx
  *      After an all-to-all of the chunks, simrank_shard_unpack puts what rank h sent at rows
  *      (h, j) x columns (rank, i) of Y.  The node order must make every shard an equal mix of short
  *      and long rows (driver.dealt_order) for the work to halve evenly.  n_changed counts mirrored
- *      elements twice.  Same reference lines as simrank_spmm with an epilogue. */
+ *      elements twice.  Replaces what simrank_spmm with an epilogue replaces — the second `.dot(G.T)`
+ *      with `C *`, `Evidence *`, the prior blend and `fill_diagonal` of SimRank.py:139-140, :361-362,
+ *      :453-454 and the count of `_converged` (:74) — for S split by column block over `world` GPUs. */
 SIMRANK_API int simrank_spmm_shard(const simrank_graph* g, const float* X, int64_t ldx, float* Y,
                                    int64_t ldy, const simrank_epilogue* epilogue, int32_t rank,
                                    int32_t world, float* send, int64_t chunk_floats, void* stream);

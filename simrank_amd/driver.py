@@ -577,7 +577,9 @@ def dealt_order(order: np.ndarray, world: int) -> np.ndarray:
     t mod world, so every shard holds the same mix of short and long rows, ascending inside.  That is
     what makes the half-form sharded leg 2 (``Side.shard_sym``) — tile i of any shard against column
     tile j of mine only when i <= j — cut every rank's gathers the way the triangle does on one
-    rank, and balances leg 1 over the ranks as well.  Unchanged when the tiles do not divide evenly."""
+    rank, and balances leg 1 over the ranks as well.  Unchanged when the tiles do not divide evenly.
+    (The reference iterates in list(self.Nodes) order, SimRank.py:43/:141; the update is equivariant
+    under renaming, results are handed back in that order.)"""
     n = order.size
     if world <= 1 or n % (32 * world):
         return order

@@ -309,6 +309,9 @@ def main():
                                             "frac": b1 / ((l1 - dense_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if half and "unpack.0" in legs:
             rl[1]["unpack_ms"] = legs["unpack.0"][0]
+        if use_dist:
+            # what the engine's stream spent waiting for / running the collectives (rank 0's events)
+            out["exchange_ms"] = {k: v[0] for k, v in legs.items() if k.startswith("exchange")}
         if tri:
             rl[1]["algorithmic_bytes_full_form"] = b2_full
             rl[1]["note"] = ("single rank: leg 2 computes the tiles on/above the diagonal and stores their "

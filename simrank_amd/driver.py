@@ -676,7 +676,7 @@ class Solver:
         """Record HIP events around every leg on the engine's stream (rank-local).  ``steps``:
         events for that many steps are created now, outside the region being timed."""
         self.events = []
-        self._event_pool = {r: [self.ops[r].event() for _ in range(6 * len(self.sides) * steps)]
+        self._event_pool = {r: [self.ops[r].event() for _ in range(10 * len(self.sides) * steps)]
                             for r in self.world.local_ranks}
 
     def _timed(self, r, fn, tag):
@@ -701,7 +701,10 @@ class Solver:
             self._timed(r, lambda: sides[r].leg1(self.cur[in_idx][r], hook), f"leg1.{side_idx}")
         local = self.world.local_ranks
         if self.mode == "sparse":
-            self.world.exchange([sides[r].x1 for r in local])
+            # (timed on the first local rank's stream: with a stream-ordered world this is the time that
+            # stream waits for the all-to-all beyond what leg 1 already hid)
+            self._timed(local[0], lambda: self.world.exchange([sides[r].x1 for r in local]),
+                        f"exchange1.{side_idx}")
         fused = sides[local[0]].symmetric
         device_sum = fused and hook is not None        # stream-ordered world: reduce on the device
         counts = []
@@ -715,7 +718,8 @@ class Solver:
         if sides[local[0]].shard_sym:
             # (the convergence counters were read above / are reduced below: the mirrored tiles were
             # counted by the rank that computed them)
-            self.world.exchange_mirrors([sides[r] for r in local])
+            self._timed(local[0], lambda: self.world.exchange_mirrors([sides[r] for r in local]),
+                        f"exchange2.{side_idx}")
             for r in local:
                 self._timed(r, lambda: sides[r].unpack(self.nxt[out_idx][r]), f"unpack.{side_idx}")
         if not fused:

@@ -133,7 +133,16 @@ typedef struct simrank_epilogue {
                                         :361: S stays inside supp(E)); same bits, fewer gathers.
                                         Worth it when few segments are live
                                         (simrank_evidence_live_segments) */
-    int32_t reserved_;
+    int32_t count_any;               /* 1: the caller only needs to know WHETHER any element moved by
+                                        more than eps — what `_converged` returns (SimRank.py:74-77:
+                                        the sum is used as a truth value).  The lean gather kernel
+                                        then stops comparing once a difference has been found: a
+                                        wave that finds its own striped counter non-zero when it
+                                        starts skips the reads of `previous` (half a pass over S per
+                                        update; ~0.5 % of the waves still compare).  The
+                                        sum of the counters is 0 exactly when nothing moved and >= 1
+                                        otherwise, no longer the exact count; the result block is
+                                        the same bits.  0: exact count (the other kernels always) */
 } simrank_epilogue;
 
 /* ---- the convergence count on the host: sum of the n striped counters an epilogue wrote

@@ -35,7 +35,7 @@ class Epilogue(C.Structure):
         ("set_diag", C.c_int32),
         ("symmetric", C.c_int32),
         ("restrict_support", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("count_any", C.c_int32),
     ]
 
 

@@ -95,6 +95,7 @@ struct SpmmArgs {
     unsigned long long* n_changed;
     int64_t diag_col0;
     int32_t set_diag;
+    int32_t count_any;        // lean kernel: stop comparing with `prev` once counter 0 is non-zero (see simrank_epilogue)
     int32_t restrict_support; // lean kernel, evidence given: skip the gathers of 32-column segments whose
                               // evidence counts are all zero (their result is exactly 0: S inside supp(E))
     // block-dense part (blockdense.hip): raw partial sums of the entries that went to the matrix
@@ -807,7 +808,7 @@ template <int MODE>
 __device__ __forceinline__ void emit_row3(const SpmmArgs& p, float* tbuf_wave, int r_local, int64_t a,
                                           int q, int64_t mycol, int64_t colofs, float rowscale,
                                           const float (&acc)[4], const float (&dsum)[4], unsigned& changed,
-                                          bool mirror) {
+                                          bool mirror, bool check_prev) {
     // colofs: where this lane's 4 columns start inside a row of Y / prev / prior / evidence
     // (row-major: the column; panel-blocked: the panel's base + 4 q, rows then 32 apart)
     constexpr int RT = 32;
@@ -843,7 +844,7 @@ __device__ __forceinline__ void emit_row3(const SpmmArgs& p, float* tbuf_wave, i
                 for (int i = 0; i < 4; ++i)
                     if (d == i) o[i] = 1.0f;
             }
-            if (p.prev) {
+            if (check_prev) {       // (false: no previous iterate, or count_any and a difference is known)
                 float old[4];
                 vload_nt<4>(old, p.prev + a * p.ld_prev + colofs);
 #pragma unroll
@@ -989,6 +990,19 @@ void gather3_kernel(const SpmmArgs p) {
     const int64_t colofs = p.blocked ? (int64_t(panel) * p.y_rows_pad) * 32 + q * 4 : mycol;
     float* tbuf_wave = smem + (TILE ? wave * PW * (RT + 1) : 0);
     unsigned changed = 0;
+    // count_any: has a wave that shares this wave's counter already found an element that moved?  (vector load at agent scope — a
+    // scalar load could be served a stale zero by the constant cache for the rest of the launch; a stale
+    // value only means this wave still compares.)  Issued here, needed at the first emitted row.
+    unsigned long long seen = 0;
+    const unsigned slot = ((blockIdx.x * 4u + unsigned(wave)) * 7u) % SIMRANK_CHANGED_SLOTS;
+    if constexpr (!TRANS) {
+        if (p.has_ep && p.prev && p.count_any) {
+            // (the wave's own striped counter: one shared flag word would be a hot spot in one L2 channel)
+            const unsigned long long* flag = p.n_changed + slot;
+            asm volatile("" : "+v"(flag));
+            seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 
     int row0 = (rt * kWaves + wave) * RT;
     int nrows = int(imin(RT, p.M - row0));
@@ -1048,6 +1062,7 @@ void gather3_kernel(const SpmmArgs p) {
         }
     }
     const int n_heavy = __popcll(__ballot(s_len >= kHeavy));
+    const bool check_prev = !TRANS && p.has_ep && p.prev && __builtin_amdgcn_readfirstlane(int(seen != 0)) == 0;
     STAMP(0);      // prologue: arguments, tile lookup, row pointers, order
 
     // ---- phase A0: huge rows, split over the four waves of the workgroup (see the generic kernel)
@@ -1098,7 +1113,7 @@ void gather3_kernel(const SpmmArgs p) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) acc[k] += t[k];
                     }
-                    emit_row3<MODE>(p, tbuf_wave, r, int64_t(row0) + r, q, mycol, colofs, sc, acc, dsum, changed, mirror);
+                    emit_row3<MODE>(p, tbuf_wave, r, int64_t(row0) + r, q, mycol, colofs, sc, acc, dsum, changed, mirror, check_prev);
                 }
             }
         }
@@ -1127,7 +1142,7 @@ void gather3_kernel(const SpmmArgs p) {
             for (int i = 0; i < 4; ++i) acc[i] = 0.f;
         }
         if (g == 0 && col_active)
-            emit_row3<MODE>(p, tbuf_wave, r, int64_t(row0) + r, q, mycol, colofs, sc, acc, dsum, changed, mirror);
+            emit_row3<MODE>(p, tbuf_wave, r, int64_t(row0) + r, q, mycol, colofs, sc, acc, dsum, changed, mirror, check_prev);
     }
 
     STAMP(2);      // phase A
@@ -1180,7 +1195,7 @@ void gather3_kernel(const SpmmArgs p) {
 
             if (!same_pass) {
                 if (pos + g < nrows && col_active)
-                    emit_row3<MODE>(p, tbuf_wave, r, int64_t(row0) + r, q, mycol, colofs, sc, acc, dsum, changed, mirror);
+                    emit_row3<MODE>(p, tbuf_wave, r, int64_t(row0) + r, q, mycol, colofs, sc, acc, dsum, changed, mirror, check_prev);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] = 0.f;
                 if (more) {
@@ -1302,9 +1317,7 @@ void gather3_kernel(const SpmmArgs p) {
         if (p.has_ep && p.prev) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) changed += __shfl_down(changed, off);
-            if (lane == 0 && changed)
-                atomicAdd(p.n_changed + ((blockIdx.x * 4u + (threadIdx.x >> 6)) * 7u) % SIMRANK_CHANGED_SLOTS,
-                          (unsigned long long)changed);
+            if (lane == 0 && changed) atomicAdd(p.n_changed + slot, (unsigned long long)changed);
         }
     }
 }
@@ -1663,6 +1676,7 @@ static int spmm_impl(const simrank_graph* g, const float* X, int64_t ldx, int64_
         a.diag_col0 = ep->diag_col0;
         a.set_diag = ep->set_diag;
         a.restrict_support = ep->restrict_support;
+        a.count_any = ep->count_any;
         if (blocked) a.ld_ev = a.ld_ap = a.ld_prev = 32;      // rows of a panel are 32 elements apart
         SR_REQUIRE(!a.ev || a.ld_ev >= n_cols_x || blocked, "evidence ld too small");
         SR_REQUIRE(!a.ap || a.ld_ap >= n_cols_x || blocked, "apriori ld too small");
@@ -1881,6 +1895,7 @@ int simrank_spmm_shard(const simrank_graph* g, const float* X, int64_t ldx, floa
     a.eps = ep->eps; a.n_changed = ep->n_changed;
     a.diag_col0 = ep->diag_col0; a.set_diag = ep->set_diag;
     a.restrict_support = ep->restrict_support;
+    a.count_any = ep->count_any;
     SR_REQUIRE(!a.prev || a.n_changed, "previous needs a counter");
     SR_REQUIRE((!a.ev || (a.ld_ev % 4 == 0 && reinterpret_cast<uintptr_t>(a.ev) % 4 == 0)) &&
                    (!a.ap || (aligned16(a.ap) && a.ld_ap % 4 == 0)) &&

@@ -372,6 +372,9 @@ class Side:
         self.x1 = self.x2 = None
         self.broadcast_error = None
         self.ev_live, self.restrict = 1.0, False
+        # `_converged` (SimRank.py:74-77) uses its sum as a truth value: the fused test may stop comparing
+        # at the first difference (epilogue count_any).  True: exact counts (Solver.exact_count)
+        self.exact_count = False
         if mode == "sparse":
             # exchange 1: leg-1 product (M rows x my Lk of K columns) -> K x Lm
             self.x1 = self._xfer(self.Lk, self.k_lo, self.K, torch_buffers)
@@ -509,7 +512,7 @@ class Side:
     def _ep(self, S_prev, eps):
         return dict(coef=self.spec.coef, evidence=self.ev, apriori=self.ap, lbd=self.spec.lbd,
                     previous=S_prev, eps=eps, diag_col0=self.m_lo, set_diag=True,
-                    restrict_support=self.restrict)
+                    restrict_support=self.restrict, count_any=not self.exact_count)
 
     def leg2(self, S_prev, S_out, eps):
         """Symmetric iterates: S_out = W . Tt with the fused epilogue.
@@ -665,6 +668,20 @@ class Solver:
             self.nxt.append(x)
         self.events = None
         self.leg_ms = []
+
+    @property
+    def exact_count(self):
+        """False (default): ``step`` returns 0 exactly when no element moved by more than eps and some
+        positive number otherwise — all the reference's loop asks (`_converged`, SimRank.py:74-77,
+        :130) — and the kernels stop reading the previous iterate once a difference is known.
+        True: the exact number of such elements."""
+        return all(sd.exact_count for side in self.sides for sd in side.values())
+
+    @exact_count.setter
+    def exact_count(self, value):
+        for side in self.sides:
+            for sd in side.values():
+                sd.exact_count = bool(value)
 
     def reset(self):
         for j, n in enumerate(self.n):

@@ -285,7 +285,8 @@ class HipOps:
                   "simrank_fill_identity")
 
     def _epilogue(self, coef, evidence=None, apriori=None, lbd=0.0, previous=None, eps=0.0,
-                  diag_col0=0, set_diag=True, symmetric=False, restrict_support=False) -> Epilogue:
+                  diag_col0=0, set_diag=True, symmetric=False, restrict_support=False,
+                  count_any=False) -> Epilogue:
         ep = Epilogue()
         ep.coef = float(coef)
         ep.lbd = float(lbd)
@@ -301,6 +302,7 @@ class HipOps:
         ep.set_diag = 1 if set_diag else 0
         ep.symmetric = 1 if symmetric else 0
         ep.restrict_support = 1 if (restrict_support and evidence is not None) else 0
+        ep.count_any = 1 if count_any else 0
         return ep
 
     def spmm(self, g: Graph, X: Matrix, Y: Matrix, n_cols: int | None = None,

@@ -412,6 +412,43 @@ def test_topk_rows_with_column_ids(ops):
         assert list(idx[a]) == [ids[c] for c in cols[:6]]
         assert list(val[a]) == [S[a, c] for c in cols[:6]]
 
+@pytest.mark.parametrize("form", ["plain", "symmetric", "blocked"])
+def test_count_any_short_circuits_the_comparison(ops, form):
+    """epilogue.count_any: the kernel may stop comparing with the previous iterate once a difference
+    is known.  Same result bits; the counter sum is zero exactly when the exact count is zero."""
+    n = 1024
+    csr = random_csr(n, n, 12, seed=77, heavy={5: 600})
+    rng = np.random.default_rng(78)
+    S = rng.random((n, n)).astype(np.float32)
+    S = ((S + S.T) / 2).astype(np.float32)
+    np.fill_diagonal(S, 1)
+    blocked = form == "blocked"
+
+    def mat(host=None):
+        m = ops.matrix(n, n, blocked=True) if blocked else ops.matrix(n, n)
+        if host is not None:
+            ops.upload(m, host)
+        return m
+    g, s_in, tt = ops.graph(csr), mat(S), mat()
+    ops.spmm(g, s_in, tt, transpose_out=True)
+    ep = dict(coef=0.8, previous=s_in, eps=0.05, diag_col0=0, symmetric=form != "plain")
+    y_exact, y_any = mat(), mat()
+    ops.spmm(g, tt, y_exact, epilogue=dict(ep))
+    exact = ops.read_changed()
+    ops.spmm(g, tt, y_any, epilogue=dict(ep, count_any=True))
+    some = ops.read_changed()
+    assert exact > 1000 and 0 < some <= exact
+    assert np.array_equal(ops.download(y_any), ops.download(y_exact))
+    # nothing moves: compare the result with itself (eps far above any difference) -> exactly zero, and
+    # with eps = 0 against itself -> still zero (strict >)
+    for eps in (10.0, 0.0):
+        ep0 = dict(ep, previous=y_exact, eps=eps, count_any=True)
+        y2 = mat()
+        ops.spmm(g, tt, y2, epilogue=ep0)
+        assert ops.read_changed() == 0
+        assert np.array_equal(ops.download(y2), ops.download(y_exact))
+
+
 @pytest.mark.parametrize("world,mb,balance", [(2, 64, 2), (4, 128, 2), (3, 96, 0), (8, 32, 2)])
 def test_half_form_shard_leg2(ops, world, mb, balance):
     """simrank_spmm_shard: for every shard h, row tile i and column tile j of the rank, i <= j is

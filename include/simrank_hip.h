@@ -316,6 +316,8 @@ SIMRANK_API int simrank_dense_part(const simrank_graph* g, const float* X, int64
  *      "ids16"    0/1  stream the neighbour ids as 16-bit values (graphs with <= 65536 columns)
  *      "dense_sym" dense part in the upper-triangle form of leg 2: 1 always, 0 never, -1 when
  *                 the dense sets hold at least half of the entries
+ *      "sym_desc" 0/1  upper-triangle leg 2: an XCD takes its panels in descending order (default 1)
+ *      "addr32"   0/1  32-bit buffer addressing of the gather operand where it spans < 2 GiB (default 1)
  *      "probe_mask", "probe_flags"  DIAGNOSTIC ONLY (wrong results): price parts of the gather
  *                 kernel — ids ANDed with a mask; 1 no gathers, 2 no stores, 4 no dense partial
  *                 sums, 8 no id loads, 16 one XCD's share of the launch only ---- */

@@ -60,7 +60,7 @@ static void append_group_order(const int32_t* rowptr, std::vector<int32_t>& tile
 }
 
 int64_t build_tiles(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int64_t balance,
-                    std::vector<int32_t>& tile_row0, std::vector<int32_t>& sym_map) {
+                    std::vector<int32_t>& tile_row0, std::vector<int32_t>& sym_map, bool sym_descending) {
     tile_row0.clear();
     sym_map.clear();
     if (balance <= 0 || nnz <= 0) return 0;
@@ -88,11 +88,17 @@ int64_t build_tiles(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int64_t 
     if (n_rows < 64) return n_tiles;
     std::vector<std::vector<int32_t>> lists(8);
     size_t t_end = 0;                            // tiles with row0 < 32 (p + 1)
+    std::vector<int64_t> groups_of((size_t)nblk);
     for (int64_t pnl = 0; pnl < nblk; ++pnl) {
         while (t_end < (size_t)n_tiles && tile_row0[t_end] < 32 * (pnl + 1)) ++t_end;
-        const int64_t groups = ((int64_t)t_end + 3) / 4;
+        groups_of[(size_t)pnl] = ((int64_t)t_end + 3) / 4;
+    }
+    // panel p needs the row groups up to its own: the late panels are the big ones.  Descending: an XCD
+    // starts with panels of ~nblk/4 workgroups (one panel at a time in its L2) and ends on the small ones
+    for (int64_t k = 0; k < nblk; ++k) {
+        const int64_t pnl = sym_descending ? nblk - 1 - k : k;
         std::vector<int32_t>& l = lists[size_t(pnl & 7)];
-        for (int64_t rt = groups - 1; rt >= 0; --rt) {     // heavy (late) groups first
+        for (int64_t rt = groups_of[(size_t)pnl] - 1; rt >= 0; --rt) {     // heavy (late) groups first
             l.push_back((int32_t)pnl);
             l.push_back((int32_t)rt);
         }
@@ -382,7 +388,7 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
     g->nnz = nnz;
     g->max_row_nnz = max_row;
     std::vector<int32_t> tile_row0, sym_map;
-    g->n_tiles = (int32_t)build_tiles(rowptr, n_rows, nnz, g->tun.balance, tile_row0, sym_map);
+    g->n_tiles = (int32_t)build_tiles(rowptr, n_rows, nnz, g->tun.balance, tile_row0, sym_map, g->tun.sym_desc != 0);
     g->sym_blocks = (int32_t)(sym_map.size() / 2);
     auto up = [&](void** d, const void* h, size_t bytes) -> int {
         size_t alloc = std::max<size_t>(bytes, 16);
@@ -482,6 +488,8 @@ int simrank_set_tuning(const char* key, int64_t value) {
         t.lean = value;
     } else if (!strcmp(key, "ids16")) {
         t.ids16 = value ? 1 : 0;
+    } else if (!strcmp(key, "sym_desc")) {
+        t.sym_desc = value ? 1 : 0;
     } else if (!strcmp(key, "dense_sym")) {
         t.dense_sym = value < 0 ? -1 : (value ? 1 : 0);
     } else if (!strcmp(key, "dense_cols")) {
@@ -506,6 +514,7 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     else if (!strcmp(key, "dense_min")) *value = t.dense_min;
     else if (!strcmp(key, "dense_cols")) *value = t.dense_cols;
     else if (!strcmp(key, "dense_sym")) *value = t.dense_sym;
+    else if (!strcmp(key, "sym_desc")) *value = t.sym_desc;
     else if (!strcmp(key, "ids16")) *value = t.ids16;
     else if (!strcmp(key, "lean")) *value = t.lean;
     else if (!strcmp(key, "addr32")) *value = t.addr32;

@@ -321,7 +321,7 @@ int build_dense_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
     }
     std::vector<int32_t> r_tile_row0, r_sym_map;
     const int64_t r_n_tiles = build_tiles(r_rowptr.data(), M, (int64_t)r_col.size(), g->tun.balance,
-                                          r_tile_row0, r_sym_map);
+                                          r_tile_row0, r_sym_map, g->tun.sym_desc != 0);
 
     simrank_dense_plan* pl = new simrank_dense_plan;
     pl->n_units = (int32_t)nu;

@@ -52,6 +52,8 @@ struct Tuning {
     int64_t lean = 1;        // 1: the lean gather kernel (32-float panels, 32-row tiles) wherever it applies,
                              // 0: the generic kernel everywhere (row-major operands only)
     int64_t ids16 = 1;       // stream neighbour ids as 16-bit values when the graph allows it
+    int64_t sym_desc = 1;    // upper-triangle leg 2: an XCD takes its panels in descending order — the big ones (N/128
+                             // workgroups: one panel at a time in its L2) first, the small ones as the tail: leg 2 -4.7 %
     int64_t dense_sym = -1;  // dense part in the upper-triangle form of leg 2: 1 yes, 0 no, -1 = when the
                              // dense sets hold at least half of the pattern's entries
 };
@@ -117,7 +119,7 @@ int launch_dense_tiles(const simrank_graph* g, const float* X, int64_t ldx, int6
 // returns the number of tiles; tile_row0 = n_tiles + 1 row offsets, then the launch order of the
 // ceil(n_tiles / 4) workgroup groups (most entries first)
 int64_t build_tiles(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int64_t balance,
-                    std::vector<int32_t>& tile_row0, std::vector<int32_t>& sym_map);
+                    std::vector<int32_t>& tile_row0, std::vector<int32_t>& sym_map, bool sym_descending);
 }
 
 // The graph object: device CSR of the 0/1 pattern + per-row scale, and the transposed

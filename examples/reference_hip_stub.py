@@ -20,7 +20,7 @@ class Epilogue(C.Structure):                   # struct simrank_epilogue
                 ("previous", vp), ("ld_previous", i64),
                 ("eps", C.c_double), ("n_changed", vp),
                 ("diag_col0", i64), ("set_diag", C.c_int32), ("symmetric", C.c_int32),
-                ("restrict_support", C.c_int32), ("reserved_", C.c_int32)]
+                ("restrict_support", C.c_int32), ("count_any", C.c_int32)]
 
 
 def _ok(rc):

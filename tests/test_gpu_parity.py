@@ -324,6 +324,40 @@ def test_config4_pl32768_eight_shards_bitwise(ops):
     np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-30)
 
 
+def test_config5_pl65536_simrank_pp_eight_shards(ops):
+    """BASELINE.json configs[4] in its stated sharded form: N = 65536 SimRank++ (evidence counts, spread
+    weights) over eight virtual ranks on the one GPU, leg 2 in its half form with the second exchange —
+    against the single-rank run on sampled rows (same values up to float32 summation order), and the
+    convergence counts of both must be non-zero together."""
+    df = synth.WORKLOADS["pl65536"][0]()
+    nodes, csr = ingest.directed(df, False, "from", "to", "weight")
+    n = csr.n_rows
+    scale = ingest.spread(csr) * csr.rowscale
+
+    def run(world):
+        s = Solver(lambda r: ops, world, [SideSpec(csr, scale, 0.8, evidence_from=csr)], "sparse")
+        s.reset()
+        moved = [s.step(1e-4) for _ in range(2)]
+        return s, moved
+    one, moved_one = run(LocalWorld(1))
+    rows = [0, 3, n // 2, n - 200, n - 1]                      # positions in the single-rank order
+    want = ops.download_rows(one.cur[0][0], rows)
+    order_one, inv_one = one.order[0], one.inv[0]
+    one.release()
+    del one
+    world = LocalWorld(8)
+    half, moved_half = run(world)
+    assert all(sd.shard_sym for sd in half.sides[0].values())
+    hrows = [int(half.inv[0][a]) for a in order_one[rows]]      # the same nodes in the dealt order
+    got = np.concatenate([ops.download_rows(half.cur[0][r], hrows) for r in world.local_ranks], axis=1)
+    inv_half = half.inv[0]
+    half.release()
+    got = got[:, inv_half][:, order_one]                         # columns: dealt -> caller's -> single-rank order
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-30)
+    assert np.all(got[np.arange(len(rows)), rows] == 1.0)
+    assert all(a > 0 for a in moved_one) and all(b > 0 for b in moved_half)
+
+
 def test_config3_movielens_shaped_bipartite_pp(ops):
     """6040 x 3706, ~1.0 M ratings: runs only with the corrected
     Evidence_N2 (the reference raises, quirk Q2); checked through sampled rows of one update

@@ -776,15 +776,17 @@ __device__ __forceinline__ void gather_range3(const SpmmArgs& p, const SRC& src,
 // Partial sums of the matrix-core part for row a (blockdense.hip), its slabs added in slab order.
 // Called BEFORE the row's gathers are issued, so these loads are in flight beside them instead
 // of forming a dependent chain in the epilogue (0.6 ms of leg 1 at pl32768 when they did).
+// (ns, slab0): number and first index of the slabs of the row's 128-row block — the same for every row of
+// a tile, so the caller looks them up ONCE per tile (wave-uniform): a tile outside the dense blocks (most
+// are) then pays no dependent load per pass.
 template <bool DENSE>
 __device__ __forceinline__ void dense_partial(const SpmmArgs& p, int64_t a, int64_t mycol, bool on,
-                                              float (&dsum)[4]) {
+                                              int ns, int slab0, float (&dsum)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) dsum[i] = 0.f;
     if constexpr (!DENSE) return;
-    if (!p.dpart || (p.probe & 4) || !on) return;
-    const int ns = p.dnslab[a >> 7];
-    const float* dp = p.dpart + (int64_t(p.dslab0[a >> 7]) * 128 + (a & 127)) * p.ldp + mycol;
+    if (ns == 0 || !on) return;
+    const float* dp = p.dpart + (int64_t(slab0) * 128 + (a & 127)) * p.ldp + mycol;
     int s = 0;
     for (; s + 4 <= ns; s += 4, dp += 4 * 128 * p.ldp) {       // four independent loads at a time
         float d0[4], d1[4], d2[4], d3[4];
@@ -1033,6 +1035,14 @@ void gather3_kernel(const SpmmArgs p) {
         my_len = p.rowptr[row0 + lane + 1] - my_start;
         my_scale = p.rowscale[row0 + lane];
     }
+    // slabs of the matrix-core part: a tile lies inside one 128-row block
+    int tile_ns = 0, tile_slab0 = 0;
+    if constexpr (DENSE) {
+        if (p.dpart && !(p.probe & 4) && nrows > 0) {
+            tile_ns = p.dnslab[row0 >> 7];            // (uniform addresses: scalar loads)
+            tile_slab0 = p.dslab0[row0 >> 7];
+        }
+    }
     int s_row, s_len, s_start;
     {
         const int nxt = __shfl_down(my_len, 1);
@@ -1105,7 +1115,7 @@ void gather3_kernel(const SpmmArgs p) {
                 const float sc = __shfl(my_scale, r);
                 if (g == 0 && col_active) {
                     float acc[4], t[4], dsum[4];
-                    dense_partial<DENSE>(p, int64_t(row0) + r, mycol, true, dsum);
+                    dense_partial<DENSE>(p, int64_t(row0) + r, mycol, true, tile_ns, tile_slab0, dsum);
                     vload<4>(acc, hpart + (i * kWaves + 0) * PW + q * 4);
 #pragma unroll
                     for (int w = 1; w < kWaves; ++w) {
@@ -1128,7 +1138,7 @@ void gather3_kernel(const SpmmArgs p) {
         const int e = s + __builtin_amdgcn_readfirstlane(__shfl(s_len, h));
         const float sc = __shfl(my_scale, r);
         float acc[4], dsum[4];
-        dense_partial<DENSE>(p, int64_t(row0) + r, mycol, g == 0 && col_active, dsum);
+        dense_partial<DENSE>(p, int64_t(row0) + r, mycol, g == 0 && col_active, tile_ns, tile_slab0, dsum);
         bool live = true;
         if constexpr (RESTRICT) {
             const unsigned w = col_active ? *reinterpret_cast<const unsigned*>(
@@ -1161,7 +1171,7 @@ void gather3_kernel(const SpmmArgs p) {
         int iv = (q < len && !(p.probe & 8)) ? (ld_id<IDS16>(p, st + q) & p.idx_mask) : xs.sent();
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         float dsum[4];
-        dense_partial<DENSE>(p, int64_t(row0) + r, mycol, src < nrows && col_active, dsum);
+        dense_partial<DENSE>(p, int64_t(row0) + r, mycol, src < nrows && col_active, tile_ns, tile_slab0, dsum);
         // RESTRICT: a lane group whose 32 evidence counts are all zero issues no gathers
         auto group_live = [&](int row, bool on) -> bool {
             if constexpr (!RESTRICT) return true;
@@ -1199,7 +1209,7 @@ void gather3_kernel(const SpmmArgs p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] = 0.f;
                 if (more) {
-                    dense_partial<DENSE>(p, int64_t(row0) + nr, mycol, npos + g < nrows && col_active, dsum);
+                    dense_partial<DENSE>(p, int64_t(row0) + nr, mycol, npos + g < nrows && col_active, tile_ns, tile_slab0, dsum);
                     glive = group_live(nr, npos + g < nrows && col_active);
                 }
             }

@@ -337,16 +337,18 @@ def main():
             rl[0]["gather_kernel_alone"] = {"achieved": b1 / ((l1 - dense_ms) * 1e-3) / 1e9, "unit": "GB/s",
                                             "frac": b1 / ((l1 - dense_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
         # The second roofline of a gather leg: what the vector-memory path returns.  Every (entry, panel) pair
-        # is one 128-byte segment pulled into registers; the guide's own measurement of rows gathered from an
-        # XCD's L2 is 66-73 GB/s per CU = 16.8-18.8 TB/s chip-wide (MI355X_MICROARCH.md, "Indexed rows").
+        # is one 128-byte segment pulled into registers; a loop of nothing but such loads (tools/micro/
+        # gather_ceiling.hip, profiles/r02_gather_ceiling.log) reads 32-33 TB/s chip-wide from an L2-resident
+        # slice and 10.4 TB/s from beyond the L2.
         for r, ms_k in ((rl[0], l1 - (dense_ms or 0.0)), (rl[1], l2)):
             if (tri or half) and r is rl[1]:
                 continue                      # (the triangle / half form gathers a row-dependent share: not charged)
             g_tbs = r["gathered_bytes"] / (ms_k * 1e-3) / 1e12
-            r["gather_path"] = {"gathered_TBps": g_tbs, "ceiling_TBps": [16.8, 18.8],
-                                "frac_of_ceiling": [g_tbs / 18.8, g_tbs / 16.8],
+            r["gather_path"] = {"gathered_TBps": g_tbs, "ceiling_TBps_L2_resident": 32.5,
+                                "ceiling_TBps_beyond_L2": 10.4, "frac_of_L2_resident_ceiling": g_tbs / 32.5,
                                 "note": "gathered segments only (4 x entries x columns bytes; id streams, partial "
-                                        "sums and the store ride on the same path on top: +15 % by the L1 counters)"}
+                                        "sums and the store ride on the same path on top: +15 % by the L1 counters); "
+                                        "ceilings measured with tools/micro/gather_ceiling.hip"}
         if half and "unpack.0" in legs:
             rl[1]["unpack_ms"] = legs["unpack.0"][0]
         if use_dist:

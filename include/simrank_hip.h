@@ -290,6 +290,16 @@ SIMRANK_API int simrank_gemm_nt(int64_t M, int64_t N, int64_t K, const float* A,
  *      The statistics: blocks with a dense set, total size of the sets, entries covered. */
 SIMRANK_API int simrank_graph_dense_stats(const simrank_graph* g, int64_t* n_tiles,
                                           int64_t* dense_cols, int64_t* nnz_covered);
+
+/* ---- leg 1 as ONE launch (round 3; first `.dot` of SimRank.py:139, :298, :301, :361, :420, :423).
+ *      simrank_spmm_blocked(transpose_out = 1) on a graph created with tuning "fuse" = 1 (default)
+ *      runs one kernel in which a workgroup owns a 128-row block x one 32-column panel: the columns
+ *      that at least "fuse_min" (default 2) rows of the block share are multiplied on the matrix
+ *      cores (each operand segment loaded ONCE per block and panel instead of once per entry), the
+ *      other entries are gathered, and the finished tile is stored transposed.  Statistics:
+ *      16-column matrix-core steps per panel, entries on the matrix cores, entries gathered. */
+SIMRANK_API int simrank_graph_fused_stats(const simrank_graph* g, int64_t* n_steps,
+                                          int64_t* nnz_covered, int64_t* nnz_remainder);
 /* The matrix-core part of simrank_spmm alone, into the graph's partial-sum buffer (measurement
  * harness: its HIP-event time and 2 * 3 * 128 * dense_cols * n_cols_x bf16 flop give the MFMA
  * rate).  X needs 8-byte alignment and an even ldx.  Fails when the graph has no dense sets. */
@@ -311,6 +321,8 @@ SIMRANK_API int simrank_dense_part(const simrank_graph* g, const float* X, int64
  *      "balance"  32-row tiles heavier than this many times the mean tile are cut in halves
  *                 (0 = uniform tiles; default 2)
  *      "dense_min" / "dense_cols"  selection of the block-dense part (see above); dense_min 0 = off
+ *      "fuse" / "fuse_min"  leg 1 of a panel-blocked update as one launch (see above); fuse 0 = the
+ *                 dense_tiles + gather launches of round 2
  *      "dense_terms" operand terms of the block-dense part: 3 = bf16 hi+mid+lo (exact f32
  *                 products, default), 1 = one fp16 term (reduced precision, BASELINE config 5)
  *      "ids16"    0/1  stream the neighbour ids as 16-bit values (graphs with <= 65536 columns)

@@ -89,6 +89,7 @@ PROTOTYPES = {
     "simrank_gemm_nt": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64,
                         C.POINTER(Epilogue), _vp],
     "simrank_graph_dense_stats": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
+    "simrank_graph_fused_stats": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
     "simrank_dense_part": [_vp, _vp, _i64, _i64, _vp],
     "simrank_set_tuning": [C.c_char_p, _i64],
     "simrank_get_tuning": [C.c_char_p, C.POINTER(_i64)],

@@ -413,6 +413,7 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
     if (!rc && g->n_tiles) rc = up((void**)&g->tile_row0, tile_row0.data(), tile_row0.size() * 4);
     if (!rc && g->sym_blocks) rc = up((void**)&g->sym_map, sym_map.data(), sym_map.size() * 4);
     if (!rc && g->tun.dense_min > 0 && nnz > 0) rc = build_dense_plan(g, rowptr, col);
+    if (!rc && g->tun.fuse && nnz > 0) rc = build_fused_plan(g, rowptr, col);
     if (rc) {
         simrank_graph_destroy(g);
         return rc;
@@ -432,6 +433,7 @@ int simrank_graph_destroy(simrank_graph* g) {
     (void)hipFree(g->tile_row0);
     (void)hipFree(g->sym_map);
     free_dense_plan(g->dense);
+    free_fused_plan(g->fused);
     delete g;
     return SIMRANK_OK;
 }
@@ -492,6 +494,28 @@ int simrank_set_tuning(const char* key, int64_t value) {
         t.sym_desc = value ? 1 : 0;
     } else if (!strcmp(key, "dense_sym")) {
         t.dense_sym = value < 0 ? -1 : (value ? 1 : 0);
+    } else if (!strcmp(key, "fuse")) {
+        t.fuse = value ? 1 : 0;
+    } else if (!strcmp(key, "fuse_min")) {
+        SR_REQUIRE(value >= 2 && value <= 128, "fuse_min must be 2 .. 128");
+        t.fuse_min = value;
+    } else if (!strcmp(key, "fuse_unit")) {
+        SR_REQUIRE(value >= 4 && value <= (1 << 20), "fuse_unit must be >= 4");
+        t.fuse_unit = value;
+    } else if (!strcmp(key, "fuse_store")) {
+        SR_REQUIRE(value >= 0 && value <= 3, "fuse_store must be 0 .. 3");
+        t.fuse_store = value;
+    } else if (!strcmp(key, "fuse_meta_nt")) {
+        t.fuse_meta_nt = value ? 1 : 0;
+    } else if (!strcmp(key, "fuse_order")) {
+        SR_REQUIRE(value >= 0 && value <= 64, "fuse_order must be 0 .. 64");
+        t.fuse_order = value;
+    } else if (!strcmp(key, "fuse_group")) {
+        SR_REQUIRE(value >= 1 && value <= 4, "fuse_group must be 1 .. 4");
+        t.fuse_group = value;
+    } else if (!strcmp(key, "fuse_steps")) {
+        SR_REQUIRE(value >= 0 && value <= (1 << 20), "fuse_steps must be >= 0");
+        t.fuse_steps = value;
     } else if (!strcmp(key, "dense_cols")) {
         SR_REQUIRE(value >= 1 && value <= (1 << 20), "dense_cols must be >= 1");
         t.dense_cols = value;
@@ -514,6 +538,14 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     else if (!strcmp(key, "dense_min")) *value = t.dense_min;
     else if (!strcmp(key, "dense_cols")) *value = t.dense_cols;
     else if (!strcmp(key, "dense_sym")) *value = t.dense_sym;
+    else if (!strcmp(key, "fuse")) *value = t.fuse;
+    else if (!strcmp(key, "fuse_min")) *value = t.fuse_min;
+    else if (!strcmp(key, "fuse_steps")) *value = t.fuse_steps;
+    else if (!strcmp(key, "fuse_unit")) *value = t.fuse_unit;
+    else if (!strcmp(key, "fuse_group")) *value = t.fuse_group;
+    else if (!strcmp(key, "fuse_order")) *value = t.fuse_order;
+    else if (!strcmp(key, "fuse_store")) *value = t.fuse_store;
+    else if (!strcmp(key, "fuse_meta_nt")) *value = t.fuse_meta_nt;
     else if (!strcmp(key, "sym_desc")) *value = t.sym_desc;
     else if (!strcmp(key, "ids16")) *value = t.ids16;
     else if (!strcmp(key, "lean")) *value = t.lean;

@@ -54,6 +54,19 @@ struct Tuning {
     int64_t ids16 = 1;       // stream neighbour ids as 16-bit values when the graph allows it
     int64_t sym_desc = 1;    // upper-triangle leg 2: an XCD takes its panels in descending order — the big ones (N/128
                              // workgroups: one panel at a time in its L2) first, the small ones as the tail: leg 2 -4.7 %
+    int64_t fuse = 1;        // leg 1 of a panel-blocked update as ONE launch (fused.hip): the columns shared by
+                             // >= fuse_min rows of a 128-row block on the matrix cores, the rest gathered, by the
+                             // same workgroup on the same L2-resident panel slice; 0 = dense_tiles + gather3 launches
+    int64_t fuse_min = 3;    // ... a column joins a block's dense set when this many of its rows reference it (2 and 4:
+                             // +8 % and +1 % on the leg at pl32768d32)
+    int64_t fuse_steps = 8;  // ... and a block keeps its set only when it makes this many 16-column steps
+    int64_t fuse_unit = 1 << 20;  // ... sets of more than this many 64-column groups are cut into units (workgroups whose
+                             // partial sums meet in memory); measured: 64 +3 %, 32 +13 %, so off by default
+    int64_t fuse_store = 1;  // ... cache policy of its tile stores: 0 plain, 1 nt, 2 sc1 (write through, drop), 3 sc0 sc1
+    int64_t fuse_meta_nt = 0; // ... id streams loaded non-temporally
+    int64_t fuse_order = 0;  // ... launch order of a panel's units: 0 heaviest first, k > 0: the units with a matrix-core
+                             // phase spread over the first 1/k of the order
+    int64_t fuse_group = 4;  // ... and up to this many consecutive blocks without a set share a workgroup (1..4)
     int64_t dense_sym = -1;  // dense part in the upper-triangle form of leg 2: 1 yes, 0 no, -1 = when the
                              // dense sets hold at least half of the pattern's entries
 };
@@ -104,7 +117,39 @@ struct simrank_dense_plan {
     size_t part_cap = 0;            // floats
 };
 
+// fused.hip: leg 1 as one launch.  Per 128-row block: the dense set (columns referenced by >= fuse_min
+// of the block's rows) with its 0/1 pattern as bits in MFMA A-fragment order, the remainder CSR, and
+// the order in which the gather phase takes the rows (descending remainder length).
+struct simrank_fused_plan {
+    int32_t n_units = 0;            // workgroups per panel, launch order: heaviest block first
+    int32_t n_blocks = 0;
+    int32_t ids16 = 0;              // ids stored in 16 bits (fewer than 65535 operand rows)
+    int64_t n_quads = 0;            // 64-column groups of all dense sets
+    int64_t n_steps = 0;            // 16-column MFMA steps of all dense sets
+    int64_t nnz_covered = 0;        // entries on the matrix cores
+    int64_t r_nnz = 0;              // entries gathered
+    int32_t* units = nullptr;       // [n_units][32] first block, first quad, quads, index in block, units of the
+                                    // block, partial slot, counter slot, block has a set, blocks of the unit, then per
+                                    // wave: first round of its id stream, rounds up to the end of each block
+    int32_t n_pslots = 0, n_cslots = 0;
+    float* partials = nullptr;      // [n_pslots][cap_panels][32 x 128] partial sums of split blocks (grown on demand;
+    int32_t* tickets = nullptr;     // [n_cslots][cap_panels]            calls on one graph are stream-ordered)
+    int32_t cap_panels = 0;
+    uint16_t* dcols16 = nullptr;    // [n_quads*64] operand rows of the sets, or
+    int32_t* dcols32 = nullptr;     //              the same in 32 bits; padding = a real row, bits zero
+    uint4* abits = nullptr;         // [n_quads*64] per lane: 4 steps x (4 row tiles x 8 k) pattern bits
+    int4* gmeta = nullptr;          // [n_units*4*32*4] per unit, block of the unit, lane group and row: row of the
+                                    // block (-1: none), rowscale bits, end of the row in the group's stream (-1: no
+                                    // remainder), -
+    uint16_t* sids16 = nullptr;     // gather id stream, 64 per round (0xFFFF: no neighbour), or
+    int32_t* sids32 = nullptr;      //              32-bit ids (-1: no neighbour)
+};
+
 namespace simrank {
+void free_fused_plan(simrank_fused_plan* p);
+int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col);
+int launch_fused_trans(const simrank_graph* g, const float* X, int64_t x_rows_pad, int64_t L, float* Y,
+                       int64_t y_rows_pad, hipStream_t st);
 struct DenseUse {                   // what the gather kernel needs from a dense launch
     const float* part = nullptr;
     int64_t ldp = 0;
@@ -142,6 +187,7 @@ struct simrank_graph {
     int32_t* sym_map = nullptr;
     int32_t sym_blocks = 0;
     simrank_dense_plan* dense = nullptr;   // NULL: no block of the pattern is dense enough
+    simrank_fused_plan* fused = nullptr;   // leg 1 as one launch (fused.hip); NULL: tuning "fuse" = 0
     simrank::Tuning tun;                   // knobs in force when the graph was created (every launch on
                                            // this graph uses these, whatever is set afterwards)
 };

@@ -1,0 +1,814 @@
+// Leg 1 of the single-rank update as ONE launch: matrix cores and row gathers on the same L2-resident
+// panel slice (gfx950, round 3).
+//
+//   Tt = (diag(rowscale) . A . X)^T        A = 0/1 CSR pattern, X and Tt panel-blocked
+//
+// Why.  The gather kernel of spmm.hip pulls one 128-byte segment per (entry, 32-column panel) through
+// the texture path, and a vector-memory instruction costs that path ~16-20 cycles whatever its width
+// (tools/micro/gather_shapes.hip: 8 lines x 16 B per lane = 50 B/clk/CU, 2 lines x 4 B per lane = 16):
+// the leg is bound by the NUMBER of gathered segments.  Rows sorted by length put rows that share their
+// hub columns next to each other: in a 128-row block of the bench graph two thirds of the entries sit
+// in columns that at least two of the block's rows reference.  A column referenced by c rows of a block
+// costs c segments when gathered and ONE when it feeds the matrix cores (B operand of a
+// 128 x 16 x 32 step), so where a block shares enough columns (its DENSE SET) they are multiplied on
+// MFMA — 0/1 pattern in bf16 x the operand split into three bf16 terms = exact f32 products — and
+// only the REMAINDER is gathered, both by the SAME workgroup while the panel's slice of X is in its
+// XCD's L2.  The separate dense_tiles launch of round 2 (blockdense.hip) streamed its operand rows a
+// second time from HBM and handed partial sums over through memory; here a segment is loaded once per
+// (block, panel) and nothing but the finished tile leaves the workgroup.
+//
+// One workgroup (4 waves) = one 128-row block x one 32-column panel:
+//   1. MFMA phase (blocks with a dense set): the set is cut into steps of 16 columns, 4 steps = a quad;
+//      the waves split the quads.  Per step a wave gathers the 16 operand segments with two
+//      16-byte-per-lane loads (8 rows each: the fast shape), turns them into a B fragment through a
+//      2 KiB LDS buffer of its own, expands the step's pattern bits (one byte per lane and 32-row
+//      tile) into A fragments by a 4 KiB lookup table in LDS, and issues 4 tiles x 3 terms = 12
+//      v_mfma_f32_32x32x16_bf16; software-pipelined, every wait counted.
+//   2. The waves' accumulators are added into one LDS tile in wave order (deterministic).
+//   3. Gather phase: the block's rows in descending remainder length, dealt to the waves 8 at a time
+//      (one row per group of 8 lanes, 16 B per lane).  A wave's four passes form ONE stream of slot
+//      instructions (slot j of pass ps gathers the j-th neighbour of each of the pass's 8 rows); the
+//      host lays the ids out in that order, 64 per round of 8 slots, so a round is one coalesced id
+//      load and 8 gathers with nothing else in front of them, and round r + 1 is in flight while round
+//      r is summed.  Row sum = (MFMA part + gathered part) x rowscale, into the LDS tile.
+//   4. Each wave stores one transposed 32 x 32 tile = 4 KiB contiguous of the panel-blocked Tt.
+// Panels are bound to XCDs as in spmm.hip (blocks equal mod 8 share an L2; speed only); within a
+// panel the heaviest blocks are launched first.  Bitwise reproducible: fixed order everywhere.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "common.h"
+
+namespace simrank {
+
+constexpr int kFB = 128;          // rows per block
+constexpr int kTS = 132;          // floats per column of the LDS tile (32 columns x 128 rows, transposed)
+constexpr int kSub = 4;            // blocks a unit without a dense set may hold
+constexpr int kMaxRem = 256;      // a row whose remainder would be longer sends all its columns to the dense set
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct FusedArgs {
+    const float* X;
+    float* Y;
+    int64_t x_rows_pad, y_rows_pad;
+    int64_t L, M;
+    int32_t n_panels, n_units, nt;
+    int32_t x_sentinel;
+    int32_t idx_mask;         // DIAGNOSTIC (tuning "probe_mask"): operand row ids are ANDed with it (wrong results)
+    int32_t meta_nt;          // the id streams are loaded non-temporally (they are re-read once per panel)
+    int32_t probe;            // DIAGNOSTIC (tuning "probe_flags"): 1 no gather phase, 2 no stores, 4 no MFMA phase
+    const int32_t* units;     // [n_units][32]: first block, first quad (absolute), quads, index among the block's
+                              // units, units of the block, partial-sum slot (-1: none), counter slot, block has a
+                              // set, blocks of the unit (1..4; > 1 only without a set), then per wave: first round
+                              // of its id stream and the round count after each of the unit's blocks
+    float* partials;          // [partial slot][panel][32 x 128] sums of the units of split blocks
+    int32_t* tickets;         // [counter slot][panel] arrivals (the last arriver resets it)
+    int32_t n_pslots, n_cslots;
+    const uint16_t* dcols16;
+    const int32_t* dcols32;
+    const uint4* abits;
+    const int4* gmeta;        // [unit][block of the unit][wave][lane group][4 rows]: row of the block (-1: none),
+                              // rowscale bits, end of the row in the lane group's stream of that block, -
+    const uint16_t* sids16;   // id stream of the gather phase, 64 per round (0xFFFF: no neighbour), or
+    const int32_t* sids32;    // the same in 32 bits (-1: no neighbour)
+};
+
+__device__ __forceinline__ void split3f(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = x0 - __uint_as_float(u0 & 0xFFFF0000u);
+    const float r1 = x1 - __uint_as_float(u1 & 0xFFFF0000u);
+    const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    mid = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float q0 = r0 - __uint_as_float(v0 & 0xFFFF0000u);
+    const float q1 = r1 - __uint_as_float(v1 & 0xFFFF0000u);
+    lo = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+}
+
+__device__ __forceinline__ bf16x8 frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    const uint4 v = make_uint4(a, b, c, d);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ float4 ld_seg(__amdgpu_buffer_rsrc_t srd, int id, uint32_t qoff) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(srd, int(__umul24(uint32_t(id), 128u) + qoff), 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// the compiler may not move LDS accesses of this wave across this point (no instruction is emitted)
+__device__ __forceinline__ void wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#ifndef SIMRANK_FUSED_LB
+#define SIMRANK_FUSED_LB 4     // waves per SIMD the register allocation aims at
+#endif
+// IDS16: 16-bit ids (fewer than 65535 operand rows; 0xFFFF marks an empty slot of the gather stream)
+template <bool IDS16>
+__global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(const FusedArgs p) {
+    __shared__ __attribute__((aligned(16))) float tile[32 * kTS];          // [column][row] of the block's result
+    __shared__ __attribute__((aligned(16))) float bbuf_all[4 * 16 * 32];    // per wave: 16 operand segments
+    __shared__ __attribute__((aligned(16))) uint4 lut[256];                 // pattern byte -> 8 bf16 (0 / 1.0)
+    __shared__ __attribute__((aligned(16))) int4 gm_lds[kSub * 4 * 8 * 4];   // per block of the unit, wave, lane group: four rows
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t bid = blockIdx.x;
+    const uint32_t local = bid >> 3;
+    const int panel = int(local / uint32_t(p.n_units)) * 8 + int(bid & 7);
+    if (panel >= p.n_panels) return;
+    const uint32_t unit = local % uint32_t(p.n_units);
+    const int32_t* un = p.units + size_t(unit) * 32;
+    const int b0 = un[0];                                   // first (usually only) block of the unit
+    const int64_t c0 = int64_t(panel) * 32;
+    const int g = lane >> 3, q = lane & 7, gbase = lane & ~7;
+    const uint32_t qoff = uint32_t(q) * 16u;
+
+    const float* xbase = p.X + (int64_t(panel) * p.x_rows_pad) * 32;
+    const __amdgpu_buffer_rsrc_t srd =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xbase), 0, int(p.x_rows_pad * 128), 0x00020000);
+    const int sent = p.x_sentinel;
+
+    const int quad0 = un[1];                                // this unit's quads of the block's dense set
+    const int nq = (p.probe & 4) ? 0 : un[2];
+    const int unit_k = un[3], unit_nb = un[4], pslot = un[5], cslot = un[6];
+    const bool has_set = !(p.probe & 4) && un[7] != 0;      // the block has a dense set (this unit may be one of several)
+    const int n_sub = un[8];                                // blocks of the unit
+    const int per = (nq + 3) >> 2;                          // quads per wave
+    const int n_active = per ? (nq + per - 1) / per : 0;    // waves that have MFMA work
+
+    // ---- everything the gather phase needs that does not depend on another load is requested now: the
+    // wave's stream geometry (scalar, part of the unit record), the rows of every lane group (into LDS),
+    // the ids of the first two rounds
+    const int32_t* wm = un + 9 + wave * 5;
+    const int round0 = wm[0];
+    const int e1 = wm[1], e2 = wm[2], e3 = wm[3], e4 = wm[4];      // rounds up to the end of each block of the unit
+    const int n_rounds = (p.probe & 1) ? 0 : (n_sub == 1 ? e1 : n_sub == 2 ? e2 : n_sub == 3 ? e3 : e4);
+    auto ld_sid = [&](int r) -> int {                        // round r of the stream: this lane's id
+        const size_t at = (size_t(round0) + size_t(min(r, max(n_rounds - 1, 0)))) * 64 + lane;
+        if constexpr (IDS16) {
+            const int v = p.meta_nt ? int(__builtin_nontemporal_load(p.sids16 + at)) : int(p.sids16[at]);
+            return v == 0xFFFF ? sent : (v & p.idx_mask);
+        } else {
+            const int v = p.meta_nt ? __builtin_nontemporal_load(p.sids32 + at) : p.sids32[at];
+            return v < 0 ? sent : (v & p.idx_mask);
+        }
+    };
+    {   // lane (g, q): row q & 3 of lane group g, blocks q >> 2 and 2 + (q >> 2) of the unit
+        const int4* src = p.gmeta + ((size_t(unit) * kSub * 4 + wave) * 8 + g) * 4 + (q & 3);
+        const int sbA = q >> 2, sbB = 2 + (q >> 2);
+        int4* dst = gm_lds + (wave * 8 + g) * 4 + (q & 3);
+        const int4 zero = make_int4(-1, 0, -1, 0);
+        const int4 a = sbA < n_sub ? src[size_t(sbA) * 4 * 8 * 4] : zero;
+        const int4 c = sbB < n_sub ? src[size_t(sbB) * 4 * 8 * 4] : zero;
+        dst[sbA * 4 * 8 * 4] = a;
+        dst[sbB * 4 * 8 * 4] = c;
+    }
+    int iv0 = sent, iv1 = sent;
+    if (n_rounds > 0) {
+        iv0 = ld_sid(0);
+        iv1 = ld_sid(1);
+    }
+
+    // ---------------------------------------------------------------- 1. MFMA phase
+    if (nq > 0) {
+        {   // lookup table: entry e, dword d: low half = bit 2d, high half = bit 2d + 1 (bf16 1.0 = 0x3F80)
+            const unsigned e = threadIdx.x;
+            uint4 v;
+            v.x = ((e >> 0) & 1u) * 0x3F80u | ((e >> 1) & 1u) * 0x3F800000u;
+            v.y = ((e >> 2) & 1u) * 0x3F80u | ((e >> 3) & 1u) * 0x3F800000u;
+            v.z = ((e >> 4) & 1u) * 0x3F80u | ((e >> 5) & 1u) * 0x3F800000u;
+            v.w = ((e >> 6) & 1u) * 0x3F80u | ((e >> 7) & 1u) * 0x3F800000u;
+            lut[e] = v;
+        }
+        __syncthreads();
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        const int q_lo = wave * per, q_hi = min(nq, q_lo + per);
+        if (q_lo < q_hi) {
+            // Software pipeline over the wave's steps, one quad (4 steps) per loop iteration: while the 12
+            // MFMAs of a step run, the next step goes registers -> LDS -> fragment -> three bf16 terms and
+            // the operand loads of the two steps after it are in flight (register sets rA / rB, one 2 KiB
+            // LDS buffer per wave).  Every iteration issues the same loads in the same order — the prefetch
+            // past the wave's last quad re-reads that quad — so the waits are counted, never drained; the
+            // steps that pad a set to whole quads multiply zero pattern bits.
+            float* bbuf = bbuf_all + wave * (16 * 32);
+            const int n = lane & 31, h = lane >> 5;
+            auto ld_ids = [&](int qd) -> int {
+                const size_t at = size_t(quad0 + qd) * 64 + lane;
+                if constexpr (IDS16) return int(p.dcols16[at]) & p.idx_mask;
+                else return p.dcols32[at] & p.idx_mask;
+            };
+            int ids_a = ld_ids(q_lo);
+            uint4 aw_a = p.abits[size_t(quad0 + q_lo) * 64 + lane];
+            int ids_b = ld_ids(min(q_lo + 1, q_hi - 1));
+            uint4 aw_b = p.abits[size_t(quad0 + min(q_lo + 1, q_hi - 1)) * 64 + lane];
+            struct Terms { uint32_t lo[4], mid[4], hi[4]; };
+            auto issue = [&](int ids, int s4, float4& x0, float4& x1) {   // two wave instructions, 8 operand rows each
+                x0 = ld_seg(srd, __shfl(ids, s4 * 16 + g), qoff);
+                x1 = ld_seg(srd, __shfl(ids, s4 * 16 + 8 + g), qoff);
+            };
+            // B fragment through the wave's LDS buffer: [k][n] -> lane (n, h) holds k = 8h .. 8h + 7
+            auto stage = [&](const float4& x0, const float4& x1, float (&x)[8]) {
+                wave_lds_order();
+                *reinterpret_cast<float4*>(bbuf + g * 32 + q * 4) = x0;
+                *reinterpret_cast<float4*>(bbuf + (8 + g) * 32 + q * 4) = x1;
+                wave_lds_order();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = bbuf[(8 * h + j) * 32 + n];
+            };
+            auto split = [&](const float (&x)[8], Terms& t) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) split3f(x[2 * j], x[2 * j + 1], t.hi[j], t.mid[j], t.lo[j]);
+            };
+            auto mma = [&](const Terms& t, uint32_t aw) {
+                const bf16x8 bl = frag(t.lo[0], t.lo[1], t.lo[2], t.lo[3]);
+                const bf16x8 bm = frag(t.mid[0], t.mid[1], t.mid[2], t.mid[3]);
+                const bf16x8 bh = frag(t.hi[0], t.hi[1], t.hi[2], t.hi[3]);
+                // per tile: smallest term first (as blockdense.hip)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, lut[(aw >> (8 * tt)) & 255u]);
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, acc[tt], 0, 0, 0);
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bm, acc[tt], 0, 0, 0);
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bh, acc[tt], 0, 0, 0);
+                }
+            };
+            float4 rA0, rA1, rB0, rB1;
+            Terms tA, tB;
+            float x[8];
+            issue(ids_a, 0, rA0, rA1);
+            issue(ids_a, 1, rB0, rB1);
+            stage(rA0, rA1, x);
+            split(x, tA);
+            issue(ids_a, 2, rA0, rA1);
+            for (int qd = q_lo; qd < q_hi; ++qd) {
+                // tA = step 0 of quad qd; rB = its step 1 (arriving); rA = its step 2 (in flight)
+                stage(rB0, rB1, x);
+                issue(ids_a, 3, rB0, rB1);
+                mma(tA, aw_a.x);
+                split(x, tB);
+                stage(rA0, rA1, x);
+                issue(ids_b, 0, rA0, rA1);
+                mma(tB, aw_a.y);
+                split(x, tA);
+                stage(rB0, rB1, x);
+                issue(ids_b, 1, rB0, rB1);
+                mma(tA, aw_a.z);
+                split(x, tB);
+                stage(rA0, rA1, x);
+                issue(ids_b, 2, rA0, rA1);
+                mma(tB, aw_a.w);
+                split(x, tA);
+                ids_a = ids_b;
+                aw_a = aw_b;
+                const int nx = min(qd + 2, q_hi - 1);
+                ids_b = ld_ids(nx);
+                aw_b = p.abits[size_t(quad0 + nx) * 64 + lane];
+            }
+        }
+        // ------------------------------------------------------------ 2. sum of the waves, in wave order
+        // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5):
+        // four consecutive registers are four consecutive rows = 16 bytes of the transposed tile
+        {
+            const int n = lane & 31, h = lane >> 5;
+            for (int w = 0; w < n_active; ++w) {
+                if (wave == w) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int i4 = 0; i4 < 4; ++i4) {
+                            float4* dst = reinterpret_cast<float4*>(tile + n * kTS + 32 * t + 8 * i4 + 4 * h);
+                            float4 v = make_float4(acc[t][4 * i4], acc[t][4 * i4 + 1], acc[t][4 * i4 + 2], acc[t][4 * i4 + 3]);
+                            if (w > 0) {
+                                const float4 o = *dst;
+                                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                            }
+                            *dst = v;
+                        }
+                }
+                __syncthreads();
+            }
+        }
+        // ------------------------------------------------------------ 2b. blocks cut into several units
+        // (a workgroup must not outlive its panel's turn in the L2): every unit publishes its sums and
+        // takes a ticket; the LAST arriver adds the partial sums in unit order (whoever it is: same
+        // bits) and goes on to the gather phase, the others are done.  No unit ever waits for another.
+        if (unit_nb > 1) {
+            float* mine = p.partials + (size_t(pslot) * p.n_panels + panel) * (32 * kFB);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int x = threadIdx.x + it * 256;      // 1024 float4 = 32 columns x 128 rows
+                const int c = x >> 5, r4 = (x & 31) * 4;
+                *reinterpret_cast<float4*>(mine + c * kFB + r4) = *reinterpret_cast<const float4*>(tile + c * kTS + r4);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* flag = reinterpret_cast<int*>(bbuf_all);
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                int* tk = p.tickets + size_t(cslot) * p.n_panels + panel;
+                const int t = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = t == unit_nb - 1;
+                if (last) {
+                    __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                *flag = last;
+            }
+            __syncthreads();
+            if (!*flag) return;
+            const int first = pslot - unit_k;                // the block's units own consecutive slots
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int x = threadIdx.x + it * 256;
+                const int c = x >> 5, r4 = (x & 31) * 4;
+                float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k = 0; k < unit_nb; ++k) {
+                    const float4 v = *reinterpret_cast<const float4*>(
+                        p.partials + (size_t(first + k) * p.n_panels + panel) * (32 * kFB) + c * kFB + r4);
+                    if (k == 0) acc4 = v;
+                    else { acc4.x += v.x; acc4.y += v.y; acc4.z += v.z; acc4.w += v.w; }
+                }
+                *reinterpret_cast<float4*>(tile + c * kTS + r4) = acc4;
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---------------------------------------------------------------- 3. gather phase (the remainder)
+    // Every lane group owns four rows of the block, their remainder ids concatenated into ONE stream (the
+    // host balances the 32 streams of a block); a slot instruction gathers the next neighbour of all 8
+    // lane groups, a round is 8 slots = one coalesced id load.  Each lane group keeps one running sum;
+    // when its stream reaches the end of a row the row goes into the LDS tile ((MFMA part + gathered
+    // part) x rowscale) and the next row's (row, scale, end) comes from LDS.
+    // Round r + 1 is in flight while round r is summed; the streams carry no padding except the tail of
+    // the last round (ids marked empty load zeros through the buffer range check).
+    {
+        // the unit's blocks one after the other; the wave's rounds run through them without a gap (the
+        // gathers of the next block's first round are in flight while this block's tile is stored)
+        int sb = 0;                                           // block of the unit the stream is in
+        int r_base = 0;                                       // first round of that block
+        auto end_of = [&](int k) -> int { return k == 0 ? e1 : k == 1 ? e2 : k == 2 ? e3 : e4; };
+        int r_end = (p.probe & 1) ? 0 : e1;                   // rounds up to the end of block sb
+        const int4* gmp = gm_lds + (wave * 8 + g) * 4;        // + sb * 128: the lane group's rows in block sb
+        wave_lds_order();
+        int4 m_cur = gmp[0];
+        float4 cur = make_float4(0.f, 0.f, 0.f, 0.f);
+        int krow = 0;                                         // rows of the lane group finished in this block
+        auto emit = [&](const int4& m, const float4& sv) {
+            if (m.x >= 0) {
+                const float sc = __int_as_float(m.y);
+                float* tp = tile + (4 * q) * kTS + m.x;
+                const float d0 = has_set ? tp[0] : 0.f, d1 = has_set ? tp[kTS] : 0.f;
+                const float d2 = has_set ? tp[2 * kTS] : 0.f, d3 = has_set ? tp[3 * kTS] : 0.f;
+                tp[0] = (sv.x + d0) * sc;
+                tp[kTS] = (sv.y + d1) * sc;
+                tp[2 * kTS] = (sv.z + d2) * sc;
+                tp[3 * kTS] = (sv.w + d3) * sc;
+            }
+        };
+        // slot f of the lane group's stream (of this block) has been added: was it the last of the current row?
+        auto row_end = [&](int f) {
+            if (f + 1 == m_cur.z) {
+                emit(m_cur, cur);
+                cur = make_float4(0.f, 0.f, 0.f, 0.f);
+                ++krow;
+                m_cur = gmp[sb * 128 + min(krow, 3)];
+                if (krow > 3) m_cur.z = -1;
+            }
+        };
+        // every round of block sb has been summed: its rows without a remainder, then the tile goes out
+        auto finish = [&]() {
+            for (int k = krow; k < 4; ++k) emit(gmp[sb * 128 + k], make_float4(0.f, 0.f, 0.f, 0.f));
+            __syncthreads();
+            // ------------------------------------------------------------ 4. transposed store
+            const int row0 = (b0 + sb) * kFB;
+            const int nrows = int(min(int64_t(kFB), p.M - row0));
+            const int rows_out = max(0, min(32, nrows - 32 * wave));
+            const int cols_here = int(min(int64_t(32), p.L - c0));
+            if (rows_out > 0 && !(p.probe & 2)) {
+                // panel-blocked Tt: the wave's 32 x 32 tile is 4 KiB contiguous, element (c, r) at c * 32 + r
+                float* base = p.Y + ((int64_t(row0 >> 5) + wave) * p.y_rows_pad + c0) * 32;
+                const float* tw = tile + 32 * wave;
+                const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(base, 0, 4096, 0x00020000);
+                if ((rows_out & 3) == 0) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int x = lane + it * 64;
+                        const int c = x >> 3;
+                        const int r4 = (x & 7) * 4;
+                        if (c < cols_here && r4 < rows_out) {
+                            const float4 v = *reinterpret_cast<const float4*>(tw + c * kTS + r4);
+                            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                            v4u o;
+                            o.x = __float_as_uint(v.x); o.y = __float_as_uint(v.y);
+                            o.z = __float_as_uint(v.z); o.w = __float_as_uint(v.w);
+                            const int off = (c * 32 + r4) * 4;
+                            // cache policy of the tile store (aux: 1 = sc0, 2 = nt, 16 = sc1): sc1 writes through
+                            // and drops the line, so the output does not take the L2 from the panel's slice
+                            switch (p.nt) {
+                                case 0: __builtin_amdgcn_raw_buffer_store_b128(o, ysrd, off, 0, 0); break;
+                                case 1: __builtin_amdgcn_raw_buffer_store_b128(o, ysrd, off, 0, 2); break;
+                                case 2: __builtin_amdgcn_raw_buffer_store_b128(o, ysrd, off, 0, 16); break;
+                                default: __builtin_amdgcn_raw_buffer_store_b128(o, ysrd, off, 0, 17); break;
+                            }
+                        }
+                    }
+                } else {
+                    for (int x = lane; x < 32 * 32; x += 64) {
+                        const int c = x >> 5, r = x & 31;
+                        if (c < cols_here && r < rows_out) base[c * 32 + r] = tw[c * kTS + r];
+                    }
+                }
+            }
+            ++sb;
+            if (sb < n_sub) {
+                __syncthreads();                              // the tile is free for the next block's rows
+                r_base = r_end;
+                r_end = (p.probe & 1) ? 0 : end_of(sb);
+                krow = 0;
+                cur = make_float4(0.f, 0.f, 0.f, 0.f);
+                m_cur = gmp[sb * 128];
+            }
+        };
+        auto issue8 = [&](int iv, float4 (&v)[8]) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ld_seg(srd, __shfl(iv, gbase + j), qoff);
+        };
+        auto consume = [&](const float4 (&v)[8], int r) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                cur.x += v[j].x; cur.y += v[j].y; cur.z += v[j].z; cur.w += v[j].w;
+                row_end(8 * (r - r_base) + j);
+            }
+            while (sb < n_sub && r + 1 == r_end) finish();    // (also the blocks after it that have no rounds)
+        };
+        while (sb < n_sub && r_end == r_base) finish();       // leading blocks without rounds
+        if (n_rounds > 0) {
+            float4 vA[8], vB[8];
+            issue8(iv0, vA);                                  // round 0
+            int r = 0;
+            while (r + 2 < n_rounds) {                        // at least two more rounds after r
+                const int iv2 = ld_sid(r + 2);
+                issue8(iv1, vB);
+                consume(vA, r);
+                iv1 = ld_sid(r + 3);
+                issue8(iv2, vA);
+                consume(vB, r + 1);
+                r += 2;
+            }
+            if (r + 1 < n_rounds) {                           // vA = round r in flight, one more after it
+                issue8(iv1, vB);
+                consume(vA, r);
+                consume(vB, r + 1);
+            } else {
+                consume(vA, r);
+            }
+        }
+        while (sb < n_sub) finish();
+    }
+}
+
+template <typename T>
+static int upload_vec(T** d, const std::vector<T>& h) {
+    const size_t bytes = std::max<size_t>(16, h.size() * sizeof(T));
+    SR_HIP(hipMalloc((void**)d, bytes));
+    if (!h.empty()) SR_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SIMRANK_OK;
+}
+
+void free_fused_plan(simrank_fused_plan* p) {
+    if (!p) return;
+    (void)hipFree(p->units); (void)hipFree(p->partials); (void)hipFree(p->tickets);
+    (void)hipFree(p->dcols16); (void)hipFree(p->dcols32); (void)hipFree(p->abits);
+    (void)hipFree(p->gmeta); (void)hipFree(p->sids16); (void)hipFree(p->sids32);
+    delete p;
+}
+
+// Host side, per 128-row block:
+//  * the dense set: columns referenced by >= fuse_min of its rows, plus every column of a row whose
+//    remainder would otherwise exceed kMaxRem entries; dropped again (everything gathered) when it would
+//    make fewer than fuse_steps 16-column steps — a short matrix-core phase costs a workgroup more in
+//    dependent latencies than its few shared columns save;
+//  * its pattern bits in A-fragment order;
+//  * the gather streams: the block's rows are dealt to 32 lane groups (4 waves x 8), four rows each, so
+//    that the groups' totals of remainder entries balance (longest row first to the lightest group with
+//    room); a group's stream is its rows' remainder ids one after the other (rows without a remainder
+//    last), a wave's stream is 64 ids per round: lane group g, slot q = id 8 r + q of the group's stream
+//    (past its end: a marker).
+int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col) {
+    const int64_t M = g->n_rows, K = g->n_cols;
+    const int64_t thr = std::max<int64_t>(2, g->tun.fuse_min);
+    const int64_t min_steps = std::max<int64_t>(0, g->tun.fuse_steps);
+    const int64_t nblk = (M + kFB - 1) / kFB;
+    const bool ids16 = K < 65535;
+    std::vector<int32_t> blk_quad0(size_t(nblk) + 1, 0);
+    std::vector<int32_t> dcols;                       // padded to 64 per block
+    std::vector<uint32_t> abits;                      // [quad][lane][4 steps]
+    // per block and wave: its rounds (64 ids each) and its lane groups' rows; laid out per unit below
+    std::vector<std::vector<int32_t>> blk_sids(size_t(nblk) * 4);
+    std::vector<int32_t> blk_gmeta(size_t(nblk) * 32 * 4 * 4, 0);
+    std::vector<uint16_t> cnt(size_t(K), 0);
+    std::vector<int32_t> kpos(size_t(K), -1), touched, set;
+    std::vector<int64_t> cost(size_t(nblk), 0);
+    std::vector<int32_t> rem[kFB];
+    int64_t covered = 0, steps_total = 0, r_nnz = 0;
+    std::vector<float> rowscale((size_t)M, 0.f);
+    SR_HIP(hipMemcpy(rowscale.data(), g->rowscale, size_t(M) * sizeof(float), hipMemcpyDeviceToHost));
+    for (int64_t b = 0; b < nblk; ++b) {
+        const int64_t lo = b * kFB, hi = std::min<int64_t>(M, lo + kFB);
+        touched.clear();
+        set.clear();
+        for (int32_t j = rowptr[lo]; j < rowptr[hi]; ++j)
+            if (cnt[col[j]]++ == 0) touched.push_back(col[j]);
+        for (int32_t c : touched)
+            if (cnt[c] >= thr) { set.push_back(c); kpos[c] = 0; }
+        if ((int64_t)(set.size() + 15) / 16 < min_steps) {
+            for (int32_t c : set) kpos[c] = -1;
+            set.clear();
+        }
+        // rows that would keep a long remainder go to the matrix cores whole
+        for (int64_t a = lo; a < hi; ++a) {
+            int32_t r = 0;
+            for (int32_t j = rowptr[a]; j < rowptr[a + 1]; ++j) r += kpos[col[j]] < 0;
+            if (r > kMaxRem)
+                for (int32_t j = rowptr[a]; j < rowptr[a + 1]; ++j)
+                    if (kpos[col[j]] < 0) { set.push_back(col[j]); kpos[col[j]] = 0; }
+        }
+        std::sort(set.begin(), set.end());
+        const int32_t U = (int32_t)set.size();
+        const int32_t nq = (U + 63) / 64;
+        blk_quad0[size_t(b) + 1] = blk_quad0[size_t(b)] + nq;
+        steps_total += (U + 15) / 16;
+        const size_t q0 = size_t(blk_quad0[size_t(b)]);
+        dcols.resize((q0 + size_t(nq)) * 64, U ? set[0] : 0);      // padding: a real row, pattern bits zero
+        abits.resize((q0 + size_t(nq)) * 64 * 4, 0u);
+        for (int32_t i = 0; i < U; ++i) {
+            dcols[q0 * 64 + size_t(i)] = set[size_t(i)];
+            kpos[set[size_t(i)]] = i;
+        }
+        const int nr = int(hi - lo);
+        for (int rr = 0; rr < nr; ++rr) {
+            const int64_t a = lo + rr;
+            rem[rr].clear();
+            for (int32_t j = rowptr[a]; j < rowptr[a + 1]; ++j) {
+                const int32_t i = kpos[col[j]];
+                if (i < 0) {
+                    rem[rr].push_back(col[j]);
+                } else {
+                    // column i of the set: quad i / 64, step (i % 64) / 16, k = i % 16 = 8 h + jj;
+                    // lane (h, m = row % 32), byte = 32-row tile, bit jj
+                    const int kk = i & 15, s = (i & 63) >> 4;
+                    const int lane = (kk >> 3) * 32 + (rr & 31);
+                    abits[((q0 + size_t(i >> 6)) * 64 + size_t(lane)) * 4 + size_t(s)] |= 1u << (8 * (rr >> 5) + (kk & 7));
+                    ++covered;
+                }
+            }
+            r_nnz += (int64_t)rem[rr].size();
+        }
+        int order[kFB];
+        std::iota(order, order + nr, 0);
+        std::stable_sort(order, order + nr, [&](int x, int y) { return rem[x].size() > rem[y].size(); });
+        // 32 lane groups x 4 rows: longest row first, to the group with the smallest total that has room
+        int grp_rows[32][4], grp_n[32];
+        int64_t grp_tot[32];
+        for (int i = 0; i < 32; ++i) { grp_n[i] = 0; grp_tot[i] = 0; }
+        for (int i = 0; i < nr; ++i) {
+            int best = -1;
+            for (int gi = 0; gi < 32; ++gi)
+                if (grp_n[gi] < 4 && (best < 0 || grp_tot[gi] < grp_tot[best])) best = gi;
+            grp_rows[best][grp_n[best]++] = order[i];
+            grp_tot[best] += (int64_t)rem[order[i]].size();
+        }
+        // groups by total, dealt to the waves in turn: every wave gets the same mix
+        int gorder[32];
+        std::iota(gorder, gorder + 32, 0);
+        std::stable_sort(gorder, gorder + 32, [&](int x, int y) { return grp_tot[x] > grp_tot[y]; });
+        int64_t slots_block = 0;
+        for (int w = 0; w < 4; ++w) {
+            int64_t longest = 0;
+            for (int gg = 0; gg < 8; ++gg) longest = std::max(longest, grp_tot[gorder[gg * 4 + w]]);
+            const int rounds = (int)((longest + 7) / 8);
+            std::vector<int32_t>& sids = blk_sids[size_t(b) * 4 + size_t(w)];
+            const size_t base = 0;
+            sids.assign(size_t(rounds) * 64, -1);
+            for (int gg = 0; gg < 8; ++gg) {
+                const int gi = gorder[gg * 4 + w];
+                int32_t* gm = &blk_gmeta[((size_t(b) * 4 + size_t(w)) * 8 + size_t(gg)) * 16];
+                int f = 0;
+                for (int k = 0; k < 4; ++k) {
+                    if (k < grp_n[gi]) {
+                        const int rr = grp_rows[gi][k];
+                        for (int32_t id : rem[rr]) {
+                            sids[base + size_t(f >> 3) * 64 + size_t(gg) * 8 + size_t(f & 7)] = id;
+                            ++f;
+                        }
+                        gm[4 * k] = rr;
+                        const float sc = rowscale[size_t(lo + rr)];
+                        memcpy(&gm[4 * k + 1], &sc, 4);
+                        gm[4 * k + 2] = rem[rr].empty() ? -1 : f;     // (an empty row never ends a stream slot)
+                    } else {
+                        gm[4 * k] = -1;
+                        gm[4 * k + 2] = -1;
+                    }
+                }
+            }
+            slots_block += longest;
+        }
+        cost[size_t(b)] = int64_t((U + 15) / 16) * 24 + slots_block * 20 + 100;
+        for (int32_t c : touched) { cnt[c] = 0; kpos[c] = -1; }
+    }
+    // Units (one workgroup per unit and panel).  A block whose set has more than fuse_unit quads is cut
+    // into units of about that many (its partial sums meet in memory, the last arriver finishes the
+    // block).  Blocks WITHOUT a set are light — a workgroup's fixed latencies (unit record -> ids ->
+    // first gathers ... barrier -> store) would outweigh their gathers — so up to fuse_group consecutive
+    // ones share a unit, their rounds one stream per wave.  Launch order by cost, heaviest first.
+    const int64_t unit_q = std::max<int64_t>(4, g->tun.fuse_unit);
+    const int64_t group = std::min<int64_t>(kSub, std::max<int64_t>(1, g->tun.fuse_group));
+    struct Unit { int32_t b0, nsub, q0, nq, k, nb; int64_t cost; };
+    std::vector<Unit> ulist;
+    for (int64_t b = 0; b < nblk;) {
+        const int32_t q0 = blk_quad0[size_t(b)], nqb = blk_quad0[size_t(b) + 1] - q0;
+        if (nqb > 0) {
+            const int32_t nb = (int32_t)std::max<int64_t>(1, (nqb + unit_q - 1) / unit_q);
+            for (int32_t k = 0; k < nb; ++k) {
+                const int32_t lo = (int32_t)(int64_t(nqb) * k / nb), hi = (int32_t)(int64_t(nqb) * (k + 1) / nb);
+                ulist.push_back({(int32_t)b, 1, q0 + lo, hi - lo, k, nb, cost[size_t(b)]});
+            }
+            ++b;
+        } else {
+            int64_t e = b + 1, c = cost[size_t(b)];
+            while (e < nblk && e - b < group && blk_quad0[size_t(e) + 1] == blk_quad0[size_t(e)]) c += cost[size_t(e++)];
+            ulist.push_back({(int32_t)b, (int32_t)(e - b), q0, 0, 0, 1, c});
+            b = e;
+        }
+    }
+    std::stable_sort(ulist.begin(), ulist.end(), [](const Unit& x, const Unit& y) {
+        return x.cost != y.cost ? x.cost > y.cost : (x.b0 != y.b0 ? x.b0 < y.b0 : x.k < y.k);
+    });
+    if (g->tun.fuse_order > 0 && ulist.size() > 8) {
+        // units with a matrix-core phase spread evenly over the first 1 / fuse_order of the launch order
+        // instead of all in front: a CU then holds matrix-core work and gather work at the same time
+        // (the two phases use different pipes), not one kind after the other.  A block's units stay together.
+        std::vector<Unit> heavy, light, mixed;
+        for (const Unit& u : ulist) (u.nq > 0 ? heavy : light).push_back(u);
+        const size_t span = std::max(heavy.size(), std::min(ulist.size(), ulist.size() / size_t(g->tun.fuse_order)));
+        size_t hi = 0, li = 0;
+        for (size_t pos = 0; pos < ulist.size(); ++pos) {
+            const bool want_heavy = hi < heavy.size() && (li >= light.size() || hi * span <= pos * heavy.size());
+            if (want_heavy) mixed.push_back(heavy[hi++]);
+            else mixed.push_back(light[li++]);
+        }
+        ulist.swap(mixed);
+    }
+    std::vector<int32_t> units(ulist.size() * 32, 0), gmeta(ulist.size() * kSub * 32 * 4 * 4, 0), sids;
+    sids.reserve(size_t(r_nnz) + ulist.size() * 512);
+    for (size_t i = 0; i < ulist.size(); ++i)             // no row, no remainder
+        for (size_t j = 0; j < size_t(kSub) * 32 * 4; ++j) {
+            gmeta[(i * kSub * 32 * 4 + j) * 4] = -1;
+            gmeta[(i * kSub * 32 * 4 + j) * 4 + 2] = -1;
+        }
+    int32_t n_pslots = 0, n_cslots = 0;
+    for (size_t i = 0; i < ulist.size(); ++i) {
+        const Unit& u = ulist[i];
+        int32_t* rec = &units[i * 32];
+        rec[0] = u.b0; rec[1] = u.q0; rec[2] = u.nq; rec[3] = u.k; rec[4] = u.nb;
+        rec[5] = -1; rec[6] = -1;
+        rec[7] = u.nq > 0 ? 1 : 0;
+        rec[8] = u.nsub;
+        if (u.nb > 1) {
+            // the units of a block are neighbours in the list (same cost, ordered by k): consecutive slots
+            if (u.k == 0) { rec[5] = n_pslots; rec[6] = n_cslots; }
+            else { rec[5] = units[(i - 1) * 32 + 5] + 1; rec[6] = units[(i - 1) * 32 + 6]; }
+            if (u.k == u.nb - 1) { n_pslots += u.nb; ++n_cslots; }
+        }
+        for (int w = 0; w < 4; ++w) {
+            int32_t* wm = rec + 9 + w * 5;
+            wm[0] = (int32_t)(sids.size() / 64);
+            int32_t rounds = 0;
+            for (int sb = 0; sb < kSub; ++sb) {
+                if (sb < u.nsub) {
+                    const std::vector<int32_t>& bs = blk_sids[size_t(u.b0 + sb) * 4 + size_t(w)];
+                    sids.insert(sids.end(), bs.begin(), bs.end());
+                    rounds += (int32_t)(bs.size() / 64);
+                    memcpy(&gmeta[(((i * kSub + size_t(sb)) * 4 + size_t(w)) * 8) * 16],
+                           &blk_gmeta[((size_t(u.b0 + sb) * 4 + size_t(w)) * 8) * 16], 8 * 16 * sizeof(int32_t));
+                }
+                wm[1 + sb] = rounds;
+            }
+        }
+    }
+
+    simrank_fused_plan* pl = new simrank_fused_plan;
+    pl->n_units = (int32_t)(units.size() / 32);
+    pl->n_blocks = (int32_t)nblk;
+    pl->n_pslots = n_pslots;
+    pl->n_cslots = n_cslots;
+    pl->n_quads = blk_quad0[size_t(nblk)];
+    pl->n_steps = steps_total;
+    pl->nnz_covered = covered;
+    pl->r_nnz = r_nnz;
+    pl->ids16 = ids16 ? 1 : 0;
+    int rc = upload_vec(&pl->units, units);
+    if (!rc) {
+        if (ids16) {
+            std::vector<uint16_t> d16(dcols.begin(), dcols.end());
+            rc = upload_vec(&pl->dcols16, d16);
+        } else {
+            rc = upload_vec(&pl->dcols32, dcols);
+        }
+    }
+    if (!rc) rc = upload_vec(reinterpret_cast<uint32_t**>(&pl->abits), abits);
+    if (!rc) rc = upload_vec(reinterpret_cast<int32_t**>(&pl->gmeta), gmeta);
+    if (!rc) {
+        if (ids16) {
+            std::vector<uint16_t> s16(sids.size());
+            for (size_t i = 0; i < sids.size(); ++i) s16[i] = sids[i] < 0 ? uint16_t(0xFFFF) : uint16_t(sids[i]);
+            rc = upload_vec(&pl->sids16, s16);
+        } else {
+            rc = upload_vec(&pl->sids32, sids);
+        }
+    }
+    if (rc) {
+        free_fused_plan(pl);
+        return rc;
+    }
+    g->fused = pl;
+    return SIMRANK_OK;
+}
+
+// Tt (panel-blocked, y_rows_pad rows per panel) = (diag(rowscale) . A . X)^T, X panel-blocked
+int launch_fused_trans(const simrank_graph* g, const float* X, int64_t x_rows_pad, int64_t L, float* Y,
+                       int64_t y_rows_pad, hipStream_t st) {
+    simrank_fused_plan* pl = g->fused;
+    SR_REQUIRE(pl, "graph has no fused plan");
+    SR_REQUIRE(aligned16(X) && aligned16(Y), "fused leg needs 16-byte aligned operands");
+    SR_REQUIRE(x_rows_pad >= g->n_cols && (x_rows_pad + 1) * 128 < (int64_t(1) << 31) && x_rows_pad < (int64_t(1) << 24) - 1,
+               "fused leg: operand of %lld rows per panel", (long long)x_rows_pad);
+    FusedArgs a{};
+    a.X = X; a.Y = Y;
+    a.x_rows_pad = x_rows_pad; a.y_rows_pad = y_rows_pad;
+    a.L = L; a.M = g->n_rows;
+    a.n_panels = int32_t((L + 31) / 32);
+    a.n_units = pl->n_units;
+    a.nt = (int32_t)(g->tun.stream_nt ? g->tun.fuse_store : 0);
+    a.x_sentinel = (int32_t)x_rows_pad;
+    a.probe = (int32_t)g->tun.probe_flags;
+    a.meta_nt = (int32_t)g->tun.fuse_meta_nt;
+    a.idx_mask = (int32_t)g->tun.probe_mask;
+    a.units = pl->units;
+    if (pl->n_pslots > 0 && a.n_panels > pl->cap_panels) {
+        // partial sums and tickets of the split blocks, sized by the widest operand seen so far
+        SR_HIP(hipStreamSynchronize(st));                  // an earlier launch may still use the old ones
+        (void)hipFree(pl->partials); (void)hipFree(pl->tickets);
+        pl->partials = nullptr; pl->tickets = nullptr; pl->cap_panels = 0;
+        SR_HIP(hipMalloc((void**)&pl->partials, size_t(pl->n_pslots) * a.n_panels * 32 * kFB * sizeof(float)));
+        SR_HIP(hipMalloc((void**)&pl->tickets, size_t(pl->n_cslots) * a.n_panels * sizeof(int32_t)));
+        SR_HIP(hipMemsetAsync(pl->tickets, 0, size_t(pl->n_cslots) * a.n_panels * sizeof(int32_t), st));
+        pl->cap_panels = a.n_panels;
+    }
+    // (tickets are indexed with the launch's own panel count: a narrower launch uses a prefix, all zero)
+    a.partials = pl->partials; a.tickets = pl->tickets;
+    a.n_pslots = pl->n_pslots; a.n_cslots = pl->n_cslots;
+    a.dcols16 = pl->dcols16; a.dcols32 = pl->dcols32; a.abits = pl->abits;
+    a.gmeta = pl->gmeta; a.sids16 = pl->sids16; a.sids32 = pl->sids32;
+    const int64_t grid = int64_t((a.n_panels + 7) / 8) * 8 * a.n_units;
+    SR_REQUIRE(grid > 0 && grid < (int64_t(1) << 31), "grid of %lld blocks", (long long)grid);
+    if (pl->ids16)
+        hipLaunchKernelGGL(fused_trans_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(fused_trans_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, a);
+    SR_HIP(hipGetLastError());
+    return SIMRANK_OK;
+}
+
+}  // namespace simrank
+
+using namespace simrank;
+
+extern "C" {
+
+int simrank_graph_fused_stats(const simrank_graph* g, int64_t* n_steps, int64_t* nnz_covered,
+                              int64_t* nnz_remainder) {
+    SR_REQUIRE(g, "graph is NULL");
+    const simrank_fused_plan* pl = g->fused;
+    if (n_steps) *n_steps = pl ? pl->n_steps : 0;
+    if (nnz_covered) *nnz_covered = pl ? pl->nnz_covered : 0;
+    if (nnz_remainder) *nnz_remainder = pl ? pl->r_nnz : g->nnz;
+    return SIMRANK_OK;
+}
+
+}  // extern "C"

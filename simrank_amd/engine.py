@@ -376,6 +376,14 @@ class HipOps:
               "simrank_graph_dense_stats")
         return a.value, b.value, c.value
 
+    def fused_stats(self, g: Graph):
+        """(16-column matrix-core steps per panel, entries on the matrix cores, entries gathered) of the
+        one-launch leg 1 of a graph (simrank_graph_fused_stats); (0, 0, nnz) when tuning "fuse" was 0."""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(self.lib.simrank_graph_fused_stats(g.handle, C.byref(a), C.byref(b), C.byref(c)),
+              "simrank_graph_fused_stats")
+        return a.value, b.value, c.value
+
     def dense_part(self, g: Graph, X: Matrix, n_cols: int | None = None):
         """The matrix-core part of ``spmm`` alone (measurement; see simrank_dense_part)."""
         check(self.lib.simrank_dense_part(g.handle, X.ptr, -X.rows_pad if X.blocked else X.ld,

@@ -1,0 +1,176 @@
+"""Leg 1 as one launch (csrc/fused.hip) on a real MI355X, through the C ABI: the matrix-core part of a
+128-row block and its gathered remainder against float64 NumPy (1e-5, north_star) and against the
+two-launch path of round 2 (rounding only), over the shapes that exercise every branch: blocks with and
+without a dense set, sets of 1 .. many 64-column groups, rows and columns off the 32/128 grids,
+rectangular (bipartite) patterns, rows sent whole to the matrix cores, 32-bit ids.
+First `.dot` of SimRank.py:139 / :298 / :301 / :361 / :420 / :423."""
+import contextlib
+
+import numpy as np
+import pytest
+
+from simrank_amd.ingest import CSR
+from tests.test_gpu_kernels import corner_csr, dense64, random_csr
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from simrank_amd.engine import HipOps
+    o = HipOps(0)
+    o.set_tuning(fuse_steps=1, fuse_min=2)   # small test graphs: a dense set however few steps it makes
+    yield o
+    o.set_tuning(fuse=1, fuse_min=3, fuse_steps=8, fuse_unit=1 << 20, fuse_group=4)
+
+
+@contextlib.contextmanager
+def knobs(ops, **kw):
+    ops.set_tuning(**kw)
+    try:
+        yield
+    finally:
+        ops.set_tuning(fuse=1, fuse_min=2, fuse_steps=1, fuse_unit=1 << 20, fuse_group=4)
+
+
+def put_blocked(ops, a, dtype=np.float32):
+    m = ops.matrix(a.shape[0], a.shape[1], dtype, blocked=True)
+    ops.upload(m, a.astype(dtype))
+    return m
+
+
+def leg1(ops, g, X, M):
+    yt = ops.matrix(X.shape[1], M, blocked=True)
+    ops.spmm(g, put_blocked(ops, X), yt, transpose_out=True)
+    return ops.download(yt)
+
+
+@pytest.mark.parametrize("shape", [(520, 400, 333), (384, 384, 384), (1000, 300, 70), (130, 200, 2),
+                                   (128, 128, 32), (129, 77, 33), (64, 1000, 96), (2100, 2100, 160)])
+@pytest.mark.parametrize("fuse_min", [2, 4])
+def test_fused_leg1_matches_numpy_and_the_two_launch_path(ops, shape, fuse_min):
+    M, K, L = shape
+    csr = corner_csr(M, K, seed=M + L, hubs=min(K, 150))
+    X = (np.random.default_rng(5).random((K, L)) ** 3).astype(np.float32)
+    want = (dense64(csr) @ X.astype(np.float64)).T
+    with knobs(ops, fuse_min=fuse_min):
+        g = ops.graph(csr)
+        steps, cov, rem = ops.fused_stats(g)
+        assert cov + rem == csr.nnz and (steps > 0) == (cov > 0)
+        got = leg1(ops, g, X, M)
+        assert np.array_equal(got, leg1(ops, g, X, M))          # reproducible
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-30)
+    with knobs(ops, fuse=0):
+        g0 = ops.graph(csr)
+        assert ops.fused_stats(g0) == (0, 0, csr.nnz)
+        old = leg1(ops, g0, X, M)
+    np.testing.assert_allclose(got, old, rtol=2e-6, atol=1e-30)
+
+
+def test_fused_split_is_exact(ops):
+    """One entry per row, every column shared by two rows of a block: everything goes through the bf16
+    hi + mid + lo split and must come back bit for bit."""
+    M, K, L = 256, 64, 128
+    rows = [np.array([a % 64], dtype=np.int32) for a in range(M)]
+    csr = CSR(M, K, np.arange(M + 1, dtype=np.int32), np.concatenate(rows), np.ones(M))
+    rng = np.random.default_rng(0)
+    X = (rng.standard_normal((K, L)) * np.exp(rng.uniform(-60, 60, size=(K, L)))).astype(np.float32)
+    X[0, :8] = [0.0, 1.0, -1.0, 2.0 ** -100, 1 + 2.0 ** -23, 16777215.0, -3.0000002, 1e-30]
+    g = ops.graph(csr)
+    assert ops.fused_stats(g) == (2 * 4, M, 0)
+    assert np.array_equal(leg1(ops, g, X, M), X[np.arange(M) % 64].T)
+
+
+def test_fused_without_any_dense_set(ops):
+    """Rows that share nothing: every block is gather-only (the LDS tile starts undefined)."""
+    M = K = 500
+    rows = [np.array(sorted({(7 * a + 3) % K, (11 * a + 5) % K}), dtype=np.int32) for a in range(M)]
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    csr = CSR(M, K, rowptr, np.concatenate(rows), np.random.default_rng(1).random(M) + 0.5)
+    X = np.random.default_rng(2).random((K, 200)).astype(np.float32)
+    with knobs(ops, fuse_min=100):
+        g = ops.graph(csr)
+        assert ops.fused_stats(g)[0] == 0
+        got = leg1(ops, g, X, M)
+    np.testing.assert_allclose(got, (dense64(csr) @ X.astype(np.float64)).T, rtol=RTOL, atol=1e-30)
+
+
+def test_fused_long_rows_go_to_the_matrix_cores_whole(ops):
+    """A star: one row references every column and shares them with nobody in its block; its remainder
+    would be K entries long, so all its columns join the block's dense set."""
+    M = K = 1500
+    rng = np.random.default_rng(4)
+    rows = [np.sort(rng.choice(K, size=3, replace=False)).astype(np.int32) for _ in range(M)]
+    rows[700] = np.arange(K, dtype=np.int32)
+    rows[701] = np.arange(0, K, 3, dtype=np.int32)
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    csr = CSR(M, K, rowptr, np.concatenate(rows), rng.random(M) + 0.1)
+    X = rng.random((K, 257)).astype(np.float32)
+    g = ops.graph(csr)
+    steps, cov, rem = ops.fused_stats(g)
+    assert cov >= K + K // 3 and steps >= K // 16
+    np.testing.assert_allclose(leg1(ops, g, X, M), (dense64(csr) @ X.astype(np.float64)).T, rtol=RTOL, atol=1e-30)
+
+
+def test_fused_ids_beyond_16_bits(ops):
+    """More than 65536 operand rows: 32-bit ids in the dense sets and the remainder."""
+    M, K, L = 300, 70000, 64
+    rng = np.random.default_rng(9)
+    hubs = rng.choice(K, size=90, replace=False)
+    rows = []
+    for a in range(M):
+        c = set(rng.choice(K, size=6, replace=False).tolist())
+        c |= set(hubs[rng.random(90) < 0.3].tolist())
+        rows.append(np.array(sorted(c), dtype=np.int32))
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    csr = CSR(M, K, rowptr, np.concatenate(rows), rng.random(M) + 0.1)
+    X = rng.random((K, L)).astype(np.float32)
+    g = ops.graph(csr)
+    assert ops.fused_stats(g)[0] > 0
+    np.testing.assert_allclose(leg1(ops, g, X, M), (dense64(csr) @ X.astype(np.float64)).T, rtol=RTOL, atol=1e-30)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fused_randomized(ops, seed):
+    rng = np.random.default_rng(3000 + seed)
+    M = int(rng.integers(1, 1200))
+    K = int(rng.integers(1, 1200))
+    L = int(rng.integers(1, 500))
+    if seed % 3 == 0:
+        csr = random_csr(M, K, int(rng.integers(1, 30)), seed, heavy={0: min(K, 400)} if M > 1 else ())
+    else:
+        csr = corner_csr(M, K, seed=seed, hubs=int(rng.integers(1, max(2, K))), p_hub=float(rng.uniform(0.05, 0.9)),
+                         avg=int(rng.integers(1, 12)))
+    X = (rng.random((K, L)) ** 2).astype(np.float32)
+    with knobs(ops, fuse_min=int(rng.integers(2, 6)), fuse_steps=int(rng.choice([0, 1, 3, 8])),
+               fuse_unit=int(rng.choice([4, 8, 32])), fuse_group=int(rng.integers(1, 5))):
+        g = ops.graph(csr)
+        got = leg1(ops, g, X, M)
+        steps, cov, rem = ops.fused_stats(g)
+        assert cov + rem == csr.nnz
+    np.testing.assert_allclose(got, (dense64(csr) @ X.astype(np.float64)).T, rtol=RTOL, atol=1e-30)
+
+
+@pytest.mark.parametrize("unit", [4, 6, 32])
+def test_fused_blocks_cut_into_units(ops, unit):
+    """A dense set of many 64-column groups is cut into units (workgroups) whose partial sums meet in
+    memory; whichever unit arrives last adds them in unit order: same bits whatever the cut, launch after
+    launch (the tickets reset themselves), also for a second, narrower operand."""
+    M, K, L = 300, 6000, 200
+    csr = corner_csr(M, K, seed=3, hubs=3000, p_hub=0.6)
+    X = np.random.default_rng(8).random((K, L)).astype(np.float32)
+    want = (dense64(csr) @ X.astype(np.float64)).T
+    with knobs(ops, fuse_unit=unit):
+        g = ops.graph(csr)
+        assert ops.fused_stats(g)[0] > 16 * 4
+        first = leg1(ops, g, X, M)
+        for _ in range(3):
+            assert np.array_equal(first, leg1(ops, g, X, M))
+        narrow = leg1(ops, g, X[:, :70], M)
+        assert np.array_equal(narrow, first[:70])
+        assert np.array_equal(first, leg1(ops, g, X, M))
+    np.testing.assert_allclose(first, want, rtol=RTOL, atol=1e-30)
+    with knobs(ops, fuse_unit=1 << 20):
+        whole = leg1(ops, ops.graph(csr), X, M)
+    np.testing.assert_allclose(first, whole, rtol=2e-6, atol=1e-30)

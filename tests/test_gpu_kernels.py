@@ -345,7 +345,9 @@ def test_panel_blocked_operands_give_the_row_major_bits(ops, n, L):
         cnt = np.minimum(cnt, cnt.T)
         prior = ((prior + prior.T) / 2).astype(np.float32)
         prev = ((prev + prev.T) / 2).astype(np.float32)
+    ops.set_tuning(fuse=0)               # the gather kernels of spmm.hip; the one-launch leg 1 is compared below
     g = ops.graph(csr)
+    ops.set_tuning(fuse=1)
 
     def put_as(a, blocked, dtype=np.float32):
         m = ops.matrix(a.shape[0], a.shape[1], dtype, blocked=blocked)
@@ -357,9 +359,9 @@ def test_panel_blocked_operands_give_the_row_major_bits(ops, n, L):
     out = {}
     for blocked in (False, True, "addr64"):
         if blocked == "addr64":              # the 64-bit addressing form (masked slots) on blocked operands
-            ops.set_tuning(addr32=0)
+            ops.set_tuning(addr32=0, fuse=0)
             g = ops.graph(csr)
-            ops.set_tuning(addr32=1)
+            ops.set_tuning(addr32=1, fuse=1)
         x = put_as(X, bool(blocked))
         yt = ops.matrix(L, n, blocked=bool(blocked))
         ops.spmm(g, x, yt, transpose_out=True)
@@ -377,6 +379,12 @@ def test_panel_blocked_operands_give_the_row_major_bits(ops, n, L):
             assert np.array_equal(a, b)
     want = (dense64(csr) @ X.astype(np.float64)).T
     np.testing.assert_allclose(out[True][0], want, rtol=RTOL, atol=1e-30)
+    # the one-launch leg 1 (fused.hip, what the solver runs on blocked operands): rows that go to the matrix
+    # cores are summed in another order, so it agrees to rounding, not to the bit
+    gf = ops.graph(csr)
+    ytf = ops.matrix(L, n, blocked=True)
+    ops.spmm(gf, put_as(X, True), ytf, transpose_out=True)
+    np.testing.assert_allclose(ops.download(ytf), out[True][0], rtol=2e-6, atol=1e-30)
     # top-k and row hand-back straight from the blocked layout
     xb = put_as(X, True)
     idx, val = ops.topk_rows(xb, 5, exclude_diag=False)

@@ -71,11 +71,13 @@ def test_logical_shards_are_bitwise_equal_to_one_shard():
     from simrank_amd.engine import HipOps
     df = synth.er_directed(1024, 0.01, seed=1)
     knob = HipOps(0)
-    knob.set_tuning(triangle=0)      # P = 1 without the single-rank upper-triangle shortcut
+    # P = 1 without the single-rank shortcuts: no upper-triangle leg 2, no one-launch leg 1 (the shards
+    # run the gather kernels of spmm.hip; the one-launch leg sums matrix-core rows in another order)
+    knob.set_tuning(triangle=0, fuse=0)
     try:
         one = SRA.SimRank().fit(df, iterations=6, eps=0, verbose=False, mode="sparse")
     finally:
-        knob.set_tuning(triangle=1)
+        knob.set_tuning(triangle=1, fuse=1)
     tri = SRA.SimRank().fit(df, iterations=6, eps=0, verbose=False, mode="sparse")
     # mirrored tiles carry the same bits (only the diagonal tiles of the solver's own node
     # order are computed on both sides): nearly all pairs (i, j), (j, i) are bit-equal
@@ -286,7 +288,7 @@ def test_config4_pl32768_eight_shards_bitwise(ops):
     nodes, csr = ingest.directed(df, False, "from", "to", "weight")
     n = csr.n_rows
     rows = [0, 1, n // 3, n // 2 + 7, n - 129, n - 1]
-    ops.set_tuning(triangle=0)
+    ops.set_tuning(triangle=0, fuse=0)   # one rank on the kernels the shards run (no triangle leg 2, no one-launch leg 1)
     try:
         one = Solver(lambda r: ops, LocalWorld(1), [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
         one.reset()
@@ -295,7 +297,7 @@ def test_config4_pl32768_eight_shards_bitwise(ops):
         want = ops.download_rows(one.cur[0][0], rows)
         one.release()
     finally:
-        ops.set_tuning(triangle=1)
+        ops.set_tuning(triangle=1, fuse=1)
     inv_one = one.inv[0]
     del one
     world = LocalWorld(8, symmetric_shards=False)
@@ -308,6 +310,14 @@ def test_config4_pl32768_eight_shards_bitwise(ops):
     assert got.shape == want.shape
     assert np.array_equal(got, want)
     assert np.all(want[np.arange(len(rows)), rows] == 1.0)
+    # the single rank as the solver really runs it (one-launch leg 1 + upper-triangle leg 2): same values
+    # up to float32 summation order
+    fast = Solver(lambda r: ops, LocalWorld(1), [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
+    fast.reset()
+    for _ in range(3):
+        fast.step(0.0)
+    np.testing.assert_allclose(ops.download_rows(fast.cur[0][0], rows), want, rtol=RTOL, atol=1e-30)
+    fast.release()
     # the same with leg 2 in its half form (tiles i <= j + a second, half-size exchange of the mirrored
     # tiles; nodes dealt to the shards in tiles of 32): same values up to float32 summation order
     world = LocalWorld(8)
@@ -705,11 +715,11 @@ def test_dense_sets_shards_equal_one_shard_bit_for_bit():
     from simrank_amd.engine import HipOps
     df = _dense_corner_graph()
     knob = HipOps(0)
-    knob.set_tuning(triangle=0)
+    knob.set_tuning(triangle=0, fuse=0)
     try:
         one = SRA.SimRank().fit(df, iterations=4, eps=0, verbose=False, mode="sparse")
     finally:
-        knob.set_tuning(triangle=1)
+        knob.set_tuning(triangle=1, fuse=1)
     for world in (2, 4):
         many = SRA.SimRank().fit(df, iterations=4, eps=0, verbose=False, mode="sparse",
                                  world=LocalWorld(world, symmetric_shards=False))

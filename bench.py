@@ -8,17 +8,19 @@ A "step" is one loop body of the reference's ``fit`` (SimRank.py:138-140): both 
 S <- C.W.S.W^T with the fused diagonal/convergence epilogue, plus the read-back of the
 convergence count (the reference tests convergence every iteration, SimRank.py:130).
 Inputs (the CSR graph and S) are resident in HBM when the timed region starts.  Default
-workload = BASELINE.json configs[3]: synthetic power-law directed graph, N = 32768, average
-degree 32, fp32 (the configuration the metric is quoted on; it fits one GPU: 3 x 4 GiB).
+workload = BASELINE.json configs[3] as stated: synthetic power-law directed graph, N = 32768, average
+degree 32 AFTER de-duplication (pl32768d32: 1 048 576 distinct edges), fp32 — the configuration the
+metric is quoted on; it fits one GPU (3 x 4 GiB).  The lighter graph of rounds 1-2 (pl32768: the
+SURVEY.md recipe keeps 783 100 of its 1 048 576 draws) is reported beside it for continuity.
 With N > 1 ranks S is column-sharded and each update does one RCCL all-to-all (strong
 scaling: total work fixed).
 
 One JSON line is printed by rank 0.  ``roofline`` is for the dominant launch (the slower
-of the two legs; a leg = one simrank_spmm call = the dense-tile MFMA kernel for the dense
-blocks of the pattern + the gather kernel for the remainder), achieved = algorithmic bytes per
-launch / mean launch duration measured with HIP events on the engine's stream inside the timed
-region; ``parts_ms`` splits it into the two kernels, and ``roofline_mfma`` prices the
-dense-tile kernel against the bf16 MFMA peak.
+of the two legs; on one rank leg 1 is ONE kernel, fused_trans_kernel: the shared columns of
+every 128-row block on the matrix cores, the rest gathered, by the same workgroup), achieved =
+algorithmic bytes per launch / mean launch duration measured with HIP events on the engine's
+stream inside the timed region; ``roofline_mfma`` prices the matrix-core work of that launch
+against the bf16 MFMA peak (a lower bound: the whole launch time is charged to it).
 ``cpu_baseline`` (rank 0, N = 1 only) times the oracle's dense float64 update on a bounded
 row slab of the same workload and scales it to a full iteration.
 """
@@ -135,7 +137,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="pl32768")
+    ap.add_argument("--workload", default="pl32768d32")
     ap.add_argument("--mode", default="auto")
     ap.add_argument("--panel", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -299,10 +301,24 @@ def main():
         b2 = leg_bytes(side.M, side.K, side.Lm, nnz, leg2=True, has_evidence=args.pp, triangle=tri or half,
                        reads_previous=not short)
         b2_full = leg_bytes(side.M, side.K, side.Lm, nnz, leg2=True, has_evidence=args.pp, reads_previous=not short)
-        # the matrix-core part of leg 1 alone (same operand, same stream), outside the timed region
+        # the matrix-core part of leg 1
         nt, dk, cov = ops.dense_stats(side.graph)
         dense_ms = None
-        if dk and side.Lk:
+        fsteps, fcov, frem = ops.fused_stats(side.graph) if hasattr(ops, "fused_stats") else (0, 0, nnz)
+        fused = bool(getattr(solver, "blocked", False)) and fsteps > 0
+        if fused:
+            # one launch: 16-column steps x 128 rows x 32 columns x 3 bf16 terms per panel
+            flop = 2.0 * 3 * 128 * 16 * fsteps * side.Lk
+            tf = flop / (l1 * 1e-3) / 1e12
+            out["roofline_mfma"] = {
+                "kernel": "matrix-core phase of fused_trans_kernel (leg 1: 0/1 pattern bits x operand rows, bf16 hi+mid+lo)",
+                "bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                "frac": tf / MFMA_BF16_PEAK_TF, "ms": l1, "flop": flop, "steps_per_panel": fsteps,
+                "entries_covered": fcov, "entries_covered_frac": fcov / max(1, nnz),
+                "entries_gathered": frem,
+                "note": "lower bound: the launch also gathers the remainder and stores the tiles, and its whole "
+                        "duration is charged here; exact f32 products (three bf16 MFMAs per operand term)"}
+        elif dk and side.Lk:
             S_in = solver.cur[0][rank if use_dist else 0]
             for _ in range(2):
                 ops.dense_part(side.graph, S_in, side.Lk)
@@ -323,7 +339,9 @@ def main():
                 "note": "exact f32 products: three bf16 MFMAs per f32 operand term; the f32-equivalent "
                         "rate is a third of this"}
         rl = []
-        for name, ms, b in (("leg 1 = dense_tiles + spmm_gather (transposed store)", l1, b1),
+        leg1_name = ("leg 1 = fused_trans_kernel (dense sets on MFMA + gathered remainder, transposed store)" if fused
+                     else "leg 1 = dense_tiles + spmm_gather (transposed store)")
+        for name, ms, b in ((leg1_name, l1, b1),
                             ("leg 2 = spmm_gather (" + ("upper triangle" if tri else "half form" if half else
                                                         "full form") + ", fused epilogue)", l2, b2)):
             gbs = b / (ms * 1e-3) / 1e9
@@ -334,6 +352,10 @@ def main():
         if dense_ms is not None:
             rl[0]["parts_ms"] = {"dense_tiles": dense_ms, "spmm_gather": l1 - dense_ms}
             rl[0]["gathered_bytes"] = 4 * (nnz - cov) * side.Lk
+        if fused:
+            # segments pulled through the vector-memory path: one per gathered entry and one per (block, dense
+            # column) pair, per 32-column panel
+            rl[0]["gathered_bytes"] = 4 * (frem + 16 * fsteps) * side.Lk
             rl[0]["gather_kernel_alone"] = {"achieved": b1 / ((l1 - dense_ms) * 1e-3) / 1e9, "unit": "GB/s",
                                             "frac": b1 / ((l1 - dense_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
         # The second roofline of a gather leg: what the vector-memory path returns.  Every (entry, panel) pair
@@ -387,7 +409,9 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc) and "roofline" in out:
         try:
-            rec = json.load(open(pmc)).get(f"{args.workload}:{world_size}", {})
+            key = f"{args.workload}:{world_size}" + (":pp" if args.pp else "") + \
+                  (":fp16" if args.dense_precision == "fp16" else "")
+            rec = json.load(open(pmc)).get(key, {})
             for r in (out["roofline"], out.get("roofline_other", {})):
                 key = "leg1" if "leg 1" in r.get("kernel", "") else "leg2"
                 if key in rec:
@@ -403,11 +427,11 @@ def main():
         barrier()
         out["converge"] = {"eps": 1e-4, "iterations": k, "seconds": time.perf_counter() - t0}
 
-    if not args.no_extras and world_size == 1 and args.workload == "pl32768" and not args.pp:
-        # the same configuration with the stated mean degree AFTER de-duplication: 1 048 576 distinct
-        # edges (the SURVEY.md recipe behind the headline keeps 783 100 of its 1 048 576 draws)
+    if not args.no_extras and world_size == 1 and args.workload == "pl32768d32" and not args.pp:
+        # continuity with rounds 1-2: the lighter graph of the SURVEY.md recipe (783 100 of its 1 048 576
+        # draws survive de-duplication: mean degree 23.9)
         try:
-            dfd = synth.WORKLOADS["pl32768d32"][0]()
+            dfd = synth.WORKLOADS["pl32768"][0]()
             _, csrd = ingest.directed(dfd, False, "from", "to", "weight")
             sd = Solver(lambda r: ops, world, [make_spec(csrd, False)], args.mode)
             sd.exact_count = True
@@ -423,9 +447,10 @@ def main():
             dt = (time.perf_counter() - t0) / 10
             lt = sd.leg_times()
             ntd, dkd, covd = ops.dense_stats(next(iter(sd.sides[0].values())).graph)
-            out["headline_mean_degree_32"] = {
-                "workload": f"pl32768d32: synthetic directed graph N={csrd.n_rows} nnz={csrd.nnz} (mean degree "
-                            f"{csrd.nnz / csrd.n_rows:.1f} after de-duplication) SimRank C=0.8 fp32",
+            out["continuity_pl32768"] = {
+                "workload": f"pl32768: synthetic directed graph N={csrd.n_rows} nnz={csrd.nnz} (mean degree "
+                            f"{csrd.nnz / csrd.n_rows:.1f} after de-duplication; the headline of rounds 1-2) "
+                            f"SimRank C=0.8 fp32",
                 "value": 1.0 / dt, "unit": "iterations/s", "ms_per_step": dt * 1e3,
                 "leg1_ms": lt["leg1.0"][0], "leg2_ms": lt["leg2.0"][0],
                 "leg1_algorithmic_GBps": leg_bytes(csrd.n_rows, csrd.n_rows, csrd.n_rows, csrd.nnz, False)
@@ -434,7 +459,7 @@ def main():
             sd.release()
             del sd
         except Exception as e:
-            out["headline_mean_degree_32"] = {"error": f"{type(e).__name__}: {e}"}
+            out["continuity_pl32768"] = {"error": f"{type(e).__name__}: {e}"}
 
     if not args.no_extras and world_size == 1 and args.workload != "er8192":
         # BASELINE.json configs[1] (ER N=8192, p=0.001) next to the headline configuration
@@ -512,7 +537,7 @@ def main():
         except Exception as e:
             out["bipartite_pp"] = {"error": f"{type(e).__name__}: {e}"}
 
-    if not args.no_extras and world_size == 1 and args.workload == "pl32768" and not args.pp:
+    if not args.no_extras and world_size == 1 and args.workload == "pl32768d32" and not args.pp:
         # BASELINE.json configs[4]: N = 65536 SimRank++ with evidence weights, once with the exact
         # dense blocks (three bf16 terms) and once with its "fp16 MFMA dense leg" (one fp16 term);
         # the reduced-precision run is priced by its error against the exact one on sampled rows

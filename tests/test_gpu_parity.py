@@ -164,12 +164,16 @@ def _sampled_rows_check(ops, solver, csr, rows, coef):
     return S_n
 
 
-@pytest.mark.parametrize("workload,iters", [("er8192", 8), ("pl32768", 3)])
+@pytest.mark.parametrize("workload,iters", [("er8192", 8), ("pl32768", 3), ("pl32768d32", 3)])
 def test_full_size_properties(ops, workload, iters):
+    """BASELINE.json configs[1] and configs[3] at full size; pl32768d32 is config 4 as it is stated (mean
+    degree 32 after de-duplication: 1 048 576 edges), pl32768 the lighter graph of the SURVEY.md recipe."""
     df = synth.WORKLOADS[workload][0]()
     nodes, csr = ingest.directed(df, False, "from", "to", "weight")
     n = csr.n_rows
-    assert n == int(workload[2:])
+    assert n == int(workload[2:].replace("d32", ""))
+    if workload == "pl32768d32":
+        assert csr.nnz == 32 * 32768
     solver = Solver(lambda r: ops, LocalWorld(1), [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
     csr = solver.specs[0].csr       # the device buffers are in the solver's own node order
     assert np.all(np.diff(np.diff(csr.rowptr)) >= 0)            # ascending row length
@@ -280,11 +284,13 @@ def test_config5_pl65536_simrank_pp_properties(ops):
     solver.release()
 
 
-def test_config4_pl32768_eight_shards_bitwise(ops):
-    """BASELINE.json configs[3] in its stated form — S sharded 8 ways — at full size: eight
-    virtual ranks on the one GPU (all-to-all by device copies) against one rank without the
-    upper-triangle shortcut; sampled rows must carry the same bits."""
-    df = synth.WORKLOADS["pl32768"][0]()
+@pytest.mark.parametrize("workload", ["pl32768d32", "pl32768"])
+def test_config4_pl32768_eight_shards_bitwise(ops, workload):
+    """BASELINE.json configs[3] in its stated form — S sharded 8 ways — at full size (pl32768d32: mean
+    degree 32 after de-duplication; pl32768: the lighter graph of rounds 1-2): eight virtual ranks on the
+    one GPU (all-to-all by device copies) against one rank on the same kernels; sampled rows must carry
+    the same bits."""
+    df = synth.WORKLOADS[workload][0]()
     nodes, csr = ingest.directed(df, False, "from", "to", "weight")
     n = csr.n_rows
     rows = [0, 1, n // 3, n // 2 + 7, n - 129, n - 1]
@@ -401,7 +407,24 @@ def test_config3_movielens_shaped_bipartite_pp(ops):
         want = 0.8 * (W12 @ (W12[a] @ S2_1).T).ravel() * E1[a]
         want[a] = 1.0
         np.testing.assert_allclose(s1.values[a], want, rtol=RTOL, atol=1e-30)
+    # the Gauss-Seidel half (SimRank.py:300-302): S2 of iteration 2 is computed from the NEW S1 of iteration 2
+    S1_2 = 0.8 * (W12 @ (W12 @ S2_1).T) * E1          # (S2_1 symmetric: W12 S2 W12^T = W12 (W12 S2)^T)
+    np.fill_diagonal(S1_2, 1)
+    for b in [0, 5, 1800, 3705]:
+        want = 0.8 * (W21 @ (W21[b] @ S1_2).T).ravel() * E2[b]
+        want[b] = 1.0
+        np.testing.assert_allclose(s2.values[b], want, rtol=RTOL, atol=1e-30)
     assert est.engine_mode in ("sparse", "dense")
+    # a 1500 x 900 sub-sample of the same graph run to convergence against the oracle (both matrices, every
+    # element, the convergence iteration)
+    sub = df[(df["user"] < 1500) & (df["item"] < 900)]
+    est2 = SRA.BipartiteSimRankPP()
+    t1, t2 = est2.fit(sub, verbose=False, strict_reference=False)
+    want = O.fit_bipartite_pp(sub, verbose=False, strict_reference=False)
+    assert list(t1.index) == want["sorted1"]
+    assert_close(t1.values, want["S1"])
+    assert_close(t2.values, want["S2"])
+    assert est2.converged_at == want["k"]
 
 
 def test_integration_stub_of_the_reference_binding():

@@ -208,16 +208,14 @@ def main():
     n, nnz = csr.n_rows, csr.nnz
     coef = 0.8
 
-    def make_spec(c, pp):
+    def make_spec(c, pp, terms=3):
         if not pp:
-            return SideSpec(c, c.rowscale, coef)
-        return SideSpec(c, ingest.spread(c) * c.rowscale, coef, evidence_from=c)   # SimRank.py:322-337, :311-320
+            return SideSpec(c, c.rowscale, coef, dense_terms=terms)
+        return SideSpec(c, ingest.spread(c) * c.rowscale, coef, evidence_from=c,      # SimRank.py:322-337, :311-320
+                        dense_terms=terms)
 
-    if gpu and args.dense_precision == "fp16":
-        ops.set_tuning(dense_terms=1)
-    solver = Solver(lambda r: ops, world, [make_spec(csr, args.pp)], args.mode)
-    if gpu:
-        ops.set_tuning(dense_terms=3)
+    solver = Solver(lambda r: ops, world,
+                    [make_spec(csr, args.pp, 1 if args.dense_precision == "fp16" else 3)], args.mode)
     solver.reset()
 
     def barrier():
@@ -547,11 +545,9 @@ def main():
             rows5 = [0, 11, csr5.n_rows // 2, csr5.n_rows - 300, csr5.n_rows - 2, csr5.n_rows - 1]
             res5, sample = {}, {}
             for prec, terms in (("f32", 3), ("fp16", 1)):
-                ops.set_tuning(dense_terms=terms)
                 t0 = time.perf_counter()
-                s5 = Solver(lambda r: ops, world, [make_spec(csr5, True)], args.mode)
+                s5 = Solver(lambda r: ops, world, [make_spec(csr5, True, terms)], args.mode)
                 s5.exact_count = True
-                ops.set_tuning(dense_terms=3)
                 ops.synchronize()
                 setup_s = time.perf_counter() - t0
                 s5.reset()

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define SIMRANK_ABI_VERSION 2
+#define SIMRANK_ABI_VERSION 3
 #define SIMRANK_CHANGED_SLOTS 1024
 
 #if defined(__GNUC__)
@@ -96,6 +96,11 @@ SIMRANK_API int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz
                          const int32_t* col, const float* rowscale, simrank_graph** out);
 SIMRANK_API int simrank_graph_destroy(simrank_graph* g);
 SIMRANK_API int simrank_graph_shape(const simrank_graph* g, int64_t* n_rows, int64_t* n_cols, int64_t* nnz);
+/* Operand terms of the matrix-core part for THIS graph (3 = exact f32 products from three bf16 terms, the
+ * default; 1 = one fp16 term: BASELINE.json config 5's reduced-precision dense leg, outside the 1e-5 parity
+ * bar).  Per graph, so that two fits of one process can differ (the process-wide "dense_terms" knob is
+ * only the default a graph starts with).  With 1 the legs run as dense_tiles + gather launches. */
+SIMRANK_API int simrank_graph_set_dense_terms(simrank_graph* g, int32_t terms);
 
 /* ---- K0: S[:, block] <- columns [col0, col0+n_cols) of the identity
  *      (SimRank.py:124-126, :280-285, :346-348, :402-407) --------------------------- */
@@ -321,8 +326,16 @@ SIMRANK_API int simrank_dense_part(const simrank_graph* g, const float* X, int64
  *      "balance"  32-row tiles heavier than this many times the mean tile are cut in halves
  *                 (0 = uniform tiles; default 2)
  *      "dense_min" / "dense_cols"  selection of the block-dense part (see above); dense_min 0 = off
- *      "fuse" / "fuse_min"  leg 1 of a panel-blocked update as one launch (see above); fuse 0 = the
+ *      "fuse" / "fuse_min" / "fuse_steps"  leg 1 of a panel-blocked update as one launch (see above): a
+ *                 column joins a 128-row block's dense set when fuse_min (3) of its rows reference it, a
+ *                 block keeps its set when it makes fuse_steps (8) 16-column steps; fuse 0 = the
  *                 dense_tiles + gather launches of round 2
+ *      "fuse_group" up to this many (1..4) consecutive blocks without a set share a workgroup
+ *      "fuse_unit"  sets of more 64-column groups than this are cut into several workgroups whose
+ *                 partial sums meet in memory (off by default: 1 << 20)
+ *      "fuse_order" launch order of a panel's workgroups: 0 heaviest first, k: matrix-core units spread
+ *                 over the first 1/k of the order
+ *      "fuse_store" cache policy of the tile stores (0 plain, 1 nt, 2 sc1, 3 sc0 sc1); "fuse_meta_nt"
  *      "dense_terms" operand terms of the block-dense part: 3 = bf16 hi+mid+lo (exact f32
  *                 products, default), 1 = one fp16 term (reduced precision, BASELINE config 5)
  *      "ids16"    0/1  stream the neighbour ids as 16-bit values (graphs with <= 65536 columns)
@@ -330,7 +343,8 @@ SIMRANK_API int simrank_dense_part(const simrank_graph* g, const float* X, int64
  *                 the dense sets hold at least half of the entries
  *      "sym_desc" 0/1  upper-triangle leg 2: an XCD takes its panels in descending order (default 1)
  *      "addr32"   0/1  32-bit buffer addressing of the gather operand where it spans < 2 GiB (default 1)
- *      "probe_mask", "probe_flags"  DIAGNOSTIC ONLY (wrong results): price parts of the gather
+ *      "probe_mask", "probe_flags"  DIAGNOSTIC ONLY (wrong results; refused unless the environment
+ *                 variable SIMRANK_ENABLE_PROBES is set): price parts of the gather
  *                 kernel — ids ANDed with a mask; 1 no gathers, 2 no stores, 4 no dense partial
  *                 sums, 8 no id loads, 16 one XCD's share of the launch only ---- */
 SIMRANK_API int simrank_set_tuning(const char* key, int64_t value);

@@ -89,6 +89,7 @@ PROTOTYPES = {
     "simrank_gemm_nt": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64,
                         C.POINTER(Epilogue), _vp],
     "simrank_graph_dense_stats": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
+    "simrank_graph_set_dense_terms": [_vp, C.c_int32],
     "simrank_graph_fused_stats": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
     "simrank_dense_part": [_vp, _vp, _i64, _i64, _vp],
     "simrank_set_tuning": [C.c_char_p, _i64],
@@ -114,7 +115,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError = symbol missing from the .so
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
-    if lib.simrank_abi_version() != 2:
+    if lib.simrank_abi_version() != 3:
         raise ImportError("libsimrank_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -392,8 +392,8 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
     g->sym_blocks = (int32_t)(sym_map.size() / 2);
     auto up = [&](void** d, const void* h, size_t bytes) -> int {
         size_t alloc = std::max<size_t>(bytes, 16);
-        hipError_t e = hipMalloc(d, alloc);
-        if (e == hipSuccess && bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+        hipError_t e = plan_alloc(d, alloc);
+        if (e == hipSuccess && bytes) e = plan_upload(*d, h, bytes);
         if (e != hipSuccess) {
             set_error("graph upload: %s", hipGetErrorString(e));
             (void)hipGetLastError();
@@ -413,7 +413,7 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
     if (!rc && g->n_tiles) rc = up((void**)&g->tile_row0, tile_row0.data(), tile_row0.size() * 4);
     if (!rc && g->sym_blocks) rc = up((void**)&g->sym_map, sym_map.data(), sym_map.size() * 4);
     if (!rc && g->tun.dense_min > 0 && nnz > 0) rc = build_dense_plan(g, rowptr, col);
-    if (!rc && g->tun.fuse && nnz > 0) rc = build_fused_plan(g, rowptr, col);
+    if (!rc && g->tun.fuse && nnz > 0) rc = build_fused_plan(g, rowptr, col, rowscale);
     if (rc) {
         simrank_graph_destroy(g);
         return rc;
@@ -424,17 +424,24 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
 
 int simrank_graph_destroy(simrank_graph* g) {
     if (!g) return SIMRANK_OK;
-    (void)hipFree(g->rowptr);
-    (void)hipFree(g->col);
-    (void)hipFree(g->col16);
-    (void)hipFree(g->rowscale);
-    (void)hipFree(g->t_rowptr);
-    (void)hipFree(g->t_col);
-    (void)hipFree(g->tile_row0);
-    (void)hipFree(g->sym_map);
+    plan_free(g->rowptr);
+    plan_free(g->col);
+    plan_free(g->col16);
+    plan_free(g->rowscale);
+    plan_free(g->t_rowptr);
+    plan_free(g->t_col);
+    plan_free(g->tile_row0);
+    plan_free(g->sym_map);
     free_dense_plan(g->dense);
     free_fused_plan(g->fused);
     delete g;
+    return SIMRANK_OK;
+}
+
+int simrank_graph_set_dense_terms(simrank_graph* g, int32_t terms) {
+    SR_REQUIRE(g, "graph is NULL");
+    SR_REQUIRE(terms == 1 || terms == 3, "dense terms must be 3 (exact) or 1 (fp16 operand)");
+    g->tun.dense_terms = terms;
     return SIMRANK_OK;
 }
 
@@ -477,11 +484,15 @@ int simrank_set_tuning(const char* key, int64_t value) {
         SR_REQUIRE(value >= 0 && value <= 128, "dense_min must be 0 (off) .. 128");
         t.dense_min = value;
     } else if (!strcmp(key, "probe_mask")) {
+        SR_REQUIRE(value < 0 || getenv("SIMRANK_ENABLE_PROBES"),
+                   "probe knobs give WRONG results (measurement only): set SIMRANK_ENABLE_PROBES=1 to use them");
         t.probe_mask = value < 0 ? -1 : value;
     } else if (!strcmp(key, "dense_terms")) {
         SR_REQUIRE(value == 1 || value == 3, "dense_terms must be 3 (exact) or 1 (fp16 operand)");
         t.dense_terms = value;
     } else if (!strcmp(key, "probe_flags")) {
+        SR_REQUIRE(value == 0 || getenv("SIMRANK_ENABLE_PROBES"),
+                   "probe knobs give WRONG results (measurement only): set SIMRANK_ENABLE_PROBES=1 to use them");
         t.probe_flags = value & 63;
     } else if (!strcmp(key, "addr32")) {
         t.addr32 = value ? 1 : 0;

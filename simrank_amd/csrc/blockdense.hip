@@ -76,6 +76,7 @@ __device__ __forceinline__ uint32_t pack_f16(float x0, float x1) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
+#ifndef SIMRANK_HOST_ONLY          // (the sanitizer build of the host logic has no device code: common.h)
 // TERMS = 3: exact f32 products (operand = hi + mid + lo in bf16).  TERMS = 1: the operand rounded
 // to ONE fp16 term (11 significant bits; S lies in [0, 1], fp16 subnormals reach 6e-8), one MFMA
 // instead of three and no split arithmetic — BASELINE.json's "fp16 MFMA dense leg" (config 5).
@@ -203,20 +204,22 @@ __global__ __launch_bounds__(256, 2) void dense_tiles_kernel(const DenseArgs p) 
         }
 }
 
+#endif  // SIMRANK_HOST_ONLY
+
 template <typename T>
 static int upload(T** d, const std::vector<T>& h) {
     const size_t bytes = std::max<size_t>(16, h.size() * sizeof(T));
-    SR_HIP(hipMalloc((void**)d, bytes));
-    if (!h.empty()) SR_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    SR_HIP(plan_alloc((void**)d, bytes));
+    if (!h.empty()) SR_HIP(plan_upload(*d, h.data(), h.size() * sizeof(T)));
     return SIMRANK_OK;
 }
 
 void free_dense_plan(simrank_dense_plan* p) {
     if (!p) return;
-    (void)hipFree(p->unit_row0); (void)hipFree(p->unit_slab); (void)hipFree(p->unit_kofs);
-    (void)hipFree(p->dcols); (void)hipFree(p->afrag); (void)hipFree(p->block_slab0);
-    (void)hipFree(p->block_nslab); (void)hipFree(p->r_rowptr);
-    (void)hipFree(p->r_col); (void)hipFree(p->r_col16); (void)hipFree(p->r_tile_row0); (void)hipFree(p->r_sym_map);
+    plan_free(p->unit_row0); plan_free(p->unit_slab); plan_free(p->unit_kofs);
+    plan_free(p->dcols); plan_free(p->afrag); plan_free(p->block_slab0);
+    plan_free(p->block_nslab); plan_free(p->r_rowptr);
+    plan_free(p->r_col); plan_free(p->r_col16); plan_free(p->r_tile_row0); plan_free(p->r_sym_map);
     (void)hipFree(p->part);
     delete p;
 }
@@ -388,10 +391,14 @@ int launch_dense_tiles(const simrank_graph* g, const float* X, int64_t ldx, int6
     a.tri = tri ? 1 : 0;
     const int64_t grid = int64_t((a.n_cblocks + 7) / 8) * 8 * a.n_units;
     SR_REQUIRE(grid > 0 && grid < (int64_t(1) << 31), "grid of %lld blocks", (long long)grid);
+#ifdef SIMRANK_HOST_ONLY
+    SR_REQUIRE(false, "host-only build: no kernels");
+#else
     if (g->tun.dense_terms == 1)
         hipLaunchKernelGGL(dense_tiles_kernel<1>, dim3((unsigned)grid), dim3((unsigned)a.wg_cols), 0, st, a);
     else
         hipLaunchKernelGGL(dense_tiles_kernel<3>, dim3((unsigned)grid), dim3((unsigned)a.wg_cols), 0, st, a);
+#endif
     SR_HIP(hipGetLastError());
     use->part = pl->part;
     use->ldp = ldp;

@@ -5,6 +5,8 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "simrank_hip.h"
@@ -72,6 +74,25 @@ struct Tuning {
 };
 Tuning& tuning();            // the process-wide defaults: simrank_set_tuning writes them, simrank_graph_create
 Tuning tuning_snapshot();    // copies them (under a lock) into the graph it builds; launches read the copy
+
+// The arrays of a graph object (CSR, plans): allocated, filled once and freed through these.  A sanitizer
+// build of the HOST logic (make asan: -DSIMRANK_HOST_ONLY, host side only, no GPU needed) keeps them in
+// host memory, so simrank_graph_create — validation, transposition, tiling, dense and fused plans —
+// runs under AddressSanitizer / UBSan and tools/host_fuzz.cpp can check the plans it built.
+#ifdef SIMRANK_HOST_ONLY
+inline hipError_t plan_alloc(void** p, size_t bytes) {
+    *p = malloc(bytes ? bytes : 1);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+inline hipError_t plan_upload(void* d, const void* h, size_t bytes) { memcpy(d, h, bytes); return hipSuccess; }
+inline hipError_t plan_download(void* h, const void* d, size_t bytes) { memcpy(h, d, bytes); return hipSuccess; }
+inline void plan_free(void* p) { free(p); }
+#else
+inline hipError_t plan_alloc(void** p, size_t bytes) { return hipMalloc(p, bytes); }
+inline hipError_t plan_upload(void* d, const void* h, size_t bytes) { return hipMemcpy(d, h, bytes, hipMemcpyHostToDevice); }
+inline hipError_t plan_download(void* h, const void* d, size_t bytes) { return hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost); }
+inline void plan_free(void* p) { (void)hipFree(p); }
+#endif
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -147,7 +168,7 @@ struct simrank_fused_plan {
 
 namespace simrank {
 void free_fused_plan(simrank_fused_plan* p);
-int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col);
+int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col, const float* rowscale);
 int launch_fused_trans(const simrank_graph* g, const float* X, int64_t x_rows_pad, int64_t L, float* Y,
                        int64_t y_rows_pad, hipStream_t st);
 struct DenseUse {                   // what the gather kernel needs from a dense launch

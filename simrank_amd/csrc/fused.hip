@@ -77,6 +77,7 @@ struct FusedArgs {
     const int32_t* sids32;    // the same in 32 bits (-1: no neighbour)
 };
 
+#ifndef SIMRANK_HOST_ONLY          // (the sanitizer build of the host logic has no device code: common.h)
 __device__ __forceinline__ void split3f(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
     const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
     hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
@@ -482,19 +483,21 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
     }
 }
 
+#endif  // SIMRANK_HOST_ONLY
+
 template <typename T>
 static int upload_vec(T** d, const std::vector<T>& h) {
     const size_t bytes = std::max<size_t>(16, h.size() * sizeof(T));
-    SR_HIP(hipMalloc((void**)d, bytes));
-    if (!h.empty()) SR_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    SR_HIP(plan_alloc((void**)d, bytes));
+    if (!h.empty()) SR_HIP(plan_upload(*d, h.data(), h.size() * sizeof(T)));
     return SIMRANK_OK;
 }
 
 void free_fused_plan(simrank_fused_plan* p) {
     if (!p) return;
-    (void)hipFree(p->units); (void)hipFree(p->partials); (void)hipFree(p->tickets);
-    (void)hipFree(p->dcols16); (void)hipFree(p->dcols32); (void)hipFree(p->abits);
-    (void)hipFree(p->gmeta); (void)hipFree(p->sids16); (void)hipFree(p->sids32);
+    plan_free(p->units); (void)hipFree(p->partials); (void)hipFree(p->tickets);
+    plan_free(p->dcols16); plan_free(p->dcols32); plan_free(p->abits);
+    plan_free(p->gmeta); plan_free(p->sids16); plan_free(p->sids32);
     delete p;
 }
 
@@ -509,7 +512,7 @@ void free_fused_plan(simrank_fused_plan* p) {
 //    room); a group's stream is its rows' remainder ids one after the other (rows without a remainder
 //    last), a wave's stream is 64 ids per round: lane group g, slot q = id 8 r + q of the group's stream
 //    (past its end: a marker).
-int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col) {
+int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col, const float* rowscale) {
     const int64_t M = g->n_rows, K = g->n_cols;
     const int64_t thr = std::max<int64_t>(2, g->tun.fuse_min);
     const int64_t min_steps = std::max<int64_t>(0, g->tun.fuse_steps);
@@ -526,8 +529,6 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
     std::vector<int64_t> cost(size_t(nblk), 0);
     std::vector<int32_t> rem[kFB];
     int64_t covered = 0, steps_total = 0, r_nnz = 0;
-    std::vector<float> rowscale((size_t)M, 0.f);
-    SR_HIP(hipMemcpy(rowscale.data(), g->rowscale, size_t(M) * sizeof(float), hipMemcpyDeviceToHost));
     for (int64_t b = 0; b < nblk; ++b) {
         const int64_t lo = b * kFB, hi = std::min<int64_t>(M, lo + kFB);
         touched.clear();
@@ -787,10 +788,14 @@ int launch_fused_trans(const simrank_graph* g, const float* X, int64_t x_rows_pa
     a.gmeta = pl->gmeta; a.sids16 = pl->sids16; a.sids32 = pl->sids32;
     const int64_t grid = int64_t((a.n_panels + 7) / 8) * 8 * a.n_units;
     SR_REQUIRE(grid > 0 && grid < (int64_t(1) << 31), "grid of %lld blocks", (long long)grid);
+#ifdef SIMRANK_HOST_ONLY
+    SR_REQUIRE(false, "host-only build: no kernels");
+#else
     if (pl->ids16)
         hipLaunchKernelGGL(fused_trans_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL(fused_trans_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, a);
+#endif
     SR_HIP(hipGetLastError());
     return SIMRANK_OK;
 }

@@ -104,6 +104,17 @@ def staged_row_order(k_dim: int, world: int, n_stages: int) -> np.ndarray:
     return perm
 
 
+def lean_knobs(ops) -> bool:
+    """The panel-blocked layout and the half-form sharded leg 2 exist for the lean gather kernel only
+    (32-column panels, 32-row tiles): with the measurement knobs set otherwise (tools/sweep.py --panel 64,
+    set_tuning(lean=0) ...) the solver falls back to row-major operands / the full form instead of
+    asking the library for a combination it refuses."""
+    get = getattr(ops, "get_tuning", None)
+    if get is None:
+        return True
+    return get("lean") == 1 and get("panel") in (0, 32) and get("tile") in (0, 32)
+
+
 def permute_columns(csr: CSR, perm: np.ndarray) -> CSR:
     """The same pattern with column j renamed perm[j] (columns re-sorted inside each row)."""
     rows = np.repeat(np.arange(csr.n_rows, dtype=np.int64), np.diff(csr.rowptr))
@@ -351,6 +362,7 @@ class SideSpec:
     apriori: np.ndarray | None = None  # M x M prior
     lbd: float = 0.0
     symmetric: bool = True       # False: a non-symmetric prior makes the iterates asymmetric
+    dense_terms: int = 3         # operand terms of the matrix-core part (3 exact; 1 = one fp16 term, config 5)
 
 
 class Side:
@@ -367,7 +379,7 @@ class Side:
         self.k_lo, self.k_hi = partition(self.K, world, rank)
         self.Lm, self.Lk = self.m_hi - self.m_lo, self.k_hi - self.k_lo
         self.mb = -(-self.M // world)
-        self.graph = ops.graph(csr, spec.rowscale)
+        self.graph = ops.graph(csr, spec.rowscale, dense_terms=spec.dense_terms)
         self.symmetric = spec.symmetric
         self.x1 = self.x2 = None
         self.broadcast_error = None
@@ -395,7 +407,8 @@ class Side:
         # the ranks that own them in a second, half-size all-to-all.  Needs equal shards of whole tiles.
         self.shard_sym = (mode == "sparse" and (world > 1 or shard_symmetric == "force") and
                           self.symmetric and bool(shard_symmetric) and
-                          self.M % (32 * world) == 0 and getattr(ops, "supports_shard_symmetric", False))
+                          self.M % (32 * world) == 0 and getattr(ops, "supports_shard_symmetric", False) and
+                          lean_knobs(ops))
         if self.shard_sym:
             t = self.mb // 32
             self.sh_chunk = max(1, t * (t - 1) // 2 * 1024)
@@ -482,7 +495,8 @@ class Side:
             recv_off += sum(out_splits)
             col0 += mine[s]
         perm = staged_row_order(self.K, P, S)
-        self.graph2 = self.ops.graph(permute_columns(self.spec.csr, perm), self.spec.rowscale)
+        self.graph2 = self.ops.graph(permute_columns(self.spec.csr, perm), self.spec.rowscale,
+                                     dense_terms=self.spec.dense_terms)
 
     # S_in: K x Lk block of the input similarity
     def leg1(self, S_in, stage_hook=None):
@@ -646,7 +660,7 @@ class Solver:
         # one 128-byte segment every 128 KiB, which is what the gathers need at N >= 16384 (TLB reach;
         # DESIGN.md §4.9).  Sharded ranks hold N x N/P blocks whose rows are close together already.
         self.blocked = (world.size == 1 and not torch_buffers and self.mode == "sparse" and
-                        all(getattr(o, "supports_blocked", False) for o in self.ops.values()))
+                        all(getattr(o, "supports_blocked", False) and lean_knobs(o) for o in self.ops.values()))
         self.sides = [{r: Side(self.ops[r], sp, r, world.size, self.mode, torch_buffers,
                                getattr(world, "stages", 1), self.blocked,
                                getattr(world, "symmetric_shards", True))

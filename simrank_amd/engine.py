@@ -7,6 +7,8 @@ no algorithm.  It fails loudly when the library or the GPU is missing.
 from __future__ import annotations
 
 import ctypes as C
+import os
+import threading
 
 import numpy as np
 
@@ -112,17 +114,63 @@ class HipOps:
             self.stream = s
         else:
             self.stream = C.c_void_p(stream)
+        self._sizes = {}              # pooled-size blocks this object handed out: ptr -> bytes
         self._counter = self._malloc(8 * CHANGED_SLOTS)
         self.pitch_pad = 32
 
     # ---- memory ----
+    # hipMalloc maps a 17 GiB matrix in 0.4-0.5 s (profiles/r03_setup.log: 1.6-2.0 s of a config-5 solver
+    # set-up, against 0.12 s for its four iterations), so large blocks are kept when a solver lets go of
+    # them and handed to the next request of the same size: the second fit of a process, every fit after a
+    # release(), bench.py's second configuration.  Per device, at most POOL_LIMIT bytes at rest; trim_pool()
+    # returns them to the driver.
+    POOL_MIN = 64 << 20
+    POOL_LIMIT = int(os.environ.get("SIMRANK_POOL_GIB", "96")) << 30
+    _pool: dict = {}                  # device -> {nbytes: [ptr, ...]}
+    _pool_bytes: dict = {}
+    _pool_lock = threading.Lock()
+
     def _malloc(self, nbytes: int) -> int:
+        nbytes = max(16, int(nbytes))
+        if nbytes >= self.POOL_MIN:
+            with self._pool_lock:
+                free = self._pool.get(self.device, {}).get(nbytes)
+                if free:
+                    self._pool_bytes[self.device] -= nbytes
+                    ptr = free.pop()
+                    self._sizes[ptr] = nbytes
+                    return ptr
         p = C.c_void_p()
-        check(self.lib.simrank_malloc(C.byref(p), max(16, int(nbytes))), "simrank_malloc")
+        check(self.lib.simrank_malloc(C.byref(p), nbytes), "simrank_malloc")
+        if nbytes >= self.POOL_MIN:
+            self._sizes[p.value] = nbytes
         return p.value
 
     def _free(self, ptr: int):
+        nbytes = self._sizes.pop(ptr, 0)
+        if nbytes:
+            # work queued on this stream may still use the block; whoever gets it next may be on another
+            self.lib.simrank_stream_synchronize(self.stream)
+            with self._pool_lock:
+                if self._pool_bytes.get(self.device, 0) + nbytes <= self.POOL_LIMIT:
+                    self._pool.setdefault(self.device, {}).setdefault(nbytes, []).append(ptr)
+                    self._pool_bytes[self.device] = self._pool_bytes.get(self.device, 0) + nbytes
+                    return
         self.lib.simrank_free(C.c_void_p(ptr))
+
+    @classmethod
+    def trim_pool(cls, device: int | None = None):
+        """Give the cached device blocks back to the driver (all devices, or one)."""
+        lib = _lib.load()
+        with cls._pool_lock:
+            for dev in list(cls._pool) if device is None else [device]:
+                blocks = cls._pool.pop(dev, {})
+                cls._pool_bytes[dev] = 0
+                if any(blocks.values()):
+                    lib.simrank_set_device(dev)
+                    for ptrs in blocks.values():
+                        for ptr in ptrs:
+                            lib.simrank_free(C.c_void_p(ptr))
 
     def pitch(self, cols: int, dtype) -> int:
         unit = 16 // np.dtype(dtype).itemsize          # 16-byte rows for the vector kernels
@@ -273,8 +321,12 @@ class HipOps:
         torch.cuda.current_stream(self.device).synchronize()
 
     # ---- graph + kernels ----
-    def graph(self, csr: CSR, rowscale=None) -> Graph:
-        return Graph(self, csr, rowscale)
+    def graph(self, csr: CSR, rowscale=None, dense_terms: int = 3) -> Graph:
+        """``dense_terms``: operand terms of the matrix-core part for this graph (3 exact, 1 = one fp16 term)."""
+        g = Graph(self, csr, rowscale)
+        if dense_terms != 3:
+            check(self.lib.simrank_graph_set_dense_terms(g.handle, int(dense_terms)), "simrank_graph_set_dense_terms")
+        return g
 
     def fill_identity(self, S: Matrix, col0: int):
         if S.rows and S.cols and S.blocked:
@@ -453,6 +505,11 @@ class HipOps:
             self.close()
         except Exception:
             pass
+
+    def get_tuning(self, key: str) -> int:
+        v = C.c_int64(0)
+        check(self.lib.simrank_get_tuning(key.encode(), C.byref(v)), f"get_tuning({key})")
+        return v.value
 
     def set_tuning(self, **kw):
         for k, v in kw.items():

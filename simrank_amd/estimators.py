@@ -27,6 +27,8 @@ from __future__ import annotations
 
 import contextlib
 import os
+import dataclasses
+import threading
 import time
 
 import numpy as np
@@ -38,7 +40,7 @@ from .progress import announce_converged, update_progress
 
 
 _DENSE_TERMS = {"f32": 3, "fp16": 1}
-_precision_now = ["f32"]
+_precision_now = threading.local()          # per thread: two threads may fit at different precisions
 
 
 @contextlib.contextmanager
@@ -48,26 +50,22 @@ def _precision(dense_precision):
     config 5's reduced-precision dense leg: faster, NOT within the 1e-5 parity bar."""
     if dense_precision not in _DENSE_TERMS:
         raise ValueError(f"dense_precision must be one of {sorted(_DENSE_TERMS)}, not {dense_precision!r}")
-    _precision_now.append(dense_precision)
+    stack = _precision_now.__dict__.setdefault("stack", ["f32"])
+    stack.append(dense_precision)
     try:
         yield
     finally:
-        _precision_now.pop()
+        stack.pop()
 
 
 def _make_solver(ops_factory, device, world, specs, mode):
-    """The solver with the graphs created under the precision asked for (the knobs are copied
-    into a graph when it is created, csrc/common.h)."""
+    """The solver with the graphs created at the precision asked for: it travels in the specs and is set
+    per graph object (simrank_graph_set_dense_terms), not through the process-wide tuning defaults."""
     factory = ops_factory or _default_ops_factory(device)
-    terms = _DENSE_TERMS[_precision_now[-1]]
-    if terms == 3:
-        return Solver(factory, world, specs, mode)
-    knob = factory(world.local_ranks[0])
-    knob.set_tuning(dense_terms=terms)
-    try:
-        return Solver(factory, world, specs, mode)
-    finally:
-        knob.set_tuning(dense_terms=3)
+    terms = _DENSE_TERMS[_precision_now.__dict__.get("stack", ["f32"])[-1]]
+    if terms != 3:
+        specs = [dataclasses.replace(s, dense_terms=terms) for s in specs]
+    return Solver(factory, world, specs, mode)
 
 
 def _default_ops_factory(device):

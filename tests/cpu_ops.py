@@ -119,7 +119,7 @@ class NumpyOps:
     def collective_done(self):
         pass
 
-    def graph(self, csr, rowscale=None):
+    def graph(self, csr, rowscale=None, dense_terms=3):
         return NpGraph(csr, rowscale)
 
     def fill_identity(self, S, col0):

@@ -31,11 +31,31 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_string():
     lib = _lib.load()
-    assert lib.simrank_abi_version() == 2
+    assert lib.simrank_abi_version() == 3
     rc = lib.simrank_set_tuning(b"no_such_knob", 1)
     assert rc == -1 and b"no_such_knob" in lib.simrank_last_error()
     assert lib.simrank_set_tuning(b"panel", 48) == -1
     assert lib.simrank_set_tuning(b"panel", 0) == 0
+    # the diagnostic knobs (wrong results on purpose) are refused in an ordinary process
+    import os
+    if "SIMRANK_ENABLE_PROBES" not in os.environ:
+        assert lib.simrank_set_tuning(b"probe_flags", 1) == -1 and b"SIMRANK_ENABLE_PROBES" in lib.simrank_last_error()
+        assert lib.simrank_set_tuning(b"probe_mask", 255) == -1
+    assert lib.simrank_set_tuning(b"probe_flags", 0) == 0 and lib.simrank_set_tuning(b"probe_mask", -1) == 0
+    v = ctypes.c_int64(-7)
+    assert lib.simrank_get_tuning(b"fuse_min", ctypes.byref(v)) == 0 and v.value == 3
+    assert lib.simrank_graph_set_dense_terms(None, 3) == -1
+
+
+def test_host_logic_under_the_sanitizers():
+    """make asan: the host side of the library (graph validation, transposed pattern, tiles, dense sets, the
+    one-launch plan) compiled for the host only with AddressSanitizer + UBSan and run over random graphs by
+    tools/host/host_fuzz.cpp, which also checks every plan entry by entry against the CSR.  No GPU needed."""
+    import os
+    csrc = os.path.join(os.path.dirname(os.path.abspath(_lib.LIB_PATH)), "csrc")
+    out = subprocess.run(["make", "-C", csrc, "asan"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "graphs passed" in out.stdout
 
 
 def test_argument_checks_need_no_device():
@@ -71,7 +91,7 @@ int main(void) {
     simrank_epilogue ep;
     memset(&ep, 0, sizeof ep);
     ep.coef = 0.8f;
-    if (simrank_abi_version() != 2) return 1;
+    if (simrank_abi_version() != 3) return 1;
     if (simrank_graph_create(0, 4, 0, NULL, NULL, NULL, &g) != SIMRANK_ERR_INVALID) return 2;
     if (simrank_spmm_shard(NULL, NULL, 0, NULL, 0, &ep, 0, 2, NULL, 0, NULL) != SIMRANK_ERR_INVALID) return 3;
     if (simrank_shard_unpack(NULL, 0, NULL, 0, 0, 2, 64, NULL) != SIMRANK_ERR_INVALID) return 4;
@@ -87,4 +107,4 @@ int main(void) {
                         capture_output=True, text=True)
     assert cc.returncode == 0, cc.stderr
     run = subprocess.run([str(exe)], capture_output=True, text=True)
-    assert run.returncode == 0 and "abi 2 ok" in run.stdout, (run.returncode, run.stdout, run.stderr)
+    assert run.returncode == 0 and "abi 3 ok" in run.stdout, (run.returncode, run.stdout, run.stderr)

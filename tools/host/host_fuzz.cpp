@@ -1,0 +1,216 @@
+// Sanitizer run of the HOST side of libsimrank_hip (make -C simrank_amd/csrc asan): the library's
+// api.hip / blockdense.hip / fused.hip compiled for the host only with -DSIMRANK_HOST_ONLY
+// -fsanitize=address,undefined, so that simrank_graph_create — argument validation, transposed pattern,
+// balanced tiles and launch lists, dense sets (blockdense.hip), the one-launch plan (fused.hip) — runs on
+// random graphs without a GPU, and the plans it builds are checked entry by entry against the CSR:
+//   * tiles: consecutive, never across a multiple of 32, every row once; launch order a permutation;
+//   * dense plan: covered + remainder = nnz, remainder rows ascending and a subset of the row;
+//   * fused plan: every entry of every block is EITHER a pattern bit of the block's dense set OR an id in
+//     exactly one lane group's stream (in ascending order inside its row), row ends and scales as recorded.
+// Exit code 0 = all graphs passed.  No kernel is launched.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <random>
+#include <set>
+#include <vector>
+
+#include "common.h"
+
+#define CHECK(c, ...)                                         \
+    do {                                                      \
+        if (!(c)) {                                           \
+            fprintf(stderr, "FAILED %s:%d: ", __FILE__, __LINE__); \
+            fprintf(stderr, __VA_ARGS__);                     \
+            fprintf(stderr, "\n");                            \
+            exit(1);                                          \
+        }                                                     \
+    } while (0)
+
+struct Csr {
+    int64_t M, K;
+    std::vector<int32_t> rowptr, col;
+    std::vector<float> scale;
+};
+
+static Csr random_graph(std::mt19937& rng, int64_t M, int64_t K, double avg, int hubs, double p_hub, bool sorted_rows) {
+    Csr g{M, K, {0}, {}, {}};
+    std::vector<std::set<int32_t>> rows((size_t)M);
+    std::poisson_distribution<int> deg(avg);
+    std::uniform_int_distribution<int32_t> any(0, (int32_t)K - 1);
+    std::uniform_real_distribution<double> u(0, 1);
+    for (int64_t a = 0; a < M; ++a) {
+        if (u(rng) < 0.08) continue;                          // empty row
+        const int d = std::min<int64_t>(K, deg(rng));
+        while ((int)rows[a].size() < d) rows[a].insert(any(rng));
+        if (a >= M / 2)
+            for (int h = 0; h < std::min<int64_t>(hubs, K); ++h)
+                if (u(rng) < p_hub * double(a) / double(M)) rows[a].insert(h);
+    }
+    if (M > 3 && u(rng) < 0.3)                                // one very long row
+        for (int32_t c = 0; c < K; c += 1 + int(u(rng) * 3)) rows[M / 3].insert(c);
+    if (sorted_rows) std::stable_sort(rows.begin(), rows.end(), [](auto& x, auto& y) { return x.size() < y.size(); });
+    for (int64_t a = 0; a < M; ++a) {
+        for (int32_t c : rows[a]) g.col.push_back(c);
+        g.rowptr.push_back((int32_t)g.col.size());
+        g.scale.push_back(u(rng) < 0.05 ? 0.f : float(0.1 + u(rng)));
+    }
+    return g;
+}
+
+static void check_tiles(const simrank_graph* g, const Csr& c) {
+    if (!g->n_tiles) return;
+    const int32_t* t = g->tile_row0;
+    CHECK(t[0] == 0 && t[g->n_tiles] == c.M, "tiles do not span the rows");
+    for (int i = 0; i < g->n_tiles; ++i) {
+        CHECK(t[i + 1] > t[i] && t[i + 1] - t[i] <= 32, "tile %d has %d rows", i, t[i + 1] - t[i]);
+        CHECK((t[i] >> 5) == ((t[i + 1] - 1) >> 5), "tile %d crosses a multiple of 32", i);
+    }
+    const int groups = (g->n_tiles + 3) / 4;
+    std::vector<int> seen((size_t)groups, 0);
+    for (int i = 0; i < groups; ++i) {
+        const int gi = t[g->n_tiles + 1 + i];
+        CHECK(gi >= 0 && gi < groups && !seen[(size_t)gi]++, "launch order is not a permutation");
+    }
+    for (int i = 0; i < g->sym_blocks; ++i) {
+        const int p = g->sym_map[2 * i], w = g->sym_map[2 * i + 1];
+        CHECK(p == -1 || (p >= 0 && p < (c.M + 31) / 32 && w >= 0 && w < groups), "bad triangle launch entry");
+    }
+}
+
+static void check_dense(const simrank_graph* g, const Csr& c) {
+    const simrank_dense_plan* pl = g->dense;
+    if (!pl) return;
+    CHECK(pl->nnz_covered + pl->r_nnz == (int64_t)c.col.size(), "dense plan loses entries");
+    for (int64_t a = 0; a < c.M; ++a) {
+        const int32_t* r = pl->r_col + pl->r_rowptr[a];
+        const int n = pl->r_rowptr[a + 1] - pl->r_rowptr[a];
+        CHECK(n >= 0 && n <= c.rowptr[a + 1] - c.rowptr[a], "remainder row longer than the row");
+        for (int j = 0; j < n; ++j) {
+            CHECK(j == 0 || r[j] > r[j - 1], "remainder row not ascending");
+            CHECK(std::binary_search(c.col.begin() + c.rowptr[a], c.col.begin() + c.rowptr[a + 1], r[j]),
+                  "remainder entry not in the row");
+        }
+    }
+}
+
+static void check_fused(const simrank_graph* g, const Csr& c) {
+    const simrank_fused_plan* pl = g->fused;
+    if (!pl) return;
+    const int64_t nblk = (c.M + 127) / 128;
+    CHECK(pl->nnz_covered + pl->r_nnz == (int64_t)c.col.size(), "fused plan loses entries");
+    std::vector<std::multiset<int32_t>> got((size_t)c.M);
+    std::vector<int> seen_block((size_t)nblk, 0);
+    const uint32_t* ab = reinterpret_cast<const uint32_t*>(pl->abits);
+    const int32_t* gm = reinterpret_cast<const int32_t*>(pl->gmeta);
+    std::map<int, int> units_of, quads_of;
+    for (int u = 0; u < pl->n_units; ++u) {
+        const int32_t* un = pl->units + size_t(u) * 32;
+        const int b0 = un[0], q0 = un[1], nq = un[2], k = un[3], nb = un[4], nsub = un[8];
+        CHECK(b0 >= 0 && b0 + nsub <= nblk && nsub >= 1 && nsub <= 4 && k >= 0 && k < nb, "bad unit record");
+        CHECK((nq > 0) == (un[7] != 0) && (nsub == 1 || nq == 0), "unit kinds mixed up");
+        CHECK((nb > 1) == (un[5] >= 0) && (nb > 1) == (un[6] >= 0), "partial slots");
+        units_of[b0] += 1;
+        // dense part: pattern bits -> entries
+        for (int qd = q0; qd < q0 + nq; ++qd)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int s = 0; s < 4; ++s) {
+                    const uint32_t w = ab[(size_t(qd) * 64 + lane) * 4 + s];
+                    for (int bit = 0; bit < 32; ++bit)
+                        if (w >> bit & 1) {
+                            const int t = bit >> 3, j = bit & 7, h = lane >> 5, m = lane & 31;
+                            const int row = b0 * 128 + 32 * t + m, kk = 16 * s + 8 * h + j;
+                            CHECK(row < c.M, "pattern bit past the last row");
+                            const int32_t id = pl->ids16 ? (int32_t)pl->dcols16[size_t(qd) * 64 + kk]
+                                                         : pl->dcols32[size_t(qd) * 64 + kk];
+                            got[(size_t)row].insert(id);
+                        }
+                }
+        if (k != nb - 1) continue;                            // the gather streams belong to the whole block: once
+        for (int sb = 0; sb < nsub; ++sb) {
+            const int b = b0 + sb;
+            CHECK(!seen_block[(size_t)b]++, "block %d gathered twice", b);
+            for (int w = 0; w < 4; ++w) {
+                const int32_t* wm = un + 9 + w * 5;
+                const int r_lo = sb ? wm[sb] : 0, r_hi = wm[1 + sb];
+                CHECK(r_hi >= r_lo, "round counts not monotone");
+                for (int gg = 0; gg < 8; ++gg) {
+                    const int32_t* m = gm + ((((size_t(u) * 4 + sb) * 4 + w) * 8) + gg) * 16;
+                    int f = 0;
+                    bool empty_seen = false;
+                    for (int kr = 0; kr < 4; ++kr) {
+                        const int row = m[4 * kr], end = m[4 * kr + 2];
+                        if (row < 0) continue;
+                        CHECK(row < 128 && b * 128 + row < c.M, "row of a lane group out of range");
+                        float sc;
+                        memcpy(&sc, &m[4 * kr + 1], 4);
+                        CHECK(sc == c.scale[size_t(b) * 128 + row], "row scale");
+                        if (end < 0) { empty_seen = true; continue; }
+                        CHECK(!empty_seen && end > f, "rows without a remainder must come last");
+                        int32_t prev = -1;
+                        for (; f < end; ++f) {
+                            CHECK(f / 8 < r_hi - r_lo, "row runs past the wave's rounds");
+                            const size_t at = (size_t(wm[0]) + r_lo + f / 8) * 64 + gg * 8 + f % 8;
+                            const int32_t id = pl->ids16 ? (pl->sids16[at] == 0xFFFF ? -1 : (int32_t)pl->sids16[at])
+                                                         : pl->sids32[at];
+                            CHECK(id > prev, "stream ids of a row not ascending (or a marker inside a row)");
+                            prev = id;
+                            got[size_t(b) * 128 + row].insert(id);
+                        }
+                    }
+                    for (; f < 8 * (r_hi - r_lo); ++f) {      // past the lane group's stream: markers only
+                        const size_t at = (size_t(wm[0]) + r_lo + f / 8) * 64 + gg * 8 + f % 8;
+                        CHECK(pl->ids16 ? pl->sids16[at] == 0xFFFF : pl->sids32[at] < 0, "id past the end of a stream");
+                    }
+                }
+            }
+        }
+    }
+    for (int64_t b = 0; b < nblk; ++b) CHECK(seen_block[(size_t)b] == 1, "block %lld not gathered", (long long)b);
+    for (int64_t a = 0; a < c.M; ++a) {
+        std::multiset<int32_t> want(c.col.begin() + c.rowptr[a], c.col.begin() + c.rowptr[a + 1]);
+        CHECK(got[(size_t)a] == want, "row %lld: plan entries differ from the CSR (%zu vs %zu)", (long long)a,
+              got[(size_t)a].size(), want.size());
+    }
+}
+
+int main(int argc, char** argv) {
+    const int n_graphs = argc > 1 ? atoi(argv[1]) : 60;
+    std::mt19937 rng(12345);
+    std::uniform_real_distribution<double> u(0, 1);
+    for (int it = 0; it < n_graphs; ++it) {
+        const int64_t M = 1 + int64_t(u(rng) * (it % 7 == 0 ? 3000 : 700));
+        const int64_t K = it % 3 == 0 ? M : 1 + int64_t(u(rng) * (it % 11 == 0 ? 70000 : 900));
+        simrank_set_tuning("balance", it % 5 == 0 ? 0 : 1 + it % 4);
+        simrank_set_tuning("dense_min", 2 + it % 4);
+        simrank_set_tuning("dense_cols", it % 2 ? 16 : 64);
+        simrank_set_tuning("fuse_min", 2 + it % 3);
+        simrank_set_tuning("fuse_steps", (it % 4) * 3);
+        simrank_set_tuning("fuse_unit", it % 3 == 0 ? 4 : 1 << 20);
+        simrank_set_tuning("fuse_group", 1 + it % 4);
+        simrank_set_tuning("fuse_order", it % 5 == 1 ? 2 : 0);
+        Csr c = random_graph(rng, M, K, 1 + u(rng) * 12, int(u(rng) * 200), u(rng), it % 2 == 0);
+        simrank_graph* g = nullptr;
+        const int rc = simrank_graph_create(c.M, c.K, (int64_t)c.col.size(), c.rowptr.data(), c.col.data(),
+                                            c.scale.data(), &g);
+        CHECK(rc == SIMRANK_OK && g, "simrank_graph_create: %s", simrank_last_error());
+        check_tiles(g, c);
+        check_dense(g, c);
+        check_fused(g, c);
+        int64_t steps = 0, cov = 0, rem = 0;
+        simrank_graph_fused_stats(g, &steps, &cov, &rem);
+        CHECK(cov + rem == (int64_t)c.col.size(), "fused stats");
+        simrank_graph_destroy(g);
+        // malformed input must be refused, not read out of bounds
+        if (c.col.size() > 2) {
+            std::vector<int32_t> bad = c.col;
+            bad[bad.size() / 2] = (int32_t)c.K;               // out of range
+            CHECK(simrank_graph_create(c.M, c.K, (int64_t)bad.size(), c.rowptr.data(), bad.data(), c.scale.data(), &g)
+                      == SIMRANK_ERR_INVALID && !g, "out-of-range column accepted");
+        }
+    }
+    printf("host_fuzz: %d graphs passed\n", n_graphs);
+    return 0;
+}

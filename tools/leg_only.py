@@ -18,6 +18,8 @@ ap.add_argument("--workload", default="pl32768")
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--set", default="")
 args = ap.parse_args()
+if "probe" in args.set:
+    os.environ["SIMRANK_ENABLE_PROBES"] = "1"       # diagnostic knobs (wrong results, timing only)
 ops = HipOps(0)
 if args.set:
     ops.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.set.split(","))})

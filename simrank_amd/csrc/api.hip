@@ -371,7 +371,9 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
                        col[j], (long long)a);
             SR_REQUIRE(j == rowptr[a] || col[j] > col[j - 1],
                        "columns of row %lld not strictly ascending", (long long)a);
-            t_rowptr[size_t(col[j]) + 1]++;
+            // (the transposed pattern serves the evidence counts, which ignore rows without weight:
+            // `G > 0` in SimRank.py:315 — it lists live rows only)
+            if (rowscale[a] > 0.f) t_rowptr[size_t(col[j]) + 1]++;
         }
     }
     for (int64_t i = 0; i < n_cols; ++i) t_rowptr[i + 1] += t_rowptr[i];
@@ -379,7 +381,8 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
     {
         std::vector<int32_t> cur(t_rowptr.begin(), t_rowptr.end() - 1);
         for (int64_t a = 0; a < n_rows; ++a)
-            for (int32_t j = rowptr[a]; j < rowptr[a + 1]; ++j) t_col[cur[col[j]]++] = (int32_t)a;
+            if (rowscale[a] > 0.f)
+                for (int32_t j = rowptr[a]; j < rowptr[a + 1]; ++j) t_col[cur[col[j]]++] = (int32_t)a;
     }
     simrank_graph* g = new simrank_graph;
     g->tun = tuning_snapshot();

@@ -1517,37 +1517,66 @@ __global__ __launch_bounds__(256) void permute_kernel(const T* __restrict__ src,
 // K7: evidence counts.  One workgroup per row a: LDS counters for a chunk of columns,
 // incremented along every 2-hop path a <- i -> b; saturated to u8 on the way out.
 // ---------------------------------------------------------------------------------------
-constexpr int kEvChunk = 16384;  // columns per pass: 64 KiB of LDS counters
+// Round 3: one workgroup of 16 waves per row, ALL columns of the block in one pass — two 16-bit counters
+// per LDS word, 65536 columns = 128 KiB (counters saturate far above the 255 that is stored).
+// Round 2 walked every path once per 16384-column pass (4 x at N = 65536) with 4 waves per workgroup and a
+// rowscale load per path; the transposed pattern now lists live rows only (simrank_graph_create).
+constexpr int kEvChunk = 65536;  // columns per pass
+constexpr int kEvThreads = 1024;
 
-__global__ __launch_bounds__(256) void evidence_counts_kernel(
+__global__ __launch_bounds__(kEvThreads) void evidence_counts_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ rowscale, const int32_t* __restrict__ t_rowptr,
     const int32_t* __restrict__ t_col, int64_t M, int64_t col0, int n_cols, uint8_t* out,
-    int64_t ld, int64_t rows_pad, int64_t out_col0) {
-    extern __shared__ unsigned cnt[];
+    int64_t ld, int64_t rows_pad, int64_t out_col0, int vec4) {
+    extern __shared__ unsigned cnt[];                 // counters of columns 2 w and 2 w + 1 in word w
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    for (int c = tid; c < n_cols; c += 256) cnt[c] = 0;
+    const int words = (n_cols + 1) >> 1;
     for (int64_t a = blockIdx.x; a < M; a += gridDim.x) {
+        for (int w = tid; w < words; w += kEvThreads) cnt[w] = 0;
         __syncthreads();
         if (rowscale[a] > 0.f) {
             const int s = rowptr[a], e = rowptr[a + 1];
-            for (int j = s + wave; j < e; j += kWaves) {
+            for (int j = s + wave; j < e; j += kEvThreads / 64) {
                 const int i = col[j];
                 const int ts = t_rowptr[i], te = t_rowptr[i + 1];
                 for (int t = ts + lane; t < te; t += 64) {
-                    const int64_t b = t_col[t];
-                    const int64_t c = b - col0;
-                    if (c >= 0 && c < n_cols && rowscale[b] > 0.f) atomicAdd(&cnt[c], 1u);
+                    const int64_t c = int64_t(t_col[t]) - col0;
+                    if (c >= 0 && c < n_cols) {
+                        // a counter stops growing at 0x4000 (only min(count, 255) is stored); the threads that
+                        // read it just below can overshoot by at most one each (1024): never a carry into
+                        // the neighbouring counter
+                        const unsigned sh = (unsigned(c) & 1u) * 16u;
+                        unsigned* wp = &cnt[c >> 1];
+                        if (((*(volatile unsigned*)wp >> sh) & 0xFFFFu) < 0x4000u) atomicAdd(wp, 1u << sh);
+                    }
                 }
             }
         }
         __syncthreads();
-        for (int c = tid; c < n_cols; c += 256) {
-            out[elem_at(a, out_col0 + c, ld, rows_pad)] = (uint8_t)min(cnt[c], 255u);
-            cnt[c] = 0;
+        if (vec4) {
+            // four columns per thread: two words -> four saturated bytes, one 4-byte store (a panel of the
+            // blocked layout and an aligned row-major row both keep 4 consecutive columns together)
+            for (int c4 = tid * 4; c4 < n_cols; c4 += kEvThreads * 4) {
+                const unsigned w0 = cnt[c4 >> 1], w1 = (c4 + 2 < n_cols) ? cnt[(c4 >> 1) + 1] : 0u;
+                const unsigned b0 = min(w0 & 0xFFFFu, 255u), b1 = min(w0 >> 16, 255u);
+                const unsigned b2 = min(w1 & 0xFFFFu, 255u), b3 = min(w1 >> 16, 255u);
+                uint8_t* dst = out + elem_at(a, out_col0 + c4, ld, rows_pad);
+                if (c4 + 4 <= n_cols) {
+                    *reinterpret_cast<unsigned*>(dst) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+                } else {
+                    dst[0] = (uint8_t)b0;
+                    if (c4 + 1 < n_cols) dst[1] = (uint8_t)b1;
+                    if (c4 + 2 < n_cols) dst[2] = (uint8_t)b2;
+                }
+            }
+        } else {
+            for (int c = tid; c < n_cols; c += kEvThreads)
+                out[elem_at(a, out_col0 + c, ld, rows_pad)] = (uint8_t)min((cnt[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu, 255u);
         }
+        __syncthreads();
     }
 }
 
@@ -2018,12 +2047,19 @@ static int evidence_counts_impl(const simrank_graph* g, int64_t col0, int64_t n_
                    (rows_pad ? rows_pad >= g->n_rows : ld >= n_cols),
                "evidence block [%lld, %lld) of %lld, ld %lld", (long long)col0,
                (long long)(col0 + n_cols), (long long)g->n_rows, (long long)ld);
-    const int grid = (int)std::min<int64_t>(g->n_rows, 256 * 2);
+    const int grid = (int)std::min<int64_t>(g->n_rows, 256 * 4);
+    // 4-byte stores need the block's first column, the pass boundaries (multiples of 65536) and the row
+    // pitch to be multiples of 4 (the blocked layout: always, out_col0 being a multiple of 4)
+    const int vec4 = (reinterpret_cast<uintptr_t>(counts) % 4 == 0) && (rows_pad ? true : ld % 4 == 0);
     for (int64_t c = 0; c < n_cols; c += kEvChunk) {
         const int nc = (int)std::min<int64_t>(kEvChunk, n_cols - c);
-        hipLaunchKernelGGL(evidence_counts_kernel, dim3(grid), dim3(256), size_t(nc) * 4,
+        const size_t lds = size_t((nc + 1) / 2) * 4;
+        if (lds > 64 * 1024)
+            SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(evidence_counts_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(evidence_counts_kernel, dim3(grid), dim3(kEvThreads), lds,
                            as_stream(stream), g->rowptr, g->col, g->rowscale, g->t_rowptr,
-                           g->t_col, g->n_rows, col0 + c, nc, counts, ld, rows_pad, c);
+                           g->t_col, g->n_rows, col0 + c, nc, counts, ld, rows_pad, c, vec4);
         SR_HIP(hipGetLastError());
     }
     return SIMRANK_OK;

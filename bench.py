@@ -485,6 +485,21 @@ def main():
                 "leg1_algorithmic_GBps": leg_bytes(n2, n2, n2, z2, False) / (lt["leg1.0"][0] * 1e-3) / 1e9,
                 "leg2_algorithmic_GBps": leg_bytes(n2, n2, n2, z2, True, triangle=True)
                                          / (lt["leg2.0"][0] * 1e-3) / 1e9}
+            try:
+                # the same loop behind the C ABI (simrank_plan_run: update k + 1 queued before the count of
+                # update k is read, no Python between the launches)
+                from simrank_amd.engine import Plan
+                plan = Plan(ops, csr2, coef=coef)
+                plan.run(5, 0.0)
+                ops.synchronize()
+                t0 = time.perf_counter()
+                plan.run(100, 0.0)
+                dtp = (time.perf_counter() - t0) / 100
+                out["secondary"]["c_plan"] = {"value": 1.0 / dtp, "unit": "iterations/s", "ms_per_step": dtp * 1e3,
+                                              "note": "simrank_plan_run, 100 updates, eps = 0 (count read every update)"}
+                plan.free()
+            except Exception as e:
+                out["secondary"]["c_plan"] = {"error": f"{type(e).__name__}: {e}"}
             if rank == 0 and not args.no_cpu_baseline:
                 # the oracle on the whole N=8192 workload (no sampling needed at this size)
                 from oracle import simrank_oracle as O

@@ -311,6 +311,40 @@ SIMRANK_API int simrank_graph_fused_stats(const simrank_graph* g, int64_t* n_ste
 SIMRANK_API int simrank_dense_part(const simrank_graph* g, const float* X, int64_t ldx,
                                    int64_t n_cols_x, void* stream);
 
+/* ---- PLAN: the loop of SimRank.fit / SimRankPP.fit / AprioriSimRank.fit on one GPU behind five calls
+ *      (SimRank.py:124-141, :346-363, :440-455; SURVEY.md §8b create_plan / step / download).
+ *      simrank_plan_create takes the normalised adjacency as CSR + per-row scale in the CALLER's node
+ *      order (row = target node, SimRank.py:45-52), re-orders the nodes for speed (ascending in-degree)
+ *      when options.reorder is set, builds the graph object, the three panel-blocked matrices of an
+ *      update, the evidence counts of SimRank++ (options.evidence) and the prior (options.apriori: HOST
+ *      n x n row-major, must be symmetric).  simrank_plan_run is the reference loop: at most
+ *      `iterations` updates, stopping at loop index k when no element moved by more than eps
+ *      (converged_at = k, exactly the "Converged at iteration k" of SimRank.py:132; -1 when the loop ran
+ *      out); update k + 1 is queued before the count of update k is read.  simrank_plan_step is one
+ *      update with its count; simrank_plan_result(_f64) hands S back in the caller's node order
+ *      (device row-major f32 / host f64: SimRank.py:141).  One plan per host thread; all work goes to the
+ *      stream given at creation. */
+typedef struct simrank_plan simrank_plan;
+typedef struct simrank_plan_options {
+    float coef;                 /* C */
+    float lbd;                  /* prior blend (used when apriori != NULL) */
+    const float* apriori;       /* HOST n x n row-major symmetric prior, or NULL */
+    int64_t ld_apriori;
+    int32_t evidence;           /* 1: SimRank++ evidence factor 1 - 2^-|common in-neighbours| */
+    int32_t reorder;            /* 1: iterate in ascending-row-length node order (recommended) */
+} simrank_plan_options;
+SIMRANK_API int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                                    const float* rowscale, const simrank_plan_options* options, void* stream,
+                                    simrank_plan** out);
+SIMRANK_API int simrank_plan_reset(simrank_plan* p);
+SIMRANK_API int simrank_plan_step(simrank_plan* p, double eps, int32_t exact_count, int64_t* n_changed);
+SIMRANK_API int simrank_plan_run(simrank_plan* p, int32_t iterations, double eps, int32_t* updates_done,
+                                 int32_t* converged_at);
+SIMRANK_API int simrank_plan_result(simrank_plan* p, float* dst, int64_t ld);
+SIMRANK_API int simrank_plan_result_f64(simrank_plan* p, double* dst, int64_t ld);
+SIMRANK_API int simrank_plan_info(const simrank_plan* p, int64_t* n, int32_t* updates, const simrank_graph** graph);
+SIMRANK_API int simrank_plan_destroy(simrank_plan* p);
+
 /* ---- tuning knobs (measurement harness; defaults are the tuned values).  simrank_set_tuning
  *      changes the process-wide DEFAULTS; simrank_graph_create copies them into the graph it
  *      builds (under a lock), and every launch on that graph uses its copy — a knob set later does

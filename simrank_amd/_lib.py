@@ -92,6 +92,14 @@ PROTOTYPES = {
     "simrank_graph_set_dense_terms": [_vp, C.c_int32],
     "simrank_graph_fused_stats": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
     "simrank_dense_part": [_vp, _vp, _i64, _i64, _vp],
+    "simrank_plan_create": [_i64, _i64, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)],
+    "simrank_plan_reset": [_vp],
+    "simrank_plan_step": [_vp, C.c_double, C.c_int32, C.POINTER(_i64)],
+    "simrank_plan_run": [_vp, C.c_int32, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    "simrank_plan_result": [_vp, _vp, _i64],
+    "simrank_plan_result_f64": [_vp, _vp, _i64],
+    "simrank_plan_info": [_vp, C.POINTER(_i64), C.POINTER(C.c_int32), C.POINTER(_vp)],
+    "simrank_plan_destroy": [_vp],
     "simrank_set_tuning": [C.c_char_p, _i64],
     "simrank_get_tuning": [C.c_char_p, C.POINTER(_i64)],
 }

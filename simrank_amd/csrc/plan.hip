@@ -1,0 +1,294 @@
+// The loop of SimRank.fit behind the C ABI (create_plan / step / download): a PLAN owns
+// everything one single-GPU fit needs — the graph in the solver's node order, the three panel-blocked
+// matrices of an update, evidence counts, prior, the striped convergence counters — and runs
+//
+//     for k in range(iterations):                 SimRank.py:129-140 (:351-362, :443-454 with evidence / prior)
+//         if converged(old, new): break
+//         new = E * C * W.S.W^T (+ lbd A); diag <- 1
+//
+// as two launches per update (leg 1: fused_trans_kernel, leg 2: upper-triangle gather with the fused
+// epilogue and count), with update k + 1 queued BEFORE the count of update k is read: the host never
+// leaves the device idle to learn whether it may go on, and when the count says "converged" the
+// speculative update is simply not adopted (it wrote the buffer of the iterate before last).
+// Python's driver.Solver does the same choreography for every world size; this is the single-rank case
+// for callers that bind the library directly (examples/reference_hip_stub.py).
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "common.h"
+
+struct simrank_plan {
+    int64_t n = 0, rows_pad = 0;
+    size_t mat_bytes = 0;
+    simrank_graph* g = nullptr;
+    float* S[2] = {nullptr, nullptr};         // ping-pong iterates, panel-blocked
+    float* Tt = nullptr;                      // (W.S)^T
+    uint8_t* ev = nullptr;                    // evidence counts (SimRank++), panel-blocked u8
+    float* prior = nullptr;                   // panel-blocked, solver order
+    int32_t* inv = nullptr;                   // device: position of caller's node i in the solver's order
+    unsigned long long* counters = nullptr;   // device, SIMRANK_CHANGED_SLOTS
+    unsigned long long* host_counters[2] = {nullptr, nullptr};   // pinned; update u lands in slot u & 1
+    hipEvent_t counted[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr;
+    float coef = 0.8f, lbd = 0.f;
+    int32_t restrict_support = 0;
+    int cur = 0;                              // S[cur] is the current iterate
+    int32_t updates = 0;                      // updates applied since the last reset
+};
+
+namespace simrank {
+
+static int leg_pair(simrank_plan* p, double eps, int32_t exact_count, int slot) {
+    const int nx = p->cur ^ 1;
+    int rc = simrank_spmm_blocked(p->g, p->S[p->cur], p->rows_pad, p->n, p->Tt, p->rows_pad, 1, nullptr, p->stream);
+    if (rc) return rc;
+    simrank_epilogue ep{};
+    ep.coef = p->coef;
+    ep.lbd = p->lbd;
+    ep.evidence = p->ev;
+    ep.ld_evidence = 32;
+    ep.apriori = p->prior;
+    ep.ld_apriori = 32;
+    ep.previous = p->S[p->cur];
+    ep.ld_previous = 32;
+    ep.eps = eps;
+    ep.n_changed = p->counters;
+    ep.diag_col0 = 0;
+    ep.set_diag = 1;
+    ep.symmetric = 1;
+    ep.restrict_support = p->restrict_support;
+    ep.count_any = exact_count ? 0 : 1;
+    rc = simrank_spmm_blocked(p->g, p->Tt, p->rows_pad, p->n, p->S[nx], p->rows_pad, 0, &ep, p->stream);
+    if (rc) return rc;
+    SR_HIP(hipMemcpyAsync(p->host_counters[slot], p->counters, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS,
+                          hipMemcpyDeviceToHost, p->stream));
+    SR_HIP(hipEventRecord(p->counted[slot], p->stream));
+    return SIMRANK_OK;
+}
+
+// the count of the update that used `slot`: waits for that update only, not for what was queued behind it
+static int read_count(simrank_plan* p, int slot, unsigned long long* sum) {
+    SR_HIP(hipEventSynchronize(p->counted[slot]));
+    unsigned long long t = 0;
+    for (int i = 0; i < SIMRANK_CHANGED_SLOTS; ++i) t += p->host_counters[slot][i];
+    *sum = t;
+    return SIMRANK_OK;
+}
+
+}  // namespace simrank
+
+using namespace simrank;
+
+extern "C" {
+
+int simrank_plan_destroy(simrank_plan* p) {
+    if (!p) return SIMRANK_OK;
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    (void)hipFree(p->S[0]); (void)hipFree(p->S[1]); (void)hipFree(p->Tt); (void)hipFree(p->ev);
+    (void)hipFree(p->prior); (void)hipFree(p->inv); (void)hipFree(p->counters);
+    for (int i = 0; i < 2; ++i) {
+        if (p->host_counters[i]) (void)hipHostFree(p->host_counters[i]);
+        if (p->counted[i]) (void)hipEventDestroy(p->counted[i]);
+    }
+    simrank_graph_destroy(p->g);
+    delete p;
+    return SIMRANK_OK;
+}
+
+int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* rowscale,
+                        const simrank_plan_options* opt, void* stream, simrank_plan** out) {
+    SR_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    SR_REQUIRE(opt && rowptr && rowscale && (col || nnz == 0) && n > 0 && nnz >= 0, "bad plan arguments");
+    SR_REQUIRE(n < (int64_t(1) << 24) - 16, "a plan holds at most 2^24 nodes");
+    SR_REQUIRE(rowptr[0] == 0 && rowptr[n] == nnz, "rowptr does not span [0, nnz]");
+    for (int64_t a = 0; a < n; ++a) SR_REQUIRE(rowptr[a + 1] >= rowptr[a], "rowptr not monotone at row %lld", (long long)a);
+    for (int64_t j = 0; j < nnz; ++j) SR_REQUIRE(col[j] >= 0 && col[j] < n, "column index %d out of range", col[j]);
+    if (opt->apriori) {
+        SR_REQUIRE(opt->ld_apriori >= n, "prior: ld %lld < n", (long long)opt->ld_apriori);
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t j = i + 1; j < n; ++j)
+                SR_REQUIRE(opt->apriori[i * opt->ld_apriori + j] == opt->apriori[j * opt->ld_apriori + i],
+                           "a plan needs a symmetric prior (element %lld, %lld)", (long long)i, (long long)j);
+    }
+    // node order of the solver: ascending row length; ord[new] = old, inv[old] = new
+    std::vector<int32_t> ord((size_t)n), inv((size_t)n);
+    std::iota(ord.begin(), ord.end(), 0);
+    if (opt->reorder)
+        std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) {
+            return rowptr[x + 1] - rowptr[x] < rowptr[y + 1] - rowptr[y];
+        });
+    for (int64_t r = 0; r < n; ++r) inv[(size_t)ord[(size_t)r]] = (int32_t)r;
+    std::vector<int32_t> rp((size_t)n + 1, 0), cl((size_t)std::max<int64_t>(1, nnz));
+    std::vector<float> rs((size_t)n);
+    for (int64_t r = 0; r < n; ++r) {
+        const int32_t a = ord[(size_t)r];
+        const int32_t s = rowptr[a], e = rowptr[a + 1];
+        int32_t* dst = cl.data() + rp[(size_t)r];
+        for (int32_t j = s; j < e; ++j) dst[j - s] = inv[(size_t)col[j]];
+        std::sort(dst, dst + (e - s));
+        for (int32_t j = 1; j < e - s; ++j) SR_REQUIRE(dst[j] != dst[j - 1], "duplicate entry in row %d", a);
+        rp[(size_t)r + 1] = rp[(size_t)r] + (e - s);
+        rs[(size_t)r] = rowscale[a];
+    }
+    simrank_plan* p = new simrank_plan;
+    p->n = n;
+    p->stream = as_stream(stream);
+    p->coef = opt->coef;
+    p->lbd = opt->lbd;
+    p->rows_pad = (n + 7) / 8 * 8 + 8;
+    const int64_t panels = (n + 31) / 32;
+    p->mat_bytes = size_t(panels) * size_t(p->rows_pad) * 32 * sizeof(float);
+    int rc = simrank_graph_create(n, n, nnz, rp.data(), cl.data(), rs.data(), &p->g);
+    auto fail = [&](int code) { simrank_plan_destroy(p); return code; };
+    if (rc) return fail(rc);
+#define PLAN_HIP(call)                                                                            \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (void)hipGetLastError();                                                              \
+            return fail(e_ == hipErrorOutOfMemory ? SIMRANK_ERR_ALLOC : SIMRANK_ERR_HIP);         \
+        }                                                                                         \
+    } while (0)
+    for (float** b : {&p->S[0], &p->S[1], &p->Tt}) {
+        PLAN_HIP(hipMalloc((void**)b, p->mat_bytes));
+        PLAN_HIP(hipMemsetAsync(*b, 0, p->mat_bytes, p->stream));
+    }
+    PLAN_HIP(hipMalloc((void**)&p->counters, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS));
+    for (int i = 0; i < 2; ++i) {
+        PLAN_HIP(hipHostMalloc((void**)&p->host_counters[i], sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS, hipHostMallocPortable));
+        PLAN_HIP(hipEventCreateWithFlags(&p->counted[i], hipEventDisableTiming));
+    }
+    PLAN_HIP(hipMalloc((void**)&p->inv, size_t(n) * sizeof(int32_t)));
+    PLAN_HIP(hipMemcpyAsync(p->inv, inv.data(), size_t(n) * sizeof(int32_t), hipMemcpyHostToDevice, p->stream));
+    PLAN_HIP(hipStreamSynchronize(p->stream));          // (inv is a host vector about to go away)
+    if (opt->evidence) {
+        // common in-neighbour counts of the pattern (SimRank.py:311-320), 1 - 2^-count in the epilogue
+        const size_t ev_bytes = size_t(panels) * size_t(p->rows_pad) * 32;
+        PLAN_HIP(hipMalloc((void**)&p->ev, ev_bytes));
+        PLAN_HIP(hipMemsetAsync(p->ev, 0, ev_bytes, p->stream));
+        rc = simrank_evidence_counts_blocked(p->g, 0, n, p->ev, p->rows_pad, p->stream);
+        if (rc) return fail(rc);
+        int64_t live = 0, total = 1;
+        rc = simrank_evidence_live_segments(p->ev, 32, p->rows_pad, n, n, &live, &total, p->stream);
+        if (rc) return fail(rc);
+        p->restrict_support = 2 * live < total ? 1 : 0;
+    }
+    if (opt->apriori) {
+        // host n x n (caller's order) -> device row-major -> panel-blocked in the solver's order
+        float* tmp = nullptr;
+        int32_t* ord_dev = nullptr;
+        PLAN_HIP(hipMalloc((void**)&tmp, size_t(n) * size_t(n) * sizeof(float)));
+        hipError_t e = hipMalloc((void**)&ord_dev, size_t(n) * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&p->prior, p->mat_bytes);
+        if (e == hipSuccess) e = hipMemsetAsync(p->prior, 0, p->mat_bytes, p->stream);
+        if (e == hipSuccess) e = hipMemcpy2DAsync(tmp, size_t(n) * 4, opt->apriori, size_t(opt->ld_apriori) * 4, size_t(n) * 4,
+                                                  size_t(n), hipMemcpyHostToDevice, p->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ord_dev, ord.data(), size_t(n) * 4, hipMemcpyHostToDevice, p->stream);
+        if (e == hipSuccess) {
+            // dst[i][j] = src[ord[i]][ord[j]]
+            rc = simrank_permute_layout(tmp, n, 0, p->prior, 32, p->rows_pad, n, n, ord_dev, ord_dev, 4, p->stream);
+            e = hipStreamSynchronize(p->stream);
+        }
+        (void)hipFree(tmp);
+        (void)hipFree(ord_dev);
+        if (e != hipSuccess) {
+            set_error("plan prior upload: %s", hipGetErrorString(e));
+            return fail(SIMRANK_ERR_HIP);
+        }
+        if (rc) return fail(rc);
+    }
+#undef PLAN_HIP
+    rc = simrank_plan_reset(p);
+    if (rc) return fail(rc);
+    *out = p;
+    return SIMRANK_OK;
+}
+
+int simrank_plan_reset(simrank_plan* p) {
+    SR_REQUIRE(p, "plan is NULL");
+    p->cur = 0;
+    p->updates = 0;
+    return simrank_fill_identity_blocked(p->S[0], p->n, p->n, p->rows_pad, 0, p->stream);
+}
+
+int simrank_plan_step(simrank_plan* p, double eps, int32_t exact_count, int64_t* n_changed) {
+    SR_REQUIRE(p, "plan is NULL");
+    const int rc = leg_pair(p, eps, exact_count, 0);
+    if (rc) return rc;
+    p->cur ^= 1;
+    ++p->updates;
+    if (n_changed) {
+        unsigned long long c = 0;
+        const int rc2 = read_count(p, 0, &c);
+        if (rc2) return rc2;
+        *n_changed = (int64_t)c;
+    }
+    return SIMRANK_OK;
+}
+
+int simrank_plan_run(simrank_plan* p, int32_t iterations, double eps, int32_t* updates_done, int32_t* converged_at) {
+    SR_REQUIRE(p, "plan is NULL");
+    SR_REQUIRE(iterations >= 0, "iterations < 0");
+    int rc = simrank_plan_reset(p);
+    if (rc) return rc;
+    int32_t conv = -1, done = 0;
+    if (iterations > 0 && !(1.0 > eps)) {
+        conv = 0;           // loop index 0 compares S_0 = I with the zero matrix: "converged" unless 1 > eps
+    } else if (iterations > 0) {
+        rc = leg_pair(p, eps, 0, 1);                 // update 1: reads S[cur], writes S[cur ^ 1]
+        if (rc) return rc;
+        for (int32_t k = 1;; ++k) {
+            // updates 1 .. k are queued, 1 .. k - 1 adopted; the count of update k is on its way
+            p->cur ^= 1;                             // S[cur] = result of update k
+            done = k;
+            if (k == iterations) break;              // the reference makes no test after its last update
+            // loop index k tests the count of update k and, if it may go on, runs update k + 1 — which is
+            // queued NOW, before the count is known (it reads S[cur], writes the buffer of the iterate before)
+            rc = leg_pair(p, eps, 0, (k + 1) & 1);
+            if (rc) return rc;
+            unsigned long long c = 0;
+            rc = read_count(p, k & 1, &c);           // waits for update k only
+            if (rc) return rc;
+            if (c == 0) {                            // converged at loop index k: k updates applied; the
+                conv = k;                            // speculative one is not adopted
+                break;
+            }
+        }
+    }
+    SR_HIP(hipStreamSynchronize(p->stream));
+    p->updates = done;
+    if (updates_done) *updates_done = done;
+    if (converged_at) *converged_at = conv;
+    return SIMRANK_OK;
+}
+
+int simrank_plan_result(simrank_plan* p, float* dst, int64_t ld) {
+    SR_REQUIRE(p && dst && ld >= p->n, "bad result arguments");
+    // dst[i][j] = S[inv[i]][inv[j]]: out of the panel-blocked layout and the solver's node order in one pass
+    return simrank_permute_layout(p->S[p->cur], 32, p->rows_pad, dst, ld, 0, p->n, p->n, p->inv, p->inv, 4, p->stream);
+}
+
+int simrank_plan_result_f64(simrank_plan* p, double* dst, int64_t ld) {
+    SR_REQUIRE(p && dst && ld >= p->n, "bad result arguments");
+    float* tmp = nullptr;
+    const int64_t ldt = (p->n + 3) / 4 * 4;
+    SR_HIP(hipMalloc((void**)&tmp, size_t(p->n) * size_t(ldt) * sizeof(float)));
+    int rc = simrank_plan_result(p, tmp, ldt);
+    if (!rc) rc = simrank_download_f64(dst, ld, tmp, ldt, p->n, p->n, p->stream);
+    (void)hipStreamSynchronize(p->stream);
+    (void)hipFree(tmp);
+    return rc;
+}
+
+int simrank_plan_info(const simrank_plan* p, int64_t* n, int32_t* updates, const simrank_graph** graph) {
+    SR_REQUIRE(p, "plan is NULL");
+    if (n) *n = p->n;
+    if (updates) *updates = p->updates;
+    if (graph) *graph = p->g;
+    return SIMRANK_OK;
+}
+
+}  // extern "C"

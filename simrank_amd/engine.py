@@ -89,6 +89,62 @@ class Graph:
             pass
 
 
+class PlanOptions(C.Structure):                # struct simrank_plan_options
+    _fields_ = [("coef", C.c_float), ("lbd", C.c_float), ("apriori", C.c_void_p), ("ld_apriori", C.c_int64),
+                ("evidence", C.c_int32), ("reorder", C.c_int32)]
+
+
+class Plan:
+    """The reference loop on one GPU behind the C ABI (simrank_plan_*: SimRank.py:124-141, :346-363,
+    :440-455): CSR + per-row scale in the caller's node order in, S (float64, caller's order) out."""
+
+    def __init__(self, ops, csr: CSR, rowscale=None, coef: float = 0.8, evidence: bool = False,
+                 apriori=None, lbd: float = 0.0, reorder: bool = True):
+        self.ops = ops
+        rs = np.ascontiguousarray(csr.rowscale if rowscale is None else rowscale, dtype=np.float32)
+        rowptr = np.ascontiguousarray(csr.rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(csr.col, dtype=np.int32)
+        ap = None if apriori is None else np.ascontiguousarray(apriori, dtype=np.float32)
+        opt = PlanOptions(coef=coef, lbd=lbd, apriori=None if ap is None else ap.ctypes.data,
+                          ld_apriori=0 if ap is None else ap.shape[1], evidence=int(evidence), reorder=int(reorder))
+        h = C.c_void_p()
+        check(ops.lib.simrank_plan_create(csr.n_rows, col.size, rowptr.ctypes.data,
+                                          col.ctypes.data if col.size else None, rs.ctypes.data, C.byref(opt),
+                                          ops.stream, C.byref(h)), "simrank_plan_create")
+        self.handle, self.n = h, csr.n_rows
+
+    def run(self, iterations: int, eps: float):
+        """-> (updates applied, loop index at which the convergence test passed or None)."""
+        done, conv = C.c_int32(0), C.c_int32(-1)
+        check(self.ops.lib.simrank_plan_run(self.handle, int(iterations), float(eps), C.byref(done), C.byref(conv)),
+              "simrank_plan_run")
+        return done.value, (None if conv.value < 0 else conv.value)
+
+    def reset(self):
+        check(self.ops.lib.simrank_plan_reset(self.handle), "simrank_plan_reset")
+
+    def step(self, eps: float, exact_count: bool = True) -> int:
+        c = C.c_int64(0)
+        check(self.ops.lib.simrank_plan_step(self.handle, float(eps), int(exact_count), C.byref(c)), "simrank_plan_step")
+        return c.value
+
+    def result(self) -> np.ndarray:
+        out = np.empty((self.n, self.n), dtype=np.float64)
+        check(self.ops.lib.simrank_plan_result_f64(self.handle, out.ctypes.data, self.n), "simrank_plan_result_f64")
+        return out
+
+    def free(self):
+        if self.handle:
+            self.ops.lib.simrank_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class HipOps:
     """Kernel launcher for one device.  ``pitch_pad``: extra elements added to the leading
     dimension of matrices it allocates when that dimension is a large power of two (keeps

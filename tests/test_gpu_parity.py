@@ -753,3 +753,62 @@ def test_dense_sets_shards_equal_one_shard_bit_for_bit():
     finally:
         knob.set_tuning(dense_min=4)
     np.testing.assert_allclose(one.values, plain.values, rtol=2e-6, atol=1e-30)
+
+
+# ---------------------------------------------------------------------------------------
+# the C-level plan (simrank_plan_*): the reference loop behind create / run / result
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["SimRank_toy5", "SimRank_er128", "SimRank_quirky_weighted", "SimRank_bts300",
+                                  "SimRankPP_toy5", "SimRankPP_er128", "SimRankPP_bts300"])
+def test_plan_api_reproduces_the_golden_vectors(ops, name):
+    """create -> run -> result against the vectors generated from the reference: S to 1e-5, the
+    "Converged at iteration k" index exactly, iterations = 0 and eps >= 1 included."""
+    from simrank_amd.engine import Plan
+    g = Golden(name)
+    G = g.out["G"]
+    n = len(G)
+    rows, cols = np.nonzero(G)
+    rowptr = np.zeros(n + 1, np.int32)
+    np.cumsum(np.bincount(rows, minlength=n), out=rowptr[1:])
+    scale = np.zeros(n)
+    scale[rows] = G[rows, cols]
+    csr = ingest.CSR(n, n, rowptr, cols.astype(np.int32), scale)
+    pp = name.startswith("SimRankPP")
+    plan = Plan(ops, csr, coef=g.kwargs.get("C", 0.8), evidence=pp)
+    done, conv = plan.run(g.kwargs.get("iterations", 100), g.kwargs.get("eps", 1e-4))
+    assert (conv if conv is not None else -1) == (g.k if g.k is not None else -1)
+    assert_close(plan.result(), g.out["S"])
+    # the same plan again, step by step with the exact count, against the one-call loop
+    plan.reset()
+    eps = g.kwargs.get("eps", 1e-4)
+    counts = [plan.step(eps, exact_count=True) for _ in range(done)]
+    if conv is not None and done:
+        assert counts[-1] == 0 and all(c > 0 for c in counts[:-1])     # the passing test is the first zero count
+    assert_close(plan.result(), g.out["S"])
+    assert plan.run(0, 1e-4) == (0, None)
+    np.testing.assert_array_equal(plan.result(), np.eye(n))
+    assert plan.run(5, 1.0) == (0, 0)
+    plan.free()
+
+
+def test_plan_api_with_a_prior_and_in_the_callers_order(ops):
+    """AprioriSimRank's loop (SimRank.py:443-454) through the plan: symmetric prior, nodes re-ordered inside
+    and handed back in the caller's order; an asymmetric prior is refused."""
+    from simrank_amd.engine import Plan
+    from simrank_amd._lib import SimRankHipError
+    df = synth.powerlaw_directed(700, 9, seed=5)
+    _, csr = ingest.directed(df, False, "from", "to", "weight")
+    rng = np.random.default_rng(2)
+    A = rng.random((csr.n_rows, csr.n_rows))
+    A = (A + A.T) / 2
+    G = csr.dense()
+    want_S, want_k = O.iterate_directed(G, C=0.7, iterations=100, eps=1e-4, E=O.evidence(G),
+                                        apriori=A.astype(np.float32).astype(np.float64), lbd=0.3)
+    plan = Plan(ops, csr, coef=0.7, evidence=True, apriori=A, lbd=0.3)
+    done, conv = plan.run(100, 1e-4)
+    assert conv == want_k
+    assert_close(plan.result(), want_S)
+    plan.free()
+    A[3, 5] += 0.5
+    with pytest.raises(SimRankHipError, match="symmetric"):
+        Plan(ops, csr, apriori=A, lbd=0.3)

@@ -303,7 +303,7 @@ def main():
         nt, dk, cov = ops.dense_stats(side.graph)
         dense_ms = None
         fsteps, fcov, frem = ops.fused_stats(side.graph) if hasattr(ops, "fused_stats") else (0, 0, nnz)
-        fused = bool(getattr(solver, "blocked", False)) and fsteps > 0
+        fused = bool(getattr(solver, "blocked", False)) and fsteps > 0 and side.K <= ops.get_tuning("fuse_max_rows")
         if fused:
             # one launch: 16-column steps x 128 rows x 32 columns x 3 bf16 terms per panel
             flop = 2.0 * 3 * 128 * 16 * fsteps * side.Lk
@@ -350,12 +350,12 @@ def main():
         if dense_ms is not None:
             rl[0]["parts_ms"] = {"dense_tiles": dense_ms, "spmm_gather": l1 - dense_ms}
             rl[0]["gathered_bytes"] = 4 * (nnz - cov) * side.Lk
+            rl[0]["gather_kernel_alone"] = {"achieved": b1 / ((l1 - dense_ms) * 1e-3) / 1e9, "unit": "GB/s",
+                                            "frac": b1 / ((l1 - dense_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if fused:
             # segments pulled through the vector-memory path: one per gathered entry and one per (block, dense
             # column) pair, per 32-column panel
             rl[0]["gathered_bytes"] = 4 * (frem + 16 * fsteps) * side.Lk
-            rl[0]["gather_kernel_alone"] = {"achieved": b1 / ((l1 - dense_ms) * 1e-3) / 1e9, "unit": "GB/s",
-                                            "frac": b1 / ((l1 - dense_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
         # The second roofline of a gather leg: what the vector-memory path returns.  Every (entry, panel) pair
         # is one 128-byte segment pulled into registers; a loop of nothing but such loads (tools/micro/
         # gather_ceiling.hip, profiles/r02_gather_ceiling.log) reads 32-33 TB/s chip-wide from an L2-resident

@@ -524,6 +524,9 @@ int simrank_set_tuning(const char* key, int64_t value) {
     } else if (!strcmp(key, "fuse_order")) {
         SR_REQUIRE(value >= 0 && value <= 64, "fuse_order must be 0 .. 64");
         t.fuse_order = value;
+    } else if (!strcmp(key, "fuse_max_rows")) {
+        SR_REQUIRE(value >= 0, "fuse_max_rows must be >= 0");
+        t.fuse_max_rows = value;
     } else if (!strcmp(key, "fuse_group")) {
         SR_REQUIRE(value >= 1 && value <= 4, "fuse_group must be 1 .. 4");
         t.fuse_group = value;
@@ -557,6 +560,7 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     else if (!strcmp(key, "fuse_steps")) *value = t.fuse_steps;
     else if (!strcmp(key, "fuse_unit")) *value = t.fuse_unit;
     else if (!strcmp(key, "fuse_group")) *value = t.fuse_group;
+    else if (!strcmp(key, "fuse_max_rows")) *value = t.fuse_max_rows;
     else if (!strcmp(key, "fuse_order")) *value = t.fuse_order;
     else if (!strcmp(key, "fuse_store")) *value = t.fuse_store;
     else if (!strcmp(key, "fuse_meta_nt")) *value = t.fuse_meta_nt;

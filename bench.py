@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--panel", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--exact-only", action="store_true",
+                    help="skip the extra steps with the short-circuit convergence test (profiling runs: every leg-2 "
+                         "dispatch is then of the timed, exact-count form)")
     ap.add_argument("--stages", type=int, default=0,
                     help="pipeline depth of the sharded exchange (all_to_all_single calls per update; "
                          "0 = by the width of a rank's column block)")
@@ -247,7 +250,7 @@ def main():
     solver.events = None
     # the same steps with the short-circuit convergence test (the product default)
     short_ms = None
-    if gpu and solver.mode == "sparse" and world_size == 1:
+    if gpu and solver.mode == "sparse" and world_size == 1 and not args.exact_only:
         solver.exact_count = False
         solver.step(0.0)
         barrier()

@@ -16,7 +16,7 @@ import os
 import sys
 
 out_dir = sys.argv[1]
-key = sys.argv[2] if len(sys.argv) > 2 else "pl32768:1"
+key = sys.argv[2] if len(sys.argv) > 2 else "pl32768d32:1"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 acc = collections.defaultdict(lambda: [0.0, 0])
 for tag in ("pmc_fetch", "pmc_write"):
@@ -35,8 +35,8 @@ def traffic(match):
     return (2 * per_launch(match, "FETCH_SIZE") + per_launch(match, "WRITE_SIZE")) * 1024
 
 
-def is_leg1_gather(k):        # transposed store = template argument MODE 1
-    return "gather3_kernel<1" in k or "spmm_gather_kernel<4, 8, 1" in k
+def is_leg1_gather(k):        # one-launch leg 1 (round 3), or transposed store = template argument MODE 1
+    return "fused_trans_kernel" in k or "gather3_kernel<1" in k or "spmm_gather_kernel<4, 8, 1" in k
 
 
 def is_leg2_gather(k):        # upper-triangle form = MODE 2 (single rank)
@@ -52,8 +52,9 @@ path = os.path.join(root, "profiles", "pmc_traffic.json")
 rec = json.load(open(path)) if os.path.exists(path) else {}
 rec["_note"] = ("HBM-side bytes per launch from rocprofv3 PMC (tools/gpu_profile.sh + tools/make_pmc_traffic.py): "
                 "(2*FETCH_SIZE + WRITE_SIZE)*1024 - FETCH_SIZE reads half of a 16 B/lane stream on gfx950 "
-                "(MI355X_MICROARCH.md §HBM). Infinity-Cache hits are included. leg1 = gather kernel (remainder, "
-                "transposed store) + dense_tiles; leg2 = gather kernel, upper-triangle form.")
+                "(MI355X_MICROARCH.md §HBM). Infinity-Cache hits are included. leg1 = fused_trans_kernel (round 3; "
+                "rounds 1-2: gather kernel of the remainder + dense_tiles); leg2 = gather kernel, upper-triangle "
+                "form, timed exact-count form only (bench.py --exact-only).")
 rec[key] = {"leg1": g1 + d, "leg2": g2, "leg1_parts": {"gather": g1, "dense_tiles": d},
             "source": os.path.basename(out_dir.rstrip("/"))}
 json.dump(rec, open(path, "w"), indent=1)

@@ -160,9 +160,9 @@ struct simrank_fused_plan {
     uint16_t* dcols16 = nullptr;    // [n_quads*64] operand rows of the sets, or
     int32_t* dcols32 = nullptr;     //              the same in 32 bits; padding = a real row, bits zero
     uint4* abits = nullptr;         // [n_quads*64] per lane: 4 steps x (4 row tiles x 8 k) pattern bits
-    int4* gmeta = nullptr;          // [n_units*4*32*4] per unit, block of the unit, lane group and row: row of the
-                                    // block (-1: none), rowscale bits, end of the row in the group's stream (-1: no
-                                    // remainder), -
+    int2* gmeta = nullptr;          // [n_blocks*32*4] per block, wave, lane group and row: (end of the row in the
+                                    // group's stream << 8 | row of the block; 255: no row, 0xFFFFFF: no remainder),
+                                    // rowscale bits
     uint16_t* sids16 = nullptr;     // gather id stream, 64 per round (0xFFFF: no neighbour), or
     int32_t* sids32 = nullptr;      //              32-bit ids (-1: no neighbour)
 };

@@ -71,8 +71,8 @@ struct FusedArgs {
     const uint16_t* dcols16;
     const int32_t* dcols32;
     const uint4* abits;
-    const int4* gmeta;        // [unit][block of the unit][wave][lane group][4 rows]: row of the block (-1: none),
-                              // rowscale bits, end of the row in the lane group's stream of that block, -
+    const int2* gmeta;        // [block][wave][lane group][4 rows]: (end of the row in the lane group's stream << 8 | row
+                              // of the block; row 255: none, end 0xFFFFFF: no remainder), rowscale bits
     const uint16_t* sids16;   // id stream of the gather phase, 64 per round (0xFFFF: no neighbour), or
     const int32_t* sids32;    // the same in 32 bits (-1: no neighbour)
 };
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
     __shared__ __attribute__((aligned(16))) float tile[32 * kTS];          // [column][row] of the block's result
     __shared__ __attribute__((aligned(16))) float bbuf_all[4 * 16 * 32];    // per wave: 16 operand segments
     __shared__ __attribute__((aligned(16))) uint4 lut[256];                 // pattern byte -> 8 bf16 (0 / 1.0)
-    __shared__ __attribute__((aligned(16))) int4 gm_lds[kSub * 4 * 8 * 4];   // per block of the unit, wave, lane group: four rows
+    __shared__ __attribute__((aligned(16))) int2 gm_lds[kSub * 4 * 8 * 4];   // per block of the unit, wave, lane group: four rows
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -163,12 +163,12 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
         }
     };
     {   // lane (g, q): row q & 3 of lane group g, blocks q >> 2 and 2 + (q >> 2) of the unit
-        const int4* src = p.gmeta + ((size_t(unit) * kSub * 4 + wave) * 8 + g) * 4 + (q & 3);
         const int sbA = q >> 2, sbB = 2 + (q >> 2);
-        int4* dst = gm_lds + (wave * 8 + g) * 4 + (q & 3);
-        const int4 zero = make_int4(-1, 0, -1, 0);
-        const int4 a = sbA < n_sub ? src[size_t(sbA) * 4 * 8 * 4] : zero;
-        const int4 c = sbB < n_sub ? src[size_t(sbB) * 4 * 8 * 4] : zero;
+        const int2* src = p.gmeta + ((size_t(b0) * 4 + wave) * 8 + g) * 4 + (q & 3);
+        int2* dst = gm_lds + (wave * 8 + g) * 4 + (q & 3);
+        const int2 none = make_int2(int(0xFFFFFFFFu), 0);
+        const int2 a = sbA < n_sub ? src[size_t(sbA) * 4 * 8 * 4] : none;
+        const int2 c = sbB < n_sub ? src[size_t(sbB) * 4 * 8 * 4] : none;
         dst[sbA * 4 * 8 * 4] = a;
         dst[sbB * 4 * 8 * 4] = c;
     }
@@ -364,12 +364,19 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
         int r_base = 0;                                       // first round of that block
         auto end_of = [&](int k) -> int { return k == 0 ? e1 : k == 1 ? e2 : k == 2 ? e3 : e4; };
         int r_end = (p.probe & 1) ? 0 : e1;                   // rounds up to the end of block sb
-        const int4* gmp = gm_lds + (wave * 8 + g) * 4;        // + sb * 128: the lane group's rows in block sb
+        const int2* gmp = gm_lds + (wave * 8 + g) * 4;        // + sb * 128: the lane group's rows in block sb
         wave_lds_order();
-        int4 m_cur = gmp[0];
+        // (row, scale, end) of the row the lane group is in: .x = row of the block or -1, .y = scale bits,
+        // .z = end of the row in the group's stream or -1
+        auto unpack = [](const int2& m) -> int3 {
+            const unsigned u = unsigned(m.x);
+            const int row = int(u & 255u), end = int(u >> 8);
+            return make_int3(row == 255 ? -1 : row, m.y, end == 0xFFFFFF ? -1 : end);
+        };
+        int3 m_cur = unpack(gmp[0]);
         float4 cur = make_float4(0.f, 0.f, 0.f, 0.f);
         int krow = 0;                                         // rows of the lane group finished in this block
-        auto emit = [&](const int4& m, const float4& sv) {
+        auto emit = [&](const int3& m, const float4& sv) {
             if (m.x >= 0) {
                 const float sc = __int_as_float(m.y);
                 float* tp = tile + (4 * q) * kTS + m.x;
@@ -387,13 +394,13 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
                 emit(m_cur, cur);
                 cur = make_float4(0.f, 0.f, 0.f, 0.f);
                 ++krow;
-                m_cur = gmp[sb * 128 + min(krow, 3)];
+                m_cur = unpack(gmp[sb * 128 + min(krow, 3)]);
                 if (krow > 3) m_cur.z = -1;
             }
         };
         // every round of block sb has been summed: its rows without a remainder, then the tile goes out
         auto finish = [&]() {
-            for (int k = krow; k < 4; ++k) emit(gmp[sb * 128 + k], make_float4(0.f, 0.f, 0.f, 0.f));
+            for (int k = krow; k < 4; ++k) emit(unpack(gmp[sb * 128 + k]), make_float4(0.f, 0.f, 0.f, 0.f));
             __syncthreads();
             // ------------------------------------------------------------ 4. transposed store
             const int row0 = (b0 + sb) * kFB;
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
                 r_end = (p.probe & 1) ? 0 : end_of(sb);
                 krow = 0;
                 cur = make_float4(0.f, 0.f, 0.f, 0.f);
-                m_cur = gmp[sb * 128];
+                m_cur = unpack(gmp[sb * 128]);
             }
         };
         auto issue8 = [&](int iv, float4 (&v)[8]) {
@@ -523,7 +530,7 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
     std::vector<uint32_t> abits;                      // [quad][lane][4 steps]
     // per block and wave: its rounds (64 ids each) and its lane groups' rows; laid out per unit below
     std::vector<std::vector<int32_t>> blk_sids(size_t(nblk) * 4);
-    std::vector<int32_t> blk_gmeta(size_t(nblk) * 32 * 4 * 4, 0);
+    std::vector<int32_t> blk_gmeta(size_t(nblk) * 32 * 4 * 2, 0);
     std::vector<uint16_t> cnt(size_t(K), 0);
     std::vector<int32_t> kpos(size_t(K), -1), touched, set;
     std::vector<int64_t> cost(size_t(nblk), 0);
@@ -608,7 +615,7 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
             sids.assign(size_t(rounds) * 64, -1);
             for (int gg = 0; gg < 8; ++gg) {
                 const int gi = gorder[gg * 4 + w];
-                int32_t* gm = &blk_gmeta[((size_t(b) * 4 + size_t(w)) * 8 + size_t(gg)) * 16];
+                int32_t* gm = &blk_gmeta[((size_t(b) * 4 + size_t(w)) * 8 + size_t(gg)) * 8];
                 int f = 0;
                 for (int k = 0; k < 4; ++k) {
                     if (k < grp_n[gi]) {
@@ -617,13 +624,13 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
                             sids[base + size_t(f >> 3) * 64 + size_t(gg) * 8 + size_t(f & 7)] = id;
                             ++f;
                         }
-                        gm[4 * k] = rr;
+                        // (an empty row never ends a stream slot: no end)
+                        const uint32_t end = rem[rr].empty() ? 0xFFFFFFu : uint32_t(f);
+                        gm[2 * k] = int32_t(end << 8 | uint32_t(rr));
                         const float sc = rowscale[size_t(lo + rr)];
-                        memcpy(&gm[4 * k + 1], &sc, 4);
-                        gm[4 * k + 2] = rem[rr].empty() ? -1 : f;     // (an empty row never ends a stream slot)
+                        memcpy(&gm[2 * k + 1], &sc, 4);
                     } else {
-                        gm[4 * k] = -1;
-                        gm[4 * k + 2] = -1;
+                        gm[2 * k] = int32_t(0xFFFFFFFFu);
                     }
                 }
             }
@@ -675,13 +682,9 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
         }
         ulist.swap(mixed);
     }
-    std::vector<int32_t> units(ulist.size() * 32, 0), gmeta(ulist.size() * kSub * 32 * 4 * 4, 0), sids;
+    std::vector<int32_t> units(ulist.size() * 32, 0), sids;
+    blk_gmeta.resize(blk_gmeta.size() + size_t(kSub) * 32 * 4 * 2, int32_t(0xFFFFFFFFu));   // (a unit's loads may run past its blocks)
     sids.reserve(size_t(r_nnz) + ulist.size() * 512);
-    for (size_t i = 0; i < ulist.size(); ++i)             // no row, no remainder
-        for (size_t j = 0; j < size_t(kSub) * 32 * 4; ++j) {
-            gmeta[(i * kSub * 32 * 4 + j) * 4] = -1;
-            gmeta[(i * kSub * 32 * 4 + j) * 4 + 2] = -1;
-        }
     int32_t n_pslots = 0, n_cslots = 0;
     for (size_t i = 0; i < ulist.size(); ++i) {
         const Unit& u = ulist[i];
@@ -705,8 +708,6 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
                     const std::vector<int32_t>& bs = blk_sids[size_t(u.b0 + sb) * 4 + size_t(w)];
                     sids.insert(sids.end(), bs.begin(), bs.end());
                     rounds += (int32_t)(bs.size() / 64);
-                    memcpy(&gmeta[(((i * kSub + size_t(sb)) * 4 + size_t(w)) * 8) * 16],
-                           &blk_gmeta[((size_t(u.b0 + sb) * 4 + size_t(w)) * 8) * 16], 8 * 16 * sizeof(int32_t));
                 }
                 wm[1 + sb] = rounds;
             }
@@ -733,7 +734,7 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
         }
     }
     if (!rc) rc = upload_vec(reinterpret_cast<uint32_t**>(&pl->abits), abits);
-    if (!rc) rc = upload_vec(reinterpret_cast<int32_t**>(&pl->gmeta), gmeta);
+    if (!rc) rc = upload_vec(reinterpret_cast<int32_t**>(&pl->gmeta), blk_gmeta);
     if (!rc) {
         if (ids16) {
             std::vector<uint16_t> s16(sids.size());

@@ -137,15 +137,17 @@ static void check_fused(const simrank_graph* g, const Csr& c) {
                 const int r_lo = sb ? wm[sb] : 0, r_hi = wm[1 + sb];
                 CHECK(r_hi >= r_lo, "round counts not monotone");
                 for (int gg = 0; gg < 8; ++gg) {
-                    const int32_t* m = gm + ((((size_t(u) * 4 + sb) * 4 + w) * 8) + gg) * 16;
+                    const int32_t* m = gm + (((size_t(b) * 4 + w) * 8) + gg) * 8;
                     int f = 0;
                     bool empty_seen = false;
                     for (int kr = 0; kr < 4; ++kr) {
-                        const int row = m[4 * kr], end = m[4 * kr + 2];
+                        const uint32_t packed = uint32_t(m[2 * kr]);
+                        const int row = int(packed & 255u) == 255 ? -1 : int(packed & 255u);
+                        const int end = (packed >> 8) == 0xFFFFFFu ? -1 : int(packed >> 8);
                         if (row < 0) continue;
                         CHECK(row < 128 && b * 128 + row < c.M, "row of a lane group out of range");
                         float sc;
-                        memcpy(&sc, &m[4 * kr + 1], 4);
+                        memcpy(&sc, &m[2 * kr + 1], 4);
                         CHECK(sc == c.scale[size_t(b) * 128 + row], "row scale");
                         if (end < 0) { empty_seen = true; continue; }
                         CHECK(!empty_seen && end > f, "rows without a remainder must come last");

@@ -280,6 +280,8 @@ def main():
                                + ("; leg 2 in its half form (tiles i <= j per rank, mirrored tiles in a second "
                                   "half-size all-to-all)" if getattr(side, "shard_sym", False) else "")},
     }
+    if use_dist and getattr(world, "form_measured", None):
+        out["shard_form_measured"] = world.form_measured      # both forms of leg 2 timed on this node's links
     if short_ms is not None:
         out["convergence_test"] = {
             "timed_form": "exact: every element of S' is compared with the previous iterate and the moved ones "

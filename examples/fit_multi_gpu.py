@@ -4,9 +4,11 @@ all-to-all per update.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
         examples/fit_multi_gpu.py [N] [average degree]
 
-Every rank passes the same edge list; every rank gets the full similarity DataFrame back
-(rank 0 prints).  `top_k=10` instead returns the ten most similar nodes of every node without
-moving N x N values over PCIe."""
+Every rank passes the same edge list.  `top_k=10` hands the ten most similar nodes of every node to every
+rank without moving N x N values over PCIe; without it the dense similarity DataFrame goes to rank 0 only
+(the other ranks' fit() returns None; TorchWorld(handback="all") gives it to every rank).  The world picks
+the pipeline depth of the exchange from the width of a rank's column block (stages=0) and, from 4096 nodes
+on, the form of leg 2 by timing one update in each form on the node's links."""
 import os
 import sys
 import time
@@ -31,7 +33,7 @@ edges = synth.powerlaw_directed(n, deg, seed=n)          # columns 'from', 'to',
 t0 = time.perf_counter()
 est = SimRank.SimRank()
 top = est.fit(edges, C=0.8, iterations=100, eps=1e-4, verbose=dist.get_rank() == 0,
-              device=local_rank, world=TorchWorld(stages=4), top_k=10)
+              device=local_rank, world=TorchWorld(stages=0), top_k=10)
 if dist.get_rank() == 0:
     print(f"\nN={n}: converged at iteration {est.converged_at} in {time.perf_counter() - t0:.2f} s "
           f"on {dist.get_world_size()} GPU(s)")

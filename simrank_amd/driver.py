@@ -29,7 +29,8 @@ from .ingest import CSR, partition, relabel
 PAD_MIN_ROWS, PAD_MULTIPLE = 1024, 256   # when exchanged chunk rows get padded (row_pad)
 RESTRICT_BELOW = 0.5     # SimRank++: leg 2 skips evidence-dead 32-column segments when fewer than this
                          # fraction of them is live (ER N=8192: 0.24 live; the power-law graphs: 0.9)
-HALF_FORM_FROM = 8      # TorchWorld(symmetric_shards="auto"): half-form leg 2 from this many ranks on
+HALF_FORM_FROM = 8      # TorchWorld(symmetric_shards="auto") when nothing is measured: half-form leg 2 from this many ranks on
+MEASURE_FORM_FROM_N = 4096   # ... with at least this many nodes (and > 1 rank) both forms are TIMED and the faster one taken
 DEAL_UNIT = 128         # nodes are dealt to the shards in runs of this many (dealt_order)
 STAGE_ALIGN = 32         # stage widths of a pipelined exchange are multiples of this (panels)
 
@@ -188,9 +189,12 @@ class TorchWorld:
         there and downloaded once; the other ranks' ``fit`` returns None.  "all": every rank gets
         the full float64 matrix (pickled all-gather: N^2 x 8 B x P per node — small N only).
         ``fit(top_k=k)`` hands k columns per row to every rank either way.
-        ``symmetric_shards``: as for ``LocalWorld``; "auto" (default) = from ``HALF_FORM_FROM`` ranks
-        on — the half form trades 50 % more bytes on the links for 30-35 % less compute per rank,
-        which pays once a rank spreads its exchange over seven xGMI links."""
+        ``symmetric_shards``: as for ``LocalWorld``; "auto" (default): the half form trades 50 % more bytes on
+        the links for 30-35 % less compute per rank, which pays once a rank spreads its exchange over enough
+        xGMI links — so the first solver built on a world of several ranks times one update in
+        each form on the real links and every rank adopts the faster one (``resolve_shard_form``; below
+        ``MEASURE_FORM_FROM_N`` nodes, or where the half form does not apply, the rule of thumb "from
+        ``HALF_FORM_FROM`` ranks on" decides)."""
         import torch.distributed as dist
         if handback not in ("root", "all"):
             raise ValueError("handback must be 'root' or 'all'")
@@ -200,8 +204,11 @@ class TorchWorld:
         self.size = dist.get_world_size(group)
         # ("force": also in a one-rank world — how the half-form path, RCCL call included, is
         # exercised on a single GPU)
-        self.symmetric_shards = (self.size >= HALF_FORM_FROM if symmetric_shards == "auto"
-                                 else "force" if symmetric_shards == "force" else bool(symmetric_shards))
+        # "auto" stays unresolved until a solver is built on this world: with more than one rank the solver
+        # TIMES one update in each form and all ranks adopt the faster one (resolve_shard_form)
+        self.symmetric_shards = (symmetric_shards if symmetric_shards in ("auto", "force")
+                                 else bool(symmetric_shards))
+        self.form_measured = None        # filled by resolve_shard_form: {"half_ms", "full_ms", "chosen"}
         self.rank = dist.get_rank(group)
         self.local_ranks = [self.rank]
         self.is_root = self.rank == 0
@@ -298,6 +305,15 @@ class TorchWorld:
         t = torch.tensor([v], dtype=torch.int64, device=self._dev())
         self.dist.all_reduce(t, group=self.group)
         return int(t.item())
+
+    def max_float(self, v: float) -> float:
+        import torch
+        t = torch.tensor([v], dtype=torch.float64, device=self._dev())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
 
     def _dev(self):
         import torch
@@ -581,6 +597,45 @@ def choose_mode(mode: str, csrs, world: int, symmetric: bool = True) -> str:
     return mode
 
 
+def resolve_shard_form(make_ops, world, specs, mode, reorder=True):
+    """``TorchWorld(symmetric_shards="auto")``: which form of the sharded leg 2 this world runs.
+
+    The half form computes a third less per rank and sends half as much again over the links; which one is
+    faster depends on what RCCL's all-to-all reaches on the node's xGMI links, so it is measured: a solver in
+    each form, one warm-up update and ``steps`` timed ones bracketed by barriers, the MAX over the ranks of
+    each time, the smaller one wins — every rank sees the same two numbers and takes the same decision.
+    Where the half form cannot run (asymmetric prior, N not a multiple of 32 x ranks, dense modes) or the
+    problem is small, ``HALF_FORM_FROM`` decides without a measurement.  Leaves the result in
+    ``world.symmetric_shards`` (bool) and the timings in ``world.form_measured``."""
+    import time
+    if getattr(world, "symmetric_shards", None) != "auto":
+        return
+    n_min = min(s.csr.n_rows for s in specs)
+    applies = (world.size > 1 and mode in ("auto", "sparse") and all(s.symmetric for s in specs) and
+               all(s.csr.n_rows % (32 * world.size) == 0 for s in specs))
+    if not applies or n_min < MEASURE_FORM_FROM_N:
+        world.symmetric_shards = world.size >= HALF_FORM_FROM
+        world.form_measured = None
+        return
+    times = {}
+    for half in (True, False):
+        world.symmetric_shards = half
+        solver = Solver(make_ops, world, specs, mode, reorder)
+        solver.reset()
+        solver.step(0.0)
+        world.barrier()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            solver.step(0.0)
+        world.barrier()
+        times[half] = world.max_float((time.perf_counter() - t0) / 2)
+        solver.release()
+        del solver
+    world.symmetric_shards = times[True] < times[False]
+    world.form_measured = {"half_ms": times[True] * 1e3, "full_ms": times[False] * 1e3,
+                           "chosen": "half" if world.symmetric_shards else "full"}
+
+
 # --------------------------------------------------------------------------------------
 # solvers
 # --------------------------------------------------------------------------------------
@@ -642,6 +697,7 @@ class Solver:
     """
 
     def __init__(self, make_ops, world, specs, mode="auto", reorder=True):
+        resolve_shard_form(make_ops, world, specs, mode, reorder)     # ("auto" worlds only, once)
         self.world = world
         self.order = [None] * len(specs)
         if reorder:

@@ -39,7 +39,28 @@ def main(argv):
         assert any(c[0] == "spmm_shard" for c in ops.calls) and any(c[0] == "shard_unpack" for c in ops.calls)
         assert list(got.index) == list(want.index)
         np.testing.assert_allclose(got.values, want.values, rtol=2e-5, atol=1e-30)
-    names = [n for n in names if not n.startswith("half:")]
+    for name in [n for n in names if n.startswith("auto:")]:
+        # TorchWorld(symmetric_shards="auto") with the measurement forced on a small graph: both forms are
+        # timed, every rank adopts the same one, the result is the one-rank result either way
+        import simrank_amd.SimRank as SRA
+        from simrank_amd import synth
+        from simrank_amd.driver import LocalWorld
+        drv.MEASURE_FORM_FROM_N = 0
+        frame = synth.powerlaw_directed(64 * dist.get_world_size(), 5, 3)
+        one = NumpyOps()
+        want = SRA.SimRank().fit(frame, verbose=False, world=LocalWorld(1), mode="sparse", _ops_factory=lambda r: one)
+        ops = NumpyOps()
+        world = TorchWorld(stages=stages, handback="all")
+        assert world.symmetric_shards == "auto"
+        got = SRA.SimRank().fit(frame, verbose=False, mode="sparse", _ops_factory=lambda r: ops, world=world)
+        m = world.form_measured
+        assert isinstance(world.symmetric_shards, bool) and m and m["chosen"] == ("half" if world.symmetric_shards else "full")
+        votes = [None] * dist.get_world_size()
+        dist.all_gather_object(votes, (m["chosen"], m["half_ms"], m["full_ms"]))
+        assert len(set(votes)) == 1, votes                   # same numbers, same decision on every rank
+        np.testing.assert_allclose(got.values, want.values, rtol=2e-5, atol=1e-30)
+        drv.MEASURE_FORM_FROM_N = 4096
+    names = [n for n in names if not n.startswith("half:") and not n.startswith("auto:")]
     for name in names:
         g = Golden(name)
         ops = NumpyOps()

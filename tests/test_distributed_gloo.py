@@ -64,3 +64,16 @@ def test_half_form_leg2_over_gloo(world, stages):
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     for r in range(world):
         assert f"RANK {r} ok" in p.stdout
+
+
+def test_shard_form_is_measured_and_agreed_over_gloo():
+    """TorchWorld(symmetric_shards="auto"), two ranks: one update is timed in each form of leg 2, the MAX over
+    the ranks decides, every rank ends with the same choice and the one-rank result."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dist_worker.py"), "1", "auto:SimRank"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    for r in range(2):
+        assert f"RANK {r} ok" in p.stdout

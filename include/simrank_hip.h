@@ -190,6 +190,19 @@ SIMRANK_API int simrank_spmm_shard(const simrank_graph* g, const float* X, int64
                                    int32_t world, float* send, int64_t chunk_floats, void* stream);
 SIMRANK_API int simrank_shard_unpack(float* Y, int64_t ldy, const float* recv, int64_t chunk_floats,
                                      int32_t rank, int32_t world, int64_t n_rows, void* stream);
+/* One STAGE of the half-form leg 2: the column tiles [tile_lo, tile_hi) of the rank's block only.  The packed
+ * mirrored tiles of those columns occupy slots [tile_lo (tile_lo - 1) / 2, tile_hi (tile_hi - 1) / 2) of a
+ * destination's chunk; `send_stage` / `recv_stage` hold just that range for every rank (stage_chunk_floats
+ * per rank), so the second all-to-all can be cut into stages too and a stage's tiles leave while the next
+ * stage computes (driver.Side: exchange 2 overlapped with leg 2).  The striped counters are
+ * zeroed when zero_counters is set (first stage of an update) and accumulate otherwise. */
+SIMRANK_API int simrank_spmm_shard_stage(const simrank_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy,
+                                         const simrank_epilogue* ep, int32_t rank, int32_t world, float* send_stage,
+                                         int64_t stage_chunk_floats, int32_t tile_lo, int32_t tile_hi,
+                                         int32_t zero_counters, void* stream);
+SIMRANK_API int simrank_shard_unpack_stage(float* Y, int64_t ldy, const float* recv_stage, int64_t stage_chunk_floats,
+                                           int32_t rank, int32_t world, int64_t n_rows, int32_t tile_lo,
+                                           int32_t tile_hi, void* stream);
 
 /* ---- K4/K5 alone: Y = epilogue(Q), element-wise over an n_rows x n_cols block (Q and Y may be
  *      the same buffer).  Used when an update cannot fuse its epilogue into leg 2: a prior

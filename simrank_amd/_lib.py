@@ -78,6 +78,9 @@ PROTOTYPES = {
     "simrank_evidence_live_segments": [_vp, _i64, _i64, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64), _vp],
     "simrank_spmm_shard": [_vp, _vp, _i64, _vp, _i64, C.POINTER(Epilogue), _i32, _i32, _vp, _i64, _vp],
     "simrank_shard_unpack": [_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp],
+    "simrank_spmm_shard_stage": [_vp, _vp, _i64, _vp, _i64, C.POINTER(Epilogue), _i32, _i32, _vp, _i64, _i32, _i32,
+                                 _i32, _vp],
+    "simrank_shard_unpack_stage": [_vp, _i64, _vp, _i64, _i32, _i32, _i64, _i32, _i32, _vp],
     "simrank_fill_identity_blocked": [_vp, _i64, _i64, _i64, _i64, _vp],
     "simrank_spmm_blocked": [_vp, _vp, _i64, _i64, _vp, _i64, _i32, C.POINTER(Epilogue), _vp],
     "simrank_epilogue_apply_blocked": [_vp, _vp, _i64, _i64, _i64, C.POINTER(Epilogue), _vp],

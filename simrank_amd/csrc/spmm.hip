@@ -54,6 +54,8 @@ struct SpmmArgs {
     int32_t sh_rank, sh_mb;   // kShard: this rank's shard, rows (= columns) per shard (multiple of 32)
     float* sh_send;           // kShard: packed mirrored tiles for the other ranks
     int64_t sh_chunk;         // kShard: floats per destination rank in sh_send
+    int32_t sh_tile0, sh_ntiles; // kShard, one STAGE of the leg: column tiles [sh_tile0, sh_tile0 + sh_ntiles) (0 tiles = all)
+    int64_t sh_slot0;         // ... whose packed mirrored tiles start at slot sh_slot0 = sh_tile0 (sh_tile0 - 1) / 2 of a chunk
     int32_t idx_mask;         // diagnostic (tuning "probe_mask"): neighbour ids are ANDed with it; -1 = off
     int32_t probe;            // diagnostic (tuning "probe_flags", lean kernel): 1 no gathers, 2 no stores of Y,
                               // 4 no partial sums of the dense part, 8 no neighbour-id loads
@@ -602,6 +604,7 @@ template <int VEC, int LPR, int MODE, int RT>
 static int launch_spmm(SpmmArgs a, hipStream_t st) {
     constexpr int PW = VEC * LPR;
     a.n_panels = int((a.L + PW - 1) / PW);
+    if (MODE == kShard && a.sh_ntiles > 0) a.n_panels = a.sh_ntiles;     // one stage of the leg
     const int64_t rows_per_block = int64_t(kWaves) * RT;
     a.row_tiles = int((a.M + rows_per_block - 1) / rows_per_block);
     if (RT != 32 || (MODE == kSym && !a.sym_map)) a.tile_row0 = nullptr;
@@ -954,7 +957,7 @@ void gather3_kernel(const SpmmArgs p) {
     if constexpr (MODE == kShard) {
         // column tile j works on the row tiles i <= j of every shard: the late panels are the heavy
         // ones and go first (a panel stays on one XCD: n_panels is a multiple of 8 or the tail is short)
-        panel = p.n_panels - 1 - panel;
+        panel = p.sh_tile0 + p.n_panels - 1 - panel;
         // the workgroup's first tile has its smallest row: if even that lies in a tile i > j, nothing to do
         const int t0 = rt * kWaves;
         const int first = p.tile_row0 ? (t0 < p.n_tiles ? p.tile_row0[t0] : int(p.M)) : t0 * RT;
@@ -1233,7 +1236,7 @@ void gather3_kernel(const SpmmArgs p) {
                 base = p.Y + (p.diag_col0 + c0) * p.ldy + (tile_i * 32 + in32);
                 rstride = p.ldy;
             } else {
-                const int64_t slot = int64_t(panel) * (panel - 1) / 2 + tile_i;
+                const int64_t slot = int64_t(panel) * (panel - 1) / 2 + tile_i - p.sh_slot0;
                 base = p.sh_send + int64_t(shard_h) * p.sh_chunk + slot * 1024 + in32;
                 rstride = 32;
             }
@@ -1336,6 +1339,7 @@ template <int MODE>
 static int launch_gather3(SpmmArgs a, hipStream_t st) {
     constexpr int PW = 32, RT = 32;
     a.n_panels = int((a.L + PW - 1) / PW);
+    if (MODE == kShard && a.sh_ntiles > 0) a.n_panels = a.sh_ntiles;     // one stage of the leg
     const int64_t rows_per_block = int64_t(kWaves) * RT;
     a.row_tiles = int((a.M + rows_per_block - 1) / rows_per_block);
     if (MODE == kSym && !a.sym_map) a.tile_row0 = nullptr;
@@ -1604,15 +1608,15 @@ __global__ __launch_bounds__(256) void live_segments_kernel(const uint8_t* __res
 // kShard: the mirrored tiles a rank received (packed 32 x 32 tiles, slot j(j-1)/2 + i of the chunk of
 // source rank h) go to rows (h, j) x columns (mine, i) of its block.  One workgroup per tile.
 __global__ __launch_bounds__(256) void shard_unpack_kernel(float* Y, int64_t ldy, const float* recv,
-                                                           int64_t chunk, int rank, int mb) {
+                                                           int64_t chunk, int rank, int mb, int64_t slot0) {
     const int h = blockIdx.y;                                   // source rank
     if (h == rank) return;
-    const int64_t slot = blockIdx.x;                            // = j (j - 1) / 2 + i, i < j
+    const int64_t slot = slot0 + blockIdx.x;                    // = j (j - 1) / 2 + i, i < j
     int j = int((1.0 + sqrt(1.0 + 8.0 * double(slot))) * 0.5);
     while (int64_t(j) * (j - 1) / 2 > slot) --j;
     while (int64_t(j + 1) * j / 2 <= slot) ++j;
     const int i = int(slot - int64_t(j) * (j - 1) / 2);
-    const float* src = recv + int64_t(h) * chunk + slot * 1024;
+    const float* src = recv + int64_t(h) * chunk + int64_t(blockIdx.x) * 1024;
     float* dst = Y + (int64_t(h) * mb + 32 * j) * ldy + 32 * i;
     const int c = threadIdx.x >> 3, r4 = (threadIdx.x & 7) * 4;
     *reinterpret_cast<float4*>(dst + c * ldy + r4) = *reinterpret_cast<const float4*>(src + c * 32 + r4);
@@ -1901,15 +1905,19 @@ static int epilogue_apply_impl(const float* Q, int64_t ldq, float* Y, int64_t ld
     return SIMRANK_OK;
 }
 
-int simrank_spmm_shard(const simrank_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy,
-                       const simrank_epilogue* ep, int32_t rank, int32_t world, float* send,
-                       int64_t chunk_floats, void* stream) {
+static int spmm_shard_impl(const simrank_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy,
+                           const simrank_epilogue* ep, int32_t rank, int32_t world, float* send,
+                           int64_t chunk_floats, int32_t tile_lo, int32_t tile_hi, int32_t zero_counters,
+                           void* stream) {
     SR_REQUIRE(g && X && Y && ep && send, "NULL argument");
     SR_REQUIRE(world >= 1 && rank >= 0 && rank < world && g->n_rows % (int64_t(world) * 32) == 0,
                "a symmetric sharded leg needs n_rows (%lld) divisible by 32 x world (%d)",
                (long long)g->n_rows, world);
     const int64_t mb = g->n_rows / world, tiles = mb / 32;
-    SR_REQUIRE(chunk_floats >= tiles * (tiles - 1) / 2 * 1024 && (tiles < 2 || chunk_floats % 4 == 0),
+    SR_REQUIRE(tile_lo >= 0 && tile_lo < tile_hi && tile_hi <= tiles, "stage tiles [%d, %d) of %lld", tile_lo, tile_hi,
+               (long long)tiles);
+    const int64_t slot_lo = int64_t(tile_lo) * (tile_lo - 1) / 2, slot_hi = int64_t(tile_hi) * (tile_hi - 1) / 2;
+    SR_REQUIRE(chunk_floats >= (slot_hi - slot_lo) * 1024 && (slot_hi == slot_lo || chunk_floats % 4 == 0),
                "send chunk too small or not a multiple of 4 floats");
     SR_REQUIRE(ep->diag_col0 == int64_t(rank) * mb && ldx >= mb && ldy >= mb && aligned16(X) && aligned16(Y) &&
                    aligned16(send) && ldx % 4 == 0 && ldy % 4 == 0, "bad shard operands");
@@ -1946,8 +1954,10 @@ int simrank_spmm_shard(const simrank_graph* g, const float* X, int64_t ldx, floa
                    (!a.ap || (aligned16(a.ap) && a.ld_ap % 4 == 0)) &&
                    (!a.prev || (aligned16(a.prev) && a.ld_prev % 4 == 0)), "unaligned epilogue operand");
     a.sh_rank = rank; a.sh_mb = (int32_t)mb; a.sh_send = send; a.sh_chunk = chunk_floats;
+    a.sh_tile0 = tile_lo; a.sh_ntiles = tile_hi - tile_lo; a.sh_slot0 = slot_lo;
     hipStream_t st = as_stream(stream);
-    if (a.prev) SR_HIP(hipMemsetAsync(a.n_changed, 0, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS, st));
+    if (a.prev && zero_counters)
+        SR_HIP(hipMemsetAsync(a.n_changed, 0, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS, st));
     if (T.balance && g->tile_row0) {
         a.tile_row0 = g->tile_row0;
         a.n_tiles = g->n_tiles;
@@ -1955,20 +1965,50 @@ int simrank_spmm_shard(const simrank_graph* g, const float* X, int64_t ldx, floa
     return launch_gather3<kShard>(a, st);
 }
 
-int simrank_shard_unpack(float* Y, int64_t ldy, const float* recv, int64_t chunk_floats, int32_t rank,
-                         int32_t world, int64_t n_rows, void* stream) {
+int simrank_spmm_shard(const simrank_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy,
+                       const simrank_epilogue* ep, int32_t rank, int32_t world, float* send,
+                       int64_t chunk_floats, void* stream) {
+    SR_REQUIRE(g && world >= 1 && g->n_rows % (int64_t(world) * 32) == 0, "bad shard arguments");
+    const int32_t tiles = (int32_t)(g->n_rows / world / 32);
+    return spmm_shard_impl(g, X, ldx, Y, ldy, ep, rank, world, send, chunk_floats, 0, tiles, 1, stream);
+}
+
+int simrank_spmm_shard_stage(const simrank_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy,
+                             const simrank_epilogue* ep, int32_t rank, int32_t world, float* send_stage,
+                             int64_t stage_chunk_floats, int32_t tile_lo, int32_t tile_hi, int32_t zero_counters,
+                             void* stream) {
+    return spmm_shard_impl(g, X, ldx, Y, ldy, ep, rank, world, send_stage, stage_chunk_floats, tile_lo, tile_hi,
+                           zero_counters, stream);
+}
+
+static int shard_unpack_impl(float* Y, int64_t ldy, const float* recv, int64_t chunk_floats, int32_t rank,
+                             int32_t world, int64_t n_rows, int32_t tile_lo, int32_t tile_hi, void* stream) {
     SR_REQUIRE(Y && recv && world >= 1 && rank >= 0 && rank < world && n_rows % (int64_t(world) * 32) == 0,
                "bad shard unpack");
     const int mb = int(n_rows / world), tiles = mb / 32;
-    const int64_t per_src = int64_t(tiles) * (tiles - 1) / 2;
+    SR_REQUIRE(tile_lo >= 0 && tile_lo < tile_hi && tile_hi <= tiles, "stage tiles [%d, %d) of %d", tile_lo, tile_hi, tiles);
+    const int64_t slot_lo = int64_t(tile_lo) * (tile_lo - 1) / 2, slot_hi = int64_t(tile_hi) * (tile_hi - 1) / 2;
+    const int64_t per_src = slot_hi - slot_lo;
     if (per_src == 0 || world == 1) return SIMRANK_OK;
     SR_REQUIRE(per_src < (int64_t(1) << 31), "too many tiles");
     SR_REQUIRE(ldy >= mb && ldy % 4 == 0 && aligned16(Y) && aligned16(recv) && chunk_floats % 4 == 0 &&
                    chunk_floats >= per_src * 1024, "bad shard unpack operands");
     hipLaunchKernelGGL(shard_unpack_kernel, dim3((unsigned)per_src, (unsigned)world), dim3(256), 0,
-                       as_stream(stream), Y, ldy, recv, chunk_floats, (int)rank, mb);
+                       as_stream(stream), Y, ldy, recv, chunk_floats, (int)rank, mb, slot_lo);
     SR_HIP(hipGetLastError());
     return SIMRANK_OK;
+}
+
+int simrank_shard_unpack(float* Y, int64_t ldy, const float* recv, int64_t chunk_floats, int32_t rank,
+                         int32_t world, int64_t n_rows, void* stream) {
+    SR_REQUIRE(world >= 1 && n_rows % (int64_t(world) * 32) == 0, "bad shard unpack");
+    return shard_unpack_impl(Y, ldy, recv, chunk_floats, rank, world, n_rows, 0, (int32_t)(n_rows / world / 32), stream);
+}
+
+int simrank_shard_unpack_stage(float* Y, int64_t ldy, const float* recv_stage, int64_t stage_chunk_floats,
+                               int32_t rank, int32_t world, int64_t n_rows, int32_t tile_lo, int32_t tile_hi,
+                               void* stream) {
+    return shard_unpack_impl(Y, ldy, recv_stage, stage_chunk_floats, rank, world, n_rows, tile_lo, tile_hi, stream);
 }
 
 int simrank_epilogue_apply(const float* Q, int64_t ldq, float* Y, int64_t ldy, int64_t n_rows,

@@ -128,14 +128,16 @@ def permute_columns(csr: CSR, perm: np.ndarray) -> CSR:
 class LocalWorld:
     """P virtual ranks inside this process (P = 1 is the ordinary single-GPU case)."""
 
-    def __init__(self, size: int = 1, symmetric_shards: bool = True):
+    def __init__(self, size: int = 1, symmetric_shards: bool = True, leg2_stages: int = 1):
         """``symmetric_shards``: sharded symmetric updates run leg 2 in its half form when the node
         count allows it (``Side.shard_sym``); False keeps the full form, whose results are bit-equal
-        to a single rank's full form."""
+        to a single rank's full form.  ``leg2_stages``: the half-form leg 2 (and its exchange) cut into
+        that many stages of column tiles, as ``TorchWorld`` does to overlap the second all-to-all."""
         self.size = int(size)
         self.local_ranks = list(range(self.size))
         self.is_root = True
         self.stages = 1
+        self.leg2_stages = int(leg2_stages)
         self.symmetric_shards = bool(symmetric_shards)
 
     def exchange(self, parts):
@@ -151,12 +153,15 @@ class LocalWorld:
                                    4 * n)
 
     def exchange_mirrors(self, sides):
-        """All-to-all of the packed mirrored tiles of a half-form leg 2 (equal chunks)."""
-        for src in sides:
-            for dst in sides:
-                if src is not dst:
-                    n = 4 * src.sh_chunk
-                    src.ops.copy_bytes(dst.sh_recv.ptr + n * src.rank, src.sh_send.ptr + n * dst.rank, n)
+        """All-to-all of the packed mirrored tiles of a half-form leg 2 (equal chunks; stage by stage when
+        the leg was cut: a stage's range of every chunk sits together, ``Side.sh_stages``)."""
+        for st in sides[0].sh_stages or [dict(off=0, chunk=sides[0].sh_chunk)]:
+            n = 4 * st["chunk"]
+            for src in sides:
+                for dst in sides:
+                    if src is not dst and n:
+                        src.ops.copy_bytes(dst.sh_recv.ptr + 4 * st["off"] + n * src.rank,
+                                           src.sh_send.ptr + 4 * st["off"] + n * dst.rank, n)
 
     def sum_int(self, values):
         return int(sum(values))
@@ -214,6 +219,7 @@ class TorchWorld:
         self.is_root = self.rank == 0
         # (a one-rank world stages only on request: that is how the path is exercised on one GPU)
         self.stages = max(0, int(stages)) if (self.size > 1 or stage_single_rank) else 1
+        self.leg2_stages = 0               # 0: the half-form leg 2 is cut like leg 1 (Side.n_stages)
 
     @property
     def stream_ordered(self):
@@ -275,17 +281,46 @@ class TorchWorld:
                                     out_splits, in_splits, group=self.group)
         x.ops.collective_done()
 
+    def begin_mirror_stage(self, sd, st):
+        """Stream-ordered pipeline of exchange 2: called right after the kernel of one stage of the half-form
+        leg 2 was queued; that stage's mirrored tiles leave while the next stage computes."""
+        import torch
+        n = self.size * st["chunk"]
+        with torch.cuda.stream(sd.ops.torch_stream()):
+            st["work"] = self.dist.all_to_all_single(sd.sh_recv_t[st["off"]:st["off"] + n],
+                                                     sd.sh_send_t[st["off"]:st["off"] + n],
+                                                     group=self.group, async_op=True)
+
     def exchange_mirrors(self, sides):
         """All-to-all of the packed mirrored tiles of a half-form leg 2: equal chunks, the one a
-        rank addresses to itself is empty on purpose (its own mirrors were stored in place)."""
+        rank addresses to itself is empty on purpose (its own mirrors were stored in place).  When the leg
+        was cut into stages the all-to-alls were issued stage by stage during the leg (stream-ordered
+        worlds) and this only makes the engine's stream wait for them."""
         (sd,) = sides
+        stages = sd.sh_stages
         if self.stream_ordered:
             import torch
             with torch.cuda.stream(sd.ops.torch_stream()):
-                self.dist.all_to_all_single(sd.sh_recv_t, sd.sh_send_t, group=self.group)
+                if stages is None:
+                    self.dist.all_to_all_single(sd.sh_recv_t, sd.sh_send_t, group=self.group)
+                    return
+                for st in stages:
+                    w = st.pop("work", None)
+                    if w is None:                      # (not issued during the leg)
+                        n = self.size * st["chunk"]
+                        w = self.dist.all_to_all_single(sd.sh_recv_t[st["off"]:st["off"] + n],
+                                                        sd.sh_send_t[st["off"]:st["off"] + n],
+                                                        group=self.group, async_op=True)
+                    w.wait()                           # the engine's stream waits, not the host
             return
         sd.ops.synchronize()
-        self.dist.all_to_all_single(sd.sh_recv_t, sd.sh_send_t, group=self.group)
+        if stages is None:
+            self.dist.all_to_all_single(sd.sh_recv_t, sd.sh_send_t, group=self.group)
+        else:
+            for st in stages:
+                n = self.size * st["chunk"]
+                self.dist.all_to_all_single(sd.sh_recv_t[st["off"]:st["off"] + n],
+                                            sd.sh_send_t[st["off"]:st["off"] + n], group=self.group)
         sd.ops.collective_done()
 
     def sum_changed(self, ops, active=True):
@@ -383,7 +418,7 @@ class SideSpec:
 
 class Side:
     def __init__(self, ops, spec: SideSpec, rank: int, world: int, mode: str, torch_buffers: bool,
-                 stages: int = 1, blocked: bool = False, shard_symmetric: bool = True):
+                 stages: int = 1, blocked: bool = False, shard_symmetric: bool = True, leg2_stages: int = 1):
         self.ops, self.spec, self.rank, self.world, self.mode = ops, spec, rank, world, mode
         self.blocked = blocked         # single rank, gather legs: every matrix panel-blocked
         csr = spec.csr
@@ -421,6 +456,7 @@ class Side:
         # Half-form leg 2 of a sharded symmetric update (simrank_spmm_shard): of the 32 x 32 tiles
         # (shard h, tile i) x (my column tile j) only i <= j is computed, the transposed tiles i < j go to
         # the ranks that own them in a second, half-size all-to-all.  Needs equal shards of whole tiles.
+        self.sh_stages = None          # half-form leg 2 in stages: [{tile_lo, tile_hi, off, chunk}], heaviest first
         self.shard_sym = (mode == "sparse" and (world > 1 or shard_symmetric == "force") and
                           self.symmetric and bool(shard_symmetric) and
                           self.M % (32 * world) == 0 and getattr(ops, "supports_shard_symmetric", False) and
@@ -437,6 +473,21 @@ class Side:
             else:
                 self.sh_send = ops.matrix(world, self.sh_chunk, ld=self.sh_chunk)
                 self.sh_recv = ops.matrix(world, self.sh_chunk, ld=self.sh_chunk)
+            # The leg (and exchange 2) in stages of column tiles: a column tile j packs j mirrored tiles per
+            # source shard, slots j (j - 1) / 2 ..., so tiles [lo, hi) own a contiguous slot range of every
+            # chunk; the buffers hold them stage-major (per stage: one piece per rank), the stages are cut at
+            # T sqrt(k / S) for equal slot counts and run heaviest (last tiles) first.
+            want = leg2_stages if leg2_stages > 0 else self.n_stages
+            want = min(want, t // 2)
+            if want > 1:
+                cuts = sorted({min(t, max(2, int(round(t * (k / want) ** 0.5)))) for k in range(1, want)} | {t})
+                lo, self.sh_stages = 0, []
+                for hi in cuts:
+                    s_lo, s_hi = lo * (lo - 1) // 2, hi * (hi - 1) // 2
+                    self.sh_stages.append(dict(tile_lo=lo, tile_hi=hi, off=world * s_lo * 1024,
+                                               chunk=(s_hi - s_lo) * 1024))
+                    lo = hi
+                self.sh_stages.reverse()
         self.ev = None
         if spec.evidence_from is not None:
             ev = spec.evidence_from
@@ -544,7 +595,7 @@ class Side:
                     previous=S_prev, eps=eps, diag_col0=self.m_lo, set_diag=True,
                     restrict_support=self.restrict, count_any=not self.exact_count)
 
-    def leg2(self, S_prev, S_out, eps):
+    def leg2(self, S_prev, S_out, eps, mirror_hook=None):
         """Symmetric iterates: S_out = W . Tt with the fused epilogue.
         Otherwise only the raw product, stored transposed (what W . Tt yields is the
         TRANSPOSE of the wanted block); ``finish`` applies the epilogue after exchange 2."""
@@ -555,6 +606,13 @@ class Side:
             return
         if self.mode != "sparse":
             o.gemm_nt(self.t, self.wd, S_out, self.M, self.M, self.K, epilogue=self._ep(S_prev, eps))
+        elif self.shard_sym and self.sh_stages is not None:
+            ep = self._ep(S_prev, eps)
+            for k, st in enumerate(self.sh_stages):
+                o.spmm_shard_stage(self.graph2, self.recv, S_out, ep, self.rank, self.world, self.sh_send,
+                                   st["off"], st["chunk"], st["tile_lo"], st["tile_hi"], k == 0)
+                if mirror_hook is not None:
+                    mirror_hook(self, st)          # this stage's mirrored tiles leave while the next computes
         elif self.shard_sym:
             o.spmm_shard(self.graph2, self.recv, S_out, self._ep(S_prev, eps), self.rank, self.world,
                          self.sh_send, self.sh_chunk)
@@ -571,7 +629,13 @@ class Side:
 
     def unpack(self, S_out):
         """Half-form leg 2, after the exchange of the mirrored tiles: put the received ones in place."""
-        self.ops.shard_unpack(S_out, self.sh_recv, self.sh_chunk, self.rank, self.world, self.M)
+        if self.sh_stages is None:
+            self.ops.shard_unpack(S_out, self.sh_recv, self.sh_chunk, self.rank, self.world, self.M)
+            return
+        for st in self.sh_stages:
+            if st["chunk"]:
+                self.ops.shard_unpack_stage(S_out, self.sh_recv, st["off"], st["chunk"], self.rank, self.world,
+                                            self.M, st["tile_lo"], st["tile_hi"])
 
     def finish(self, S_prev, S_out, eps):
         """Second half of an update with asymmetric iterates: the stand-alone epilogue."""
@@ -719,7 +783,7 @@ class Solver:
                         all(getattr(o, "supports_blocked", False) and lean_knobs(o) for o in self.ops.values()))
         self.sides = [{r: Side(self.ops[r], sp, r, world.size, self.mode, torch_buffers,
                                getattr(world, "stages", 1), self.blocked,
-                               getattr(world, "symmetric_shards", True))
+                               getattr(world, "symmetric_shards", True), getattr(world, "leg2_stages", 1))
                        for r in world.local_ranks} for sp in specs]
         # similarity matrices: index j -> size n_j; S_j is n_j x (block of n_j), ping-pong
         if self.bipartite:
@@ -798,7 +862,8 @@ class Solver:
         for r in local:
             if device_sum:
                 self.ops[r].counter_tensor()            # (before the epilogue takes its address)
-            self._timed(r, lambda: sides[r].leg2(self.cur[out_idx][r], self.nxt[out_idx][r], eps),
+            mhook = getattr(self.world, "begin_mirror_stage", None) if hook is not None else None
+            self._timed(r, lambda: sides[r].leg2(self.cur[out_idx][r], self.nxt[out_idx][r], eps, mhook),
                         f"leg2.{side_idx}")
             if fused and not device_sum:   # virtual ranks may share one device counter: read it per launch
                 counts.append(self.ops[r].read_changed() if sides[r].Lm else 0)

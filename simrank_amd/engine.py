@@ -453,6 +453,22 @@ class HipOps:
                                             int(world), int(n_rows), self.stream),
               "simrank_shard_unpack")
 
+    def spmm_shard_stage(self, g: Graph, X: Matrix, Y: Matrix, epilogue: dict, rank: int, world: int,
+                         send: Matrix, send_off: int, stage_chunk: int, tile_lo: int, tile_hi: int, zero_counters: bool):
+        """One stage of ``spmm_shard``: column tiles [tile_lo, tile_hi); their packed mirrored tiles go to
+        ``send`` from float offset ``send_off`` on, ``stage_chunk`` floats per destination rank."""
+        ep = self._epilogue(**epilogue)
+        check(self.lib.simrank_spmm_shard_stage(g.handle, X.ptr, X.ld, Y.ptr, Y.ld, C.byref(ep), int(rank), int(world),
+                                                send.ptr + 4 * int(send_off), int(stage_chunk), int(tile_lo),
+                                                int(tile_hi), int(bool(zero_counters)), self.stream),
+              "simrank_spmm_shard_stage")
+
+    def shard_unpack_stage(self, Y: Matrix, recv: Matrix, recv_off: int, stage_chunk: int, rank: int, world: int,
+                           n_rows: int, tile_lo: int, tile_hi: int):
+        check(self.lib.simrank_shard_unpack_stage(Y.ptr, Y.ld, recv.ptr + 4 * int(recv_off), int(stage_chunk), int(rank),
+                                                  int(world), int(n_rows), int(tile_lo), int(tile_hi), self.stream),
+              "simrank_shard_unpack_stage")
+
     def epilogue_apply(self, Q: Matrix, Y: Matrix, n_rows: int, n_cols: int, epilogue: dict):
         """Y = epilogue(Q) element-wise; see simrank_epilogue_apply."""
         ep = self._epilogue(**epilogue)

@@ -154,13 +154,20 @@ class NumpyOps:
         Y.a[:M, :L] = v
 
     def spmm_shard(self, g, X, Y, epilogue, rank, world, send, chunk_floats):
-        """simrank_spmm_shard: only tiles i <= j are computed; what is not written keeps its junk."""
+        T = g.n_rows // world // 32
+        self.spmm_shard_stage(g, X, Y, epilogue, rank, world, send, 0, chunk_floats, 0, T, True)
+
+    def spmm_shard_stage(self, g, X, Y, epilogue, rank, world, send, send_off, chunk_floats, tile_lo, tile_hi,
+                         zero_counters):
+        """simrank_spmm_shard(_stage): only tiles i <= j (of the stage's column tiles) are computed; what is
+        not written keeps its junk; the counters accumulate over the stages of an update."""
         self.calls.append(("spmm_shard",))
         M = g.n_rows
         mb = M // world
         T = mb // 32
         assert mb * world == M and T * 32 == mb and epilogue["diag_col0"] == rank * mb
-        assert chunk_floats >= T * (T - 1) // 2 * 1024
+        slot0 = tile_lo * (tile_lo - 1) // 2
+        assert 0 <= tile_lo < tile_hi <= T and chunk_floats >= (tile_hi * (tile_hi - 1) // 2 - slot0) * 1024
         x = X.a[:g.n_cols, :mb]
         v = (g.pattern @ x) * (g.rowscale * np.float32(epilogue["coef"]))[:, None]
         old_changed = self._changed
@@ -168,12 +175,12 @@ class NumpyOps:
         prev, eps = epilogue.get("previous"), epilogue.get("eps", 0.0)
         moved = (np.abs(v.astype(np.float64) - prev.a[:M, :mb].astype(np.float64)) > eps
                  if prev is not None else np.zeros((M, mb), bool))
-        changed = 0
+        changed = 0 if zero_counters else old_changed
         for h in range(world):
-            chunk = send.flat[h * chunk_floats:(h + 1) * chunk_floats]
+            chunk = send.flat[send_off + h * chunk_floats:send_off + (h + 1) * chunk_floats]
             for i in range(T):
                 rows = slice(h * mb + 32 * i, h * mb + 32 * i + 32)
-                for j in range(i, T):
+                for j in range(max(i, tile_lo), tile_hi):
                     cols = slice(32 * j, 32 * j + 32)
                     Y.a[rows, cols] = v[rows, cols]
                     changed += int(moved[rows, cols].sum()) * (2 if i < j else 1)
@@ -182,21 +189,24 @@ class NumpyOps:
                     if h == rank:
                         Y.a[rank * mb + 32 * j: rank * mb + 32 * j + 32, 32 * i:32 * i + 32] = v[rows, cols].T
                     else:
-                        slot = j * (j - 1) // 2 + i
+                        slot = j * (j - 1) // 2 + i - slot0
                         chunk[slot * 1024:(slot + 1) * 1024] = v[rows, cols].T.reshape(-1)
         self._changed = changed if prev is not None else old_changed
 
     def shard_unpack(self, Y, recv, chunk_floats, rank, world, n_rows):
+        self.shard_unpack_stage(Y, recv, 0, chunk_floats, rank, world, n_rows, 0, n_rows // world // 32)
+
+    def shard_unpack_stage(self, Y, recv, recv_off, chunk_floats, rank, world, n_rows, tile_lo, tile_hi):
         self.calls.append(("shard_unpack",))
         mb = n_rows // world
-        T = mb // 32
+        slot0 = tile_lo * (tile_lo - 1) // 2
         for h in range(world):
             if h == rank:
                 continue
-            chunk = recv.flat[h * chunk_floats:(h + 1) * chunk_floats]
-            for j in range(T):
+            chunk = recv.flat[recv_off + h * chunk_floats:recv_off + (h + 1) * chunk_floats]
+            for j in range(tile_lo, tile_hi):
                 for i in range(j):
-                    slot = j * (j - 1) // 2 + i
+                    slot = j * (j - 1) // 2 + i - slot0
                     Y.a[h * mb + 32 * j: h * mb + 32 * j + 32, 32 * i:32 * i + 32] = \
                         chunk[slot * 1024:(slot + 1) * 1024].reshape(32, 32)
 

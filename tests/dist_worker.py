@@ -27,7 +27,9 @@ def main(argv):
         from simrank_amd import synth
         from simrank_amd.driver import LocalWorld
         cls = name.split(":")[1]
-        frame = synth.powerlaw_directed(64 * dist.get_world_size(), 5, 3)
+        # (256 nodes per rank = 8 column tiles when the exchange is staged: leg 2 and its second all-to-all
+        # are then cut into stages too, Side.sh_stages)
+        frame = synth.powerlaw_directed((256 if stages > 1 else 64) * dist.get_world_size(), 5, 3)
         kw = dict(weighted=True) if cls.endswith("PP") else {}
         one = NumpyOps()
         want = getattr(SRA, cls)().fit(frame, verbose=False, world=LocalWorld(1), mode="sparse",

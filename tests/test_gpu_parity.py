@@ -94,6 +94,11 @@ def test_logical_shards_are_bitwise_equal_to_one_shard():
         np.testing.assert_allclose(half.values, one.values, rtol=1e-6, atol=1e-30)
         # (tiles i == j of two different shards are computed on both sides: 1/4 of them at P = 8)
         assert (half.values == half.values.T).mean() > 0.7
+        # the half form in stages of column tiles (how exchange 2 is overlapped on a real node): same bits
+        if 1024 // (32 * world) >= 4:
+            staged = SRA.SimRank().fit(df, iterations=6, eps=0, verbose=False, mode="sparse",
+                                       world=LocalWorld(world, leg2_stages=3))
+            assert np.array_equal(staged.values, half.values)
 
 
 def test_runs_are_bitwise_reproducible():

@@ -19,9 +19,9 @@ import itertools
 huges = [int(x) for x in os.environ.get('HUGE', '512').split(',')]
 dmins = [int(x) for x in os.environ.get('DMIN', '4').split(',')]
 for huge, dmin, P in itertools.product(huges, dmins, (1, 8) if len(huges) > 1 else (1, 2, 4, 8)):
-    for half in ((False,) if P == 1 else (False, True)):
+    for half, st2 in (((False, 1),) if P == 1 else ((False, 1), (True, 1), (True, int(os.environ.get("LEG2_STAGES", "2"))))):
         ops.set_tuning(huge=huge, dense_min=dmin)
-        s = Solver(lambda r: ops, LocalWorld(P, symmetric_shards=half),
+        s = Solver(lambda r: ops, LocalWorld(P, symmetric_shards=half, leg2_stages=st2),
                    [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
         s.reset()
         s.step(0.0)
@@ -34,7 +34,7 @@ for huge, dmin, P in itertools.product(huges, dmins, (1, 8) if len(huges) > 1 el
         xfer = 4.0 * n * n / P * (P - 1) / P
         form = "full form"
         if half and s.sides[0][0].shard_sym:
-            form = "half form"
+            form = "half form" + (f" in {len(s.sides[0][0].sh_stages)} stages" if s.sides[0][0].sh_stages else "")
             xfer += 4.0 * s.sides[0][0].sh_chunk * (P - 1)
         print(f"{w} huge={huge} dense_min={dmin} P={P} leg 2 in its {form}: per-rank leg1 {l1:.3f} ms, "
               f"leg2 {l2:.3f} ms, unpack {un:.3f} ms -> compute {l1 + l2 + un:.3f} ms/iteration; "

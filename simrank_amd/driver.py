@@ -184,7 +184,7 @@ class TorchWorld:
     GPU box; "gloo" in the CPU tests)."""
 
     def __init__(self, group=None, stages: int = 0, stage_single_rank: bool = False,
-                 handback: str = "root", symmetric_shards="auto"):
+                 handback: str = "root", symmetric_shards="auto", measure_single_rank: bool = False):
         """``stages``: leg 1 is cut into that many column slices, each exchanged by its own
         all_to_all_single as soon as its kernel has finished, so the transfers over xGMI overlap
         the remaining leg-1 kernels (1 = one exchange after the whole leg; 0 = by the width of a
@@ -214,6 +214,8 @@ class TorchWorld:
         self.symmetric_shards = (symmetric_shards if symmetric_shards in ("auto", "force")
                                  else bool(symmetric_shards))
         self.form_measured = None        # filled by resolve_shard_form: {"half_ms", "full_ms", "chosen"}
+        # (tests: run the measurement in a one-rank world too — how its RCCL calls are exercised on one GPU)
+        self.measure_single_rank = bool(measure_single_rank)
         self.rank = dist.get_rank(group)
         self.local_ranks = [self.rank]
         self.is_root = self.rank == 0
@@ -675,7 +677,8 @@ def resolve_shard_form(make_ops, world, specs, mode, reorder=True):
     if getattr(world, "symmetric_shards", None) != "auto":
         return
     n_min = min(s.csr.n_rows for s in specs)
-    applies = (world.size > 1 and mode in ("auto", "sparse") and all(s.symmetric for s in specs) and
+    single = world.size == 1 and getattr(world, "measure_single_rank", False)
+    applies = ((world.size > 1 or single) and mode in ("auto", "sparse") and all(s.symmetric for s in specs) and
                all(s.csr.n_rows % (32 * world.size) == 0 for s in specs))
     if not applies or n_min < MEASURE_FORM_FROM_N:
         world.symmetric_shards = world.size >= HALF_FORM_FROM
@@ -683,7 +686,7 @@ def resolve_shard_form(make_ops, world, specs, mode, reorder=True):
         return
     times = {}
     for half in (True, False):
-        world.symmetric_shards = half
+        world.symmetric_shards = ("force" if single else True) if half else False
         solver = Solver(make_ops, world, specs, mode, reorder)
         solver.reset()
         solver.step(0.0)
@@ -695,9 +698,9 @@ def resolve_shard_form(make_ops, world, specs, mode, reorder=True):
         times[half] = world.max_float((time.perf_counter() - t0) / 2)
         solver.release()
         del solver
-    world.symmetric_shards = times[True] < times[False]
+    world.symmetric_shards = (("force" if single else True) if times[True] < times[False] else False)
     world.form_measured = {"half_ms": times[True] * 1e3, "full_ms": times[False] * 1e3,
-                           "chosen": "half" if world.symmetric_shards else "full"}
+                           "chosen": "half" if times[True] < times[False] else "full"}
 
 
 # --------------------------------------------------------------------------------------

@@ -63,6 +63,15 @@ def main():
             np.testing.assert_allclose(got.values, want.values, rtol=2e-6, atol=1e-30)
     finally:
         drv.Solver.__init__ = orig
+    # the measured choice between the two forms of leg 2 (driver.resolve_shard_form): both solvers, the barriers
+    # and the MAX all-reduce of the times over RCCL; whichever form wins, the values are the one-rank values
+    drv.MEASURE_FORM_FROM_N = 0
+    world = TorchWorld(stages=2, stage_single_rank=True, handback="all", measure_single_rank=dist.get_world_size() == 1)
+    got = SRA.SimRankPP().fit(df, iterations=4, eps=0, verbose=False, mode="sparse", world=world)
+    m = world.form_measured
+    assert m and m["half_ms"] > 0 and m["full_ms"] > 0 and m["chosen"] in ("half", "full"), m
+    np.testing.assert_allclose(got.values, want.values, rtol=2e-6, atol=1e-30)
+    drv.MEASURE_FORM_FROM_N = 4096
     dist.barrier()
     print("RCCL WORLD ok", flush=True)
     dist.destroy_process_group()

@@ -377,7 +377,7 @@ SIMRANK_API int simrank_plan_destroy(simrank_plan* p);
  *                 column joins a 128-row block's dense set when fuse_min (3) of its rows reference it, a
  *                 block keeps its set when it makes fuse_steps (8) 16-column steps; fuse 0 = the
  *                 dense_tiles + gather launches of round 2
- *      "fuse_max_rows" operands with more rows than this (49152) keep the two-launch leg 1
+ *      "fuse_max_rows" operands with more rows than this (default 2^20: never) keep the two-launch leg 1
  *      "fuse_group" up to this many (1..4) consecutive blocks without a set share a workgroup
  *      "fuse_unit"  sets of more 64-column groups than this are cut into several workgroups whose
  *                 partial sums meet in memory (off by default: 1 << 20)

@@ -46,6 +46,8 @@ namespace simrank {
 constexpr int kFB = 128;          // rows per block
 constexpr int kTS = 132;          // floats per column of the LDS tile (32 columns x 128 rows, transposed)
 constexpr int kSub = 4;            // blocks a unit without a dense set may hold
+constexpr int kMinUnits = 160;      // units per panel below which blocks are grouped less
+constexpr int kGroupEntries = 6144; // gathered entries a unit of several set-less blocks may hold
 constexpr int kMaxRem = 256;      // a row whose remainder would be longer sends all its columns to the dense set
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -533,7 +535,7 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
     std::vector<int32_t> blk_gmeta(size_t(nblk) * 32 * 4 * 2, 0);
     std::vector<uint16_t> cnt(size_t(K), 0);
     std::vector<int32_t> kpos(size_t(K), -1), touched, set;
-    std::vector<int64_t> cost(size_t(nblk), 0);
+    std::vector<int64_t> cost(size_t(nblk), 0), blk_rem(size_t(nblk), 0);
     std::vector<int32_t> rem[kFB];
     int64_t covered = 0, steps_total = 0, r_nnz = 0;
     for (int64_t b = 0; b < nblk; ++b) {
@@ -586,6 +588,7 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
                 }
             }
             r_nnz += (int64_t)rem[rr].size();
+            blk_rem[size_t(b)] += (int64_t)rem[rr].size();
         }
         int order[kFB];
         std::iota(order, order + nr, 0);
@@ -645,24 +648,37 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
     // first gathers ... barrier -> store) would outweigh their gathers — so up to fuse_group consecutive
     // ones share a unit, their rounds one stream per wave.  Launch order by cost, heaviest first.
     const int64_t unit_q = std::max<int64_t>(4, g->tun.fuse_unit);
-    const int64_t group = std::min<int64_t>(kSub, std::max<int64_t>(1, g->tun.fuse_group));
     struct Unit { int32_t b0, nsub, q0, nq, k, nb; int64_t cost; };
     std::vector<Unit> ulist;
-    for (int64_t b = 0; b < nblk;) {
-        const int32_t q0 = blk_quad0[size_t(b)], nqb = blk_quad0[size_t(b) + 1] - q0;
-        if (nqb > 0) {
-            const int32_t nb = (int32_t)std::max<int64_t>(1, (nqb + unit_q - 1) / unit_q);
-            for (int32_t k = 0; k < nb; ++k) {
-                const int32_t lo = (int32_t)(int64_t(nqb) * k / nb), hi = (int32_t)(int64_t(nqb) * (k + 1) / nb);
-                ulist.push_back({(int32_t)b, 1, q0 + lo, hi - lo, k, nb, cost[size_t(b)]});
+    // (a panel should offer an XCD more workgroups than it has slots — 32 CUs x 4 — or several panels are
+    // in flight at once and share its L2: with too few units the grouping is halved; N = 8192, 64 blocks:
+    // groups of four left 16 units per panel and eight 1 MiB slices in a 4 MiB L2, leg 1 +8 %)
+    for (int64_t group = std::min<int64_t>(kSub, std::max<int64_t>(1, g->tun.fuse_group));; group /= 2) {
+        ulist.clear();
+        for (int64_t b = 0; b < nblk;) {
+            const int32_t q0 = blk_quad0[size_t(b)], nqb = blk_quad0[size_t(b) + 1] - q0;
+            if (nqb > 0) {
+                const int32_t nb = (int32_t)std::max<int64_t>(1, (nqb + unit_q - 1) / unit_q);
+                for (int32_t k = 0; k < nb; ++k) {
+                    const int32_t lo = (int32_t)(int64_t(nqb) * k / nb), hi = (int32_t)(int64_t(nqb) * (k + 1) / nb);
+                    ulist.push_back({(int32_t)b, 1, q0 + lo, hi - lo, k, nb, cost[size_t(b)]});
+                }
+                ++b;
+            } else {
+                // (at most kGroupEntries gathered entries per unit: blocks of an Erdos-Renyi pattern — every
+                // row its 32 entries, no set — are work enough alone; four of them in one workgroup left half
+                // of an XCD's workgroup slots empty: leg 1 +47 % at N = 32768, mean degree 32)
+                int64_t e = b + 1, c = cost[size_t(b)], entries = blk_rem[size_t(b)];
+                while (e < nblk && e - b < group && blk_quad0[size_t(e) + 1] == blk_quad0[size_t(e)] &&
+                       entries + blk_rem[size_t(e)] <= kGroupEntries) {
+                    entries += blk_rem[size_t(e)];
+                    c += cost[size_t(e++)];
+                }
+                ulist.push_back({(int32_t)b, (int32_t)(e - b), q0, 0, 0, 1, c});
+                b = e;
             }
-            ++b;
-        } else {
-            int64_t e = b + 1, c = cost[size_t(b)];
-            while (e < nblk && e - b < group && blk_quad0[size_t(e) + 1] == blk_quad0[size_t(e)]) c += cost[size_t(e++)];
-            ulist.push_back({(int32_t)b, (int32_t)(e - b), q0, 0, 0, 1, c});
-            b = e;
         }
+        if (group <= 1 || (int64_t)ulist.size() >= kMinUnits) break;
     }
     std::stable_sort(ulist.begin(), ulist.end(), [](const Unit& x, const Unit& y) {
         return x.cost != y.cost ? x.cost > y.cost : (x.b0 != y.b0 ? x.b0 < y.b0 : x.k < y.k);

@@ -1740,8 +1740,7 @@ static int spmm_impl(const simrank_graph* g, const float* X, int64_t ldx, int64_
     const bool want_sym = ep && ep->symmetric && T.triangle && vec_ok && !transpose_out &&
                           n_cols_x == g->n_rows && ep->diag_col0 == 0 && g->n_rows >= 64;
     // leg 1 of a panel-blocked update: one launch, matrix cores + gathers on the same panel slice (fused.hip)
-    // (measured: -13 % at K = 32768 where a panel's slice is the size of an XCD's L2, +7 % at K = 65536 where it is
-    // twice that and the gather kernel's 8 waves per SIMD hide the misses better: fuse_max_rows)
+    // (measured against the two-launch leg: -13 % at K = 32768 power-law, -10 % Erdos-Renyi, -6 % at K = 65536)
     if (blocked && transpose_out && g->fused && T.fuse && vec_ok && T.dense_terms == 3 && g->n_cols <= T.fuse_max_rows &&
         (x_rows_pad + 1) * 128 < (int64_t(1) << 31))
         return launch_fused_trans(g, X, x_rows_pad, n_cols_x, Y, y_rows_pad, st);

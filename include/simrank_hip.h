@@ -287,6 +287,29 @@ SIMRANK_API int simrank_permute_layout(const void* src, int64_t ld_src, int64_t 
                                        int64_t n_rows, int64_t n_cols, const int32_t* row_idx,
                                        const int32_t* col_idx, int32_t elem_bytes, void* stream);
 
+/* ---- FP16 STORAGE (round 3; BASELINE.json config 5's reduced-precision mode, both `.dot`s of
+ *      SimRank.py:361 and the element-wise lines :315-316, :362, :453 on matrices held in fp16).
+ *      NEVER the default and outside the 1e-5 parity bar: S, the transposed product and the previous
+ *      iterate are IEEE binary16, panel-blocked with 64-COLUMN panels (element (r, c) at
+ *      ((c >> 6) * rows_pad + r) * 64 + (c & 63): a row segment is one 128-byte line, as in the f32
+ *      layout, and serves twice the columns); sums and the epilogue are f32, a value is rounded (nearest
+ *      even) once, when stored; the convergence count compares the rounded values.  One GPU, symmetric
+ *      iterates, graphs created with tuning "fuse" = 1 (half.hip).
+ *      simrank_spmm_blocked_h16: transpose_out = 1 and epilogue = NULL is leg 1 (Y = transposed
+ *      product); transpose_out = 0 with an epilogue (symmetric = 1, diag_col0 = 0) is leg 2.  The
+ *      epilogue's evidence counts and prior keep the f32 era's 32-column panels of aux_rows_pad rows;
+ *      its `previous` is an fp16 matrix laid out like Y.
+ *      simrank_widen_blocked_h16 converts to the f32 panel-blocked layout every hand-back entry reads. */
+SIMRANK_API int simrank_fill_identity_blocked_h16(void* S, int64_t n_rows, int64_t n_cols,
+                                                  int64_t rows_pad, int64_t col0, void* stream);
+SIMRANK_API int simrank_spmm_blocked_h16(const simrank_graph* g, const void* X, int64_t x_rows_pad,
+                                         int64_t n_cols_x, void* Y, int64_t y_rows_pad,
+                                         int32_t transpose_out, const simrank_epilogue* epilogue,
+                                         int64_t aux_rows_pad, void* stream);
+SIMRANK_API int simrank_widen_blocked_h16(const void* src, int64_t src_rows_pad, float* dst,
+                                          int64_t dst_rows_pad, int64_t n_rows, int64_t n_cols,
+                                          void* stream);
+
 /* ---- dense MFMA path (second `.dot(G.T)` of SimRank.py:139 when W really is dense) -- */
 /* Wd[a*ld + i] = rowscale[a] where (a,i) is stored, 0 elsewhere */
 SIMRANK_API int simrank_graph_densify(const simrank_graph* g, float* Wd, int64_t ld, void* stream);

@@ -169,6 +169,8 @@ struct simrank_fused_plan {
 };
 
 namespace simrank {
+constexpr int kFB = 128;          // rows per block of the one-launch plan
+constexpr int kSub = 4;           // blocks a unit without a dense set may hold
 void free_fused_plan(simrank_fused_plan* p);
 int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col, const float* rowscale);
 int launch_fused_trans(const simrank_graph* g, const float* X, int64_t x_rows_pad, int64_t L, float* Y,

@@ -43,9 +43,7 @@
 
 namespace simrank {
 
-constexpr int kFB = 128;          // rows per block
 constexpr int kTS = 132;          // floats per column of the LDS tile (32 columns x 128 rows, transposed)
-constexpr int kSub = 4;            // blocks a unit without a dense set may hold
 constexpr int kMinUnits = 64;       // units per panel below which blocks are grouped less
 constexpr int kGroupEntries = 6144; // gathered entries a unit of several set-less blocks may hold
 constexpr int kMaxRem = 256;      // a row whose remainder would be longer sends all its columns to the dense set

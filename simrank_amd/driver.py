@@ -416,6 +416,7 @@ class SideSpec:
     lbd: float = 0.0
     symmetric: bool = True       # False: a non-symmetric prior makes the iterates asymmetric
     dense_terms: int = 3         # operand terms of the matrix-core part (3 exact; 1 = one fp16 term, config 5)
+    storage: str = "f32"         # "fp16": S and the transposed product held in fp16 (config 5; one rank, gather legs)
 
 
 class Side:
@@ -423,6 +424,7 @@ class Side:
                  stages: int = 1, blocked: bool = False, shard_symmetric: bool = True, leg2_stages: int = 1):
         self.ops, self.spec, self.rank, self.world, self.mode = ops, spec, rank, world, mode
         self.blocked = blocked         # single rank, gather legs: every matrix panel-blocked
+        self.sdtype = np.float16 if spec.storage == "fp16" else np.float32    # S and the transposed product
         csr = spec.csr
         if stages == 0:
             stages = auto_stages(csr.n_cols, world)
@@ -528,7 +530,7 @@ class Side:
         x = Xfer(o, self.rank, None, None, ncols, col_lo, col_dim, self.M, self.mb, self.Lm)
         if self.world == 1 and not torch_buffers:
             # one rank: recv aliases send (pitched rows, or panel-blocked with the solver's matrices)
-            x.send = x.recv = (o.matrix(col_dim, self.M, blocked=True) if self.blocked
+            x.send = x.recv = (o.matrix(col_dim, self.M, self.sdtype, blocked=True) if self.blocked
                                else o.matrix(col_dim, self.M))
             return x
         x.pad = row_pad(self.mb)
@@ -784,6 +786,18 @@ class Solver:
         # DESIGN.md §4.9).  Sharded ranks hold N x N/P blocks whose rows are close together already.
         self.blocked = (world.size == 1 and not torch_buffers and self.mode == "sparse" and
                         all(getattr(o, "supports_blocked", False) and lean_knobs(o) for o in self.ops.values()))
+        # fp16 storage (SideSpec.storage): the panel-blocked single-rank gather solver only, symmetric iterates
+        self.storage = specs[0].storage
+        if any(s.storage != self.storage for s in specs):
+            raise ValueError("every side must use the same storage precision")
+        if self.storage == "fp16":
+            if not (self.blocked and all(s.symmetric for s in specs) and
+                    all(getattr(o, "supports_half_storage", False) for o in self.ops.values())):
+                raise ValueError("storage_precision='fp16' needs one GPU, the gather legs (mode 'sparse' or 'auto' "
+                                 "choosing it), default kernel knobs and a symmetric prior")
+        elif self.storage != "f32":
+            raise ValueError(f"storage {self.storage!r}")
+        self.sdtype = np.float16 if self.storage == "fp16" else np.float32
         self.sides = [{r: Side(self.ops[r], sp, r, world.size, self.mode, torch_buffers,
                                getattr(world, "stages", 1), self.blocked,
                                getattr(world, "symmetric_shards", True), getattr(world, "leg2_stages", 1))
@@ -799,8 +813,8 @@ class Solver:
             for r in world.local_ranks:
                 lo, hi = partition(n, world.size, r)
                 kw = dict(blocked=True) if self.blocked else {}
-                c[r] = self.ops[r].matrix(n, hi - lo, **kw)
-                x[r] = self.ops[r].matrix(n, hi - lo, **kw)
+                c[r] = self.ops[r].matrix(n, hi - lo, self.sdtype, **kw)
+                x[r] = self.ops[r].matrix(n, hi - lo, self.sdtype, **kw)
             self.cur.append(c)
             self.nxt.append(x)
         self.events = None
@@ -931,7 +945,9 @@ class Solver:
         blocks = {}
         for r in self.world.local_ranks:
             o, src = self.ops[r], self.cur[j][r]
-            tmp = None
+            tmp = wide = None
+            if src.dtype == np.float16:
+                src = wide = o.widen(src)
             if self.blocked:
                 # out of the panel-blocked layout and the solver's node order in one pass
                 rows = None if inv is None else self._index_vector(r, ("inv", j), inv)
@@ -945,8 +961,9 @@ class Solver:
                 o.permute(src, self.nxt[j][r], rows, rows if self.world.size == 1 else None)
                 src = self.nxt[j][r]
             blocks[r] = o.download_f64(src)
-            if tmp is not None:
-                tmp.free()
+            for m in (tmp, wide):
+                if m is not None:
+                    m.free()
         full = self.world.gather_columns(blocks, self.n[j], self.n[j])
         if inv is not None and self.world.size > 1:
             full = np.ascontiguousarray(full[:, inv])
@@ -985,7 +1002,9 @@ class Solver:
                 ids = None
                 if self.order[j] is not None:      # report (and break ties by) the caller's ids
                     ids = self._index_vector(r, ("ids", j), self.order[j][lo:hi])
-                src, tmp = self.cur[j][r], None
+                src, tmp, wide = self.cur[j][r], None, None
+                if src.dtype == np.float16:
+                    src = wide = self.ops[r].widen(src)
                 if getattr(src, "blocked", False):
                     # a row of a panel-blocked matrix is 128-byte pieces 4 MiB apart: the k selection
                     # rounds re-read it, so they run on a row-major copy (one pass)
@@ -994,8 +1013,9 @@ class Solver:
                     src = tmp
                 per_rank[r] = self.ops[r].topk_rows(src, min(k, hi - lo), col0=lo,
                                                     exclude_diag=exclude_diag, col_ids=ids)
-                if tmp is not None:
-                    tmp.free()
+                for m in (tmp, wide):
+                    if m is not None:
+                        m.free()
             else:
                 per_rank[r] = (np.full((n, 1), -1, np.int32), np.zeros((n, 1), np.float32))
         parts = self.world.gather_list(per_rank)

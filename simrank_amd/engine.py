@@ -24,7 +24,8 @@ class Matrix:
     """Device matrix (float32, uint8 or int32): row-major with a leading dimension, or
     PANEL-BLOCKED (``blocked=True``): 32-column panels of ``rows_pad`` rows, element (r, c) at
     ((c >> 5) * rows_pad + r) * 32 + (c & 31) — the layout the single-rank solver iterates in
-    (include/simrank_hip.h, "PANEL-BLOCKED operands")."""
+    (include/simrank_hip.h, "PANEL-BLOCKED operands").  A float16 matrix exists only panel-blocked and
+    with 64-column panels (a row segment is one 128-byte line either way; "FP16 STORAGE")."""
 
     def __init__(self, ops, rows: int, cols: int, dtype, ld: int | None = None,
                  external=None, blocked: bool = False):
@@ -38,10 +39,11 @@ class Matrix:
             assert external is None and ld is None
             # (+8 rows: panels are not a power of two apart, and every panel starts 16-byte aligned)
             self.rows_pad = -(-max(1, self.rows) // 8) * 8 + 8
-            self.panels = -(-max(1, self.cols) // 32)
-            self.ld = 32
-            self.nbytes = self.panels * self.rows_pad * 32 * self.dtype.itemsize
+            self.ld = 64 if self.dtype == np.float16 else 32
+            self.panels = -(-max(1, self.cols) // self.ld)
+            self.nbytes = self.panels * self.rows_pad * self.ld * self.dtype.itemsize
         else:
+            assert self.dtype != np.float16, "float16 matrices are panel-blocked"
             self.rows_pad = 0
             self.ld = int(ld if ld is not None else ops.pitch(cols, self.dtype))
             self.nbytes = max(1, self.rows) * self.ld * self.dtype.itemsize
@@ -152,6 +154,7 @@ class HipOps:
 
     name = "hip"
     supports_blocked = True      # the solver may keep its matrices panel-blocked (Matrix.blocked)
+    supports_half_storage = True      # fp16-held matrices on 64-column panels (half.hip)
     supports_shard_symmetric = True   # sharded leg 2 in its half form (spmm_shard / shard_unpack)
 
     def __init__(self, device: int | None = None, stream: int | None = None):
@@ -251,6 +254,14 @@ class HipOps:
     def upload(self, m: Matrix, host: np.ndarray):
         host = np.asarray(host)
         assert host.shape == (m.rows, m.cols), (host.shape, m.rows, m.cols)
+        if m.dtype == np.float16:           # laid out on the host (tests and warm starts: small)
+            buf = np.zeros((m.panels, m.rows_pad, 64), dtype=np.float16)
+            for pnl in range(m.panels):
+                w = min(64, m.cols - 64 * pnl)
+                buf[pnl, :m.rows, :w] = host[:, 64 * pnl:64 * pnl + w]
+            check(self.lib.simrank_memcpy_h2d(m.ptr, buf.ctypes.data, buf.nbytes, self.stream),
+                  "simrank_memcpy_h2d")
+            return
         if m.blocked:                       # through a row-major copy on the device
             tmp = self.matrix(m.rows, m.cols, m.dtype)
             self.upload(tmp, host)
@@ -263,8 +274,21 @@ class HipOps:
         check(self.lib.simrank_memcpy_h2d(m.ptr, buf.ctypes.data, buf.nbytes, self.stream),
               "simrank_memcpy_h2d")
 
+    def widen(self, src: Matrix) -> Matrix:
+        """float32 panel-blocked copy of a float16 matrix (what the hand-back entries read)."""
+        assert src.dtype == np.float16 and src.blocked
+        dst = self.matrix(src.rows, src.cols, blocked=True)
+        check(self.lib.simrank_widen_blocked_h16(src.ptr, src.rows_pad, dst.ptr, dst.rows_pad, src.rows, src.cols,
+                                                 self.stream), "simrank_widen_blocked_h16")
+        return dst
+
     def download(self, m: Matrix) -> np.ndarray:
         """Device matrix -> host array of its own dtype."""
+        if m.dtype == np.float16:
+            wide = self.widen(m)
+            out = self.download(wide).astype(np.float16)       # (exact: every value is an fp16 number)
+            wide.free()
+            return out
         if m.blocked:
             tmp = self.matrix(m.rows, m.cols, m.dtype)
             self.permute(m, tmp)
@@ -385,7 +409,10 @@ class HipOps:
         return g
 
     def fill_identity(self, S: Matrix, col0: int):
-        if S.rows and S.cols and S.blocked:
+        if S.rows and S.cols and S.dtype == np.float16:
+            check(self.lib.simrank_fill_identity_blocked_h16(S.ptr, S.rows, S.cols, S.rows_pad, col0,
+                                                             self.stream), "simrank_fill_identity_blocked_h16")
+        elif S.rows and S.cols and S.blocked:
             check(self.lib.simrank_fill_identity_blocked(S.ptr, S.rows, S.cols, S.rows_pad, col0,
                                                          self.stream), "simrank_fill_identity_blocked")
         elif S.rows and S.cols:
@@ -420,6 +447,21 @@ class HipOps:
         column sub-block of X (first column), ``y_offset`` an element offset into Y."""
         n_cols = X.cols if n_cols is None else n_cols
         ep = self._epilogue(**epilogue) if epilogue is not None else None
+        if X.dtype == np.float16:
+            # fp16 storage: both legs on 64-column panels (half.hip); evidence and prior keep their f32-era layout
+            assert Y.dtype == np.float16 and not x_col0 and not y_offset and n_cols == X.cols
+            aux_pad = 0
+            for name in ("evidence", "apriori"):
+                m = (epilogue or {}).get(name)
+                assert m is None or m.blocked, name
+                aux_pad = m.rows_pad if m is not None else aux_pad
+            prev = (epilogue or {}).get("previous")
+            assert prev is None or (prev.dtype == np.float16 and prev.rows_pad == Y.rows_pad)
+            check(self.lib.simrank_spmm_blocked_h16(g.handle, X.ptr, X.rows_pad, n_cols, Y.ptr, Y.rows_pad,
+                                                    1 if transpose_out else 0,
+                                                    C.byref(ep) if ep is not None else None, aux_pad,
+                                                    self.stream), "simrank_spmm_blocked_h16")
+            return
         if X.blocked:
             assert Y.blocked and not x_col0 and not y_offset and n_cols == X.cols
             for name in ("evidence", "apriori", "previous"):

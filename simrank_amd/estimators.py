@@ -44,14 +44,20 @@ _precision_now = threading.local()          # per thread: two threads may fit at
 
 
 @contextlib.contextmanager
-def _precision(dense_precision):
+def _precision(dense_precision, storage_precision="f32"):
     """``fit(dense_precision=...)``: "f32" (default) keeps the matrix-core part of the legs exact
     (operand split into three bf16 terms); "fp16" rounds its operand to one fp16 term — BASELINE.json
-    config 5's reduced-precision dense leg: faster, NOT within the 1e-5 parity bar."""
+    config 5's reduced-precision dense leg: faster, NOT within the 1e-5 parity bar.
+    ``fit(storage_precision=...)``: "f32" (default), or "fp16": the similarity matrices and the
+    intermediate product are HELD in fp16 (f32 sums and epilogue, one rounding per stored value; one GPU,
+    gather mode, symmetric iterates) — half the bytes and half the gathered lines per update, the
+    reduced-precision mode that pays on config 5; NOT within the parity bar either."""
     if dense_precision not in _DENSE_TERMS:
         raise ValueError(f"dense_precision must be one of {sorted(_DENSE_TERMS)}, not {dense_precision!r}")
-    stack = _precision_now.__dict__.setdefault("stack", ["f32"])
-    stack.append(dense_precision)
+    if storage_precision not in ("f32", "fp16"):
+        raise ValueError(f"storage_precision must be 'f32' or 'fp16', not {storage_precision!r}")
+    stack = _precision_now.__dict__.setdefault("stack", [("f32", "f32")])
+    stack.append((dense_precision, storage_precision))
     try:
         yield
     finally:
@@ -62,9 +68,10 @@ def _make_solver(ops_factory, device, world, specs, mode):
     """The solver with the graphs created at the precision asked for: it travels in the specs and is set
     per graph object (simrank_graph_set_dense_terms), not through the process-wide tuning defaults."""
     factory = ops_factory or _default_ops_factory(device)
-    terms = _DENSE_TERMS[_precision_now.__dict__.get("stack", ["f32"])[-1]]
-    if terms != 3:
-        specs = [dataclasses.replace(s, dense_terms=terms) for s in specs]
+    dense, storage = _precision_now.__dict__.get("stack", [("f32", "f32")])[-1]
+    terms = _DENSE_TERMS[dense]
+    if terms != 3 or storage != "f32":
+        specs = [dataclasses.replace(s, dense_terms=terms, storage=storage) for s in specs]
     return Solver(factory, world, specs, mode)
 
 
@@ -171,9 +178,9 @@ class SimRank(object):
 
     def fit(self, data, C=0.8, weighted=False, from_node_column="from", to_node_column="to",
             weight_column="weight", iterations=100, eps=1e-4, verbose=True, *,
-            mode="auto", device=None, world=None, top_k=None, dense_precision="f32",
+            mode="auto", device=None, world=None, top_k=None, dense_precision="f32", storage_precision="f32",
             _ops_factory=None):
-        with _precision(dense_precision):
+        with _precision(dense_precision, storage_precision):
             csr = self._create_graph(data, weighted, from_node_column, to_node_column, weight_column)
             solver, k = _solve([self._side(csr, C)], iterations, eps, verbose, mode, device, world,
                                _ops_factory)
@@ -231,9 +238,9 @@ class SimRankPP(SimRank):
 
     def fit(self, data, C=0.8, weighted=False, from_node_column="from", to_node_column="to",
             weight_column="weight", iterations=100, eps=1e-4, verbose=True, *,
-            mode="auto", device=None, world=None, top_k=None, dense_precision="f32",
+            mode="auto", device=None, world=None, top_k=None, dense_precision="f32", storage_precision="f32",
             _ops_factory=None):
-        with _precision(dense_precision):
+        with _precision(dense_precision, storage_precision):
             return self._fit_pp(data, C, weighted, from_node_column, to_node_column, weight_column,
                                 iterations, eps, verbose, mode, device, world, _ops_factory,
                                 top_k=top_k)
@@ -248,8 +255,8 @@ class AprioriSimRank(SimRankPP):
     def fit(self, data, AprioriSim, C=0.8, lbd=0.5, weighted=False, from_node_column="from",
             to_node_column="to", weight_column="weight", iterations=100, eps=1e-4,
             verbose=True, *, mode="auto", device=None, world=None, top_k=None,
-            dense_precision="f32", _ops_factory=None):
-        with _precision(dense_precision):
+            dense_precision="f32", storage_precision="f32", _ops_factory=None):
+        with _precision(dense_precision, storage_precision):
             if not isinstance(AprioriSim, np.ndarray):
                 # the reference fails at np.fill_diagonal for anything but an ndarray
                 raise AttributeError(f"'{type(AprioriSim).__name__}' object has no attribute 'flat'")
@@ -302,8 +309,8 @@ class BipartiteSimRank(object):
     def fit(self, data, C1=0.8, C2=0.8, weighted=False, node_group1_column="user",
             node_group2_column="item", weight_column="weight", iterations=100, eps=1e-4,
             verbose=True, *, mode="auto", device=None, world=None, strict_reference=True,
-            top_k=None, dense_precision="f32", _ops_factory=None):
-        with _precision(dense_precision):
+            top_k=None, dense_precision="f32", storage_precision="f32", _ops_factory=None):
+        with _precision(dense_precision, storage_precision):
             g12, g21 = self._create_graph(data, weighted, node_group1_column, node_group2_column,
                                           weight_column)
             specs = [SideSpec(g12, g12.rowscale, C1), SideSpec(g21, g21.rowscale, C2)]
@@ -371,8 +378,8 @@ class BipartiteSimRankPP(SimRankPP):
     def fit(self, data, C1=0.8, C2=0.8, weighted=False, node_group1_column="user",
             node_group2_column="item", weight_column="weight", iterations=100, eps=1e-4,
             verbose=True, *, mode="auto", device=None, world=None, strict_reference=True,
-            top_k=None, dense_precision="f32", _ops_factory=None):
-        with _precision(dense_precision):
+            top_k=None, dense_precision="f32", storage_precision="f32", _ops_factory=None):
+        with _precision(dense_precision, storage_precision):
             return self._fit_bpp(data, C1, C2, weighted, node_group1_column, node_group2_column,
                                  weight_column, iterations, eps, verbose, mode, device, world,
                                  strict_reference, _ops_factory, top_k=top_k)
@@ -388,9 +395,9 @@ class BipartitleAprioriSimRank(BipartiteSimRankPP):
     def fit(self, data, AprioriSim1, AprioriSim2, C1=0.8, C2=0.8, lbd1=0.5, lbd2=0.5,
             weighted=False, node_group1_column="user", node_group2_column="item",
             weight_column="weight", iterations=100, eps=1e-4, verbose=True, *, mode="auto",
-            device=None, world=None, strict_reference=True, top_k=None, dense_precision="f32",
+            device=None, world=None, strict_reference=True, top_k=None, dense_precision="f32", storage_precision="f32",
             _ops_factory=None):
-        with _precision(dense_precision):
+        with _precision(dense_precision, storage_precision):
             for a in (AprioriSim1, AprioriSim2):
                 if not isinstance(a, np.ndarray):
                     raise AttributeError(f"'{type(a).__name__}' object has no attribute 'flat'")

@@ -1,0 +1,217 @@
+"""fp16-held matrices (csrc/half.hip, `fit(storage_precision="fp16")`) on a real MI355X, through the C ABI.
+BASELINE.json config 5's reduced-precision mode: outside the 1e-5 parity bar by construction, so the tests
+state the error it is allowed — ONE rounding to fp16 per stored value on top of f32 sums — and check it
+against float64 NumPy on the same fp16 inputs (kernel level) and against the oracle (whole fits).
+Both `.dot`s of SimRank.py:361, the element-wise lines :315-316 / :362 / :453, the test of :74."""
+import numpy as np
+import pytest
+
+from simrank_amd.ingest import CSR
+from tests.test_gpu_kernels import corner_csr, dense64, random_csr
+
+pytestmark = pytest.mark.gpu
+HALF_ULP = 2.0 ** -11          # relative half-ulp of fp16 for normal numbers
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from simrank_amd.engine import HipOps
+    o = HipOps(0)
+    o.set_tuning(fuse_steps=1, fuse_min=2)   # small test graphs: a dense set however few steps it makes
+    yield o
+    o.set_tuning(fuse=1, fuse_min=3, fuse_steps=8, fuse_unit=1 << 20, fuse_group=4)
+
+
+def put_half(ops, a):
+    m = ops.matrix(a.shape[0], a.shape[1], np.float16, blocked=True)
+    ops.upload(m, a.astype(np.float16))
+    return m
+
+
+def put_blocked(ops, a, dtype=np.float32):
+    m = ops.matrix(a.shape[0], a.shape[1], dtype, blocked=True)
+    ops.upload(m, a.astype(dtype))
+    return m
+
+
+def close_to_rounded(got, want64, slack=1.02):
+    """``got`` (fp16) is ``want64`` rounded once, up to the f32 summation error: within a bit more than half
+    an fp16 ulp relative (normal range) or half the subnormal spacing absolute."""
+    got = got.astype(np.float64)
+    err = np.abs(got - want64)
+    bound = slack * np.maximum(HALF_ULP * np.abs(want64), 2.0 ** -25) + 1e-6 * np.abs(want64)
+    bad = err > bound
+    assert not bad.any(), (int(bad.sum()), float(err[bad].max()), float(np.abs(want64[bad]).max()))
+
+
+def test_layout_round_trip(ops):
+    rng = np.random.default_rng(0)
+    a = rng.random((77, 203)).astype(np.float16)
+    m = put_half(ops, a)
+    assert np.array_equal(ops.download(m), a)
+    s = ops.matrix(130, 130, np.float16, blocked=True)
+    ops.fill_identity(s, 0)
+    assert np.array_equal(ops.download(s), np.eye(130, dtype=np.float16))
+
+
+@pytest.mark.parametrize("shape", [(520, 400, 333), (384, 384, 384), (1000, 300, 70), (130, 200, 2),
+                                   (128, 128, 64), (129, 77, 65), (64, 1000, 96), (2100, 2100, 160)])
+@pytest.mark.parametrize("fuse_min", [2, 4, 128])
+def test_leg1_on_half_storage(ops, shape, fuse_min):
+    M, K, L = shape
+    csr = corner_csr(M, K, seed=M + L, hubs=min(K, 150))
+    X = (np.random.default_rng(5).random((K, L)) ** 3).astype(np.float16)
+    want = (dense64(csr) @ X.astype(np.float64)).T
+    ops.set_tuning(fuse_min=fuse_min)
+    try:
+        g = ops.graph(csr)
+        steps, cov, rem = ops.fused_stats(g)
+        assert cov + rem == csr.nnz
+        yt = ops.matrix(L, M, np.float16, blocked=True)
+        ops.spmm(g, put_half(ops, X), yt, transpose_out=True)
+        got = ops.download(yt)
+        yt2 = ops.matrix(L, M, np.float16, blocked=True)
+        ops.spmm(g, put_half(ops, X), yt2, transpose_out=True)
+        assert np.array_equal(got, ops.download(yt2))            # reproducible
+    finally:
+        ops.set_tuning(fuse_min=2)
+    close_to_rounded(got, want)
+
+
+def test_matrix_core_part_is_exact_on_half_operands(ops):
+    """One entry per row, every column shared: everything goes through v_mfma_f32_32x32x16_f16 with a 0/1
+    pattern and must come back bit for bit (any fp16 value, subnormals and the largest included)."""
+    M, K, L = 256, 64, 128
+    csr = CSR(M, K, np.arange(M + 1, dtype=np.int32), (np.arange(M) % 64).astype(np.int32), np.ones(M))
+    rng = np.random.default_rng(0)
+    X = rng.integers(0, 0x7C00, size=(K, L)).astype(np.uint16).view(np.float16)     # every finite positive pattern
+    X[1::2] = -X[1::2]
+    g = ops.graph(csr)
+    assert ops.fused_stats(g) == (2 * 4, M, 0)
+    yt = ops.matrix(L, M, np.float16, blocked=True)
+    ops.spmm(g, put_half(ops, X), yt, transpose_out=True)
+    got, want = ops.download(yt), X[np.arange(M) % 64].T
+    assert np.array_equal(got, want)                 # (values: -0 comes back as +0, 0 + (-0) in the accumulator)
+    nz = want != 0
+    assert np.array_equal(got.view(np.uint16)[nz], want.view(np.uint16)[nz])    # subnormals included
+
+
+def reference_leg2(csr, Tt, coef, counts=None, prior=None, lbd=0.0):
+    v = coef * (dense64(csr) @ Tt.astype(np.float64))
+    if counts is not None:
+        v = v * (1.0 - 0.5 ** counts.astype(np.float64))
+    if prior is not None:
+        v = (1.0 - lbd) * v + lbd * prior.astype(np.float64)
+    np.fill_diagonal(v, 1.0)
+    return v
+
+
+@pytest.mark.parametrize("n", [64, 129, 200, 520, 1000, 2100])
+@pytest.mark.parametrize("variant", ["plain", "evidence", "prior"])
+def test_leg2_on_half_storage(ops, n, variant):
+    """Upper triangle + mirror with the fused epilogue: a symmetric product (Tt = W^T-ish built so that
+    W . Tt is symmetric), symmetric counts and prior; the result must be exactly symmetric, within one
+    rounding of float64, and the count must be the count of the stored values."""
+    csr = corner_csr(n, n, seed=n, hubs=min(n, 120))
+    rng = np.random.default_rng(n)
+    W = dense64(csr)
+    Ssym = rng.random((n, n)) ** 4
+    Ssym = ((Ssym + Ssym.T) / 2).astype(np.float16)
+    Tt = (W @ Ssym.astype(np.float64)).T.astype(np.float16)      # what leg 1 would have stored, rounded
+    # W . Tt is symmetric only up to the rounding of Tt: the kernel computes the upper triangle and mirrors
+    counts = prior = None
+    lbd = 0.0
+    if variant == "evidence":
+        c = rng.integers(0, 6, size=(n, n))
+        counts = np.triu(c) + np.triu(c, 1).T
+        counts = counts.astype(np.uint8)
+    if variant == "prior":
+        pr = rng.random((n, n)).astype(np.float32)
+        prior = ((pr + pr.T) / 2).astype(np.float32)
+        lbd = 0.3
+    want = reference_leg2(csr, Tt, 0.8, counts, prior, lbd)
+    prev = (rng.random((n, n)) ** 4)
+    prev = ((prev + prev.T) / 2).astype(np.float16)
+    g = ops.graph(csr)
+    y = ops.matrix(n, n, np.float16, blocked=True)
+    ep = dict(coef=0.8, previous=put_half(ops, prev), eps=1e-3, set_diag=True, symmetric=True, lbd=lbd,
+              evidence=None if counts is None else put_blocked(ops, counts, np.uint8),
+              apriori=None if prior is None else put_blocked(ops, prior))
+    ops.spmm(g, put_half(ops, Tt), y, epilogue=ep)
+    got = ops.download(y)
+    changed = ops.read_changed()
+    assert np.array_equal(got, got.T)
+    iu = np.triu_indices(n)
+    close_to_rounded(got[iu], want[iu])
+    assert changed == int((np.abs(got.astype(np.float64) - prev.astype(np.float64)) > 1e-3).sum())
+    # the short-circuit form of the count: zero exactly when nothing moved
+    ep["count_any"] = True
+    ops.spmm(g, put_half(ops, Tt), y, epilogue=ep)
+    assert (ops.read_changed() > 0) == (changed > 0)
+    ep["previous"] = put_half(ops, got)
+    ep["count_any"] = False
+    ops.spmm(g, put_half(ops, Tt), y, epilogue=ep)
+    assert ops.read_changed() == 0 and np.array_equal(ops.download(y), got)
+
+
+def test_half_storage_needs_what_it_says(ops):
+    from simrank_amd._lib import SimRankHipError
+    csr = random_csr(200, 200, 0.05, seed=1)
+    ops.set_tuning(fuse=0)
+    try:
+        g = ops.graph(csr)
+    finally:
+        ops.set_tuning(fuse=1)
+    x = put_half(ops, np.zeros((200, 200)))
+    y = ops.matrix(200, 200, np.float16, blocked=True)
+    with pytest.raises(SimRankHipError, match="one-launch plan"):
+        ops.spmm(g, x, y, transpose_out=True)
+    g = ops.graph(csr)
+    with pytest.raises(SimRankHipError, match="leg 1"):
+        ops.spmm(g, x, y)                                       # neither transposed nor an epilogue
+    with pytest.raises(SimRankHipError, match="symmetric single-rank"):
+        ops.spmm(g, x, y, epilogue=dict(coef=0.8, symmetric=False))
+
+
+# ------------------------------------------------------------------------------------------------
+# whole fits
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cls", ["SimRank", "SimRankPP", "AprioriSimRank"])
+def test_fit_with_half_storage_against_the_oracle(cls):
+    """N = 2048 power-law: the fp16-held fit against the float64 oracle — max abs error of a few fp16
+    roundings of values <= 0.8 (the iteration is a contraction with factor C, so roundings do not pile up
+    beyond 1 / (1 - C) of them), exactly symmetric, diagonal 1, and a convergence iteration not before
+    the reference's."""
+    import simrank_amd.SimRank as SRA
+    from oracle import simrank_oracle as O
+    from simrank_amd import synth
+    df = synth.powerlaw_directed(2048, 24, seed=12)
+    args, okw = (), {}
+    if cls == "AprioriSimRank":
+        rng = np.random.default_rng(0)
+        prior = rng.random((2048, 2048))
+        prior = (prior + prior.T) / 2
+        args, okw = (prior,), dict(apriori=prior, lbd=0.2)
+    kw = dict(lbd=0.2) if cls == "AprioriSimRank" else {}
+    want = (O.fit_simrank if cls == "SimRank" else O.fit_simrank_pp)(df, verbose=False, **okw)
+    est = getattr(SRA, cls)()
+    got = est.fit(df, *args, verbose=False, storage_precision="fp16", **kw)
+    assert list(got.index) == want["labels"]
+    a, b = got.values, want["S"]
+    assert np.array_equal(a, a.T) and np.all(np.diag(a) == 1.0)
+    err = np.abs(a - b)
+    assert err.max() < 5 * 0.8 * HALF_ULP, err.max()
+    big = b > 1e-3
+    rel = err[big] / b[big]
+    assert np.median(rel) < HALF_ULP and rel.max() < 8 * HALF_ULP, (np.median(rel), rel.max())
+    assert want["k"] is None or est.converged_at is None or est.converged_at >= want["k"] - 1
+
+
+def test_half_storage_is_refused_where_it_does_not_exist():
+    import simrank_amd.SimRank as SRA
+    from simrank_amd import synth
+    df = synth.er_directed(300, 0.02, seed=5)
+    with pytest.raises(ValueError, match="storage_precision"):
+        SRA.SimRank().fit(df, verbose=False, storage_precision="bf16")
+    with pytest.raises(ValueError, match="storage_precision='fp16' needs"):
+        SRA.SimRank().fit(df, verbose=False, storage_precision="fp16", mode="dense")

@@ -17,6 +17,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="pl32768")
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--set", default="")
+ap.add_argument("--storage", default="f32", choices=["f32", "fp16"])
+ap.add_argument("--pp", action="store_true", help="SimRank++ (evidence counts in the epilogue)")
 args = ap.parse_args()
 if "probe" in args.set:
     os.environ["SIMRANK_ENABLE_PROBES"] = "1"       # diagnostic knobs (wrong results, timing only)
@@ -25,7 +27,10 @@ if args.set:
     ops.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.set.split(","))})
 df = synth.WORKLOADS[args.workload][0]()
 _, csr = ingest.directed(df, False, "from", "to", "weight")
-s = Solver(lambda r: ops, LocalWorld(1), [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
+spec = SideSpec(csr, csr.rowscale, 0.8, storage=args.storage)
+if args.pp:
+    spec = SideSpec(csr, ingest.spread(csr) * csr.rowscale, 0.8, evidence_from=csr, storage=args.storage)
+s = Solver(lambda r: ops, LocalWorld(1), [spec], "sparse")
 import time                                                        # noqa: E402
 s.reset()
 s.step(0.0)
@@ -39,4 +44,4 @@ s.enable_timing()
 for _ in range(args.steps):
     s.step(0.0)
 ops.synchronize()
-print(args.set, {k: round(v[0], 3) for k, v in s.leg_times().items()}, f"wall {wall:.3f} ms/step", flush=True)
+print(args.set, args.storage, {k: round(v[0], 3) for k, v in s.leg_times().items()}, f"wall {wall:.3f} ms/step", flush=True)

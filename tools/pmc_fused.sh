@@ -2,11 +2,11 @@
 # SQ / TA / TCP / L2 counters of the legs under one tuning setting, one rocprofv3 pass per counter group
 # (counters only: no trace domains beside --pmc).  usage: bash tools/pmc_fused.sh TAG "fuse=1" [workload]
 set -u
-TAG=$1; SET=$2; WL=${3:-pl32768d32}
+TAG=$1; SET=$2; WL=${3:-pl32768d32}; EXTRA=${4:-}
 OUT=$PWD/gpurun_out/pmcf_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-PROG="python3 $PWD/tools/leg_only.py --workload $WL --steps 2 --set $SET"
+PROG="python3 $PWD/tools/leg_only.py --workload $WL --steps 2 --set $SET $EXTRA"
 cd /tmp
 i=0
 for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM" \
@@ -25,9 +25,9 @@ print("== $TAG: $SET ($WL)")
 acc = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob("$OUT/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if not any(k in r["Kernel_Name"] for k in ("fused", "gather3", "dense_tiles")):
+        if not any(k in r["Kernel_Name"] for k in ("fused", "gather3", "dense_tiles", "half_leg")):
             continue
-        k = (r["Kernel_Name"][:44], r["Counter_Name"])
+        k = (r["Kernel_Name"][-52:], r["Counter_Name"])
         acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
 for k in sorted(acc):
     print("  %-46s %-32s %.4e" % (k[0], k[1], acc[k][0] / acc[k][1]))

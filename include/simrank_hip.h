@@ -299,16 +299,21 @@ SIMRANK_API int simrank_permute_layout(const void* src, int64_t ld_src, int64_t 
  *      product); transpose_out = 0 with an epilogue (symmetric = 1, diag_col0 = 0) is leg 2.  The
  *      epilogue's evidence counts and prior keep the f32 era's 32-column panels of aux_rows_pad rows;
  *      its `previous` is an fp16 matrix laid out like Y.
- *      simrank_widen_blocked_h16 converts to the f32 panel-blocked layout every hand-back entry reads. */
+ *      simrank_widen_blocked_h16 converts to the f32 panel-blocked layout every hand-back entry reads.
+ *      SCALE: similarities of a large sparse graph are mostly far below fp16's normal range (6.1e-5),
+ *      so the matrices hold value x scale, scale a power of two in 1 .. 32768 (the solver uses 16384:
+ *      the diagonal 1.0 is stored as 16384, the smallest normal number stands for 3.7e-9).  Both legs are
+ *      linear, so only the diagonal, the prior (x scale), eps (x scale) and the hand-back (/ scale) see it. */
 SIMRANK_API int simrank_fill_identity_blocked_h16(void* S, int64_t n_rows, int64_t n_cols,
-                                                  int64_t rows_pad, int64_t col0, void* stream);
+                                                  int64_t rows_pad, int64_t col0, float scale,
+                                                  void* stream);
 SIMRANK_API int simrank_spmm_blocked_h16(const simrank_graph* g, const void* X, int64_t x_rows_pad,
                                          int64_t n_cols_x, void* Y, int64_t y_rows_pad,
                                          int32_t transpose_out, const simrank_epilogue* epilogue,
-                                         int64_t aux_rows_pad, void* stream);
+                                         int64_t aux_rows_pad, float scale, void* stream);
 SIMRANK_API int simrank_widen_blocked_h16(const void* src, int64_t src_rows_pad, float* dst,
                                           int64_t dst_rows_pad, int64_t n_rows, int64_t n_cols,
-                                          void* stream);
+                                          float scale, void* stream);
 
 /* ---- dense MFMA path (second `.dot(G.T)` of SimRank.py:139 when W really is dense) -- */
 /* Wd[a*ld + i] = rowscale[a] where (a,i) is stored, 0 elsewhere */

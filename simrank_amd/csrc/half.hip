@@ -10,9 +10,14 @@
 // streams and stores serve twice the columns: S, Tt and the previous iterate are fp16, PANEL-BLOCKED with
 // 64-column panels (element (r, c) at ((c >> 6) * rows_pad + r) * 64 + (c & 63): a row segment is still one
 // 128-byte line), sums are f32, the epilogue is f32, and a value is rounded to fp16 (nearest even) once,
-// when it is stored.  The convergence test compares the ROUNDED new value with the stored old one — the
-// iterates grow monotonically from the identity and rounding is monotone, so the rounded sequence reaches
-// a fixed point and the test `|new - old| > eps` (SimRank.py:74) ends exactly as in f32 arithmetic.
+// when it is stored.  SCALE: the matrices hold value x 2^k (the solver: 2^14) because most similarities of a
+// large sparse graph lie below fp16's normal range; both legs are linear, so only the diagonal, the prior,
+// eps and the hand-back see the scale.  CONVERGENCE (SimRank.py:74): the previous iterate exists only rounded,
+// so an element counts as moved when |new (before rounding) - old (stored)| > eps + half the fp16 spacing at
+// the old value, i.e. by more than eps beyond what the old value's rounding explains.  Below 1/8 that spacing
+// is under eps / 4 at the default eps and scale and the test is the reference's; for the few larger values
+// it keeps a drift of less than eps per iteration from being counted each time it crosses a rounding
+// boundary (comparing rounded with rounded ran 52 iterations where the reference stops at 20).
 //
 // One kernel for both legs, built on the one-launch plan of fused.hip (same units, pattern bits, balanced
 // gather streams): a workgroup owns a 128-row block x one 64-column panel.
@@ -27,6 +32,8 @@
 //      rounded value is compared, stored for a <= c, written back to the tile and mirrored for a < c.
 //      Blocks that lie wholly left of the diagonal do nothing.
 // Deterministic: fixed summation order everywhere.
+#include <cmath>
+
 #include "common.h"
 
 namespace simrank {
@@ -58,6 +65,7 @@ struct HalfArgs {
     const int32_t* sids32;
     // leg 2
     float coef, lbd;
+    float scale;               // stored value = true value x scale (a power of two): diagonal, prior and eps follow it
     double eps;
     const uint8_t* ev;         // counts, 32-column panels of ev_rows_pad rows
     int64_t ev_rows_pad;
@@ -407,13 +415,13 @@ __global__ __launch_bounds__(256, 3) void half_leg_kernel(const HalfArgs p) {
                                                      __uint_as_float(u0.w), __uint_as_float(u1.x), __uint_as_float(u1.y),
                                                      __uint_as_float(u1.z), __uint_as_float(u1.w)};
 #pragma unroll
-                                for (int i = 0; i < 8; ++i) o[i] = keep * o[i] + p.lbd * pr[i];
+                                for (int i = 0; i < 8; ++i) o[i] = keep * o[i] + (p.lbd * p.scale) * pr[i];
                             }
                             if (p.set_diag) {
                                 const int d = a - cb;
 #pragma unroll
                                 for (int i = 0; i < 8; ++i)
-                                    if (d == i) o[i] = 1.0f;
+                                    if (d == i) o[i] = p.scale;
                             }
                             v4u out;
                             out.x = pack2(o[0], o[1]); out.y = pack2(o[2], o[3]);
@@ -427,10 +435,16 @@ __global__ __launch_bounds__(256, 3) void half_leg_kernel(const HalfArgs p) {
                                 const float nv = half_bits_to_float((ow[i >> 1] >> (16 * (i & 1))) & 0xFFFFu);
                                 tp[i * kHT] = nv;
                                 if (check) {
-                                    const float ov = half_bits_to_float((dw[i >> 1] >> (16 * (i & 1))) & 0xFFFFu);
+                                    // moved by more than eps beyond what the rounding of the stored old value explains:
+                                    // the new value before rounding against the old one, eps widened by half the fp16
+                                    // spacing at the old value (far below eps for values under 1/8; see the file header)
+                                    const uint32_t ob = (dw[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                                    const float ov = half_bits_to_float(ob);
+                                    const float hu = __builtin_ldexpf(1.0f, max(int((ob >> 10) & 31u), 1) - 26);
                                     const int c = cb + i;
                                     const bool counts = c >= a && c < Lc;
-                                    changed += (counts && fabs(double(nv) - double(ov)) > p.eps) ? (c > a ? 2u : 1u) : 0u;
+                                    changed += (counts && fabs(double(o[i]) - double(ov)) > p.eps + double(hu))
+                                                   ? (c > a ? 2u : 1u) : 0u;
                                 }
                             }
                             const int yoff = int(uint32_t(a) * 128u + qoff);
@@ -547,16 +561,18 @@ __global__ __launch_bounds__(256, 3) void half_leg_kernel(const HalfArgs p) {
 }
 
 __global__ __launch_bounds__(256) void half_diagonal_kernel(uint16_t* S, int64_t n_rows, int64_t n_cols,
-                                                            int64_t rows_pad, int64_t col0) {
+                                                            int64_t rows_pad, int64_t col0, float one) {
     const int64_t c = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
     const int64_t a = col0 + c;
-    if (c < n_cols && a < n_rows) S[((c >> 6) * rows_pad + a) * 64 + (c & 63)] = 0x3C00u;
+    if (c < n_cols && a < n_rows)
+        S[((c >> 6) * rows_pad + a) * 64 + (c & 63)] = __builtin_bit_cast(uint16_t, _Float16(one));
 }
 
 // fp16, 64-column panels -> f32, 32-column panels (the layout every hand-back routine reads)
 __global__ __launch_bounds__(256) void half_widen_kernel(const uint16_t* __restrict__ src, int64_t src_rows_pad,
                                                          float* __restrict__ dst, int64_t dst_rows_pad,
-                                                         int64_t n_rows, int64_t n_panels64, int64_t n_panels32) {
+                                                         int64_t n_rows, int64_t n_panels64, int64_t n_panels32,
+                                                         float inv_scale) {
     // one thread = 8 columns of one row
     const int64_t total = n_panels64 * n_rows * 8;
     for (int64_t t = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; t < total; t += int64_t(gridDim.x) * blockDim.x) {
@@ -569,8 +585,8 @@ __global__ __launch_bounds__(256) void half_widen_kernel(const uint16_t* __restr
         float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         add8(o, v);
         float4* d = reinterpret_cast<float4*>(dst + (p32 * dst_rows_pad + r) * 32 + ((8 * q) & 31));
-        d[0] = make_float4(o[0], o[1], o[2], o[3]);
-        d[1] = make_float4(o[4], o[5], o[6], o[7]);
+        d[0] = make_float4(o[0] * inv_scale, o[1] * inv_scale, o[2] * inv_scale, o[3] * inv_scale);
+        d[1] = make_float4(o[4] * inv_scale, o[5] * inv_scale, o[6] * inv_scale, o[7] * inv_scale);
     }
 }
 #endif  // SIMRANK_HOST_ONLY
@@ -581,22 +597,29 @@ using namespace simrank;
 
 extern "C" {
 
+static bool power_of_two_scale(float s) {
+    int e = 0;
+    return s >= 1.0f && s <= 32768.0f && std::frexp(s, &e) == 0.5f;
+}
+
 int simrank_fill_identity_blocked_h16(void* S, int64_t n_rows, int64_t n_cols, int64_t rows_pad, int64_t col0,
-                                      void* stream) {
+                                      float scale, void* stream) {
     SR_REQUIRE(S && n_rows > 0 && n_cols > 0 && rows_pad >= n_rows, "bad identity block");
+    SR_REQUIRE(power_of_two_scale(scale), "scale must be a power of two in 1 .. 32768");
     const size_t bytes = size_t((n_cols + 63) / 64) * size_t(rows_pad) * 64 * sizeof(uint16_t);
     SR_HIP(hipMemsetAsync(S, 0, bytes, as_stream(stream)));
 #ifndef SIMRANK_HOST_ONLY
     const int grid = (int)((n_cols + 255) / 256);
     hipLaunchKernelGGL(half_diagonal_kernel, dim3(grid), dim3(256), 0, as_stream(stream), (uint16_t*)S, n_rows,
-                       n_cols, rows_pad, col0);
+                       n_cols, rows_pad, col0, scale);
 #endif
     SR_HIP(hipGetLastError());
     return SIMRANK_OK;
 }
 
 int simrank_widen_blocked_h16(const void* src, int64_t src_rows_pad, float* dst, int64_t dst_rows_pad,
-                              int64_t n_rows, int64_t n_cols, void* stream) {
+                              int64_t n_rows, int64_t n_cols, float scale, void* stream) {
+    SR_REQUIRE(power_of_two_scale(scale), "scale must be a power of two in 1 .. 32768");
     SR_REQUIRE(src && dst && n_rows > 0 && n_cols > 0 && src_rows_pad >= n_rows && dst_rows_pad >= n_rows,
                "bad arguments");
     SR_REQUIRE(aligned16(src) && aligned16(dst), "operands must be 16-byte aligned");
@@ -605,7 +628,7 @@ int simrank_widen_blocked_h16(const void* src, int64_t src_rows_pad, float* dst,
     const int64_t total = p64 * n_rows * 8;
     const int grid = (int)std::min<int64_t>((total + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(half_widen_kernel, dim3(grid), dim3(256), 0, as_stream(stream), (const uint16_t*)src,
-                       src_rows_pad, dst, dst_rows_pad, n_rows, p64, p32);
+                       src_rows_pad, dst, dst_rows_pad, n_rows, p64, p32, 1.0f / scale);
 #endif
     SR_HIP(hipGetLastError());
     return SIMRANK_OK;
@@ -613,8 +636,9 @@ int simrank_widen_blocked_h16(const void* src, int64_t src_rows_pad, float* dst,
 
 int simrank_spmm_blocked_h16(const simrank_graph* g, const void* X, int64_t x_rows_pad, int64_t n_cols_x, void* Y,
                              int64_t y_rows_pad, int32_t transpose_out, const simrank_epilogue* ep,
-                             int64_t aux_rows_pad, void* stream) {
+                             int64_t aux_rows_pad, float scale, void* stream) {
     SR_REQUIRE(g && X && Y && n_cols_x > 0, "bad arguments");
+    SR_REQUIRE(power_of_two_scale(scale), "scale must be a power of two in 1 .. 32768");
     SR_REQUIRE(x_rows_pad >= g->n_cols && y_rows_pad >= (transpose_out ? n_cols_x : g->n_rows),
                "padded row counts %lld / %lld too small", (long long)x_rows_pad, (long long)y_rows_pad);
     SR_REQUIRE((transpose_out != 0) != (ep != nullptr), "leg 1: transpose_out and no epilogue; leg 2: an epilogue");
@@ -638,7 +662,8 @@ int simrank_spmm_blocked_h16(const simrank_graph* g, const void* X, int64_t x_ro
     if (ep) {
         SR_REQUIRE(ep->symmetric && n_cols_x == g->n_rows && ep->diag_col0 == 0,
                    "fp16 storage: leg 2 is the symmetric single-rank form only");
-        a.coef = ep->coef; a.lbd = ep->lbd; a.eps = ep->eps;
+        a.coef = ep->coef; a.lbd = ep->lbd; a.eps = ep->eps * double(scale);
+        a.scale = scale;
         a.ev = ep->evidence; a.ap = ep->apriori;
         a.ev_rows_pad = a.ap_rows_pad = aux_rows_pad;
         a.prev = (const uint16_t*)ep->previous; a.prev_rows_pad = y_rows_pad;

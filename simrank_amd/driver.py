@@ -532,6 +532,8 @@ class Side:
             # one rank: recv aliases send (pitched rows, or panel-blocked with the solver's matrices)
             x.send = x.recv = (o.matrix(col_dim, self.M, self.sdtype, blocked=True) if self.blocked
                                else o.matrix(col_dim, self.M))
+            if self.sdtype == np.float16:
+                x.send.scale = o.HALF_SCALE
             return x
         x.pad = row_pad(self.mb)
         send_ld = self.M + self.world * x.pad                    # floats per column, all chunks
@@ -815,6 +817,8 @@ class Solver:
                 kw = dict(blocked=True) if self.blocked else {}
                 c[r] = self.ops[r].matrix(n, hi - lo, self.sdtype, **kw)
                 x[r] = self.ops[r].matrix(n, hi - lo, self.sdtype, **kw)
+                if self.storage == "fp16":      # stored value = value x 2^14 (fp16's range is too short below)
+                    c[r].scale = x[r].scale = self.ops[r].HALF_SCALE
             self.cur.append(c)
             self.nxt.append(x)
         self.events = None

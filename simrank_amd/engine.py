@@ -35,6 +35,7 @@ class Matrix:
         self.rows, self.cols = int(rows), int(cols)
         self.dtype = np.dtype(dtype)
         self.blocked = bool(blocked)
+        self.scale = 1.0                   # float16 matrices: stored value = value x scale (HipOps.HALF_SCALE in the solver)
         if self.blocked:
             assert external is None and ld is None
             # (+8 rows: panels are not a power of two apart, and every panel starts 16-byte aligned)
@@ -155,6 +156,7 @@ class HipOps:
     name = "hip"
     supports_blocked = True      # the solver may keep its matrices panel-blocked (Matrix.blocked)
     supports_half_storage = True      # fp16-held matrices on 64-column panels (half.hip)
+    HALF_SCALE = 16384.0              # what the solver's fp16 matrices are scaled by (include/simrank_hip.h, SCALE)
     supports_shard_symmetric = True   # sharded leg 2 in its half form (spmm_shard / shard_unpack)
 
     def __init__(self, device: int | None = None, stream: int | None = None):
@@ -258,7 +260,7 @@ class HipOps:
             buf = np.zeros((m.panels, m.rows_pad, 64), dtype=np.float16)
             for pnl in range(m.panels):
                 w = min(64, m.cols - 64 * pnl)
-                buf[pnl, :m.rows, :w] = host[:, 64 * pnl:64 * pnl + w]
+                buf[pnl, :m.rows, :w] = host[:, 64 * pnl:64 * pnl + w].astype(np.float32) * np.float32(m.scale)
             check(self.lib.simrank_memcpy_h2d(m.ptr, buf.ctypes.data, buf.nbytes, self.stream),
                   "simrank_memcpy_h2d")
             return
@@ -279,14 +281,14 @@ class HipOps:
         assert src.dtype == np.float16 and src.blocked
         dst = self.matrix(src.rows, src.cols, blocked=True)
         check(self.lib.simrank_widen_blocked_h16(src.ptr, src.rows_pad, dst.ptr, dst.rows_pad, src.rows, src.cols,
-                                                 self.stream), "simrank_widen_blocked_h16")
+                                                 src.scale, self.stream), "simrank_widen_blocked_h16")
         return dst
 
     def download(self, m: Matrix) -> np.ndarray:
         """Device matrix -> host array of its own dtype."""
         if m.dtype == np.float16:
             wide = self.widen(m)
-            out = self.download(wide).astype(np.float16)       # (exact: every value is an fp16 number)
+            out = self.download(wide)       # float32: the values the matrix stands for (stored / scale, exact)
             wide.free()
             return out
         if m.blocked:
@@ -302,6 +304,11 @@ class HipOps:
 
     def download_rows(self, m: Matrix, rows) -> np.ndarray:
         """Selected rows of a device matrix (partial hand-back: no N x N host copy)."""
+        if m.dtype == np.float16:
+            wide = self.widen(m)
+            out = self.download_rows(wide, rows)
+            wide.free()
+            return out
         if m.blocked:
             idx = self.index_vector(rows)
             tmp = self.matrix(len(rows), m.cols, m.dtype)
@@ -410,7 +417,7 @@ class HipOps:
 
     def fill_identity(self, S: Matrix, col0: int):
         if S.rows and S.cols and S.dtype == np.float16:
-            check(self.lib.simrank_fill_identity_blocked_h16(S.ptr, S.rows, S.cols, S.rows_pad, col0,
+            check(self.lib.simrank_fill_identity_blocked_h16(S.ptr, S.rows, S.cols, S.rows_pad, col0, S.scale,
                                                              self.stream), "simrank_fill_identity_blocked_h16")
         elif S.rows and S.cols and S.blocked:
             check(self.lib.simrank_fill_identity_blocked(S.ptr, S.rows, S.cols, S.rows_pad, col0,
@@ -450,16 +457,17 @@ class HipOps:
         if X.dtype == np.float16:
             # fp16 storage: both legs on 64-column panels (half.hip); evidence and prior keep their f32-era layout
             assert Y.dtype == np.float16 and not x_col0 and not y_offset and n_cols == X.cols
+            assert X.scale == Y.scale
             aux_pad = 0
             for name in ("evidence", "apriori"):
                 m = (epilogue or {}).get(name)
                 assert m is None or m.blocked, name
                 aux_pad = m.rows_pad if m is not None else aux_pad
             prev = (epilogue or {}).get("previous")
-            assert prev is None or (prev.dtype == np.float16 and prev.rows_pad == Y.rows_pad)
+            assert prev is None or (prev.dtype == np.float16 and prev.rows_pad == Y.rows_pad and prev.scale == Y.scale)
             check(self.lib.simrank_spmm_blocked_h16(g.handle, X.ptr, X.rows_pad, n_cols, Y.ptr, Y.rows_pad,
                                                     1 if transpose_out else 0,
-                                                    C.byref(ep) if ep is not None else None, aux_pad,
+                                                    C.byref(ep) if ep is not None else None, aux_pad, Y.scale,
                                                     self.stream), "simrank_spmm_blocked_h16")
             return
         if X.blocked:

@@ -22,9 +22,11 @@ def ops():
     o.set_tuning(fuse=1, fuse_min=3, fuse_steps=8, fuse_unit=1 << 20, fuse_group=4)
 
 
-def put_half(ops, a):
+def put_half(ops, a, scale=1.0):
+    """fp16 matrix holding ``a`` x ``scale`` (``a`` must be exactly representable after scaling)."""
     m = ops.matrix(a.shape[0], a.shape[1], np.float16, blocked=True)
-    ops.upload(m, a.astype(np.float16))
+    m.scale = scale
+    ops.upload(m, a)
     return m
 
 
@@ -34,12 +36,12 @@ def put_blocked(ops, a, dtype=np.float32):
     return m
 
 
-def close_to_rounded(got, want64, slack=1.02):
-    """``got`` (fp16) is ``want64`` rounded once, up to the f32 summation error: within a bit more than half
-    an fp16 ulp relative (normal range) or half the subnormal spacing absolute."""
+def close_to_rounded(got, want64, slack=1.02, scale=1.0):
+    """``got`` (fp16 values / scale) is ``want64`` rounded once, up to the f32 summation error: within a bit
+    more than half an fp16 ulp relative (normal range) or half the subnormal spacing absolute."""
     got = got.astype(np.float64)
     err = np.abs(got - want64)
-    bound = slack * np.maximum(HALF_ULP * np.abs(want64), 2.0 ** -25) + 1e-6 * np.abs(want64)
+    bound = slack * np.maximum(HALF_ULP * np.abs(want64), 2.0 ** -25 / scale) + 1e-6 * np.abs(want64)
     bad = err > bound
     assert not bad.any(), (int(bad.sum()), float(err[bad].max()), float(np.abs(want64[bad]).max()))
 
@@ -49,9 +51,13 @@ def test_layout_round_trip(ops):
     a = rng.random((77, 203)).astype(np.float16)
     m = put_half(ops, a)
     assert np.array_equal(ops.download(m), a)
-    s = ops.matrix(130, 130, np.float16, blocked=True)
-    ops.fill_identity(s, 0)
-    assert np.array_equal(ops.download(s), np.eye(130, dtype=np.float16))
+    for scale in (1.0, 16384.0):
+        s = ops.matrix(130, 130, np.float16, blocked=True)
+        s.scale = scale
+        ops.fill_identity(s, 0)
+        assert np.array_equal(ops.download(s), np.eye(130, dtype=np.float32))
+        b = put_half(ops, a / 4, scale)                 # (values x 2^14 stay below fp16's largest number)
+        assert np.array_equal(ops.download(b), (a / 4).astype(np.float32))
 
 
 @pytest.mark.parametrize("shape", [(520, 400, 333), (384, 384, 384), (1000, 300, 70), (130, 200, 2),
@@ -93,7 +99,7 @@ def test_matrix_core_part_is_exact_on_half_operands(ops):
     got, want = ops.download(yt), X[np.arange(M) % 64].T
     assert np.array_equal(got, want)                 # (values: -0 comes back as +0, 0 + (-0) in the accumulator)
     nz = want != 0
-    assert np.array_equal(got.view(np.uint16)[nz], want.view(np.uint16)[nz])    # subnormals included
+    assert np.array_equal(got.astype(np.float16).view(np.uint16)[nz], want.view(np.uint16)[nz])    # subnormals included
 
 
 def reference_leg2(csr, Tt, coef, counts=None, prior=None, lbd=0.0):
@@ -107,17 +113,19 @@ def reference_leg2(csr, Tt, coef, counts=None, prior=None, lbd=0.0):
 
 
 @pytest.mark.parametrize("n", [64, 129, 200, 520, 1000, 2100])
-@pytest.mark.parametrize("variant", ["plain", "evidence", "prior"])
+@pytest.mark.parametrize("variant", ["plain", "evidence", "prior", "prior-scaled", "evidence-scaled"])
 def test_leg2_on_half_storage(ops, n, variant):
     """Upper triangle + mirror with the fused epilogue: a symmetric product (Tt = W^T-ish built so that
     W . Tt is symmetric), symmetric counts and prior; the result must be exactly symmetric, within one
     rounding of float64, and the count must be the count of the stored values."""
+    scale = 16384.0 if variant.endswith("-scaled") else 1.0      # stored = value x scale (the solver's 2^14)
+    variant = variant.split("-")[0]
     csr = corner_csr(n, n, seed=n, hubs=min(n, 120))
     rng = np.random.default_rng(n)
     W = dense64(csr)
-    Ssym = rng.random((n, n)) ** 4
+    Ssym = rng.random((n, n)) ** 4 / (4096.0 if scale > 1 else 1.0)
     Ssym = ((Ssym + Ssym.T) / 2).astype(np.float16)
-    Tt = (W @ Ssym.astype(np.float64)).T.astype(np.float16)      # what leg 1 would have stored, rounded
+    Tt = ((W @ Ssym.astype(np.float64)).T * scale).astype(np.float16).astype(np.float64) / scale   # as leg 1 stores it
     # W . Tt is symmetric only up to the rounding of Tt: the kernel computes the upper triangle and mirrors
     counts = prior = None
     lbd = 0.0
@@ -130,27 +138,37 @@ def test_leg2_on_half_storage(ops, n, variant):
         prior = ((pr + pr.T) / 2).astype(np.float32)
         lbd = 0.3
     want = reference_leg2(csr, Tt, 0.8, counts, prior, lbd)
-    prev = (rng.random((n, n)) ** 4)
-    prev = ((prev + prev.T) / 2).astype(np.float16)
+    prev = (rng.random((n, n)) ** 4) / (4096.0 if scale > 1 else 1.0)
+    prev = (((prev + prev.T) / 2) * scale).astype(np.float16).astype(np.float64) / scale
     g = ops.graph(csr)
     y = ops.matrix(n, n, np.float16, blocked=True)
-    ep = dict(coef=0.8, previous=put_half(ops, prev), eps=1e-3, set_diag=True, symmetric=True, lbd=lbd,
+    y.scale = scale
+    put_half_s = lambda a: put_half(ops, a, scale)
+    ep = dict(coef=0.8, previous=put_half_s(prev), eps=1e-3, set_diag=True, symmetric=True, lbd=lbd,
               evidence=None if counts is None else put_blocked(ops, counts, np.uint8),
               apriori=None if prior is None else put_blocked(ops, prior))
-    ops.spmm(g, put_half(ops, Tt), y, epilogue=ep)
+    ops.spmm(g, put_half_s(Tt), y, epilogue=ep)
     got = ops.download(y)
     changed = ops.read_changed()
     assert np.array_equal(got, got.T)
     iu = np.triu_indices(n)
-    close_to_rounded(got[iu], want[iu])
-    assert changed == int((np.abs(got.astype(np.float64) - prev.astype(np.float64)) > 1e-3).sum())
+    close_to_rounded(got[iu], want[iu], scale=scale)
+    # the count: new value BEFORE rounding against the stored old one, eps widened by half the fp16 spacing at
+    # the old value; bracketed, because the device's f32 sum is not the float64 one
+    e16 = np.maximum(np.frexp(prev * scale)[1] + 14, 1)               # fp16 exponent field of the stored old value
+    tol = 1e-3 + np.ldexp(1.0, e16 - 26) / scale
+    upper = np.triu(want) + np.triu(want, 1).T       # (a < c is computed once and counted twice)
+    move = np.abs(upper - prev)
+    lo, hi = int((move > tol + 1e-5 * want + 1e-7).sum()), int((move > tol - 1e-5 * want - 1e-7).sum())
+    assert lo <= changed <= hi, (lo, changed, hi)
     # the short-circuit form of the count: zero exactly when nothing moved
     ep["count_any"] = True
-    ops.spmm(g, put_half(ops, Tt), y, epilogue=ep)
+    ops.spmm(g, put_half_s(Tt), y, epilogue=ep)
     assert (ops.read_changed() > 0) == (changed > 0)
-    ep["previous"] = put_half(ops, got)
+    ep["previous"] = put_half_s(got)
     ep["count_any"] = False
-    ops.spmm(g, put_half(ops, Tt), y, epilogue=ep)
+    ep["eps"] = 1e-6 / scale                 # own rounding never counts: |new - round(new)| <= half a spacing
+    ops.spmm(g, put_half_s(Tt), y, epilogue=ep)
     assert ops.read_changed() == 0 and np.array_equal(ops.download(y), got)
 
 
@@ -178,10 +196,14 @@ def test_half_storage_needs_what_it_says(ops):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cls", ["SimRank", "SimRankPP", "AprioriSimRank"])
 def test_fit_with_half_storage_against_the_oracle(cls):
-    """N = 2048 power-law: the fp16-held fit against the float64 oracle — max abs error of a few fp16
-    roundings of values <= 0.8 (the iteration is a contraction with factor C, so roundings do not pile up
-    beyond 1 / (1 - C) of them), exactly symmetric, diagonal 1, and a convergence iteration not before
-    the reference's."""
+    """N = 2048 power-law, whole fits against the float64 oracle.
+    (1) Exactly 10 updates on both sides: the arithmetic error — two roundings to fp16 per update, damped by
+    the contraction — measured 1.2e-3 max / 1.8e-4 median relative (profiles/r03_half_errors.log); bars at
+    about twice that.  Exactly symmetric, diagonal exactly 1.
+    (2) To eps = 1e-4: the loop may end LATER than the reference's (never earlier by more than one update):
+    values above 1/8 are stored with a spacing above eps, and when one of them crosses a rounding boundary
+    its dependents move by more than eps.  What comes back is then closer to the fixed point than the
+    reference's iterate, within the distance the reference still had to go: eps . C / (1 - C)."""
     import simrank_amd.SimRank as SRA
     from oracle import simrank_oracle as O
     from simrank_amd import synth
@@ -193,18 +215,20 @@ def test_fit_with_half_storage_against_the_oracle(cls):
         prior = (prior + prior.T) / 2
         args, okw = (prior,), dict(apriori=prior, lbd=0.2)
     kw = dict(lbd=0.2) if cls == "AprioriSimRank" else {}
-    want = (O.fit_simrank if cls == "SimRank" else O.fit_simrank_pp)(df, verbose=False, **okw)
-    est = getattr(SRA, cls)()
-    got = est.fit(df, *args, verbose=False, storage_precision="fp16", **kw)
+    oracle = O.fit_simrank if cls == "SimRank" else O.fit_simrank_pp
+    want = oracle(df, verbose=False, iterations=10, eps=1e-30, **okw)
+    got = getattr(SRA, cls)().fit(df, *args, verbose=False, storage_precision="fp16", iterations=10, eps=1e-30, **kw)
     assert list(got.index) == want["labels"]
     a, b = got.values, want["S"]
     assert np.array_equal(a, a.T) and np.all(np.diag(a) == 1.0)
     err = np.abs(a - b)
-    assert err.max() < 5 * 0.8 * HALF_ULP, err.max()
-    big = b > 1e-3
-    rel = err[big] / b[big]
-    assert np.median(rel) < HALF_ULP and rel.max() < 8 * HALF_ULP, (np.median(rel), rel.max())
-    assert want["k"] is None or est.converged_at is None or est.converged_at >= want["k"] - 1
+    rel = err[b > 0] / b[b > 0]
+    assert err.max() < 6e-4 and rel.max() < 2.5e-3 and np.median(rel) < 4e-4, (err.max(), rel.max(), np.median(rel))
+    want = oracle(df, verbose=False, **okw)
+    est = getattr(SRA, cls)()
+    got = est.fit(df, *args, verbose=False, storage_precision="fp16", **kw)
+    assert est.converged_at is not None and est.converged_at >= want["k"] - 1
+    assert np.abs(got.values - want["S"]).max() < 1e-4 * 0.8 / 0.2 + 6e-4
 
 
 def test_half_storage_is_refused_where_it_does_not_exist():

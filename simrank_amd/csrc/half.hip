@@ -38,7 +38,7 @@
 
 namespace simrank {
 
-constexpr int kHT = 132;          // floats per column of the LDS tile
+constexpr int kHR = 68;           // floats per ROW of the LDS tile (64 columns + 4: rows stay 16-byte aligned)
 constexpr int kBRow = 40;         // halves per operand row of a wave's B buffer (64 bytes + 16: the two K groups
                                   // of a fragment read from different banks)
 
@@ -110,11 +110,22 @@ __device__ __forceinline__ float half_bits_to_float(uint32_t bits16) {
 
 // SYM: leg 2 (epilogue, upper triangle + mirror); otherwise leg 1 (transposed store)
 // PRIOR: leg 2 with a prior matrix (two rows of a lane group per batch of epilogue loads instead of four)
+#ifndef SIMRANK_HALF_LB1
+#define SIMRANK_HALF_LB1 4      // waves per SIMD the register allocation of leg 1 aims at
+#endif
+#ifndef SIMRANK_HALF_LB2
+#define SIMRANK_HALF_LB2 3      // ... of leg 2
+#endif
 template <bool IDS16, bool SYM, bool PRIOR>
-__global__ __launch_bounds__(256, 3) void half_leg_kernel(const HalfArgs p) {
-    __shared__ __attribute__((aligned(16))) float tile[64 * kHT];               // [column][row] of the block's result
-    __shared__ __attribute__((aligned(16))) uint16_t bbuf_all[4 * 16 * kBRow];  // per wave: 16 operand half segments
-    __shared__ __attribute__((aligned(16))) uint4 lut[256];                      // pattern byte -> 8 fp16 (0 / 1.0)
+__global__ __launch_bounds__(256, SYM ? SIMRANK_HALF_LB2 : SIMRANK_HALF_LB1) void half_leg_kernel(const HalfArgs p) {
+    // [row][column] of the block's result: a lane group finishes a row with two 16-byte writes per lane; the
+    // strided reads are left to the transposed store, which runs with all lanes
+    __shared__ __attribute__((aligned(16))) float tile[kFB * kHR];
+    // the MFMA phase's buffers live in the tile's memory (the tile is first written when that phase has ended):
+    // 37.8 KiB per workgroup = four workgroups per CU
+    uint4* const lut = reinterpret_cast<uint4*>(tile);                          // pattern byte -> 8 fp16 (0 / 1.0), 4 KiB
+    uint16_t* const bbuf_all = reinterpret_cast<uint16_t*>(tile + 1024);        // per wave: 16 operand half segments
+    static_assert(1024 * 4 + 4 * 16 * kBRow * 2 <= kFB * kHR * 4, "MFMA buffers inside the tile");
     __shared__ __attribute__((aligned(16))) int2 gm_lds[kSub * 4 * 8 * 4];
 
     const int lane = threadIdx.x & 63;
@@ -272,6 +283,7 @@ __global__ __launch_bounds__(256, 3) void half_leg_kernel(const HalfArgs p) {
         // (the pipeline's last prefetches are never used: retire them here, so that no wait on their registers
         // lands inside the gather loop)
         __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0), in a form the compiler's wait insertion sees
+        __syncthreads();                                     // every wave is done with the table and its operand buffer
         // ------------------------------------------------------------ 2. the two K halves, in order
         {
             const int n = lane & 31, h = lane >> 5;
@@ -281,13 +293,12 @@ __global__ __launch_bounds__(256, 3) void half_leg_kernel(const HalfArgs p) {
                     for (int t = 0; t < 4; ++t)
 #pragma unroll
                         for (int i4 = 0; i4 < 4; ++i4) {
-                            float4* dst = reinterpret_cast<float4*>(tile + (32 * ch + n) * kHT + 32 * t + 8 * i4 + 4 * h);
+                            float* dst = tile + (32 * t + 8 * i4 + 4 * h) * kHR + 32 * ch + n;   // four consecutive rows
                             float4 v = make_float4(acc[t][4 * i4], acc[t][4 * i4 + 1], acc[t][4 * i4 + 2], acc[t][4 * i4 + 3]);
                             if (w > 0) {
-                                const float4 o = *dst;
-                                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                                v.x += dst[0]; v.y += dst[kHR]; v.z += dst[2 * kHR]; v.w += dst[3 * kHR];
                             }
-                            *dst = v;
+                            dst[0] = v.x; dst[kHR] = v.y; dst[2 * kHR] = v.z; dst[3 * kHR] = v.w;
                         }
                 }
                 __syncthreads();
@@ -318,12 +329,11 @@ __global__ __launch_bounds__(256, 3) void half_leg_kernel(const HalfArgs p) {
         auto emit = [&](const int3& m, const float (&sv)[8]) __attribute__((always_inline)) {
             if (m.x >= 0) {
                 const float sc = __int_as_float(m.y) * post;
-                float* tp = tile + (8 * q) * kHT + m.x;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float d = has_set ? tp[i * kHT] : 0.f;
-                    tp[i * kHT] = (sv[i] + d) * sc;
-                }
+                float4* tp = reinterpret_cast<float4*>(tile + m.x * kHR + 8 * q);
+                float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f), d1 = d0;
+                if (has_set) { d0 = tp[0]; d1 = tp[1]; }
+                tp[0] = make_float4((sv[0] + d0.x) * sc, (sv[1] + d0.y) * sc, (sv[2] + d0.z) * sc, (sv[3] + d0.w) * sc);
+                tp[1] = make_float4((sv[4] + d1.x) * sc, (sv[5] + d1.y) * sc, (sv[6] + d1.z) * sc, (sv[7] + d1.w) * sc);
             }
         };
         auto row_end = [&](int f) __attribute__((always_inline)) {
@@ -393,10 +403,9 @@ __global__ __launch_bounds__(256, 3) void half_leg_kernel(const HalfArgs p) {
                         const int a = row0 + r;
                         const bool on = r < nrows && a <= cb + 7 && cb < Lc;
                         if (on) {
-                            float* tp = tile + (8 * q) * kHT + r;
-                            float o[8];
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) o[i] = tp[i * kHT];
+                            float4* tp = reinterpret_cast<float4*>(tile + r * kHR + 8 * q);
+                            const float4 t0 = tp[0], t1 = tp[1];
+                            float o[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
                             if (p.ev) {
                                 const unsigned w0 = evw[it].x, w1 = evw[it].y;
                                 o[0] *= 1.0f - __builtin_ldexpf(1.0f, -int(w0 & 255u));
@@ -430,10 +439,11 @@ __global__ __launch_bounds__(256, 3) void half_leg_kernel(const HalfArgs p) {
                             const uint32_t ow[4] = {out.x, out.y, out.z, out.w};
                             const uint32_t dw[4] = {od.x, od.y, od.z, od.w};
                             // what was stored is what the next update reads and what the mirror image gets
+                            float nvs[8];
 #pragma unroll
                             for (int i = 0; i < 8; ++i) {
                                 const float nv = half_bits_to_float((ow[i >> 1] >> (16 * (i & 1))) & 0xFFFFu);
-                                tp[i * kHT] = nv;
+                                nvs[i] = nv;
                                 if (check) {
                                     // moved by more than eps beyond what the rounding of the stored old value explains:
                                     // the new value before rounding against the old one, eps widened by half the fp16
@@ -447,6 +457,8 @@ __global__ __launch_bounds__(256, 3) void half_leg_kernel(const HalfArgs p) {
                                                    ? (c > a ? 2u : 1u) : 0u;
                                 }
                             }
+                            tp[0] = make_float4(nvs[0], nvs[1], nvs[2], nvs[3]);
+                            tp[1] = make_float4(nvs[4], nvs[5], nvs[6], nvs[7]);
                             const int yoff = int(uint32_t(a) * 128u + qoff);
                             if (a <= cb && cb + 7 < Lc) {
                                 __builtin_amdgcn_raw_buffer_store_b128(out, ysrd, yoff, 0, 2);
@@ -477,12 +489,10 @@ __global__ __launch_bounds__(256, 3) void half_leg_kernel(const HalfArgs p) {
                         const int a8 = (x & 7) * 8;                    // first of 8 rows of the output panel
                         const int64_t cg = c0 + 32 * cw + c;
                         if (cg < p.L && a8 < rows_here) {
-                        const float* t = tile + (32 * cw + c) * kHT + 64 * ap + a8;
-                        const float4 u0 = *reinterpret_cast<const float4*>(t);
-                        const float4 u1 = *reinterpret_cast<const float4*>(t + 4);
+                        const float* t = tile + (64 * ap + a8) * kHR + 32 * cw + c;     // eight rows of one column
                         v4u out;
-                        out.x = pack2(u0.x, u0.y); out.y = pack2(u0.z, u0.w);
-                        out.z = pack2(u1.x, u1.y); out.w = pack2(u1.z, u1.w);
+                        out.x = pack2(t[0], t[kHR]); out.y = pack2(t[2 * kHR], t[3 * kHR]);
+                        out.z = pack2(t[4 * kHR], t[5 * kHR]); out.w = pack2(t[6 * kHR], t[7 * kHR]);
                         uint16_t* y = base + c * 64 + a8;
                         bool full = a8 + 7 < rows_here;
                         int64_t lim = rows_here;                       // rows a8 + i < lim are stored

@@ -113,6 +113,9 @@ __device__ __forceinline__ float half_bits_to_float(uint32_t bits16) {
 #ifndef SIMRANK_HALF_LB1
 #define SIMRANK_HALF_LB1 4      // waves per SIMD the register allocation of leg 1 aims at
 #endif
+#ifndef SIMRANK_HALF_RB
+#define SIMRANK_HALF_RB 4       // rows of a lane group whose epilogue operands are loaded together (leg 2)
+#endif
 #ifndef SIMRANK_HALF_LB2
 #define SIMRANK_HALF_LB2 3      // ... of leg 2
 #endif
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(256, SYM ? SIMRANK_HALF_LB2 : SIMRANK_HALF_LB1) voi
                 const uint32_t ev_off = (half32 * uint32_t(p.ev_rows_pad)) * 32u + o32;
                 const uint32_t ap_off = (half32 * uint32_t(p.ap_rows_pad)) * 128u + o32 * 4u;
                 // (the loads of RB rows of the lane group together, then the arithmetic; aux 2 = non-temporal)
-                constexpr int RB = PRIOR ? 2 : 4;
+                constexpr int RB = PRIOR ? 2 : SIMRANK_HALF_RB;
 #pragma unroll 1
                 for (int pair = 0; pair < 4 / RB; ++pair) {
                     v2u evw[RB];

@@ -649,6 +649,7 @@ def main():
         try:
             import simrank_amd.SimRank as SRA
             walls = {}
+            type(ops).trim_pool()            # (the block pool is full of this process's earlier configurations)
 
             def timed_fit(name, make, *a, **kw):
                 best = None

@@ -373,6 +373,10 @@ typedef struct simrank_plan_options {
     int64_t ld_apriori;
     int32_t evidence;           /* 1: SimRank++ evidence factor 1 - 2^-|common in-neighbours| */
     int32_t reorder;            /* 1: iterate in ascending-row-length node order (recommended) */
+    int32_t storage_fp16;       /* 1: the matrices are HELD in fp16 ("FP16 STORAGE" above: value x 2^14 on 64-column
+                                   panels, f32 sums, one rounding per stored value) — BASELINE config 5's
+                                   reduced-precision mode, outside the parity bar; 0 (default): f32 */
+    int32_t reserved;           /* 0 */
 } simrank_plan_options;
 SIMRANK_API int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col,
                                     const float* rowscale, const simrank_plan_options* options, void* stream,

@@ -33,15 +33,21 @@ struct simrank_plan {
     hipStream_t stream = nullptr;
     float coef = 0.8f, lbd = 0.f;
     int32_t restrict_support = 0;
+    int32_t half = 0;                         // 1: S and Tt are fp16 on 64-column panels (half.hip), value x kHalfScale
     int cur = 0;                              // S[cur] is the current iterate
     int32_t updates = 0;                      // updates applied since the last reset
 };
 
 namespace simrank {
 
+constexpr float kHalfScale = 16384.0f;        // what fp16-held matrices are scaled by (include/simrank_hip.h, SCALE)
+
 static int leg_pair(simrank_plan* p, double eps, int32_t exact_count, int slot) {
     const int nx = p->cur ^ 1;
-    int rc = simrank_spmm_blocked(p->g, p->S[p->cur], p->rows_pad, p->n, p->Tt, p->rows_pad, 1, nullptr, p->stream);
+    int rc = p->half ? simrank_spmm_blocked_h16(p->g, p->S[p->cur], p->rows_pad, p->n, p->Tt, p->rows_pad, 1, nullptr,
+                                                0, kHalfScale, p->stream)
+                     : simrank_spmm_blocked(p->g, p->S[p->cur], p->rows_pad, p->n, p->Tt, p->rows_pad, 1, nullptr,
+                                            p->stream);
     if (rc) return rc;
     simrank_epilogue ep{};
     ep.coef = p->coef;
@@ -59,7 +65,9 @@ static int leg_pair(simrank_plan* p, double eps, int32_t exact_count, int slot) 
     ep.symmetric = 1;
     ep.restrict_support = p->restrict_support;
     ep.count_any = exact_count ? 0 : 1;
-    rc = simrank_spmm_blocked(p->g, p->Tt, p->rows_pad, p->n, p->S[nx], p->rows_pad, 0, &ep, p->stream);
+    rc = p->half ? simrank_spmm_blocked_h16(p->g, p->Tt, p->rows_pad, p->n, p->S[nx], p->rows_pad, 0, &ep, p->rows_pad,
+                                            kHalfScale, p->stream)
+                 : simrank_spmm_blocked(p->g, p->Tt, p->rows_pad, p->n, p->S[nx], p->rows_pad, 0, &ep, p->stream);
     if (rc) return rc;
     SR_HIP(hipMemcpyAsync(p->host_counters[slot], p->counters, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS,
                           hipMemcpyDeviceToHost, p->stream));
@@ -138,11 +146,19 @@ int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int
     p->coef = opt->coef;
     p->lbd = opt->lbd;
     p->rows_pad = (n + 7) / 8 * 8 + 8;
+    p->half = opt->storage_fp16 ? 1 : 0;
     const int64_t panels = (n + 31) / 32;
-    p->mat_bytes = size_t(panels) * size_t(p->rows_pad) * 32 * sizeof(float);
+    // (fp16: 64-column panels of 2-byte elements — a row segment is 128 bytes either way)
+    p->mat_bytes = p->half ? size_t((n + 63) / 64) * size_t(p->rows_pad) * 128
+                           : size_t(panels) * size_t(p->rows_pad) * 32 * sizeof(float);
+    const size_t prior_bytes = size_t(panels) * size_t(p->rows_pad) * 32 * sizeof(float);
     int rc = simrank_graph_create(n, n, nnz, rp.data(), cl.data(), rs.data(), &p->g);
     auto fail = [&](int code) { simrank_plan_destroy(p); return code; };
     if (rc) return fail(rc);
+    if (p->half && !p->g->fused) {
+        set_error("storage_fp16 needs the one-launch plan (tuning fuse = 1) and a graph that has one");
+        return fail(SIMRANK_ERR_INVALID);
+    }
 #define PLAN_HIP(call)                                                                            \
     do {                                                                                          \
         hipError_t e_ = (call);                                                                   \
@@ -182,8 +198,8 @@ int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int
         int32_t* ord_dev = nullptr;
         PLAN_HIP(hipMalloc((void**)&tmp, size_t(n) * size_t(n) * sizeof(float)));
         hipError_t e = hipMalloc((void**)&ord_dev, size_t(n) * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&p->prior, p->mat_bytes);
-        if (e == hipSuccess) e = hipMemsetAsync(p->prior, 0, p->mat_bytes, p->stream);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->prior, prior_bytes);
+        if (e == hipSuccess) e = hipMemsetAsync(p->prior, 0, prior_bytes, p->stream);
         if (e == hipSuccess) e = hipMemcpy2DAsync(tmp, size_t(n) * 4, opt->apriori, size_t(opt->ld_apriori) * 4, size_t(n) * 4,
                                                   size_t(n), hipMemcpyHostToDevice, p->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(ord_dev, ord.data(), size_t(n) * 4, hipMemcpyHostToDevice, p->stream);
@@ -211,6 +227,7 @@ int simrank_plan_reset(simrank_plan* p) {
     SR_REQUIRE(p, "plan is NULL");
     p->cur = 0;
     p->updates = 0;
+    if (p->half) return simrank_fill_identity_blocked_h16(p->S[0], p->n, p->n, p->rows_pad, 0, kHalfScale, p->stream);
     return simrank_fill_identity_blocked(p->S[0], p->n, p->n, p->rows_pad, 0, p->stream);
 }
 
@@ -268,6 +285,17 @@ int simrank_plan_run(simrank_plan* p, int32_t iterations, double eps, int32_t* u
 int simrank_plan_result(simrank_plan* p, float* dst, int64_t ld) {
     SR_REQUIRE(p && dst && ld >= p->n, "bad result arguments");
     // dst[i][j] = S[inv[i]][inv[j]]: out of the panel-blocked layout and the solver's node order in one pass
+    if (p->half) {
+        // through an f32 panel-blocked scratch copy
+        float* wide = nullptr;
+        const size_t bytes = size_t((p->n + 31) / 32) * size_t(p->rows_pad) * 32 * sizeof(float);
+        SR_HIP(hipMalloc((void**)&wide, bytes));
+        int rc = simrank_widen_blocked_h16(p->S[p->cur], p->rows_pad, wide, p->rows_pad, p->n, p->n, kHalfScale, p->stream);
+        if (!rc) rc = simrank_permute_layout(wide, 32, p->rows_pad, dst, ld, 0, p->n, p->n, p->inv, p->inv, 4, p->stream);
+        (void)hipStreamSynchronize(p->stream);
+        (void)hipFree(wide);
+        return rc;
+    }
     return simrank_permute_layout(p->S[p->cur], 32, p->rows_pad, dst, ld, 0, p->n, p->n, p->inv, p->inv, 4, p->stream);
 }
 

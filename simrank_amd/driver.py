@@ -387,6 +387,10 @@ class TorchWorld:
                          dst=self.dist.get_global_rank(self.group, 0) if self.group else 0,
                          group=self.group)
         if not self.is_root:
+            import warnings
+            warnings.warn("TorchWorld(handback='root'): only rank 0 receives the similarity matrix, fit() returns "
+                          "None on this rank (pass handback='all', or fit(top_k=k), to get results on every rank)",
+                          RuntimeWarning, stacklevel=4)       # (shown once per call site by the warnings filter)
             return None
         side = big.view(P, n, mb).permute(1, 0, 2).reshape(n, P * mb).contiguous()   # [i][h*mb + j]
         if side.is_cuda:

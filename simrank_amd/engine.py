@@ -94,7 +94,7 @@ class Graph:
 
 class PlanOptions(C.Structure):                # struct simrank_plan_options
     _fields_ = [("coef", C.c_float), ("lbd", C.c_float), ("apriori", C.c_void_p), ("ld_apriori", C.c_int64),
-                ("evidence", C.c_int32), ("reorder", C.c_int32)]
+                ("evidence", C.c_int32), ("reorder", C.c_int32), ("storage_fp16", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Plan:
@@ -102,14 +102,17 @@ class Plan:
     :440-455): CSR + per-row scale in the caller's node order in, S (float64, caller's order) out."""
 
     def __init__(self, ops, csr: CSR, rowscale=None, coef: float = 0.8, evidence: bool = False,
-                 apriori=None, lbd: float = 0.0, reorder: bool = True):
+                 apriori=None, lbd: float = 0.0, reorder: bool = True, storage: str = "f32"):
+        """``storage``: "f32", or "fp16" (matrices held in fp16: config 5's reduced-precision mode)."""
+        assert storage in ("f32", "fp16")
         self.ops = ops
         rs = np.ascontiguousarray(csr.rowscale if rowscale is None else rowscale, dtype=np.float32)
         rowptr = np.ascontiguousarray(csr.rowptr, dtype=np.int32)
         col = np.ascontiguousarray(csr.col, dtype=np.int32)
         ap = None if apriori is None else np.ascontiguousarray(apriori, dtype=np.float32)
         opt = PlanOptions(coef=coef, lbd=lbd, apriori=None if ap is None else ap.ctypes.data,
-                          ld_apriori=0 if ap is None else ap.shape[1], evidence=int(evidence), reorder=int(reorder))
+                          ld_apriori=0 if ap is None else ap.shape[1], evidence=int(evidence), reorder=int(reorder),
+                          storage_fp16=int(storage == "fp16"), reserved=0)
         h = C.c_void_p()
         check(ops.lib.simrank_plan_create(csr.n_rows, col.size, rowptr.ctypes.data,
                                           col.ctypes.data if col.size else None, rs.ctypes.data, C.byref(opt),

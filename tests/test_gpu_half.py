@@ -239,3 +239,37 @@ def test_half_storage_is_refused_where_it_does_not_exist():
         SRA.SimRank().fit(df, verbose=False, storage_precision="bf16")
     with pytest.raises(ValueError, match="storage_precision='fp16' needs"):
         SRA.SimRank().fit(df, verbose=False, storage_precision="fp16", mode="dense")
+
+
+def test_plan_api_with_half_storage(ops):
+    """The C-level loop (simrank_plan_*) with `storage_fp16`: the same updates as the Python solver in that
+    mode (same kernels; the two order equal-length nodes differently, so sums may round differently: a
+    couple of fp16 spacings), prior and evidence included; hand-back through the f32 layout in the
+    caller's order."""
+    from simrank_amd import ingest, synth
+    from simrank_amd.driver import LocalWorld, SideSpec, Solver
+    from simrank_amd.engine import Plan
+    df = synth.powerlaw_directed(1500, 12, seed=7)
+    _, csr = ingest.directed(df, False, "from", "to", "weight")
+    rng = np.random.default_rng(3)
+    A = rng.random((csr.n_rows, csr.n_rows)).astype(np.float32)
+    A = (A + A.T) / 2
+    ops.set_tuning(fuse_steps=8, fuse_min=3)
+    try:
+        plan = Plan(ops, csr, coef=0.8, evidence=True, apriori=A, lbd=0.25, storage="fp16")
+        plan.reset()
+        counts = [plan.step(1e-4, exact_count=True) for _ in range(5)]
+        got = plan.result()
+        plan.free()
+        s = Solver(lambda r: ops, LocalWorld(1),
+                   [SideSpec(csr, csr.rowscale, 0.8, evidence_from=csr, apriori=A, lbd=0.25, storage="fp16")], "sparse")
+        s.exact_count = True
+        s.reset()
+        want_counts = [s.step(1e-4) for _ in range(5)]
+        want = s.result(0)
+        s.release()
+    finally:
+        ops.set_tuning(fuse_steps=1, fuse_min=2)
+    assert all(abs(c - w) <= 0.01 * w + 8 for c, w in zip(counts, want_counts)), (counts, want_counts)
+    np.testing.assert_allclose(got, want, rtol=4 * HALF_ULP, atol=1e-7)
+    assert np.array_equal(got, got.T) and np.all(np.diag(got) == 1.0)

@@ -238,8 +238,11 @@ def test_n98304_beyond_16_bit_ids_and_32_bit_element_offsets(ops):
     solver.release()
 
 
-def test_config5_pl65536_simrank_pp_properties(ops):
-    """BASELINE.json configs[4] shape: N = 65536 power-law graph, SimRank++ with evidence
+@pytest.mark.parametrize("storage", ["f32", "fp16"])
+def test_config5_pl65536_simrank_pp_properties(ops, storage):
+    """(storage = "fp16": the same checks on matrices HELD in fp16 — config 5's reduced-precision mode,
+    csrc/half.hip — with the bar that mode states: a few fp16 roundings, 2e-3 relative.)
+    BASELINE.json configs[4] shape: N = 65536 power-law graph, SimRank++ with evidence
     (SimRank.py:351-362, evidence :311-320), f32, on one GPU.  The dense f64 oracle would need
     100 GB and hours, so: rows of one more update recomputed on the host in float64 from the
     device's S_k — evidence factor 1 - 2^-|common in-neighbours| included — plus the
@@ -251,7 +254,8 @@ def test_config5_pl65536_simrank_pp_properties(ops):
     assert n == 65536
     scale = ingest.spread(csr) * csr.rowscale                      # _cal_Weight, SimRank.py:322-337
     solver = Solver(lambda r: ops, LocalWorld(1),
-                    [SideSpec(csr, scale, 0.8, evidence_from=csr)], "sparse")
+                    [SideSpec(csr, scale, 0.8, evidence_from=csr, storage=storage)], "sparse")
+    tol = dict(rtol=RTOL, atol=1e-30) if storage == "f32" else dict(rtol=2e-3, atol=1e-9)
     csr = solver.specs[0].csr                                      # the solver's own node order
     rs = np.asarray(solver.specs[0].rowscale, dtype=np.float32).astype(np.float64)
     solver.reset()
@@ -272,7 +276,7 @@ def test_config5_pl65536_simrank_pp_properties(ops):
         cnt = np.asarray((live[a] @ live.T).todense()).ravel()
         want = 0.8 * (W @ t_rows[a]) * (1.0 - 0.5 ** cnt)
         want[a] = 1.0
-        np.testing.assert_allclose(got[k], want, rtol=RTOL, atol=1e-30)
+        np.testing.assert_allclose(got[k], want, **tol)
         outside = cnt == 0                                         # S stays inside supp(E), quirk Q6
         outside[a] = False
         assert np.all(got[k][outside] == 0.0)
@@ -282,6 +286,8 @@ def test_config5_pl65536_simrank_pp_properties(ops):
     A = ops.download_rows(solver.cur[0][0], lo)[:, hi]
     B = ops.download_rows(solver.cur[0][0], hi)[:, lo]
     np.testing.assert_allclose(A, B.T, rtol=RTOL, atol=1e-30)
+    if storage == "fp16":
+        assert np.array_equal(A, B.T)                              # one triangle is the other's mirror image
     lonely = np.flatnonzero(np.diff(csr.rowptr) == 0)[:3]
     if lonely.size:
         L = ops.download_rows(solver.cur[0][0], lonely)

@@ -782,6 +782,8 @@ class Solver:
         self._index = {}
         self.specs = specs
         self.bipartite = len(specs) == 2
+        if mode == "auto" and any(s.storage == "fp16" for s in specs):
+            mode = "sparse"              # fp16-held matrices exist for the gather legs only
         self.mode = choose_mode(mode, [s.csr for s in specs], world.size,
                                 all(s.symmetric for s in specs))
         torch_buffers = isinstance(world, TorchWorld)

@@ -273,3 +273,25 @@ def test_plan_api_with_half_storage(ops):
     assert all(abs(c - w) <= 0.01 * w + 8 for c, w in zip(counts, want_counts)), (counts, want_counts)
     np.testing.assert_allclose(got, want, rtol=4 * HALF_ULP, atol=1e-7)
     assert np.array_equal(got, got.T) and np.all(np.diag(got) == 1.0)
+
+
+def test_bipartite_fit_with_half_storage():
+    """BipartiteSimRankPP (SimRank.py:410-424, Gauss-Seidel order): rectangular legs on fp16-held matrices,
+    ten updates on both sides against the oracle; a tiny graph (where mode "auto" would pick the dense legs)
+    runs the gather legs instead of being refused."""
+    import simrank_amd.SimRank as SRA
+    from oracle import simrank_oracle as O
+    from tests.graphs import bipartite_random
+    df = bipartite_random(900, 500, 0.03, seed=14)
+    want = O.fit_bipartite_pp(df, verbose=False, strict_reference=False, iterations=10, eps=1e-30)
+    s1, s2 = SRA.BipartiteSimRankPP().fit(df, verbose=False, strict_reference=False, iterations=10, eps=1e-30,
+                                          storage_precision="fp16")
+    for got, ref in ((s1.values, want["S1"]), (s2.values, want["S2"])):
+        assert np.array_equal(got, got.T) and np.all(np.diag(got) == 1.0)
+        err = np.abs(got - ref)
+        rel = err[ref > 0] / ref[ref > 0]
+        assert err.max() < 6e-4 and rel.max() < 3e-3 and np.median(rel) < 4e-4, (err.max(), rel.max(), np.median(rel))
+    small = bipartite_random(40, 30, 0.2, seed=2)
+    a, b = SRA.BipartiteSimRank().fit(small, verbose=False, storage_precision="fp16")
+    wa = O.fit_bipartite(small, verbose=False)
+    assert np.abs(a.values - wa["S1"]).max() < 1e-3 and np.abs(b.values - wa["S2"]).max() < 1e-3

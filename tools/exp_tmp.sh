@@ -1,4 +1,2 @@
-timeout -k 10 900 python -m pytest tests/test_gpu_half.py -x -q -k "plan or refused or needs" > gpurun_out/half_tests7.log 2>&1; echo "tests rc $?"
-tail -12 gpurun_out/half_tests7.log
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -k "config5 or plan_api" > gpurun_out/half_tests8.log 2>&1; echo "tests rc $?"
-tail -6 gpurun_out/half_tests8.log
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/r03_gpu_tests.log 2>&1; echo "tests rc $?"
+tail -12 gpurun_out/r03_gpu_tests.log

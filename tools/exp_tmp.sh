@@ -1,2 +1,3 @@
-timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/r03_gpu_tests.log 2>&1; echo "tests rc $?"
-tail -12 gpurun_out/r03_gpu_tests.log
+ONLY_HALF=1 bash tools/gpu_profile.sh r03 > gpurun_out/prof_r03_half.txt 2>&1; echo "profile rc $?"
+grep -n "config 5" -A8 gpurun_out/prof_r03_half.txt | head -30
+grep "^half_" gpurun_out/prof_r03_half.txt

@@ -526,6 +526,9 @@ class Side:
             if a.shape != (self.M, self.M):
                 raise ValueError(f"operands could not be broadcast together with shapes "
                                  f"({self.M},{self.M}) {a.shape} ")
+            if self.sdtype == np.float16 and not (np.isfinite(a).all() and float(np.abs(a).max()) < 3.99):
+                # (fp16-held matrices store value x 2^14: anything from 4 up is out of fp16's range)
+                raise ValueError("storage_precision='fp16' needs prior values below 4 in magnitude")
             self.ap = ops.matrix(self.M, self.Lm, blocked=True) if self.blocked else ops.matrix(self.M, self.Lm)
             ops.upload(self.ap, a[:, self.m_lo:self.m_hi].astype(np.float32))
 

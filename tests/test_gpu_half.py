@@ -239,7 +239,8 @@ def test_half_storage_is_refused_where_it_does_not_exist():
         SRA.SimRank().fit(df, verbose=False, storage_precision="bf16")
     with pytest.raises(ValueError, match="storage_precision='fp16' needs"):
         SRA.SimRank().fit(df, verbose=False, storage_precision="fp16", mode="dense")
-    big = np.full((300, 300), 5.0)
+    n = len(SRA.SimRank().fit(df, verbose=False, iterations=1))
+    big = np.full((n, n), 5.0)
     with pytest.raises(ValueError, match="prior values below 4"):
         SRA.AprioriSimRank().fit(df, big, verbose=False, storage_precision="fp16")
 

@@ -357,3 +357,20 @@ def test_dealt_order():
     assert list(d[:32]) == list(range(32)) and list(d[32:64]) == list(range(128, 160))
     assert list(d[64:96]) == list(range(32, 64))          # shard 1 starts with tile 1
     assert dealt_order(np.arange(100), 4) is not None and list(dealt_order(np.arange(100), 4)) == list(range(100))
+
+
+def test_storage_precision_is_validated_on_the_host():
+    """`fit(storage_precision=...)` (config 5's reduced-precision mode, csrc/half.hip): unknown values are
+    refused before anything touches a device, and an engine without fp16-held matrices (this NumPy stand-in;
+    sharded worlds; the dense legs) refuses the mode instead of silently running f32."""
+    import simrank_amd.SimRank as SRA
+    df = pd.DataFrame({"from": [0, 1, 2, 3], "to": [1, 2, 3, 0], "weight": [1.0, 1.0, 1.0, 1.0]})
+    with pytest.raises(ValueError, match="storage_precision must be"):
+        SRA.SimRank().fit(df, verbose=False, storage_precision="bf16", _ops_factory=lambda r: NumpyOps())
+    with pytest.raises(ValueError, match="storage_precision='fp16' needs"):
+        SRA.SimRank().fit(df, verbose=False, storage_precision="fp16", _ops_factory=lambda r: NumpyOps())
+    with pytest.raises(ValueError, match="storage_precision='fp16' needs"):
+        SRA.SimRank().fit(df, verbose=False, storage_precision="fp16", world=LocalWorld(2),
+                          _ops_factory=lambda r: NumpyOps())
+    ok = SRA.SimRank().fit(df, verbose=False, storage_precision="f32", _ops_factory=lambda r: NumpyOps())
+    assert ok.shape == (4, 4)

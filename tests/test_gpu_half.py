@@ -299,3 +299,26 @@ def test_bipartite_fit_with_half_storage():
     a, b = SRA.BipartiteSimRank().fit(small, verbose=False, storage_precision="fp16")
     wa = O.fit_bipartite(small, verbose=False)
     assert np.abs(a.values - wa["S1"]).max() < 1e-3 and np.abs(b.values - wa["S2"]).max() < 1e-3
+
+
+@pytest.mark.parametrize("n", [2, 3, 7, 33, 63, 64, 65, 127, 128, 129, 257, 700])
+def test_odd_sizes_with_half_storage(n):
+    """Node counts around every grid the kernel has (8-row pieces, 64-column panels, 128-row blocks): five
+    updates of SimRank++ on fp16-held matrices against the f32 run of the same build."""
+    import pandas as pd
+    import simrank_amd.SimRank as SRA
+    rng = np.random.default_rng(n)
+    m = max(2, int(n * min(n - 1, 6)))
+    src, dst = rng.integers(0, n, size=m), rng.integers(0, n, size=m)
+    ring = np.arange(n)
+    df = pd.DataFrame({"from": np.concatenate([src, ring]), "to": np.concatenate([dst, (ring + 1) % n]),
+                       "weight": 1.0}).drop_duplicates(["from", "to"])
+    df = df[df["from"] != df["to"]].reset_index(drop=True)
+    kw = dict(verbose=False, iterations=5, eps=1e-30, weighted=False)
+    want = SRA.SimRankPP().fit(df, **kw)
+    got = SRA.SimRankPP().fit(df, storage_precision="fp16", **kw)
+    assert list(got.index) == list(want.index)
+    a, b = got.values, want.values
+    assert np.array_equal(a, a.T) and np.all(np.diag(a) == 1.0)
+    np.testing.assert_allclose(a, b, rtol=3e-3, atol=2e-8)
+    assert np.array_equal(a == 0, b == 0) or np.abs(a - b).max() < 1e-7      # same support (above fp16's floor)

@@ -1,3 +1,2 @@
-ONLY_HALF=1 bash tools/gpu_profile.sh r03 > gpurun_out/prof_r03_half.txt 2>&1; echo "profile rc $?"
-grep -n "config 5" -A8 gpurun_out/prof_r03_half.txt | head -30
-grep "^half_" gpurun_out/prof_r03_half.txt
+timeout -k 10 900 python -m pytest tests/test_gpu_half.py -x -q -k "odd_sizes or refused" > gpurun_out/half_tests9.log 2>&1; echo "tests rc $?"
+tail -12 gpurun_out/half_tests9.log

@@ -438,7 +438,14 @@ class Side:
         self.k_lo, self.k_hi = partition(self.K, world, rank)
         self.Lm, self.Lk = self.m_hi - self.m_lo, self.k_hi - self.k_lo
         self.mb = -(-self.M // world)
-        self.graph = ops.graph(csr, spec.rowscale, dense_terms=spec.dense_terms)
+        knobs = {}
+        if spec.storage == "fp16" and hasattr(ops, "get_tuning") and ops.get_tuning("fuse_min") == 3:
+            # one fp16 MFMA term instead of three bf16 ones, but each operand segment serves 64 columns, so the
+            # gathers got cheaper still: the break-even moves up by one (measured: 4 is 3 % faster than 3, 2 is
+            # 12 % slower).  Only while the knob is at its default.
+            knobs = {"fuse_min": 4}
+        self.graph = (ops.graph(csr, spec.rowscale, dense_terms=spec.dense_terms, knobs=knobs) if knobs
+                      else ops.graph(csr, spec.rowscale, dense_terms=spec.dense_terms))
         self.symmetric = spec.symmetric
         self.x1 = self.x2 = None
         self.broadcast_error = None

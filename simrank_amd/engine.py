@@ -411,9 +411,21 @@ class HipOps:
         torch.cuda.current_stream(self.device).synchronize()
 
     # ---- graph + kernels ----
-    def graph(self, csr: CSR, rowscale=None, dense_terms: int = 3) -> Graph:
-        """``dense_terms``: operand terms of the matrix-core part for this graph (3 exact, 1 = one fp16 term)."""
-        g = Graph(self, csr, rowscale)
+    _knob_lock = threading.RLock()    # graph creation with per-graph knobs: set, create, restore as one step
+
+    def graph(self, csr: CSR, rowscale=None, dense_terms: int = 3, knobs: dict | None = None) -> Graph:
+        """``dense_terms``: operand terms of the matrix-core part for this graph (3 exact, 1 = one fp16 term).
+        ``knobs``: tuning values for THIS graph only (a graph keeps the knobs it was created with): set, create
+        and restore under a lock that every graph creation of this module takes."""
+        with HipOps._knob_lock:
+            saved = {k: self.get_tuning(k) for k in (knobs or {})}
+            try:
+                if knobs:
+                    self.set_tuning(**knobs)
+                g = Graph(self, csr, rowscale)
+            finally:
+                if saved:
+                    self.set_tuning(**saved)
         if dense_terms != 3:
             check(self.lib.simrank_graph_set_dense_terms(g.handle, int(dense_terms)), "simrank_graph_set_dense_terms")
         return g

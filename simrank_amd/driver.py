@@ -881,8 +881,9 @@ class Solver:
         return out
 
     def _update(self, side_idx, in_idx, out_idx, eps):
-        """One similarity update on every local virtual rank; returns the global count of
-        elements that moved by more than eps."""
+        """One similarity update on every local virtual rank.  Returns 0 when no element moved by more than
+        eps and a positive number otherwise — the exact global count of such elements only with
+        ``exact_count`` set (the default short-circuit test stops comparing once one has been found)."""
         sides = self.sides[side_idx]
         hook = self.world.begin_stage if getattr(self.world, "stream_ordered", False) else None
         for r in self.world.local_ranks:
@@ -925,7 +926,8 @@ class Solver:
         return self.world.sum_int(counts)
 
     def step(self, eps=0.0):
-        """One loop body of the reference (both updates for the bipartite classes)."""
+        """One loop body of the reference (both updates for the bipartite classes); the return value as
+        ``_update``: 0 = nothing moved by more than eps."""
         if self.bipartite:
             c1 = self._update(0, 1, 0, eps)      # S1 <- f1(S2)           SimRank.py:297-299
             c2 = self._update(1, 0, 1, eps)      # S2 <- f2(S1 new)       SimRank.py:300-302

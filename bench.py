@@ -321,6 +321,39 @@ def main():
                 "entries_gathered": frem,
                 "note": "lower bound: the launch also gathers the remainder and stores the tiles, and its whole "
                         "duration is charged here; exact f32 products (three bf16 MFMAs per operand term)"}
+            if gpu and world_size == 1 and not args.no_extras:
+                # the matrix-core phase by itself: the same launch on a graph whose gather phase is switched
+                # off (diagnostic knob probe_flags = 1; wrong results, timing only) minus the launch with both
+                # phases off (5): what the phase costs when nothing else runs beside it
+                try:
+                    os.environ["SIMRANK_ENABLE_PROBES"] = "1"
+                    S_in = solver.cur[0][0]
+                    scratch = ops.matrix(side.K, side.M, blocked=True)
+                    t_probe = {}
+                    for flags in (1, 5):
+                        gp = ops.graph(side.spec.csr, side.spec.rowscale, knobs={"probe_flags": flags})
+                        for _ in range(2):
+                            ops.spmm(gp, S_in, scratch, n_cols=side.Lk, transpose_out=True)
+                        e0, e1 = ops.event(), ops.event()
+                        ops.record(e0)
+                        for _ in range(5):
+                            ops.spmm(gp, S_in, scratch, n_cols=side.Lk, transpose_out=True)
+                        ops.record(e1)
+                        ops.synchronize()
+                        t_probe[flags] = ops.elapsed_ms(e0, e1) / 5
+                        gp.free()
+                    scratch.free()
+                    ph = t_probe[1] - t_probe[5]
+                    out["roofline_mfma"]["phase_alone"] = {
+                        "ms": ph, "achieved": flop / (ph * 1e-3) / 1e12, "unit": "TFLOP/s",
+                        "frac": flop / (ph * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
+                        "ms_launch_without_gather_phase": t_probe[1], "ms_launch_with_neither_phase": t_probe[5],
+                        "note": "operand segments come from the real (L2-missing) ids; the phase adds "
+                                "~1.3 ms to the whole launch (DESIGN.md §4.10)"}
+                except Exception as e:
+                    out["roofline_mfma"]["phase_alone"] = {"error": f"{type(e).__name__}: {e}"}
+                finally:
+                    os.environ.pop("SIMRANK_ENABLE_PROBES", None)
         elif dk and side.Lk:
             S_in = solver.cur[0][rank if use_dist else 0]
             for _ in range(2):

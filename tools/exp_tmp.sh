@@ -1,7 +1,4 @@
-timeout -k 10 1000 python bench.py --no-cpu-baseline > gpurun_out/bench_probe.json 2> gpurun_out/bench_probe.err; echo "bench rc $?"
-python - <<'PY'
-import json
-d=json.load(open('gpurun_out/bench_probe.json'))
-print(d['value'], d['ms_per_step'])
-print(json.dumps(d['roofline_mfma'], indent=1)[:1800])
-PY
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/r03_gpu_tests.log 2>&1; echo "tests rc $?"
+tail -4 gpurun_out/r03_gpu_tests.log
+timeout -k 10 1000 python bench.py > gpurun_out/bench_r03.json 2> gpurun_out/bench_r03.err; echo "bench rc $?"
+python tools/bench_summary.py gpurun_out/bench_r03.json 2>/dev/null | head -4

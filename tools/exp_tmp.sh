@@ -1,4 +1,8 @@
-timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/r03_gpu_tests.log 2>&1; echo "tests rc $?"
-tail -4 gpurun_out/r03_gpu_tests.log
-timeout -k 10 1000 python bench.py > gpurun_out/bench_r03.json 2> gpurun_out/bench_r03.err; echo "bench rc $?"
-python tools/bench_summary.py gpurun_out/bench_r03.json 2>/dev/null | head -4
+rm -f gpurun_out/fused_exp22.log
+run() { timeout -k 10 200 python tools/leg_only.py --workload $1 --steps 8 --set fuse=1 >> gpurun_out/fused_exp22.log 2>&1; }
+for wl in pl32768d32 pl32768; do
+echo "== $wl base" >> gpurun_out/fused_exp22.log; run $wl
+echo "== $wl prio2" >> gpurun_out/fused_exp22.log; SIMRANK_LIB=$PWD/gpurun_variants/libsimrank_hip_prio2.so run $wl
+echo "== $wl prio3" >> gpurun_out/fused_exp22.log; SIMRANK_LIB=$PWD/gpurun_variants/libsimrank_hip_prio3.so run $wl
+done
+grep "wall\|==" gpurun_out/fused_exp22.log | sed 's/exchange1.0.: [0-9.]*, //'

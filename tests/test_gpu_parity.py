@@ -722,6 +722,17 @@ def test_support_restricted_simrank_pp_is_bit_equal(world, monkeypatch):
     c = ops.download(cnt)
     segs = c.reshape(csr.n_rows, -1, 32).any(axis=2)
     assert abs(frac - segs.mean()) < 1e-12 and frac < drv.RESTRICT_BELOW
+    # the panel-blocked layout (what the single-rank solver holds) takes another path through the kernel:
+    # a width off the 32-column grid, a few isolated counts, one of them in the last, partial segment
+    rng = np.random.default_rng(0)
+    c2 = np.zeros((777, 777), dtype=np.uint8)
+    c2[rng.integers(0, 777, 300), rng.integers(0, 777, 300)] = 1
+    c2[5, 776] = 3
+    blk = ops.matrix(777, 777, np.uint8, blocked=True)
+    ops.upload(blk, c2)
+    padded = np.zeros((777, 25 * 32), dtype=np.uint8)
+    padded[:, :777] = c2
+    assert abs(ops.evidence_live_fraction(blk) - padded.reshape(777, 25, 32).any(axis=2).mean()) < 1e-12
 
 
 def test_fp16_dense_blocks_are_an_explicit_reduced_precision_choice():

@@ -1496,6 +1496,89 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
     }
 }
 
+// The same selection in ONE pass over the row for k <= K (16 or 32): every lane keeps the K best of its own
+// columns in registers, sorted by the same total order (an element that does not beat the lane's K-th is one
+// compare), then the wave takes the best head k times.  At N = 65536 the k + 1 passes of the kernel above move
+// 190 GB for k = 10; this one 17 GB.
+template <int K>
+__global__ __launch_bounds__(256) void topk_rows_onepass_kernel(const float* __restrict__ S, int64_t ld,
+                                                                int64_t n_rows, int64_t n_cols, int64_t col0,
+                                                                int k, int exclude_diag,
+                                                                const int32_t* __restrict__ col_ids,
+                                                                int32_t* idx_out, float* val_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * int64_t(blockDim.x) + threadIdx.x) >> 6;
+    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(S) & 15) == 0 &&
+                     (!col_ids || (reinterpret_cast<uintptr_t>(col_ids) & 15) == 0);
+    for (int64_t a = wave; a < n_rows; a += nwaves) {
+        const int64_t skip = exclude_diag ? a - col0 : -1;
+        float tv[K];
+        int ti[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) { tv[i] = -__builtin_inff(); ti[i] = 0x7fffffff; }
+        const float* row = S + a * ld;
+        auto offer = [&](float v, int id, int64_t c) __attribute__((always_inline)) {
+            if (c != skip && ((v > tv[K - 1]) || (v == tv[K - 1] && id < ti[K - 1]))) {
+                // insert: carry the element down the sorted list, swapping where it is better
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    const bool better = (v > tv[i]) || (v == tv[i] && id < ti[i]);
+                    const float nv = better ? tv[i] : v;
+                    const int ni = better ? ti[i] : id;
+                    tv[i] = better ? v : tv[i];
+                    ti[i] = better ? id : ti[i];
+                    v = nv;
+                    id = ni;
+                }
+            }
+        };
+        // 16 bytes per lane and load (rows are 16-byte aligned: ld is a multiple of 4), two loads in flight
+        typedef float v4f32 __attribute__((ext_vector_type(4)));
+        typedef int v4i32 __attribute__((ext_vector_type(4)));
+        const int64_t n4 = vec ? (n_cols & ~int64_t(3)) : 0;
+        for (int64_t c = 4 * lane; c < n4; c += 512) {
+            const int64_t c2 = c + 256;
+            const bool two = c2 < n4;
+            const v4f32 x0 = __builtin_nontemporal_load(reinterpret_cast<const v4f32*>(row + c));
+            const v4f32 x1 = two ? __builtin_nontemporal_load(reinterpret_cast<const v4f32*>(row + c2)) : v4f32{0, 0, 0, 0};
+            v4i32 i0 = v4i32{int(col0 + c), int(col0 + c + 1), int(col0 + c + 2), int(col0 + c + 3)};
+            v4i32 i1 = v4i32{int(col0 + c2), int(col0 + c2 + 1), int(col0 + c2 + 2), int(col0 + c2 + 3)};
+            if (col_ids) {
+                i0 = *reinterpret_cast<const v4i32*>(col_ids + c);
+                if (two) i1 = *reinterpret_cast<const v4i32*>(col_ids + c2);
+            }
+            offer(x0.x, i0.x, c); offer(x0.y, i0.y, c + 1); offer(x0.z, i0.z, c + 2); offer(x0.w, i0.w, c + 3);
+            if (two) {
+                offer(x1.x, i1.x, c2); offer(x1.y, i1.y, c2 + 1); offer(x1.z, i1.z, c2 + 2); offer(x1.w, i1.w, c2 + 3);
+            }
+        }
+        for (int64_t c = n4 + lane; c < n_cols; c += 64)
+            offer(row[c], col_ids ? col_ids[c] : int(col0 + c), c);
+        for (int j = 0; j < k; ++j) {
+            float bv = tv[0];
+            int bi = ti[0];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ov = __shfl_xor(bv, off);
+                const int oi = __shfl_xor(bi, off);
+                if ((ov > bv) || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            const bool found = bi != 0x7fffffff;
+            if (lane == 0) {
+                idx_out[a * k + j] = found ? bi : -1;
+                val_out[a * k + j] = found ? bv : 0.f;
+            }
+            if (found && ti[0] == bi) {          // ids are distinct: exactly one lane owns the pick; it pops its head
+#pragma unroll
+                for (int i = 0; i + 1 < K; ++i) { tv[i] = tv[i + 1]; ti[i] = ti[i + 1]; }
+                tv[K - 1] = -__builtin_inff();
+                ti[K - 1] = 0x7fffffff;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // dst[i][j] = src[row_idx[i]][col_idx[j]] (a NULL index list = identity): moves a matrix
 // between the solver's node order (rows sorted by length) and the caller's.  One workgroup
@@ -2050,6 +2133,17 @@ static int topk_impl(const float* S, int64_t ld, int64_t rows_pad, int64_t n_row
     SR_REQUIRE(n_rows > 0 && n_cols > 0 && (rows_pad ? rows_pad >= n_rows : ld >= n_cols) &&
                    n_cols < (int64_t(1) << 31) && k > 0 && k <= 1024, "bad top-k request");
     const int grid = (int)std::min<int64_t>((n_rows + 3) / 4, 256 * 8);
+    // row-major rows longer than the L2 keeps: one pass with the k best per lane in registers
+    if (!rows_pad && k <= 32 && n_cols >= 8192) {
+        if (k <= 16)
+            hipLaunchKernelGGL(topk_rows_onepass_kernel<16>, dim3(grid), dim3(256), 0, as_stream(stream), S, ld, n_rows,
+                               n_cols, col0, k, exclude_diag, col_ids, idx_out, val_out);
+        else
+            hipLaunchKernelGGL(topk_rows_onepass_kernel<32>, dim3(grid), dim3(256), 0, as_stream(stream), S, ld, n_rows,
+                               n_cols, col0, k, exclude_diag, col_ids, idx_out, val_out);
+        SR_HIP(hipGetLastError());
+        return SIMRANK_OK;
+    }
     hipLaunchKernelGGL(topk_rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), S, ld, rows_pad,
                        n_rows, n_cols, col0, k, exclude_diag, col_ids, idx_out, val_out);
     SR_HIP(hipGetLastError());

@@ -420,6 +420,32 @@ def test_topk_rows_with_column_ids(ops):
         assert list(idx[a]) == [ids[c] for c in cols[:6]]
         assert list(val[a]) == [S[a, c] for c in cols[:6]]
 
+@pytest.mark.parametrize("cols,k,with_ids", [(8192, 10, False), (9001, 10, True), (9001, 16, False), (8500, 20, True),
+                                              (8200, 32, False), (9001, 40, True)])
+def test_topk_rows_of_long_rows(ops, cols, k, with_ids):
+    """Rows longer than 8192 columns take the one-pass selection for k <= 32 (the k best of every lane's
+    columns in registers); same total order — value descending, id ascending — as the k-pass kernel (k = 40
+    here), on rows full of ties, rows with fewer than k nonzeros, a width off the 4-column grid."""
+    rows, c0 = 37, 3
+    rng = np.random.default_rng(cols + k)
+    h = (rng.integers(0, 6, size=(rows, cols)) * (rng.random((rows, cols)) < 0.01)).astype(np.float32) / 8   # sparse, ties
+    h[1] = 0.0                                           # nothing but ties at zero
+    h[2, :5] = [0.5, 0.5, 0.25, 0.5, 0.125]
+    h[3] = rng.random(cols).astype(np.float32)           # dense, no ties
+    ids = rng.permutation(3 * cols)[:cols].astype(np.int32) if with_ids else None
+    key = ids if with_ids else c0 + np.arange(cols)
+    idx, val = ops.topk_rows(put(ops, h), k, col0=c0, exclude_diag=True,
+                             col_ids=ops.index_vector(ids) if with_ids else None)
+    for r in range(rows):
+        keep = np.ones(cols, bool)
+        if 0 <= r - c0 < cols:
+            keep[r - c0] = False
+        cand = np.flatnonzero(keep)
+        order = cand[np.lexsort((key[cand], -h[r, cand]))][:k]
+        assert list(idx[r]) == [int(key[c]) for c in order]
+        np.testing.assert_array_equal(val[r], h[r, order])
+
+
 @pytest.mark.parametrize("form", ["plain", "symmetric", "blocked"])
 def test_count_any_short_circuits_the_comparison(ops, form):
     """epilogue.count_any: the kernel may stop comparing with the previous iterate once a difference

@@ -416,7 +416,7 @@ int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
     if (!rc && g->n_tiles) rc = up((void**)&g->tile_row0, tile_row0.data(), tile_row0.size() * 4);
     if (!rc && g->sym_blocks) rc = up((void**)&g->sym_map, sym_map.data(), sym_map.size() * 4);
     if (!rc && g->tun.dense_min > 0 && nnz > 0) rc = build_dense_plan(g, rowptr, col);
-    if (!rc && g->tun.fuse && nnz > 0) rc = build_fused_plan(g, rowptr, col, rowscale);
+    if (!rc && g->tun.fuse) rc = build_fused_plan(g, rowptr, col, rowscale);    // (also without entries: fp16-held updates have no other path)
     if (rc) {
         simrank_graph_destroy(g);
         return rc;

@@ -322,3 +322,19 @@ def test_odd_sizes_with_half_storage(n):
     assert np.array_equal(a, a.T) and np.all(np.diag(a) == 1.0)
     np.testing.assert_allclose(a, b, rtol=3e-3, atol=2e-8)
     assert np.array_equal(a == 0, b == 0) or np.abs(a - b).max() < 1e-7      # same support (above fp16's floor)
+
+
+def test_graph_without_entries_on_half_storage(ops):
+    """No edges at all (found by tools/soak_kernels.py): the one-launch plan exists for such a graph too, leg 1
+    gives zeros and leg 2 the identity (and the prior, where there is one)."""
+    n = 70
+    csr = CSR(n, n, np.zeros(n + 1, np.int32), np.empty(0, np.int32), np.ones(n))
+    g = ops.graph(csr)
+    x = put_half(ops, np.random.default_rng(0).random((n, n)))
+    yt = ops.matrix(n, n, np.float16, blocked=True)
+    ops.spmm(g, x, yt, transpose_out=True)
+    assert not ops.download(yt).any()
+    y = ops.matrix(n, n, np.float16, blocked=True)
+    ops.spmm(g, yt, y, epilogue=dict(coef=0.8, previous=x, eps=1e-4, set_diag=True, symmetric=True))
+    assert np.array_equal(ops.download(y), np.eye(n, dtype=np.float32))
+    assert ops.read_changed() > 0

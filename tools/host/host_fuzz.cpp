@@ -193,7 +193,13 @@ int main(int argc, char** argv) {
         simrank_set_tuning("fuse_unit", it % 3 == 0 ? 4 : 1 << 20);
         simrank_set_tuning("fuse_group", 1 + it % 4);
         simrank_set_tuning("fuse_order", it % 5 == 1 ? 2 : 0);
-        Csr c = random_graph(rng, M, K, 1 + u(rng) * 12, int(u(rng) * 200), u(rng), it % 2 == 0);
+        // (every 17th graph has no entries at all: plans of nothing but empty rows)
+        Csr c = random_graph(rng, M, K, it % 17 == 16 ? 0.0 : 1 + u(rng) * 12, it % 17 == 16 ? 0 : int(u(rng) * 200),
+                             u(rng), it % 2 == 0);
+        if (it % 17 == 16) {
+            c.col.clear();
+            std::fill(c.rowptr.begin(), c.rowptr.end(), 0);
+        }
         simrank_graph* g = nullptr;
         const int rc = simrank_graph_create(c.M, c.K, (int64_t)c.col.size(), c.rowptr.data(), c.col.data(),
                                             c.scale.data(), &g);

@@ -1,2 +1,2 @@
-timeout -k 10 1100 python tools/soak_fits_half.py 0 600 > gpurun_out/r03_soak_fits_half.log 2>&1; echo "soak rc $?"
-tail -6 gpurun_out/r03_soak_fits_half.log
+timeout -k 10 1100 python tools/soak_plan.py 0 600 > gpurun_out/r03_soak_plan.log 2>&1; echo "soak rc $?"
+tail -5 gpurun_out/r03_soak_plan.log

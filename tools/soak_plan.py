@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Soak of the C-level loop (simrank_plan_*: create / run / result) on a real GPU: random directed graphs,
+SimRank and SimRank++ (and a symmetric prior every third case), against the float64 oracle at 1e-5 with the
+reference's convergence iteration.  `python3 tools/soak_plan.py [first_seed] [count]`."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import simrank_oracle as O                 # noqa: E402
+from simrank_amd import ingest, synth                  # noqa: E402
+from simrank_amd.engine import HipOps, Plan            # noqa: E402
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+ops = HipOps(0)
+t0 = time.time()
+for seed in range(first, first + count):
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.integers(2, 700))
+    df = (synth.er_directed(n, float(rng.uniform(0.005, 0.2)), seed) if seed % 2
+          else synth.powerlaw_directed(n, float(rng.uniform(1, 25)), seed))
+    if len(df) == 0:
+        continue
+    pp = bool(rng.integers(0, 2)) or seed % 3 == 0           # (the prior classes of the reference are SimRank++ ones)
+    coef = float(rng.uniform(0.5, 0.9))
+    nodes, csr = ingest.directed(df, False, "from", "to", "weight")
+    scale = ingest.spread(csr) * csr.rowscale if pp else csr.rowscale
+    kw = {}
+    prior = None
+    if seed % 3 == 0:
+        prior = rng.random((csr.n_rows, csr.n_rows)).astype(np.float32)
+        prior = ((prior + prior.T) / 2).astype(np.float32)
+        kw = dict(apriori=prior.astype(np.float64), lbd=0.3)
+    want = (O.fit_simrank_pp if pp else O.fit_simrank)(df, C=coef, verbose=False, **kw)
+    plan = Plan(ops, csr, rowscale=scale, coef=coef, evidence=pp, apriori=prior, lbd=0.3 if prior is not None else 0.0)
+    done, conv = plan.run(100, 1e-4)
+    got = plan.result()
+    plan.free()
+    assert (conv if conv is not None else -1) == (want["k"] if want["k"] is not None else -1), (seed, conv, want["k"])
+    np.testing.assert_allclose(got, want["S"], rtol=1e-5, atol=1e-30, err_msg=str(seed))
+    if (seed - first) % 25 == 24:
+        print(f"{seed - first + 1} cases, {time.time() - t0:.0f} s", flush=True)
+print(f"soak_plan: seeds {first}..{first + count - 1} passed")

@@ -1,2 +1,4 @@
-timeout -k 10 1100 python tools/soak_plan.py 0 600 > gpurun_out/r03_soak_plan.log 2>&1; echo "soak rc $?"
-tail -5 gpurun_out/r03_soak_plan.log
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/r03_gpu_tests.log 2>&1; echo "tests rc $?"
+tail -3 gpurun_out/r03_gpu_tests.log
+timeout -k 10 1000 python bench.py > gpurun_out/bench_r03.json 2> gpurun_out/bench_r03.err; echo "bench rc $?"
+python tools/bench_summary.py gpurun_out/bench_r03.json 2>/dev/null | head -3

@@ -410,7 +410,7 @@ SIMRANK_API int simrank_plan_destroy(simrank_plan* p);
  *                 block keeps its set when it makes fuse_steps (8) 16-column steps; fuse 0 = the
  *                 dense_tiles + gather launches of round 2
  *      "fuse_max_rows" operands with more rows than this (default 2^20: never) keep the two-launch leg 1
- *      "fuse_group" up to this many (1..4) consecutive blocks without a set share a workgroup
+ *      "fuse_group" up to this many (1..4, default 3) consecutive blocks without a set share a workgroup
  *      "fuse_unit"  sets of more 64-column groups than this are cut into several workgroups whose
  *                 partial sums meet in memory (off by default: 1 << 20)
  *      "fuse_order" launch order of a panel's workgroups: 0 heaviest first, k: matrix-core units spread

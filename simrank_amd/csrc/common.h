@@ -70,7 +70,7 @@ struct Tuning {
                              // phase spread over the first 1/k of the order
     int64_t fuse_max_rows = 1 << 20;  // ... operands with more rows than this keep the two-launch leg (N = 65536: 20.4
                              // against 21.8 ms, so practically never)
-    int64_t fuse_group = 4;  // ... and up to this many consecutive blocks without a set share a workgroup (1..4)
+    int64_t fuse_group = 3;  // ... and up to this many consecutive blocks without a set share a workgroup (1..4)
     int64_t dense_sym = -1;  // dense part in the upper-triangle form of leg 2: 1 yes, 0 no, -1 = when the
                              // dense sets hold at least half of the pattern's entries
 };

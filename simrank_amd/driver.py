@@ -444,6 +444,8 @@ class Side:
             # gathers got cheaper still: the break-even moves up by one (measured: 4 is 3 % faster than 3, 2 is
             # 12 % slower).  Only while the knob is at its default.
             knobs = {"fuse_min": 4}
+            if ops.get_tuning("fuse_group") == 3:      # (and groups of four: 7 % faster than three at config 5 here,
+                knobs["fuse_group"] = 4                #  where three is 5 % faster than four in f32)
         self.graph = (ops.graph(csr, spec.rowscale, dense_terms=spec.dense_terms, knobs=knobs) if knobs
                       else ops.graph(csr, spec.rowscale, dense_terms=spec.dense_terms))
         self.symmetric = spec.symmetric

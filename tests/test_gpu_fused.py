@@ -22,7 +22,7 @@ def ops():
     o = HipOps(0)
     o.set_tuning(fuse_steps=1, fuse_min=2)   # small test graphs: a dense set however few steps it makes
     yield o
-    o.set_tuning(fuse=1, fuse_min=3, fuse_steps=8, fuse_unit=1 << 20, fuse_group=4)
+    o.set_tuning(fuse=1, fuse_min=3, fuse_steps=8, fuse_unit=1 << 20, fuse_group=3)
 
 
 @contextlib.contextmanager
@@ -31,7 +31,7 @@ def knobs(ops, **kw):
     try:
         yield
     finally:
-        ops.set_tuning(fuse=1, fuse_min=2, fuse_steps=1, fuse_unit=1 << 20, fuse_group=4)
+        ops.set_tuning(fuse=1, fuse_min=2, fuse_steps=1, fuse_unit=1 << 20, fuse_group=3)
 
 
 def put_blocked(ops, a, dtype=np.float32):

@@ -42,7 +42,7 @@ for case in range(cases):
                  fuse_group=int(rng.choice([1, 2, 4])))
     ops.set_tuning(**knobs)
     g = ops.graph(csr)
-    ops.set_tuning(fuse_min=3, fuse_steps=8, fuse_group=4)
+    ops.set_tuning(fuse_min=3, fuse_steps=8, fuse_group=3)
     W = dense64(csr)
     X = (rng.random((K, L)) ** 3).astype(np.float32)
     want = (W @ X.astype(np.float64)).T

@@ -44,9 +44,18 @@
 namespace simrank {
 
 constexpr int kTS = 132;          // floats per column of the LDS tile (32 columns x 128 rows, transposed)
-constexpr int kMinUnits = 64;       // units per panel below which blocks are grouped less
-constexpr int kGroupEntries = 6144; // gathered entries a unit of several set-less blocks may hold
-constexpr int kMaxRem = 256;      // a row whose remainder would be longer sends all its columns to the dense set
+#ifndef SIMRANK_KMINUNITS
+#define SIMRANK_KMINUNITS 64
+#endif
+#ifndef SIMRANK_KGROUPENTRIES
+#define SIMRANK_KGROUPENTRIES 6144
+#endif
+#ifndef SIMRANK_KMAXREM
+#define SIMRANK_KMAXREM 256
+#endif
+constexpr int kMinUnits = SIMRANK_KMINUNITS;       // units per panel below which blocks are grouped less
+constexpr int kGroupEntries = SIMRANK_KGROUPENTRIES; // gathered entries a unit of several set-less blocks may hold
+constexpr int kMaxRem = SIMRANK_KMAXREM;      // a row whose remainder would be longer sends all its columns to the dense set
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -390,6 +390,37 @@ SIMRANK_API int simrank_plan_result_f64(simrank_plan* p, double* dst, int64_t ld
 SIMRANK_API int simrank_plan_info(const simrank_plan* p, int64_t* n, int32_t* updates, const simrank_graph** graph);
 SIMRANK_API int simrank_plan_destroy(simrank_plan* p);
 
+/* ---- BIPARTITE PLAN: the loop of BipartiteSimRank.fit / BipartiteSimRankPP.fit / BipartitleAprioriSimRank.fit
+ *      on one GPU (SimRank.py:288-302, :410-424, :478-492; SURVEY.md §8b create_plan(N or (n1, n2))).
+ *      ONE edge set describes both patterns: the CSR of group 1 (n1 rows, columns = group-2 ids) with the
+ *      per-row scales of both groups — W12 = diag(rowscale1) . A, W21 = diag(rowscale2) . A^T.  Each loop index
+ *      updates S1 from S2 and then S2 from the NEW S1 (Gauss-Seidel, :300-302); the loop ends at index k when
+ *      neither matrix moved by more than eps (:289).  Evidence (options.evidence): E1 from the group-1
+ *      pattern, E2 from the group-2 pattern — the corrected form (the reference multiplies both updates by
+ *      Evidence_N1 and cannot run n1 != n2).  Priors: HOST row-major, symmetric.
+ *      simrank_biplan_result_f64(group = 1 | 2) hands S1 / S2 back in the caller's node order. */
+typedef struct simrank_biplan simrank_biplan;
+typedef struct simrank_biplan_options {
+    float c1, c2;               /* C1, C2 */
+    float lbd1, lbd2;           /* prior blends (used when the prior is given) */
+    const float* apriori1;      /* HOST n1 x n1 row-major symmetric prior, or NULL */
+    int64_t ld_apriori1;
+    const float* apriori2;      /* HOST n2 x n2, or NULL */
+    int64_t ld_apriori2;
+    int32_t evidence;           /* 1: SimRank++ evidence factors */
+    int32_t reorder;            /* 1: iterate in ascending-row-length node order within each group (recommended) */
+} simrank_biplan_options;
+SIMRANK_API int simrank_biplan_create(int64_t n1, int64_t n2, int64_t nnz, const int32_t* rowptr12,
+                                      const int32_t* col12, const float* rowscale1, const float* rowscale2,
+                                      const simrank_biplan_options* options, void* stream, simrank_biplan** out);
+SIMRANK_API int simrank_biplan_reset(simrank_biplan* p);
+SIMRANK_API int simrank_biplan_step(simrank_biplan* p, double eps, int32_t exact_count, int64_t* changed1,
+                                    int64_t* changed2);
+SIMRANK_API int simrank_biplan_run(simrank_biplan* p, int32_t iterations, double eps, int32_t* updates_done,
+                                   int32_t* converged_at);
+SIMRANK_API int simrank_biplan_result_f64(simrank_biplan* p, int32_t group, double* dst, int64_t ld);
+SIMRANK_API int simrank_biplan_destroy(simrank_biplan* p);
+
 /* ---- tuning knobs (measurement harness; defaults are the tuned values).  simrank_set_tuning
  *      changes the process-wide DEFAULTS; simrank_graph_create copies them into the graph it
  *      builds (under a lock), and every launch on that graph uses its copy — a knob set later does

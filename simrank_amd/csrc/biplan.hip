@@ -1,0 +1,355 @@
+// The loop of BipartiteSimRank.fit / BipartiteSimRankPP.fit / BipartitleAprioriSimRank.fit behind the C ABI
+// (create_plan(N or (n1, n2)) / step / download), the two-matrix twin of plan.hip:
+//
+//     for k in range(iterations):                               SimRank.py:288-302 (:410-424, :478-492)
+//         if converged(S1_old, S1) and converged(S2_old, S2): break
+//         S1 = E1 * C1 * W12.S2.W12^T (+ lbd1 A1); diag <- 1       the group-1 update reads S2 of the iteration before,
+//         S2 = E2 * C2 * W21.S1.W21^T (+ lbd2 A2); diag <- 1       the group-2 update the NEW S1 (Gauss-Seidel, :300-302)
+//
+// One edge set describes both patterns: W12 = diag(rowscale1) . A (n1 x n2), W21 = diag(rowscale2) . A^T.
+// Each update is two launches (leg 1: fused_trans_kernel on a rectangular pattern, leg 2: upper-triangle gather
+// with the fused epilogue and count); iteration k + 1 is queued before the counts of iteration k are read, as in
+// plan.hip.  Evidence: the corrected form — E1 from the group-1 pattern, E2 from the group-2 pattern (the
+// reference multiplies BOTH updates by Evidence_N1 and cannot run n1 != n2: SURVEY.md quirk Q2; the Python
+// class keeps that behaviour under strict_reference, this entry point does not reproduce a crash).
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct side_t {
+    int64_t n = 0, k = 0, rows_pad = 0, k_rows_pad = 0;    // n: own group, k: the other group
+    size_t mat_bytes = 0, t_bytes = 0;
+    simrank_graph* g = nullptr;                // n x k, solver order on both sides
+    float* S[2] = {nullptr, nullptr};          // n x n, panel-blocked, ping-pong
+    float* Tt = nullptr;                       // k x n: (W . S_other)^T
+    uint8_t* ev = nullptr;
+    float* prior = nullptr;
+    int32_t* inv = nullptr;                    // device: position of caller's node i in the solver's order
+    float coef = 0.8f, lbd = 0.f;
+    int32_t restrict_support = 0;
+    int cur = 0;
+};
+
+}  // namespace
+
+struct simrank_biplan {
+    side_t s[2];
+    unsigned long long* counters = nullptr;                          // device, SIMRANK_CHANGED_SLOTS (zeroed per leg 2)
+    unsigned long long* host_counters[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [iteration & 1][side]
+    hipEvent_t counted[2] = {nullptr, nullptr};                      // both counts of an iteration have landed
+    hipStream_t stream = nullptr;
+    int32_t updates = 0;
+};
+
+namespace simrank {
+
+static int side_update(simrank_biplan* p, int w, double eps, int32_t exact_count, unsigned long long* host_slot) {
+    side_t& a = p->s[w];
+    const side_t& o = p->s[w ^ 1];
+    // leg 1: Tt (k x n) = (W . S_other)^T; S_other is k x k
+    int rc = simrank_spmm_blocked(a.g, o.S[o.cur], o.rows_pad, a.k, a.Tt, a.k_rows_pad, 1, nullptr, p->stream);
+    if (rc) return rc;
+    simrank_epilogue ep{};
+    ep.coef = a.coef;
+    ep.lbd = a.lbd;
+    ep.evidence = a.ev;
+    ep.ld_evidence = 32;
+    ep.apriori = a.prior;
+    ep.ld_apriori = 32;
+    ep.previous = a.S[a.cur];
+    ep.ld_previous = 32;
+    ep.eps = eps;
+    ep.n_changed = p->counters;
+    ep.diag_col0 = 0;
+    ep.set_diag = 1;
+    ep.symmetric = 1;
+    ep.restrict_support = a.restrict_support;
+    ep.count_any = exact_count ? 0 : 1;
+    rc = simrank_spmm_blocked(a.g, a.Tt, a.k_rows_pad, a.n, a.S[a.cur ^ 1], a.rows_pad, 0, &ep, p->stream);
+    if (rc) return rc;
+    SR_HIP(hipMemcpyAsync(host_slot, p->counters, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS,
+                          hipMemcpyDeviceToHost, p->stream));
+    a.cur ^= 1;              // (the group-2 update of the same iteration reads the new S1)
+    return SIMRANK_OK;
+}
+
+// one loop body: both updates, counts into slot `it`
+static int iteration(simrank_biplan* p, double eps, int32_t exact_count, int it) {
+    int rc = side_update(p, 0, eps, exact_count, p->host_counters[it][0]);
+    if (!rc) rc = side_update(p, 1, eps, exact_count, p->host_counters[it][1]);
+    if (rc) return rc;
+    SR_HIP(hipEventRecord(p->counted[it], p->stream));
+    return SIMRANK_OK;
+}
+
+static int read_counts(simrank_biplan* p, int it, unsigned long long* c1, unsigned long long* c2) {
+    SR_HIP(hipEventSynchronize(p->counted[it]));
+    unsigned long long t[2] = {0, 0};
+    for (int w = 0; w < 2; ++w)
+        for (int i = 0; i < SIMRANK_CHANGED_SLOTS; ++i) t[w] += p->host_counters[it][w][i];
+    *c1 = t[0];
+    *c2 = t[1];
+    return SIMRANK_OK;
+}
+
+}  // namespace simrank
+
+using namespace simrank;
+
+extern "C" {
+
+int simrank_biplan_destroy(simrank_biplan* p) {
+    if (!p) return SIMRANK_OK;
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    for (side_t& a : p->s) {
+        (void)hipFree(a.S[0]); (void)hipFree(a.S[1]); (void)hipFree(a.Tt); (void)hipFree(a.ev);
+        (void)hipFree(a.prior); (void)hipFree(a.inv);
+        simrank_graph_destroy(a.g);
+    }
+    (void)hipFree(p->counters);
+    for (int i = 0; i < 2; ++i) {
+        for (int w = 0; w < 2; ++w)
+            if (p->host_counters[i][w]) (void)hipHostFree(p->host_counters[i][w]);
+        if (p->counted[i]) (void)hipEventDestroy(p->counted[i]);
+    }
+    delete p;
+    return SIMRANK_OK;
+}
+
+int simrank_biplan_reset(simrank_biplan* p) {
+    SR_REQUIRE(p, "plan is NULL");
+    p->updates = 0;
+    for (side_t& a : p->s) {
+        a.cur = 0;
+        const int rc = simrank_fill_identity_blocked(a.S[0], a.n, a.n, a.rows_pad, 0, p->stream);
+        if (rc) return rc;
+    }
+    return SIMRANK_OK;
+}
+
+int simrank_biplan_create(int64_t n1, int64_t n2, int64_t nnz, const int32_t* rowptr12, const int32_t* col12,
+                          const float* rowscale1, const float* rowscale2, const simrank_biplan_options* opt,
+                          void* stream, simrank_biplan** out) {
+    SR_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    SR_REQUIRE(opt && rowptr12 && rowscale1 && rowscale2 && (col12 || nnz == 0) && n1 > 0 && n2 > 0 && nnz >= 0,
+               "bad plan arguments");
+    SR_REQUIRE(n1 < (int64_t(1) << 24) - 16 && n2 < (int64_t(1) << 24) - 16, "a plan holds at most 2^24 nodes per group");
+    SR_REQUIRE(rowptr12[0] == 0 && rowptr12[n1] == nnz, "rowptr does not span [0, nnz]");
+    for (int64_t a = 0; a < n1; ++a)
+        SR_REQUIRE(rowptr12[a + 1] >= rowptr12[a], "rowptr not monotone at row %lld", (long long)a);
+    for (int64_t j = 0; j < nnz; ++j) SR_REQUIRE(col12[j] >= 0 && col12[j] < n2, "column index %d out of range", col12[j]);
+    const float* priors[2] = {opt->apriori1, opt->apriori2};
+    const int64_t lds[2] = {opt->ld_apriori1, opt->ld_apriori2};
+    const int64_t ns[2] = {n1, n2};
+    for (int w = 0; w < 2; ++w)
+        if (priors[w]) {
+            SR_REQUIRE(lds[w] >= ns[w], "prior %d: ld %lld < n", w + 1, (long long)lds[w]);
+            for (int64_t i = 0; i < ns[w]; ++i)
+                for (int64_t j = i + 1; j < ns[w]; ++j)
+                    SR_REQUIRE(priors[w][i * lds[w] + j] == priors[w][j * lds[w] + i],
+                               "a plan needs symmetric priors (prior %d, element %lld, %lld)", w + 1, (long long)i,
+                               (long long)j);
+        }
+    // the group-2 pattern: the transpose
+    std::vector<int32_t> rowptr21((size_t)n2 + 1, 0), col21((size_t)std::max<int64_t>(1, nnz));
+    for (int64_t j = 0; j < nnz; ++j) ++rowptr21[(size_t)col12[j] + 1];
+    for (int64_t i = 0; i < n2; ++i) rowptr21[(size_t)i + 1] += rowptr21[(size_t)i];
+    {
+        std::vector<int32_t> fill(rowptr21.begin(), rowptr21.end() - 1);
+        for (int64_t a = 0; a < n1; ++a)
+            for (int32_t j = rowptr12[a]; j < rowptr12[a + 1]; ++j) col21[(size_t)fill[(size_t)col12[j]]++] = (int32_t)a;
+    }
+    // node orders of the solver: ascending row length within each group; ord[new] = old, inv[old] = new
+    std::vector<int32_t> ord[2], inv[2];
+    const int32_t* rps[2] = {rowptr12, rowptr21.data()};
+    for (int w = 0; w < 2; ++w) {
+        ord[w].resize((size_t)ns[w]);
+        inv[w].resize((size_t)ns[w]);
+        std::iota(ord[w].begin(), ord[w].end(), 0);
+        if (opt->reorder) {
+            const int32_t* rp = rps[w];
+            std::stable_sort(ord[w].begin(), ord[w].end(),
+                             [rp](int32_t x, int32_t y) { return rp[x + 1] - rp[x] < rp[y + 1] - rp[y]; });
+        }
+        for (int64_t r = 0; r < ns[w]; ++r) inv[w][(size_t)ord[w][(size_t)r]] = (int32_t)r;
+    }
+    simrank_biplan* p = new simrank_biplan;
+    p->stream = as_stream(stream);
+    auto fail = [&](int code) { simrank_biplan_destroy(p); return code; };
+    const int32_t* cls[2] = {col12, col21.data()};
+    const float* scales[2] = {rowscale1, rowscale2};
+    for (int w = 0; w < 2; ++w) {
+        side_t& a = p->s[w];
+        a.n = ns[w];
+        a.k = ns[w ^ 1];
+        a.coef = w == 0 ? opt->c1 : opt->c2;
+        a.lbd = w == 0 ? opt->lbd1 : opt->lbd2;
+        a.rows_pad = (a.n + 7) / 8 * 8 + 8;
+        a.k_rows_pad = (a.k + 7) / 8 * 8 + 8;
+        a.mat_bytes = size_t((a.n + 31) / 32) * size_t(a.rows_pad) * 32 * sizeof(float);     // n x n
+        a.t_bytes = size_t((a.n + 31) / 32) * size_t(a.k_rows_pad) * 32 * sizeof(float);      // k x n
+        // the pattern with both sides renamed
+        std::vector<int32_t> rp((size_t)a.n + 1, 0), cl((size_t)std::max<int64_t>(1, nnz));
+        std::vector<float> rs((size_t)a.n);
+        for (int64_t r = 0; r < a.n; ++r) {
+            const int32_t src = ord[w][(size_t)r];
+            const int32_t b = rps[w][src], e = rps[w][src + 1];
+            int32_t* dst = cl.data() + rp[(size_t)r];
+            for (int32_t j = b; j < e; ++j) dst[j - b] = inv[w ^ 1][(size_t)cls[w][j]];
+            std::sort(dst, dst + (e - b));
+            for (int32_t j = 1; j < e - b; ++j) {
+                if (dst[j] == dst[j - 1]) {
+                    set_error("duplicate entry in row %d of group %d", src, w + 1);
+                    return fail(SIMRANK_ERR_INVALID);
+                }
+            }
+            rp[(size_t)r + 1] = rp[(size_t)r] + (e - b);
+            rs[(size_t)r] = scales[w][src];
+        }
+        const int rc = simrank_graph_create(a.n, a.k, nnz, rp.data(), cl.data(), rs.data(), &a.g);
+        if (rc) return fail(rc);
+    }
+#define BIPLAN_HIP(call)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (void)hipGetLastError();                                                              \
+            return fail(e_ == hipErrorOutOfMemory ? SIMRANK_ERR_ALLOC : SIMRANK_ERR_HIP);         \
+        }                                                                                         \
+    } while (0)
+    BIPLAN_HIP(hipMalloc((void**)&p->counters, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS));
+    for (int i = 0; i < 2; ++i) {
+        for (int w = 0; w < 2; ++w)
+            BIPLAN_HIP(hipHostMalloc((void**)&p->host_counters[i][w], sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS,
+                                     hipHostMallocPortable));
+        BIPLAN_HIP(hipEventCreateWithFlags(&p->counted[i], hipEventDisableTiming));
+    }
+    for (int w = 0; w < 2; ++w) {
+        side_t& a = p->s[w];
+        for (float** b : {&a.S[0], &a.S[1]}) {
+            BIPLAN_HIP(hipMalloc((void**)b, a.mat_bytes));
+            BIPLAN_HIP(hipMemsetAsync(*b, 0, a.mat_bytes, p->stream));
+        }
+        BIPLAN_HIP(hipMalloc((void**)&a.Tt, a.t_bytes));
+        BIPLAN_HIP(hipMemsetAsync(a.Tt, 0, a.t_bytes, p->stream));
+        BIPLAN_HIP(hipMalloc((void**)&a.inv, size_t(a.n) * sizeof(int32_t)));
+        BIPLAN_HIP(hipMemcpyAsync(a.inv, inv[w].data(), size_t(a.n) * sizeof(int32_t), hipMemcpyHostToDevice, p->stream));
+        BIPLAN_HIP(hipStreamSynchronize(p->stream));
+        if (opt->evidence) {
+            // common-neighbour counts inside the group (SimRank.py:311-320 on this group's pattern)
+            const size_t ev_bytes = size_t((a.n + 31) / 32) * size_t(a.rows_pad) * 32;
+            BIPLAN_HIP(hipMalloc((void**)&a.ev, ev_bytes));
+            BIPLAN_HIP(hipMemsetAsync(a.ev, 0, ev_bytes, p->stream));
+            int rc = simrank_evidence_counts_blocked(a.g, 0, a.n, a.ev, a.rows_pad, p->stream);
+            if (rc) return fail(rc);
+            int64_t live = 0, total = 1;
+            rc = simrank_evidence_live_segments(a.ev, 32, a.rows_pad, a.n, a.n, &live, &total, p->stream);
+            if (rc) return fail(rc);
+            a.restrict_support = 2 * live < total ? 1 : 0;
+        }
+        if (priors[w]) {
+            float* tmp = nullptr;
+            int32_t* ord_dev = nullptr;
+            BIPLAN_HIP(hipMalloc((void**)&tmp, size_t(a.n) * size_t(a.n) * sizeof(float)));
+            hipError_t e = hipMalloc((void**)&ord_dev, size_t(a.n) * sizeof(int32_t));
+            if (e == hipSuccess) e = hipMalloc((void**)&a.prior, a.mat_bytes);
+            if (e == hipSuccess) e = hipMemsetAsync(a.prior, 0, a.mat_bytes, p->stream);
+            if (e == hipSuccess) e = hipMemcpy2DAsync(tmp, size_t(a.n) * 4, priors[w], size_t(lds[w]) * 4, size_t(a.n) * 4,
+                                                      size_t(a.n), hipMemcpyHostToDevice, p->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(ord_dev, ord[w].data(), size_t(a.n) * 4, hipMemcpyHostToDevice, p->stream);
+            int rc = SIMRANK_OK;
+            if (e == hipSuccess) {
+                rc = simrank_permute_layout(tmp, a.n, 0, a.prior, 32, a.rows_pad, a.n, a.n, ord_dev, ord_dev, 4, p->stream);
+                e = hipStreamSynchronize(p->stream);
+            }
+            (void)hipFree(tmp);
+            (void)hipFree(ord_dev);
+            if (e != hipSuccess) {
+                set_error("plan prior upload: %s", hipGetErrorString(e));
+                return fail(SIMRANK_ERR_HIP);
+            }
+            if (rc) return fail(rc);
+        }
+    }
+#undef BIPLAN_HIP
+    const int rc = simrank_biplan_reset(p);
+    if (rc) return fail(rc);
+    *out = p;
+    return SIMRANK_OK;
+}
+
+int simrank_biplan_step(simrank_biplan* p, double eps, int32_t exact_count, int64_t* changed1, int64_t* changed2) {
+    SR_REQUIRE(p, "plan is NULL");
+    const int rc = iteration(p, eps, exact_count, 0);
+    if (rc) return rc;
+    ++p->updates;
+    if (changed1 || changed2) {
+        unsigned long long c1 = 0, c2 = 0;
+        const int rc2 = read_counts(p, 0, &c1, &c2);
+        if (rc2) return rc2;
+        if (changed1) *changed1 = (int64_t)c1;
+        if (changed2) *changed2 = (int64_t)c2;
+    }
+    return SIMRANK_OK;
+}
+
+int simrank_biplan_run(simrank_biplan* p, int32_t iterations, double eps, int32_t* updates_done, int32_t* converged_at) {
+    SR_REQUIRE(p, "plan is NULL");
+    SR_REQUIRE(iterations >= 0, "iterations < 0");
+    int rc = simrank_biplan_reset(p);
+    if (rc) return rc;
+    int32_t conv = -1, done = 0;
+    if (iterations > 0 && !(1.0 > eps)) {
+        conv = 0;           // loop index 0 compares the identities with zero matrices: "converged" unless 1 > eps
+    } else if (iterations > 0) {
+        rc = iteration(p, eps, 0, 1);                    // iteration 1
+        if (rc) return rc;
+        for (int32_t k = 1;; ++k) {
+            done = k;
+            if (k == iterations) break;                  // the reference makes no test after its last iteration
+            // iteration k + 1 is queued before the counts of iteration k are known; if they say "converged" it is
+            // not adopted: it wrote the buffers of the iterates before last, the current ones are untouched
+            const int c1_cur = p->s[0].cur, c2_cur = p->s[1].cur;
+            rc = iteration(p, eps, 0, (k + 1) & 1);
+            if (rc) return rc;
+            unsigned long long c1 = 0, c2 = 0;
+            rc = read_counts(p, k & 1, &c1, &c2);
+            if (rc) return rc;
+            if (c1 == 0 && c2 == 0) {                    // SimRank.py:289: both groups
+                conv = k;
+                SR_HIP(hipStreamSynchronize(p->stream));  // (the speculative iteration must not outlive its inputs)
+                p->s[0].cur = c1_cur;
+                p->s[1].cur = c2_cur;
+                break;
+            }
+        }
+    }
+    SR_HIP(hipStreamSynchronize(p->stream));
+    p->updates = done;
+    if (updates_done) *updates_done = done;
+    if (converged_at) *converged_at = conv;
+    return SIMRANK_OK;
+}
+
+int simrank_biplan_result_f64(simrank_biplan* p, int32_t group, double* dst, int64_t ld) {
+    SR_REQUIRE(p && dst && (group == 1 || group == 2), "bad result arguments");
+    side_t& a = p->s[group - 1];
+    SR_REQUIRE(ld >= a.n, "ld %lld < n", (long long)ld);
+    float* tmp = nullptr;
+    const int64_t ldt = (a.n + 3) / 4 * 4;
+    SR_HIP(hipMalloc((void**)&tmp, size_t(a.n) * size_t(ldt) * sizeof(float)));
+    // dst[i][j] = S[inv[i]][inv[j]]: out of the panel-blocked layout and the solver's node order in one pass
+    int rc = simrank_permute_layout(a.S[a.cur], 32, a.rows_pad, tmp, ldt, 0, a.n, a.n, a.inv, a.inv, 4, p->stream);
+    if (!rc) rc = simrank_download_f64(dst, ld, tmp, ldt, a.n, a.n, p->stream);
+    (void)hipStreamSynchronize(p->stream);
+    (void)hipFree(tmp);
+    return rc;
+}
+
+}  // extern "C"

@@ -151,6 +151,73 @@ class Plan:
             pass
 
 
+class BiPlanOptions(C.Structure):              # struct simrank_biplan_options
+    _fields_ = [("c1", C.c_float), ("c2", C.c_float), ("lbd1", C.c_float), ("lbd2", C.c_float),
+                ("apriori1", C.c_void_p), ("ld_apriori1", C.c_int64), ("apriori2", C.c_void_p),
+                ("ld_apriori2", C.c_int64), ("evidence", C.c_int32), ("reorder", C.c_int32)]
+
+
+class BiPlan:
+    """The bipartite loop on one GPU behind the C ABI (simrank_biplan_*: SimRank.py:288-302, :410-424,
+    :478-492): the group-1 CSR (columns = group-2 ids) and both groups' row scales in, (S1, S2) out."""
+
+    def __init__(self, ops, csr12: CSR, rowscale1, rowscale2, c1: float = 0.8, c2: float = 0.8,
+                 evidence: bool = False, apriori1=None, apriori2=None, lbd1: float = 0.0, lbd2: float = 0.0,
+                 reorder: bool = True):
+        self.ops = ops
+        rowptr = np.ascontiguousarray(csr12.rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(csr12.col, dtype=np.int32)
+        rs1 = np.ascontiguousarray(rowscale1, dtype=np.float32)
+        rs2 = np.ascontiguousarray(rowscale2, dtype=np.float32)
+        assert rs1.size == csr12.n_rows and rs2.size == csr12.n_cols
+        a1 = None if apriori1 is None else np.ascontiguousarray(apriori1, dtype=np.float32)
+        a2 = None if apriori2 is None else np.ascontiguousarray(apriori2, dtype=np.float32)
+        opt = BiPlanOptions(c1=c1, c2=c2, lbd1=lbd1, lbd2=lbd2,
+                            apriori1=None if a1 is None else a1.ctypes.data, ld_apriori1=0 if a1 is None else a1.shape[1],
+                            apriori2=None if a2 is None else a2.ctypes.data, ld_apriori2=0 if a2 is None else a2.shape[1],
+                            evidence=int(evidence), reorder=int(reorder))
+        h = C.c_void_p()
+        check(ops.lib.simrank_biplan_create(csr12.n_rows, csr12.n_cols, col.size, rowptr.ctypes.data,
+                                            col.ctypes.data if col.size else None, rs1.ctypes.data, rs2.ctypes.data,
+                                            C.byref(opt), ops.stream, C.byref(h)), "simrank_biplan_create")
+        self.handle, self.n1, self.n2 = h, csr12.n_rows, csr12.n_cols
+
+    def run(self, iterations: int, eps: float):
+        """-> (loop bodies applied, loop index at which the convergence test passed or None)."""
+        done, conv = C.c_int32(0), C.c_int32(-1)
+        check(self.ops.lib.simrank_biplan_run(self.handle, int(iterations), float(eps), C.byref(done), C.byref(conv)),
+              "simrank_biplan_run")
+        return done.value, (None if conv.value < 0 else conv.value)
+
+    def reset(self):
+        check(self.ops.lib.simrank_biplan_reset(self.handle), "simrank_biplan_reset")
+
+    def step(self, eps: float, exact_count: bool = True):
+        c1, c2 = C.c_int64(0), C.c_int64(0)
+        check(self.ops.lib.simrank_biplan_step(self.handle, float(eps), int(exact_count), C.byref(c1), C.byref(c2)),
+              "simrank_biplan_step")
+        return c1.value, c2.value
+
+    def result(self):
+        out = []
+        for group, n in ((1, self.n1), (2, self.n2)):
+            m = np.empty((n, n), dtype=np.float64)
+            check(self.ops.lib.simrank_biplan_result_f64(self.handle, group, m.ctypes.data, n), "simrank_biplan_result_f64")
+            out.append(m)
+        return tuple(out)
+
+    def free(self):
+        if self.handle:
+            self.ops.lib.simrank_biplan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class HipOps:
     """Kernel launcher for one device.  ``pitch_pad``: extra elements added to the leading
     dimension of matrices it allocates when that dimension is a large power of two (keeps

@@ -834,3 +834,80 @@ def test_plan_api_with_a_prior_and_in_the_callers_order(ops):
     A[3, 5] += 0.5
     with pytest.raises(SimRankHipError, match="symmetric"):
         Plan(ops, csr, apriori=A, lbd=0.3)
+
+
+# ---------------------------------------------------------------------------------------
+# the bipartite loop behind the C ABI (simrank_biplan_*)
+# ---------------------------------------------------------------------------------------
+def _csr_and_scales(G12, G21):
+    """Pattern of the group-1 adjacency and the per-row values of both normalised adjacencies."""
+    n1, n2 = G12.shape
+    rows, cols = np.nonzero(G12)
+    rowptr = np.zeros(n1 + 1, np.int32)
+    np.cumsum(np.bincount(rows, minlength=n1), out=rowptr[1:])
+    rs1 = np.zeros(n1)
+    rs1[rows] = G12[rows, cols]
+    r2, c2 = np.nonzero(G21)
+    rs2 = np.zeros(n2)
+    rs2[r2] = G21[r2, c2]
+    return ingest.CSR(n1, n2, rowptr, cols.astype(np.int32), rs1), rs1, rs2
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if n.startswith("BipartiteSimRank_")])
+def test_biplan_reproduces_the_golden_vectors(ops, name):
+    """create -> run -> result for BipartiteSimRank against the vectors generated from the reference: S1 and S2
+    to 1e-5, the "Converged at iteration k" index exactly, iterations = 0 included; step by step the same."""
+    from simrank_amd.engine import BiPlan
+    g = Golden(name)
+    csr, rs1, rs2 = _csr_and_scales(g.out["G12"], g.out["G21"])
+    plan = BiPlan(ops, csr, rs1, rs2, c1=g.kwargs.get("C1", 0.8), c2=g.kwargs.get("C2", 0.8))
+    its, eps = g.kwargs.get("iterations", 100), g.kwargs.get("eps", 1e-4)
+    done, conv = plan.run(its, eps)
+    assert (conv if conv is not None else -1) == (g.k if g.k is not None else -1)
+    s1, s2 = plan.result()
+    assert_close(s1, g.out["S1"])
+    assert_close(s2, g.out["S2"])
+    plan.reset()
+    counts = [plan.step(eps, exact_count=True) for _ in range(done)]
+    if conv is not None and done:
+        assert counts[-1] == (0, 0) and all(sum(c) > 0 for c in counts[:-1])
+    t1, t2 = plan.result()
+    assert_close(t1, g.out["S1"])
+    assert_close(t2, g.out["S2"])
+    plan.free()
+
+
+def test_biplan_with_evidence_and_priors_against_the_oracle(ops):
+    """BipartiteSimRankPP in its corrected form (E2 from the group-2 pattern, strict_reference = False) and
+    BipartitleAprioriSimRank with symmetric priors, n1 != n2, through the C-level loop."""
+    from simrank_amd.engine import BiPlan
+    from simrank_amd._lib import SimRankHipError
+    df = bipartite_random(700, 300, 0.03, seed=21)
+    want = O.fit_bipartite_pp(df, verbose=False, strict_reference=False, C1=0.7, C2=0.85)
+    csr, rs1, rs2 = _csr_and_scales(want["G12"], want["G21"])
+    # SimRank++ row scales: spread x normalisation (W1 / W2 of the reference, one value per row)
+    w1 = np.array([want["W1"][a][want["W1"][a] != 0][0] if (want["W1"][a] != 0).any() else 0.0 for a in range(700)])
+    w2 = np.array([want["W2"][a][want["W2"][a] != 0][0] if (want["W2"][a] != 0).any() else 0.0 for a in range(300)])
+    plan = BiPlan(ops, csr, w1, w2, c1=0.7, c2=0.85, evidence=True)
+    done, conv = plan.run(100, 1e-4)
+    s1, s2 = plan.result()
+    assert conv == want["k"]
+    assert_close(s1, want["S1"])
+    assert_close(s2, want["S2"])
+    plan.free()
+    rng = np.random.default_rng(3)
+    a1, a2 = rng.random((700, 700)), rng.random((300, 300))
+    a1, a2 = (a1 + a1.T) / 2, (a2 + a2.T) / 2
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    want = O.fit_bipartite_pp(df, verbose=False, strict_reference=False, apriori1=f32(a1), apriori2=f32(a2),
+                              lbd1=0.2, lbd2=0.4)
+    plan = BiPlan(ops, csr, w1, w2, evidence=True, apriori1=a1, apriori2=a2, lbd1=0.2, lbd2=0.4)
+    done, conv = plan.run(100, 1e-4)
+    s1, s2 = plan.result()
+    assert conv == want["k"]
+    assert_close(s1, want["S1"])
+    assert_close(s2, want["S2"])
+    plan.free()
+    a2[1, 2] += 0.25
+    with pytest.raises(SimRankHipError, match="symmetric"):
+        BiPlan(ops, csr, w1, w2, apriori2=a2)

@@ -43,4 +43,33 @@ for seed in range(first, first + count):
     np.testing.assert_allclose(got, want["S"], rtol=1e-5, atol=1e-30, err_msg=str(seed))
     if (seed - first) % 25 == 24:
         print(f"{seed - first + 1} cases, {time.time() - t0:.0f} s", flush=True)
-print(f"soak_plan: seeds {first}..{first + count - 1} passed")
+print(f"soak_plan: seeds {first}..{first + count - 1} passed (directed)")
+# the bipartite loop (simrank_biplan_*): plain and SimRank++ in its corrected form, n1 != n2
+from simrank_amd.engine import BiPlan                  # noqa: E402
+from tests.graphs import bipartite_random              # noqa: E402
+from tests.test_gpu_parity import _csr_and_scales      # noqa: E402
+t0 = time.time()
+for seed in range(first, first + count // 2):
+    rng = np.random.default_rng(19000 + seed)
+    n1, n2 = int(rng.integers(1, 500)), int(rng.integers(1, 300))
+    df = bipartite_random(n1, n2, float(rng.uniform(0.005, 0.3)), seed=seed)
+    pp = bool(rng.integers(0, 2))
+    c1, c2 = float(rng.uniform(0.5, 0.9)), float(rng.uniform(0.5, 0.9))
+    if pp:
+        want = O.fit_bipartite_pp(df, verbose=False, strict_reference=False, C1=c1, C2=c2)
+        m1, m2 = want["W1"], want["W2"]
+    else:
+        want = O.fit_bipartite(df, verbose=False, C1=c1, C2=c2)
+        m1, m2 = want["G12"], want["G21"]
+    csr, _, _ = _csr_and_scales(want["G12"], want["G21"])
+    rs1, rs2 = np.asarray(m1).max(axis=1), np.asarray(m2).max(axis=1)     # one value per row
+    plan = BiPlan(ops, csr, rs1, rs2, c1=c1, c2=c2, evidence=pp)
+    done, conv = plan.run(100, 1e-4)
+    s1, s2 = plan.result()
+    plan.free()
+    assert (conv if conv is not None else -1) == (want["k"] if want["k"] is not None else -1), (seed, conv, want["k"])
+    np.testing.assert_allclose(s1, want["S1"], rtol=1e-5, atol=1e-30, err_msg=str(seed))
+    np.testing.assert_allclose(s2, want["S2"], rtol=1e-5, atol=1e-30, err_msg=str(seed))
+    if (seed - first) % 25 == 24:
+        print(f"{seed - first + 1} bipartite cases, {time.time() - t0:.0f} s", flush=True)
+print(f"soak_plan: {count // 2} bipartite graphs passed")

@@ -585,6 +585,22 @@ def main():
                 "entries_in_dense_sets": [c / max(1, g12.nnz) for _, _, c in st3]}
             s3.release()
             del s3
+            if gpu:
+                # the same loop behind the C ABI (simrank_biplan_run: iteration k + 1 queued before the counts of
+                # iteration k are read); 50 loop bodies with eps = 0: the counts are read every iteration
+                from simrank_amd.engine import BiPlan
+                t0 = time.perf_counter()
+                bp = BiPlan(ops, g12, g12.rowscale, g21.rowscale, c1=coef, c2=coef, evidence=True)
+                ops.synchronize()
+                setup_s = time.perf_counter() - t0
+                bp.run(5, 0.0)
+                t0 = time.perf_counter()
+                done, _ = bp.run(50, 0.0)
+                dt_p = (time.perf_counter() - t0) / max(1, done)
+                bp.free()
+                out["bipartite_pp"]["c_biplan"] = {"value": 1.0 / dt_p, "unit": "iterations/s", "ms_per_step": dt_p * 1e3,
+                                                   "setup_s": setup_s,
+                                                   "note": "simrank_biplan_run, 50 loop bodies, eps = 0"}
         except Exception as e:
             out["bipartite_pp"] = {"error": f"{type(e).__name__}: {e}"}
 

@@ -454,6 +454,14 @@ def test_integration_stub_of_the_reference_binding():
                             g.kwargs.get("eps", 1e-4))
         assert_close(S, g.out["S"])
         assert k == g.k
+    for name in ("BipartiteSimRank_b40", "BipartiteSimRank_b5030"):
+        g = Golden(name)
+        S1, S2, k = stub.iterate_bipartite(g.out["G12"], g.out["G21"], g.kwargs.get("C1", 0.8),
+                                           g.kwargs.get("C2", 0.8), g.kwargs.get("iterations", 100),
+                                           g.kwargs.get("eps", 1e-4))
+        assert_close(S1, g.out["S1"])
+        assert_close(S2, g.out["S2"])
+        assert k == g.k
 
 
 def test_rccl_world_of_one_rank():

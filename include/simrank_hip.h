@@ -387,6 +387,11 @@ SIMRANK_API int simrank_plan_run(simrank_plan* p, int32_t iterations, double eps
                                  int32_t* converged_at);
 SIMRANK_API int simrank_plan_result(simrank_plan* p, float* dst, int64_t ld);
 SIMRANK_API int simrank_plan_result_f64(simrank_plan* p, double* dst, int64_t ld);
+/* the k most similar nodes of every node (HOST int32 / float [n][k], caller's ids, largest first, ties by the
+ * lower id, -1 / 0 where a row has fewer; exclude_diag = 1 leaves the node itself out): 2 n k values cross
+ * PCIe instead of n^2 */
+SIMRANK_API int simrank_plan_topk(simrank_plan* p, int32_t k, int32_t exclude_diag, int32_t* idx_host,
+                                  float* val_host);
 SIMRANK_API int simrank_plan_info(const simrank_plan* p, int64_t* n, int32_t* updates, const simrank_graph** graph);
 SIMRANK_API int simrank_plan_destroy(simrank_plan* p);
 

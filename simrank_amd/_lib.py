@@ -83,6 +83,7 @@ PROTOTYPES = {
     "simrank_shard_unpack_stage": [_vp, _i64, _vp, _i64, _i32, _i32, _i64, _i32, _i32, _vp],
     "simrank_fill_identity_blocked": [_vp, _i64, _i64, _i64, _i64, _vp],
     "simrank_spmm_blocked": [_vp, _vp, _i64, _i64, _vp, _i64, _i32, C.POINTER(Epilogue), _vp],
+    "simrank_plan_topk": [_vp, _i32, _i32, _vp, _vp],
     "simrank_biplan_create": [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "simrank_biplan_reset": [_vp],
     "simrank_biplan_step": [_vp, C.c_double, _i32, _vp, _vp],

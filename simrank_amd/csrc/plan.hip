@@ -311,6 +311,36 @@ int simrank_plan_result_f64(simrank_plan* p, double* dst, int64_t ld) {
     return rc;
 }
 
+int simrank_plan_topk(simrank_plan* p, int32_t k, int32_t exclude_diag, int32_t* idx_host, float* val_host) {
+    SR_REQUIRE(p && idx_host && val_host && k > 0 && k <= 1024, "bad top-k arguments");
+    // S in the caller's node order as a row-major device copy (as simrank_plan_result), the selection there,
+    // and 2 x n x k values across PCIe instead of n^2 (ids = the caller's, ties by the lower id)
+    const int64_t n = p->n, ldt = (n + 3) / 4 * 4;
+    float* rowm = nullptr;
+    int32_t* idx_dev = nullptr;
+    float* val_dev = nullptr;
+    hipError_t e = hipMalloc((void**)&rowm, size_t(n) * size_t(ldt) * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&idx_dev, size_t(n) * size_t(k) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&val_dev, size_t(n) * size_t(k) * sizeof(float));
+    int rc = SIMRANK_OK;
+    if (e == hipSuccess) rc = simrank_plan_result(p, rowm, ldt);
+    if (e == hipSuccess && !rc)
+        rc = simrank_topk_rows(rowm, ldt, n, n, 0, k, exclude_diag, idx_dev, val_dev, p->stream);
+    if (e == hipSuccess && !rc)
+        e = hipMemcpyAsync(idx_host, idx_dev, size_t(n) * size_t(k) * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess && !rc)
+        e = hipMemcpyAsync(val_host, val_dev, size_t(n) * size_t(k) * sizeof(float), hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    else (void)hipStreamSynchronize(p->stream);
+    (void)hipFree(rowm); (void)hipFree(idx_dev); (void)hipFree(val_dev);
+    if (e != hipSuccess) {
+        set_error("simrank_plan_topk: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return SIMRANK_ERR_HIP;
+    }
+    return rc;
+}
+
 int simrank_plan_info(const simrank_plan* p, int64_t* n, int32_t* updates, const simrank_graph** graph) {
     SR_REQUIRE(p, "plan is NULL");
     if (n) *n = p->n;

@@ -139,6 +139,14 @@ class Plan:
         check(self.ops.lib.simrank_plan_result_f64(self.handle, out.ctypes.data, self.n), "simrank_plan_result_f64")
         return out
 
+    def topk(self, k: int, exclude_diag: bool = True):
+        """(ids int32 [n, k], values float32 [n, k]): the k most similar nodes of every node, caller's ids."""
+        idx = np.empty((self.n, k), dtype=np.int32)
+        val = np.empty((self.n, k), dtype=np.float32)
+        check(self.ops.lib.simrank_plan_topk(self.handle, int(k), int(exclude_diag), idx.ctypes.data, val.ctypes.data),
+              "simrank_plan_topk")
+        return idx, val
+
     def free(self):
         if self.handle:
             self.ops.lib.simrank_plan_destroy(self.handle)

@@ -821,6 +821,26 @@ def test_plan_api_reproduces_the_golden_vectors(ops, name):
     plan.free()
 
 
+def test_plan_topk_in_the_callers_ids(ops):
+    """simrank_plan_topk: the k most similar nodes per node from the plan's own matrices (f32 and fp16-held),
+    ids and tie order the caller's, against a sort of the dense result."""
+    from simrank_amd.engine import Plan
+    df = synth.powerlaw_directed(600, 7, seed=9)
+    _, csr = ingest.directed(df, False, "from", "to", "weight")
+    for storage in ("f32", "fp16"):
+        plan = Plan(ops, csr, coef=0.8, evidence=True, storage=storage)
+        plan.run(6, 1e-30)
+        S = plan.result()
+        idx, val = plan.topk(7)
+        plan.free()
+        n = csr.n_rows
+        for a in range(n):
+            cand = np.array([c for c in range(n) if c != a])
+            order = cand[np.lexsort((cand, -S[a, cand]))][:7]
+            assert list(idx[a]) == list(order)
+            np.testing.assert_array_equal(val[a].astype(np.float64), S[a, order])
+
+
 def test_plan_api_with_a_prior_and_in_the_callers_order(ops):
     """AprioriSimRank's loop (SimRank.py:443-454) through the plan: symmetric prior, nodes re-ordered inside
     and handed back in the caller's order; an asymmetric prior is refused."""

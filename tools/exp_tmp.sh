@@ -1,1 +1,1 @@
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -k "integration_stub or biplan" 2>&1 | tail -3
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -k "plan" 2>&1 | tail -3

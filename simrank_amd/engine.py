@@ -114,9 +114,10 @@ class Plan:
                           ld_apriori=0 if ap is None else ap.shape[1], evidence=int(evidence), reorder=int(reorder),
                           storage_fp16=int(storage == "fp16"), reserved=0)
         h = C.c_void_p()
-        check(ops.lib.simrank_plan_create(csr.n_rows, col.size, rowptr.ctypes.data,
-                                          col.ctypes.data if col.size else None, rs.ctypes.data, C.byref(opt),
-                                          ops.stream, C.byref(h)), "simrank_plan_create")
+        with HipOps._knob_lock:          # (the graph inside snapshots the process-wide knobs: not while another
+            check(ops.lib.simrank_plan_create(csr.n_rows, col.size, rowptr.ctypes.data,       # thread has per-graph ones set)
+                                              col.ctypes.data if col.size else None, rs.ctypes.data, C.byref(opt),
+                                              ops.stream, C.byref(h)), "simrank_plan_create")
         self.handle, self.n = h, csr.n_rows
 
     def run(self, iterations: int, eps: float):
@@ -185,9 +186,10 @@ class BiPlan:
                             apriori2=None if a2 is None else a2.ctypes.data, ld_apriori2=0 if a2 is None else a2.shape[1],
                             evidence=int(evidence), reorder=int(reorder))
         h = C.c_void_p()
-        check(ops.lib.simrank_biplan_create(csr12.n_rows, csr12.n_cols, col.size, rowptr.ctypes.data,
-                                            col.ctypes.data if col.size else None, rs1.ctypes.data, rs2.ctypes.data,
-                                            C.byref(opt), ops.stream, C.byref(h)), "simrank_biplan_create")
+        with HipOps._knob_lock:
+            check(ops.lib.simrank_biplan_create(csr12.n_rows, csr12.n_cols, col.size, rowptr.ctypes.data,
+                                                col.ctypes.data if col.size else None, rs1.ctypes.data, rs2.ctypes.data,
+                                                C.byref(opt), ops.stream, C.byref(h)), "simrank_biplan_create")
         self.handle, self.n1, self.n2 = h, csr12.n_rows, csr12.n_cols
 
     def run(self, iterations: int, eps: float):

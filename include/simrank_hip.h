@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define SIMRANK_ABI_VERSION 3
+#define SIMRANK_ABI_VERSION 4
 #define SIMRANK_CHANGED_SLOTS 1024
 
 #if defined(__GNUC__)
@@ -65,8 +65,18 @@ SIMRANK_API int simrank_device_count(int* count);
 SIMRANK_API int simrank_set_device(int device);
 SIMRANK_API int simrank_device_info(int device, char* name, int name_len, int64_t* total_bytes,
                         int* compute_units, char* arch, int arch_len);
+/* Device memory.  Blocks of at least 64 MiB come from / go back to a per-device pool inside the library
+ * (hipMalloc maps a 17 GiB similarity matrix in up to 0.5 s; the reference pays nothing comparable for
+ * np.zeros at SimRank.py:124-125): a request takes the smallest cached block of its size up to 1/8 more,
+ * simrank_free synchronises the device (as hipFree does) and keeps the block, least recently freed blocks
+ * leave when more than SIMRANK_POOL_GIB (environment, default 96) GiB are at rest, and an allocation that
+ * fails empties the pool and is tried once more.  The plans (simrank_plan_*, simrank_biplan_*) allocate
+ * their matrices and scratch through the same pool.  Cached blocks are invisible to other allocators of
+ * the process: simrank_pool_trim(device) (-1 = every device) returns them to the driver. */
 SIMRANK_API int simrank_malloc(void** dptr, size_t bytes);
 SIMRANK_API int simrank_free(void* dptr);
+SIMRANK_API int simrank_pool_trim(int device);
+SIMRANK_API int simrank_pool_stats(int device, int64_t* cached_bytes, int64_t* cached_blocks, int64_t* limit_bytes);
 SIMRANK_API int simrank_memset(void* dptr, int byte_value, size_t bytes, void* stream);
 /* copies are enqueued on `stream` and the call returns after they completed */
 SIMRANK_API int simrank_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes, void* stream);

@@ -52,6 +52,8 @@ PROTOTYPES = {
                             C.c_char_p, _int],
     "simrank_malloc": [_pvp, C.c_size_t],
     "simrank_free": [_vp],
+    "simrank_pool_trim": [_int],
+    "simrank_pool_stats": [_int, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
     "simrank_memset": [_vp, _int, C.c_size_t, _vp],
     "simrank_memcpy_h2d": [_vp, _vp, C.c_size_t, _vp],
     "simrank_memcpy_d2h": [_vp, _vp, C.c_size_t, _vp],
@@ -136,7 +138,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError = symbol missing from the .so
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
-    if lib.simrank_abi_version() != 3:
+    if lib.simrank_abi_version() != 4:
         raise ImportError("libsimrank_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -113,6 +113,159 @@ int64_t build_tiles(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int64_t 
         }
     return n_tiles;
 }
+
+// ---- device block pool.  hipMalloc maps a 17 GiB matrix in 0.4-0.5 s on some boxes (1.6-2.0 s of a config-5
+// set-up against 0.12 s for its four updates: profiles/r03_setup_before_pool.log), so blocks of at least
+// kPoolMin bytes are kept when their owner lets go of them and handed to the next request they fit (smallest
+// cached block of at least the size asked for and at most 1/8 larger).  Per device at most SIMRANK_POOL_GIB
+// (default 96) GiB at rest, least recently freed blocks leave first; a failed hipMalloc anywhere behind this
+// interface empties the pool and tries once more, so cached blocks never cause an out-of-memory error the
+// process would not have had without them.  Cached memory is invisible to other allocators of the process
+// (torch's caching allocator, the caller's own hipMalloc): simrank_pool_trim() hands it back.
+namespace {
+constexpr size_t kPoolMin = size_t(64) << 20;
+struct PoolBlock { void* ptr; size_t bytes; uint64_t age; };
+struct PoolState {
+    std::mutex m;
+    std::vector<std::vector<PoolBlock>> cached;      // per device
+    std::vector<size_t> cached_bytes;
+    std::vector<std::pair<void*, std::pair<size_t, int>>> live;   // blocks handed out: ptr -> (bytes, device)
+    uint64_t clock = 0;
+    size_t limit = size_t(96) << 30;
+    PoolState() {
+        if (const char* e = getenv("SIMRANK_POOL_GIB")) limit = size_t(std::max(0ll, atoll(e))) << 30;
+    }
+    void grow(int dev) {
+        if ((int)cached.size() <= dev) { cached.resize(size_t(dev) + 1); cached_bytes.resize(size_t(dev) + 1, 0); }
+    }
+};
+PoolState& pool() {
+    static PoolState* p = new PoolState;     // (never destroyed: frees at exit would race the runtime's teardown)
+    return *p;
+}
+void pool_trim_locked(PoolState& P, int device) {
+    int restore = -1;
+    (void)hipGetDevice(&restore);
+    for (int d = 0; d < (int)P.cached.size(); ++d) {
+        if (device >= 0 && d != device) continue;
+        if (P.cached[size_t(d)].empty()) continue;
+        (void)hipSetDevice(d);
+        for (PoolBlock& b : P.cached[size_t(d)]) (void)hipFree(b.ptr);
+        P.cached[size_t(d)].clear();
+        P.cached_bytes[size_t(d)] = 0;
+    }
+    if (restore >= 0) (void)hipSetDevice(restore);
+}
+}  // namespace
+
+int pool_alloc(void** dptr, size_t bytes) {
+    *dptr = nullptr;
+    PoolState& P = pool();
+    int dev = 0;
+    SR_HIP(hipGetDevice(&dev));
+    if (bytes >= kPoolMin) {
+        std::lock_guard<std::mutex> lock(P.m);
+        P.grow(dev);
+        std::vector<PoolBlock>& c = P.cached[size_t(dev)];
+        int best = -1;
+        for (int i = 0; i < (int)c.size(); ++i)
+            if (c[size_t(i)].bytes >= bytes && c[size_t(i)].bytes - bytes <= bytes / 8 &&
+                (best < 0 || c[size_t(i)].bytes < c[size_t(best)].bytes))
+                best = i;
+        if (best >= 0) {
+            const PoolBlock b = c[size_t(best)];
+            c.erase(c.begin() + best);
+            P.cached_bytes[size_t(dev)] -= b.bytes;
+            P.live.push_back({b.ptr, {b.bytes, dev}});
+            *dptr = b.ptr;
+            return SIMRANK_OK;
+        }
+    }
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> lock(P.m);
+            pool_trim_locked(P, dev);
+        }
+        e = hipMalloc(dptr, bytes);
+    }
+    if (e != hipSuccess) {
+        *dptr = nullptr;
+        set_error("hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+        (void)hipGetLastError();
+        return e == hipErrorOutOfMemory ? SIMRANK_ERR_ALLOC : SIMRANK_ERR_HIP;
+    }
+    if (bytes >= kPoolMin) {
+        std::lock_guard<std::mutex> lock(P.m);
+        P.live.push_back({*dptr, {bytes, dev}});
+    }
+    return SIMRANK_OK;
+}
+
+int pool_free(void* ptr) {
+    if (!ptr) return SIMRANK_OK;
+    PoolState& P = pool();
+    size_t bytes = 0;
+    int dev = -1;
+    {
+        std::lock_guard<std::mutex> lock(P.m);
+        for (size_t i = 0; i < P.live.size(); ++i)
+            if (P.live[i].first == ptr) {
+                bytes = P.live[i].second.first;
+                dev = P.live[i].second.second;
+                P.live[i] = P.live.back();
+                P.live.pop_back();
+                break;
+            }
+    }
+    if (bytes && bytes <= P.limit) {
+        // like hipFree: nothing queued anywhere on the device may still use the block when the next owner gets it
+        int cur = 0;
+        SR_HIP(hipGetDevice(&cur));
+        if (cur != dev) SR_HIP(hipSetDevice(dev));
+        const hipError_t e = hipDeviceSynchronize();
+        if (cur != dev) (void)hipSetDevice(cur);
+        if (e == hipSuccess) {
+            std::lock_guard<std::mutex> lock(P.m);
+            P.grow(dev);
+            std::vector<PoolBlock>& c = P.cached[size_t(dev)];
+            while (!c.empty() && P.cached_bytes[size_t(dev)] + bytes > P.limit) {      // least recently freed first
+                size_t oldest = 0;
+                for (size_t i = 1; i < c.size(); ++i)
+                    if (c[i].age < c[oldest].age) oldest = i;
+                if (cur != dev) (void)hipSetDevice(dev);
+                (void)hipFree(c[oldest].ptr);
+                if (cur != dev) (void)hipSetDevice(cur);
+                P.cached_bytes[size_t(dev)] -= c[oldest].bytes;
+                c.erase(c.begin() + (long)oldest);
+            }
+            c.push_back({ptr, bytes, ++P.clock});
+            P.cached_bytes[size_t(dev)] += bytes;
+            return SIMRANK_OK;
+        }
+        (void)hipGetLastError();
+    }
+    SR_HIP(hipFree(ptr));
+    return SIMRANK_OK;
+}
+
+void pool_trim(int device) {
+    PoolState& P = pool();
+    std::lock_guard<std::mutex> lock(P.m);
+    pool_trim_locked(P, device);
+}
+
+void pool_stats(int device, int64_t* cached_bytes, int64_t* cached_blocks, int64_t* limit_bytes) {
+    PoolState& P = pool();
+    std::lock_guard<std::mutex> lock(P.m);
+    int64_t b = 0, n = 0;
+    for (int d = 0; d < (int)P.cached.size(); ++d)
+        if (device < 0 || d == device) { b += (int64_t)P.cached_bytes[size_t(d)]; n += (int64_t)P.cached[size_t(d)].size(); }
+    if (cached_bytes) *cached_bytes = b;
+    if (cached_blocks) *cached_blocks = n;
+    if (limit_bytes) *limit_bytes = (int64_t)P.limit;
+}
 }  // namespace simrank
 
 using namespace simrank;
@@ -156,17 +309,21 @@ int simrank_malloc(void** dptr, size_t bytes) {
     SR_REQUIRE(dptr, "dptr is NULL");
     *dptr = nullptr;
     if (bytes == 0) return SIMRANK_OK;
-    hipError_t e = hipMalloc(dptr, bytes);
-    if (e != hipSuccess) {
-        set_error("hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
-        (void)hipGetLastError();
-        return e == hipErrorOutOfMemory ? SIMRANK_ERR_ALLOC : SIMRANK_ERR_HIP;
-    }
-    return SIMRANK_OK;
+    return pool_alloc(dptr, bytes);
 }
 
 int simrank_free(void* dptr) {
-    if (dptr) SR_HIP(hipFree(dptr));
+    if (dptr) return pool_free(dptr);
+    return SIMRANK_OK;
+}
+
+int simrank_pool_trim(int device) {
+    pool_trim(device);
+    return SIMRANK_OK;
+}
+
+int simrank_pool_stats(int device, int64_t* cached_bytes, int64_t* cached_blocks, int64_t* limit_bytes) {
+    pool_stats(device, cached_bytes, cached_blocks, limit_bytes);
     return SIMRANK_OK;
 }
 

@@ -106,11 +106,11 @@ int simrank_biplan_destroy(simrank_biplan* p) {
     if (!p) return SIMRANK_OK;
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     for (side_t& a : p->s) {
-        (void)hipFree(a.S[0]); (void)hipFree(a.S[1]); (void)hipFree(a.Tt); (void)hipFree(a.ev);
-        (void)hipFree(a.prior); (void)hipFree(a.inv);
+        (void)pool_free(a.S[0]); (void)pool_free(a.S[1]); (void)pool_free(a.Tt); (void)pool_free(a.ev);
+        (void)pool_free(a.prior); (void)pool_free(a.inv);
         simrank_graph_destroy(a.g);
     }
-    (void)hipFree(p->counters);
+    (void)pool_free(p->counters);
     for (int i = 0; i < 2; ++i) {
         for (int w = 0; w < 2; ++w)
             if (p->host_counters[i][w]) (void)hipHostFree(p->host_counters[i][w]);
@@ -223,7 +223,7 @@ int simrank_biplan_create(int64_t n1, int64_t n2, int64_t nnz, const int32_t* ro
             return fail(e_ == hipErrorOutOfMemory ? SIMRANK_ERR_ALLOC : SIMRANK_ERR_HIP);         \
         }                                                                                         \
     } while (0)
-    BIPLAN_HIP(hipMalloc((void**)&p->counters, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS));
+    BIPLAN_HIP(pool_hip_alloc((void**)&p->counters, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS));
     for (int i = 0; i < 2; ++i) {
         for (int w = 0; w < 2; ++w)
             BIPLAN_HIP(hipHostMalloc((void**)&p->host_counters[i][w], sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS,
@@ -233,18 +233,18 @@ int simrank_biplan_create(int64_t n1, int64_t n2, int64_t nnz, const int32_t* ro
     for (int w = 0; w < 2; ++w) {
         side_t& a = p->s[w];
         for (float** b : {&a.S[0], &a.S[1]}) {
-            BIPLAN_HIP(hipMalloc((void**)b, a.mat_bytes));
+            BIPLAN_HIP(pool_hip_alloc((void**)b, a.mat_bytes));
             BIPLAN_HIP(hipMemsetAsync(*b, 0, a.mat_bytes, p->stream));
         }
-        BIPLAN_HIP(hipMalloc((void**)&a.Tt, a.t_bytes));
+        BIPLAN_HIP(pool_hip_alloc((void**)&a.Tt, a.t_bytes));
         BIPLAN_HIP(hipMemsetAsync(a.Tt, 0, a.t_bytes, p->stream));
-        BIPLAN_HIP(hipMalloc((void**)&a.inv, size_t(a.n) * sizeof(int32_t)));
+        BIPLAN_HIP(pool_hip_alloc((void**)&a.inv, size_t(a.n) * sizeof(int32_t)));
         BIPLAN_HIP(hipMemcpyAsync(a.inv, inv[w].data(), size_t(a.n) * sizeof(int32_t), hipMemcpyHostToDevice, p->stream));
         BIPLAN_HIP(hipStreamSynchronize(p->stream));
         if (opt->evidence) {
             // common-neighbour counts inside the group (SimRank.py:311-320 on this group's pattern)
             const size_t ev_bytes = size_t((a.n + 31) / 32) * size_t(a.rows_pad) * 32;
-            BIPLAN_HIP(hipMalloc((void**)&a.ev, ev_bytes));
+            BIPLAN_HIP(pool_hip_alloc((void**)&a.ev, ev_bytes));
             BIPLAN_HIP(hipMemsetAsync(a.ev, 0, ev_bytes, p->stream));
             int rc = simrank_evidence_counts_blocked(a.g, 0, a.n, a.ev, a.rows_pad, p->stream);
             if (rc) return fail(rc);
@@ -256,9 +256,9 @@ int simrank_biplan_create(int64_t n1, int64_t n2, int64_t nnz, const int32_t* ro
         if (priors[w]) {
             float* tmp = nullptr;
             int32_t* ord_dev = nullptr;
-            BIPLAN_HIP(hipMalloc((void**)&tmp, size_t(a.n) * size_t(a.n) * sizeof(float)));
-            hipError_t e = hipMalloc((void**)&ord_dev, size_t(a.n) * sizeof(int32_t));
-            if (e == hipSuccess) e = hipMalloc((void**)&a.prior, a.mat_bytes);
+            BIPLAN_HIP(pool_hip_alloc((void**)&tmp, size_t(a.n) * size_t(a.n) * sizeof(float)));
+            hipError_t e = pool_hip_alloc((void**)&ord_dev, size_t(a.n) * sizeof(int32_t));
+            if (e == hipSuccess) e = pool_hip_alloc((void**)&a.prior, a.mat_bytes);
             if (e == hipSuccess) e = hipMemsetAsync(a.prior, 0, a.mat_bytes, p->stream);
             if (e == hipSuccess) e = hipMemcpy2DAsync(tmp, size_t(a.n) * 4, priors[w], size_t(lds[w]) * 4, size_t(a.n) * 4,
                                                       size_t(a.n), hipMemcpyHostToDevice, p->stream);
@@ -268,8 +268,8 @@ int simrank_biplan_create(int64_t n1, int64_t n2, int64_t nnz, const int32_t* ro
                 rc = simrank_permute_layout(tmp, a.n, 0, a.prior, 32, a.rows_pad, a.n, a.n, ord_dev, ord_dev, 4, p->stream);
                 e = hipStreamSynchronize(p->stream);
             }
-            (void)hipFree(tmp);
-            (void)hipFree(ord_dev);
+            (void)pool_free(tmp);
+            (void)pool_free(ord_dev);
             if (e != hipSuccess) {
                 set_error("plan prior upload: %s", hipGetErrorString(e));
                 return fail(SIMRANK_ERR_HIP);
@@ -343,12 +343,12 @@ int simrank_biplan_result_f64(simrank_biplan* p, int32_t group, double* dst, int
     SR_REQUIRE(ld >= a.n, "ld %lld < n", (long long)ld);
     float* tmp = nullptr;
     const int64_t ldt = (a.n + 3) / 4 * 4;
-    SR_HIP(hipMalloc((void**)&tmp, size_t(a.n) * size_t(ldt) * sizeof(float)));
+    SR_HIP(pool_hip_alloc((void**)&tmp, size_t(a.n) * size_t(ldt) * sizeof(float)));
     // dst[i][j] = S[inv[i]][inv[j]]: out of the panel-blocked layout and the solver's node order in one pass
     int rc = simrank_permute_layout(a.S[a.cur], 32, a.rows_pad, tmp, ldt, 0, a.n, a.n, a.inv, a.inv, 4, p->stream);
     if (!rc) rc = simrank_download_f64(dst, ld, tmp, ldt, a.n, a.n, p->stream);
     (void)hipStreamSynchronize(p->stream);
-    (void)hipFree(tmp);
+    (void)pool_free(tmp);
     return rc;
 }
 

@@ -96,6 +96,16 @@ inline hipError_t plan_download(void* h, const void* d, size_t bytes) { return h
 inline void plan_free(void* p) { (void)hipFree(p); }
 #endif
 
+// device block pool (api.hip): what simrank_malloc / simrank_free and the plans allocate through
+int pool_alloc(void** dptr, size_t bytes);
+int pool_free(void* ptr);
+void pool_trim(int device);          // -1: every device
+void pool_stats(int device, int64_t* cached_bytes, int64_t* cached_blocks, int64_t* limit_bytes);
+inline hipError_t pool_hip_alloc(void** p, size_t bytes) {       // (for call sites that speak hipError_t)
+    const int rc = pool_alloc(p, bytes);
+    return rc == SIMRANK_OK ? hipSuccess : (rc == SIMRANK_ERR_ALLOC ? hipErrorOutOfMemory : hipErrorUnknown);
+}
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

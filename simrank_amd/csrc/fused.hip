@@ -117,6 +117,30 @@ __device__ __forceinline__ void wave_lds_order() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifdef SIMRANK_FUSED_STAMPS
+// Diagnostic build only (bash tools/build_variant.sh fst -DSIMRANK_FUSED_STAMPS; tools/fused_stamps.py): the
+// timeline of the workgroups with blockIdx in [g_fst_base, g_fst_base + kFstCap): s_memtime at the phase
+// boundaries of wave 0, the XCC and the hardware id, into a __device__ array nothing else reads.
+constexpr int kFstCap = 1 << 15;
+__device__ unsigned long long g_fst[kFstCap * 8];
+__device__ unsigned int g_fst_base;
+__device__ __forceinline__ unsigned long long fst_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define FST(i)                                                                              \
+    do {                                                                                    \
+        const unsigned long long now_ = fst_now();                                          \
+        if (threadIdx.x == 0 && blockIdx.x - g_fst_base < unsigned(kFstCap))                \
+            g_fst[size_t(blockIdx.x - g_fst_base) * 8 + (i)] = now_;                        \
+    } while (0)
+#else
+#define FST(i) do {} while (0)
+#endif
+
 #ifndef SIMRANK_FUSED_LB
 #define SIMRANK_FUSED_LB 4     // waves per SIMD the register allocation aims at
 #endif
@@ -136,6 +160,15 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
     if (panel >= p.n_panels) return;
     const uint32_t unit = local % uint32_t(p.n_units);
     const int32_t* un = p.units + size_t(unit) * 32;
+    FST(0);
+#ifdef SIMRANK_FUSED_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x - g_fst_base < unsigned(kFstCap)) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);     // HW_REG_XCC_ID[3:0]
+        const unsigned hw = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4);       // HW_REG_HW_ID[15:0]
+        g_fst[size_t(blockIdx.x - g_fst_base) * 8 + 5] = (unsigned long long)xcc << 32 | hw;
+        g_fst[size_t(blockIdx.x - g_fst_base) * 8 + 6] = (unsigned long long)panel << 32 | unit;
+    }
+#endif
     const int b0 = un[0];                                   // first (usually only) block of the unit
     const int64_t c0 = int64_t(panel) * 32;
     const int g = lane >> 3, q = lane & 7, gbase = lane & ~7;
@@ -187,6 +220,7 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
         iv1 = ld_sid(1);
     }
 
+    FST(1);
     // ---------------------------------------------------------------- 1. MFMA phase
     if (nq > 0) {
         {   // lookup table: entry e, dword d: low half = bit 2d, high half = bit 2d + 1 (bf16 1.0 = 0x3F80)
@@ -358,6 +392,7 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
         }
     }
 
+    FST(2);
     // ---------------------------------------------------------------- 3. gather phase (the remainder)
     // Every lane group owns four rows of the block, their remainder ids concatenated into ONE stream (the
     // host balances the 32 streams of a block); a slot instruction gathers the next neighbour of all 8
@@ -410,6 +445,7 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
         // every round of block sb has been summed: its rows without a remainder, then the tile goes out
         auto finish = [&]() {
             for (int k = krow; k < 4; ++k) emit(unpack(gmp[sb * 128 + k]), make_float4(0.f, 0.f, 0.f, 0.f));
+            FST(3);
             __syncthreads();
             // ------------------------------------------------------------ 4. transposed store
             const int row0 = (b0 + sb) * kFB;
@@ -497,6 +533,7 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
         }
         while (sb < n_sub) finish();
     }
+    FST(4);
 }
 
 #endif  // SIMRANK_HOST_ONLY
@@ -812,13 +849,23 @@ int launch_fused_trans(const simrank_graph* g, const float* X, int64_t x_rows_pa
     a.gmeta = pl->gmeta; a.sids16 = pl->sids16; a.sids32 = pl->sids32;
     const int64_t grid = int64_t((a.n_panels + 7) / 8) * 8 * a.n_units;
     SR_REQUIRE(grid > 0 && grid < (int64_t(1) << 31), "grid of %lld blocks", (long long)grid);
+#ifdef SIMRANK_FUSED_STAMPS
+    static const unsigned lds_pad = getenv("SIMRANK_FUSED_PAD") ? (unsigned)atoi(getenv("SIMRANK_FUSED_PAD")) : 0u;
+    {
+        const char* e = getenv("SIMRANK_FST_BASE");
+        const unsigned base = e ? (unsigned)atoll(e) : 0u;
+        SR_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_fst_base), &base, sizeof(base), 0, hipMemcpyHostToDevice, st));
+    }
+#else
+    const unsigned lds_pad = 0;
+#endif
 #ifdef SIMRANK_HOST_ONLY
     SR_REQUIRE(false, "host-only build: no kernels");
 #else
     if (pl->ids16)
-        hipLaunchKernelGGL(fused_trans_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(fused_trans_kernel<true>, dim3((unsigned)grid), dim3(256), lds_pad, st, a);
     else
-        hipLaunchKernelGGL(fused_trans_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(fused_trans_kernel<false>, dim3((unsigned)grid), dim3(256), lds_pad, st, a);
 #endif
     SR_HIP(hipGetLastError());
     return SIMRANK_OK;
@@ -829,6 +876,14 @@ int launch_fused_trans(const simrank_graph* g, const float* X, int64_t x_rows_pa
 using namespace simrank;
 
 extern "C" {
+
+#ifdef SIMRANK_FUSED_STAMPS
+__attribute__((visibility("default"))) int simrank_read_fused_stamps(unsigned long long* out, int64_t n_wg) {
+    SR_HIP(hipDeviceSynchronize());
+    SR_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(simrank::g_fst), size_t(std::min<int64_t>(n_wg, simrank::kFstCap)) * 8 * sizeof(unsigned long long)));
+    return SIMRANK_OK;
+}
+#endif
 
 int simrank_graph_fused_stats(const simrank_graph* g, int64_t* n_steps, int64_t* nnz_covered,
                               int64_t* nnz_remainder) {

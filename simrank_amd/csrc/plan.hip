@@ -93,8 +93,8 @@ extern "C" {
 int simrank_plan_destroy(simrank_plan* p) {
     if (!p) return SIMRANK_OK;
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    (void)hipFree(p->S[0]); (void)hipFree(p->S[1]); (void)hipFree(p->Tt); (void)hipFree(p->ev);
-    (void)hipFree(p->prior); (void)hipFree(p->inv); (void)hipFree(p->counters);
+    (void)pool_free(p->S[0]); (void)pool_free(p->S[1]); (void)pool_free(p->Tt); (void)pool_free(p->ev);
+    (void)pool_free(p->prior); (void)pool_free(p->inv); (void)pool_free(p->counters);
     for (int i = 0; i < 2; ++i) {
         if (p->host_counters[i]) (void)hipHostFree(p->host_counters[i]);
         if (p->counted[i]) (void)hipEventDestroy(p->counted[i]);
@@ -169,21 +169,21 @@ int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int
         }                                                                                         \
     } while (0)
     for (float** b : {&p->S[0], &p->S[1], &p->Tt}) {
-        PLAN_HIP(hipMalloc((void**)b, p->mat_bytes));
+        PLAN_HIP(pool_hip_alloc((void**)b, p->mat_bytes));
         PLAN_HIP(hipMemsetAsync(*b, 0, p->mat_bytes, p->stream));
     }
-    PLAN_HIP(hipMalloc((void**)&p->counters, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS));
+    PLAN_HIP(pool_hip_alloc((void**)&p->counters, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS));
     for (int i = 0; i < 2; ++i) {
         PLAN_HIP(hipHostMalloc((void**)&p->host_counters[i], sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS, hipHostMallocPortable));
         PLAN_HIP(hipEventCreateWithFlags(&p->counted[i], hipEventDisableTiming));
     }
-    PLAN_HIP(hipMalloc((void**)&p->inv, size_t(n) * sizeof(int32_t)));
+    PLAN_HIP(pool_hip_alloc((void**)&p->inv, size_t(n) * sizeof(int32_t)));
     PLAN_HIP(hipMemcpyAsync(p->inv, inv.data(), size_t(n) * sizeof(int32_t), hipMemcpyHostToDevice, p->stream));
     PLAN_HIP(hipStreamSynchronize(p->stream));          // (inv is a host vector about to go away)
     if (opt->evidence) {
         // common in-neighbour counts of the pattern (SimRank.py:311-320), 1 - 2^-count in the epilogue
         const size_t ev_bytes = size_t(panels) * size_t(p->rows_pad) * 32;
-        PLAN_HIP(hipMalloc((void**)&p->ev, ev_bytes));
+        PLAN_HIP(pool_hip_alloc((void**)&p->ev, ev_bytes));
         PLAN_HIP(hipMemsetAsync(p->ev, 0, ev_bytes, p->stream));
         rc = simrank_evidence_counts_blocked(p->g, 0, n, p->ev, p->rows_pad, p->stream);
         if (rc) return fail(rc);
@@ -196,9 +196,9 @@ int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int
         // host n x n (caller's order) -> device row-major -> panel-blocked in the solver's order
         float* tmp = nullptr;
         int32_t* ord_dev = nullptr;
-        PLAN_HIP(hipMalloc((void**)&tmp, size_t(n) * size_t(n) * sizeof(float)));
-        hipError_t e = hipMalloc((void**)&ord_dev, size_t(n) * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&p->prior, prior_bytes);
+        PLAN_HIP(pool_hip_alloc((void**)&tmp, size_t(n) * size_t(n) * sizeof(float)));
+        hipError_t e = pool_hip_alloc((void**)&ord_dev, size_t(n) * sizeof(int32_t));
+        if (e == hipSuccess) e = pool_hip_alloc((void**)&p->prior, prior_bytes);
         if (e == hipSuccess) e = hipMemsetAsync(p->prior, 0, prior_bytes, p->stream);
         if (e == hipSuccess) e = hipMemcpy2DAsync(tmp, size_t(n) * 4, opt->apriori, size_t(opt->ld_apriori) * 4, size_t(n) * 4,
                                                   size_t(n), hipMemcpyHostToDevice, p->stream);
@@ -208,8 +208,8 @@ int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int
             rc = simrank_permute_layout(tmp, n, 0, p->prior, 32, p->rows_pad, n, n, ord_dev, ord_dev, 4, p->stream);
             e = hipStreamSynchronize(p->stream);
         }
-        (void)hipFree(tmp);
-        (void)hipFree(ord_dev);
+        (void)pool_free(tmp);
+        (void)pool_free(ord_dev);
         if (e != hipSuccess) {
             set_error("plan prior upload: %s", hipGetErrorString(e));
             return fail(SIMRANK_ERR_HIP);
@@ -289,11 +289,11 @@ int simrank_plan_result(simrank_plan* p, float* dst, int64_t ld) {
         // through an f32 panel-blocked scratch copy
         float* wide = nullptr;
         const size_t bytes = size_t((p->n + 31) / 32) * size_t(p->rows_pad) * 32 * sizeof(float);
-        SR_HIP(hipMalloc((void**)&wide, bytes));
+        SR_HIP(pool_hip_alloc((void**)&wide, bytes));
         int rc = simrank_widen_blocked_h16(p->S[p->cur], p->rows_pad, wide, p->rows_pad, p->n, p->n, kHalfScale, p->stream);
         if (!rc) rc = simrank_permute_layout(wide, 32, p->rows_pad, dst, ld, 0, p->n, p->n, p->inv, p->inv, 4, p->stream);
         (void)hipStreamSynchronize(p->stream);
-        (void)hipFree(wide);
+        (void)pool_free(wide);
         return rc;
     }
     return simrank_permute_layout(p->S[p->cur], 32, p->rows_pad, dst, ld, 0, p->n, p->n, p->inv, p->inv, 4, p->stream);
@@ -303,11 +303,11 @@ int simrank_plan_result_f64(simrank_plan* p, double* dst, int64_t ld) {
     SR_REQUIRE(p && dst && ld >= p->n, "bad result arguments");
     float* tmp = nullptr;
     const int64_t ldt = (p->n + 3) / 4 * 4;
-    SR_HIP(hipMalloc((void**)&tmp, size_t(p->n) * size_t(ldt) * sizeof(float)));
+    SR_HIP(pool_hip_alloc((void**)&tmp, size_t(p->n) * size_t(ldt) * sizeof(float)));
     int rc = simrank_plan_result(p, tmp, ldt);
     if (!rc) rc = simrank_download_f64(dst, ld, tmp, ldt, p->n, p->n, p->stream);
     (void)hipStreamSynchronize(p->stream);
-    (void)hipFree(tmp);
+    (void)pool_free(tmp);
     return rc;
 }
 
@@ -319,9 +319,9 @@ int simrank_plan_topk(simrank_plan* p, int32_t k, int32_t exclude_diag, int32_t*
     float* rowm = nullptr;
     int32_t* idx_dev = nullptr;
     float* val_dev = nullptr;
-    hipError_t e = hipMalloc((void**)&rowm, size_t(n) * size_t(ldt) * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&idx_dev, size_t(n) * size_t(k) * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc((void**)&val_dev, size_t(n) * size_t(k) * sizeof(float));
+    hipError_t e = pool_hip_alloc((void**)&rowm, size_t(n) * size_t(ldt) * sizeof(float));
+    if (e == hipSuccess) e = pool_hip_alloc((void**)&idx_dev, size_t(n) * size_t(k) * sizeof(int32_t));
+    if (e == hipSuccess) e = pool_hip_alloc((void**)&val_dev, size_t(n) * size_t(k) * sizeof(float));
     int rc = SIMRANK_OK;
     if (e == hipSuccess) rc = simrank_plan_result(p, rowm, ldt);
     if (e == hipSuccess && !rc)
@@ -332,7 +332,7 @@ int simrank_plan_topk(simrank_plan* p, int32_t k, int32_t exclude_diag, int32_t*
         e = hipMemcpyAsync(val_host, val_dev, size_t(n) * size_t(k) * sizeof(float), hipMemcpyDeviceToHost, p->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
     else (void)hipStreamSynchronize(p->stream);
-    (void)hipFree(rowm); (void)hipFree(idx_dev); (void)hipFree(val_dev);
+    (void)pool_free(rowm); (void)pool_free(idx_dev); (void)pool_free(val_dev);
     if (e != hipSuccess) {
         set_error("simrank_plan_topk: %s", hipGetErrorString(e));
         (void)hipGetLastError();

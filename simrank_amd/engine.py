@@ -255,63 +255,35 @@ class HipOps:
             self.stream = s
         else:
             self.stream = C.c_void_p(stream)
-        self._sizes = {}              # pooled-size blocks this object handed out: ptr -> bytes
         self._counter = self._malloc(8 * CHANGED_SLOTS)
         self.pitch_pad = 32
 
     # ---- memory ----
-    # hipMalloc maps a 17 GiB matrix in 0.4-0.5 s (profiles/r03_setup.log: 1.6-2.0 s of a config-5 solver
-    # set-up, against 0.12 s for its four iterations), so large blocks are kept when a solver lets go of
-    # them and handed to the next request of the same size: the second fit of a process, every fit after a
-    # release(), bench.py's second configuration.  Per device, at most POOL_LIMIT bytes at rest; trim_pool()
-    # returns them to the driver.
-    POOL_MIN = 64 << 20
-    POOL_LIMIT = int(os.environ.get("SIMRANK_POOL_GIB", "96")) << 30
-    _pool: dict = {}                  # device -> {nbytes: [ptr, ...]}
-    _pool_bytes: dict = {}
-    _pool_lock = threading.Lock()
-
+    # hipMalloc maps a 17 GiB matrix in 0.4-0.5 s (profiles/r03_setup_before_pool.log: 1.6-2.0 s of a config-5
+    # solver set-up, against 0.12 s for its four iterations), so blocks of at least 64 MiB are pooled INSIDE the
+    # library (csrc/api.hip: simrank_malloc / simrank_free; best fit within 1/8, least recently freed first out,
+    # an allocation that fails empties the pool and is tried again; the C-level plans use the same pool).
+    # Pooled memory is invisible to other allocators of the process (torch's among them): trim_pool() hands
+    # it back; SIMRANK_POOL_GIB bounds what may rest per device (default 96).
     def _malloc(self, nbytes: int) -> int:
-        nbytes = max(16, int(nbytes))
-        if nbytes >= self.POOL_MIN:
-            with self._pool_lock:
-                free = self._pool.get(self.device, {}).get(nbytes)
-                if free:
-                    self._pool_bytes[self.device] -= nbytes
-                    ptr = free.pop()
-                    self._sizes[ptr] = nbytes
-                    return ptr
         p = C.c_void_p()
-        check(self.lib.simrank_malloc(C.byref(p), nbytes), "simrank_malloc")
-        if nbytes >= self.POOL_MIN:
-            self._sizes[p.value] = nbytes
+        check(self.lib.simrank_malloc(C.byref(p), max(16, int(nbytes))), "simrank_malloc")
         return p.value
 
     def _free(self, ptr: int):
-        nbytes = self._sizes.pop(ptr, 0)
-        if nbytes:
-            # work queued on this stream may still use the block; whoever gets it next may be on another
-            self.lib.simrank_stream_synchronize(self.stream)
-            with self._pool_lock:
-                if self._pool_bytes.get(self.device, 0) + nbytes <= self.POOL_LIMIT:
-                    self._pool.setdefault(self.device, {}).setdefault(nbytes, []).append(ptr)
-                    self._pool_bytes[self.device] = self._pool_bytes.get(self.device, 0) + nbytes
-                    return
         self.lib.simrank_free(C.c_void_p(ptr))
 
     @classmethod
     def trim_pool(cls, device: int | None = None):
-        """Give the cached device blocks back to the driver (all devices, or one)."""
-        lib = _lib.load()
-        with cls._pool_lock:
-            for dev in list(cls._pool) if device is None else [device]:
-                blocks = cls._pool.pop(dev, {})
-                cls._pool_bytes[dev] = 0
-                if any(blocks.values()):
-                    lib.simrank_set_device(dev)
-                    for ptrs in blocks.values():
-                        for ptr in ptrs:
-                            lib.simrank_free(C.c_void_p(ptr))
+        """Give the library's cached device blocks back to the driver (all devices, or one)."""
+        _lib.load().simrank_pool_trim(-1 if device is None else int(device))
+
+    @classmethod
+    def pool_stats(cls, device: int | None = None):
+        """(bytes at rest, blocks at rest, limit in bytes) of the library's device block pool."""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _lib.load().simrank_pool_stats(-1 if device is None else int(device), C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
 
     def pitch(self, cols: int, dtype) -> int:
         unit = 16 // np.dtype(dtype).itemsize          # 16-byte rows for the vector kernels

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_string():
     lib = _lib.load()
-    assert lib.simrank_abi_version() == 3
+    assert lib.simrank_abi_version() == 4
     rc = lib.simrank_set_tuning(b"no_such_knob", 1)
     assert rc == -1 and b"no_such_knob" in lib.simrank_last_error()
     assert lib.simrank_set_tuning(b"panel", 48) == -1
@@ -91,7 +91,7 @@ int main(void) {
     simrank_epilogue ep;
     memset(&ep, 0, sizeof ep);
     ep.coef = 0.8f;
-    if (simrank_abi_version() != 3) return 1;
+    if (simrank_abi_version() != 4) return 1;
     if (simrank_graph_create(0, 4, 0, NULL, NULL, NULL, &g) != SIMRANK_ERR_INVALID) return 2;
     if (simrank_spmm_shard(NULL, NULL, 0, NULL, 0, &ep, 0, 2, NULL, 0, NULL) != SIMRANK_ERR_INVALID) return 3;
     if (simrank_shard_unpack(NULL, 0, NULL, 0, 0, 2, 64, NULL) != SIMRANK_ERR_INVALID) return 4;
@@ -107,4 +107,4 @@ int main(void) {
                         capture_output=True, text=True)
     assert cc.returncode == 0, cc.stderr
     run = subprocess.run([str(exe)], capture_output=True, text=True)
-    assert run.returncode == 0 and "abi 3 ok" in run.stdout, (run.returncode, run.stdout, run.stderr)
+    assert run.returncode == 0 and "abi 4 ok" in run.stdout, (run.returncode, run.stdout, run.stderr)

@@ -48,7 +48,7 @@ def iterate(G, C_, iterations, eps, evidence=False):
 class BiPlanOptions(C.Structure):              # struct simrank_biplan_options
     _fields_ = [("c1", C.c_float), ("c2", C.c_float), ("lbd1", C.c_float), ("lbd2", C.c_float),
                 ("apriori1", vp), ("ld_apriori1", i64), ("apriori2", vp), ("ld_apriori2", i64),
-                ("evidence", C.c_int32), ("reorder", C.c_int32)]
+                ("evidence", C.c_int32), ("reorder", C.c_int32), ("strict_reference", C.c_int32)]
 
 
 def iterate_bipartite(G12, G21, C1, C2, iterations, eps):
@@ -64,7 +64,7 @@ def iterate_bipartite(G12, G21, C1, C2, iterations, eps):
     r2, c2 = np.nonzero(G21)
     s2 = np.zeros(n2, np.float32)
     s2[r2] = G21[r2, c2]
-    opt = BiPlanOptions(c1=C1, c2=C2, evidence=0, reorder=1)
+    opt = BiPlanOptions(c1=C1, c2=C2, evidence=0, reorder=1, strict_reference=1)
     plan = vp()
     _ok(_lib.simrank_biplan_create(i64(n1), i64(n2), i64(col.size), vp(rowptr.ctypes.data), vp(col.ctypes.data),
                                    vp(s1.ctypes.data), vp(s2.ctypes.data), C.byref(opt), None, C.byref(plan)))

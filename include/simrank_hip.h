@@ -411,8 +411,13 @@ SIMRANK_API int simrank_plan_destroy(simrank_plan* p);
  *      per-row scales of both groups — W12 = diag(rowscale1) . A, W21 = diag(rowscale2) . A^T.  Each loop index
  *      updates S1 from S2 and then S2 from the NEW S1 (Gauss-Seidel, :300-302); the loop ends at index k when
  *      neither matrix moved by more than eps (:289).  Evidence (options.evidence): E1 from the group-1
- *      pattern, E2 from the group-2 pattern — the corrected form (the reference multiplies both updates by
- *      Evidence_N1 and cannot run n1 != n2).  Priors: HOST row-major, symmetric.
+ *      pattern, E2 from the group-2 pattern — the corrected form — unless options.strict_reference = 1, which is
+ *      what the reference does (SimRank.py:420-423, :488-491): both updates are multiplied by
+ *      Evidence_N1, position by position; with n1 != n2 (and n1 != 1, where NumPy broadcasts the 1 x 1 array)
+ *      simrank_biplan_step / _run fail with NumPy's "operands could not be broadcast together with shapes
+ *      (n1,n1) (n2,n2) " at the first group-2 update, i.e. not for iterations = 0 or eps >= 1.
+ *      Priors: HOST row-major, symmetric (an asymmetric prior is SIMRANK_ERR_INVALID: the Python classes run
+ *      that case through their un-fused path).
  *      simrank_biplan_result_f64(group = 1 | 2) hands S1 / S2 back in the caller's node order. */
 typedef struct simrank_biplan simrank_biplan;
 typedef struct simrank_biplan_options {
@@ -424,6 +429,7 @@ typedef struct simrank_biplan_options {
     int64_t ld_apriori2;
     int32_t evidence;           /* 1: SimRank++ evidence factors */
     int32_t reorder;            /* 1: iterate in ascending-row-length node order within each group (recommended) */
+    int32_t strict_reference;   /* 1: Evidence_N1 on BOTH updates, as SimRank.py:423 / :491 (quirk Q2); 0: E2 on group 2 */
 } simrank_biplan_options;
 SIMRANK_API int simrank_biplan_create(int64_t n1, int64_t n2, int64_t nnz, const int32_t* rowptr12,
                                       const int32_t* col12, const float* rowscale1, const float* rowscale2,

@@ -9,9 +9,12 @@
 // One edge set describes both patterns: W12 = diag(rowscale1) . A (n1 x n2), W21 = diag(rowscale2) . A^T.
 // Each update is two launches (leg 1: fused_trans_kernel on a rectangular pattern, leg 2: upper-triangle gather
 // with the fused epilogue and count); iteration k + 1 is queued before the counts of iteration k are read, as in
-// plan.hip.  Evidence: the corrected form — E1 from the group-1 pattern, E2 from the group-2 pattern (the
-// reference multiplies BOTH updates by Evidence_N1 and cannot run n1 != n2: SURVEY.md quirk Q2; the Python
-// class keeps that behaviour under strict_reference, this entry point does not reproduce a crash).
+// plan.hip.  Evidence: by default the corrected form — E1 from the group-1 pattern, E2 from the group-2 pattern.
+// options.strict_reference = 1 is the reference's own behaviour (SimRank.py:420-423, :488-491, SURVEY.md quirk
+// Q2): BOTH updates are multiplied by Evidence_N1, position by position in the caller's node order — n1 = n2:
+// the group-2 update is gated by the counts of the group-1 pattern; n1 = 1: NumPy broadcasts the 1 x 1 array,
+// one count gates every element; otherwise NumPy raises "operands could not be broadcast together" when the
+// first group-2 update RUNS (iterations = 0 or eps >= 1 still return the identities): so do step / run here.
 #include <algorithm>
 #include <numeric>
 #include <vector>
@@ -43,6 +46,7 @@ struct simrank_biplan {
     hipEvent_t counted[2] = {nullptr, nullptr};                      // both counts of an iteration have landed
     hipStream_t stream = nullptr;
     int32_t updates = 0;
+    int32_t broadcast_error = 0;     // strict_reference with evidence and n1 != n2, n1 != 1 (quirk Q2)
 };
 
 namespace simrank {
@@ -79,6 +83,9 @@ static int side_update(simrank_biplan* p, int w, double eps, int32_t exact_count
 
 // one loop body: both updates, counts into slot `it`
 static int iteration(simrank_biplan* p, double eps, int32_t exact_count, int it) {
+    // (the reference has updated S1 when NumPy raises at :423 / :491; nobody sees that S1: the exception ends fit)
+    SR_REQUIRE(!p->broadcast_error, "operands could not be broadcast together with shapes (%lld,%lld) (%lld,%lld) ",
+               (long long)p->s[0].n, (long long)p->s[0].n, (long long)p->s[1].n, (long long)p->s[1].n);
     int rc = side_update(p, 0, eps, exact_count, p->host_counters[it][0]);
     if (!rc) rc = side_update(p, 1, eps, exact_count, p->host_counters[it][1]);
     if (rc) return rc;
@@ -136,53 +143,19 @@ int simrank_biplan_create(int64_t n1, int64_t n2, int64_t nnz, const int32_t* ro
                           void* stream, simrank_biplan** out) {
     SR_REQUIRE(out, "out is NULL");
     *out = nullptr;
-    SR_REQUIRE(opt && rowptr12 && rowscale1 && rowscale2 && (col12 || nnz == 0) && n1 > 0 && n2 > 0 && nnz >= 0,
-               "bad plan arguments");
-    SR_REQUIRE(n1 < (int64_t(1) << 24) - 16 && n2 < (int64_t(1) << 24) - 16, "a plan holds at most 2^24 nodes per group");
-    SR_REQUIRE(rowptr12[0] == 0 && rowptr12[n1] == nnz, "rowptr does not span [0, nnz]");
-    for (int64_t a = 0; a < n1; ++a)
-        SR_REQUIRE(rowptr12[a + 1] >= rowptr12[a], "rowptr not monotone at row %lld", (long long)a);
-    for (int64_t j = 0; j < nnz; ++j) SR_REQUIRE(col12[j] >= 0 && col12[j] < n2, "column index %d out of range", col12[j]);
+    BiPlanPrep pp;
+    {
+        const int rc = biplan_prepare(n1, n2, nnz, rowptr12, col12, rowscale1, rowscale2, opt, &pp);   // (planprep.hip)
+        if (rc) return rc;
+    }
     const float* priors[2] = {opt->apriori1, opt->apriori2};
     const int64_t lds[2] = {opt->ld_apriori1, opt->ld_apriori2};
     const int64_t ns[2] = {n1, n2};
-    for (int w = 0; w < 2; ++w)
-        if (priors[w]) {
-            SR_REQUIRE(lds[w] >= ns[w], "prior %d: ld %lld < n", w + 1, (long long)lds[w]);
-            for (int64_t i = 0; i < ns[w]; ++i)
-                for (int64_t j = i + 1; j < ns[w]; ++j)
-                    SR_REQUIRE(priors[w][i * lds[w] + j] == priors[w][j * lds[w] + i],
-                               "a plan needs symmetric priors (prior %d, element %lld, %lld)", w + 1, (long long)i,
-                               (long long)j);
-        }
-    // the group-2 pattern: the transpose
-    std::vector<int32_t> rowptr21((size_t)n2 + 1, 0), col21((size_t)std::max<int64_t>(1, nnz));
-    for (int64_t j = 0; j < nnz; ++j) ++rowptr21[(size_t)col12[j] + 1];
-    for (int64_t i = 0; i < n2; ++i) rowptr21[(size_t)i + 1] += rowptr21[(size_t)i];
-    {
-        std::vector<int32_t> fill(rowptr21.begin(), rowptr21.end() - 1);
-        for (int64_t a = 0; a < n1; ++a)
-            for (int32_t j = rowptr12[a]; j < rowptr12[a + 1]; ++j) col21[(size_t)fill[(size_t)col12[j]]++] = (int32_t)a;
-    }
-    // node orders of the solver: ascending row length within each group; ord[new] = old, inv[old] = new
-    std::vector<int32_t> ord[2], inv[2];
-    const int32_t* rps[2] = {rowptr12, rowptr21.data()};
-    for (int w = 0; w < 2; ++w) {
-        ord[w].resize((size_t)ns[w]);
-        inv[w].resize((size_t)ns[w]);
-        std::iota(ord[w].begin(), ord[w].end(), 0);
-        if (opt->reorder) {
-            const int32_t* rp = rps[w];
-            std::stable_sort(ord[w].begin(), ord[w].end(),
-                             [rp](int32_t x, int32_t y) { return rp[x + 1] - rp[x] < rp[y + 1] - rp[y]; });
-        }
-        for (int64_t r = 0; r < ns[w]; ++r) inv[w][(size_t)ord[w][(size_t)r]] = (int32_t)r;
-    }
+    const std::vector<int32_t>* ord = pp.ord;
+    const std::vector<int32_t>* inv = pp.inv;
     simrank_biplan* p = new simrank_biplan;
     p->stream = as_stream(stream);
     auto fail = [&](int code) { simrank_biplan_destroy(p); return code; };
-    const int32_t* cls[2] = {col12, col21.data()};
-    const float* scales[2] = {rowscale1, rowscale2};
     for (int w = 0; w < 2; ++w) {
         side_t& a = p->s[w];
         a.n = ns[w];
@@ -193,25 +166,7 @@ int simrank_biplan_create(int64_t n1, int64_t n2, int64_t nnz, const int32_t* ro
         a.k_rows_pad = (a.k + 7) / 8 * 8 + 8;
         a.mat_bytes = size_t((a.n + 31) / 32) * size_t(a.rows_pad) * 32 * sizeof(float);     // n x n
         a.t_bytes = size_t((a.n + 31) / 32) * size_t(a.k_rows_pad) * 32 * sizeof(float);      // k x n
-        // the pattern with both sides renamed
-        std::vector<int32_t> rp((size_t)a.n + 1, 0), cl((size_t)std::max<int64_t>(1, nnz));
-        std::vector<float> rs((size_t)a.n);
-        for (int64_t r = 0; r < a.n; ++r) {
-            const int32_t src = ord[w][(size_t)r];
-            const int32_t b = rps[w][src], e = rps[w][src + 1];
-            int32_t* dst = cl.data() + rp[(size_t)r];
-            for (int32_t j = b; j < e; ++j) dst[j - b] = inv[w ^ 1][(size_t)cls[w][j]];
-            std::sort(dst, dst + (e - b));
-            for (int32_t j = 1; j < e - b; ++j) {
-                if (dst[j] == dst[j - 1]) {
-                    set_error("duplicate entry in row %d of group %d", src, w + 1);
-                    return fail(SIMRANK_ERR_INVALID);
-                }
-            }
-            rp[(size_t)r + 1] = rp[(size_t)r] + (e - b);
-            rs[(size_t)r] = scales[w][src];
-        }
-        const int rc = simrank_graph_create(a.n, a.k, nnz, rp.data(), cl.data(), rs.data(), &a.g);
+        const int rc = simrank_graph_create(a.n, a.k, nnz, pp.rp[w].data(), pp.cl[w].data(), pp.rs[w].data(), &a.g);
         if (rc) return fail(rc);
     }
 #define BIPLAN_HIP(call)                                                                          \
@@ -241,12 +196,42 @@ int simrank_biplan_create(int64_t n1, int64_t n2, int64_t nnz, const int32_t* ro
         BIPLAN_HIP(pool_hip_alloc((void**)&a.inv, size_t(a.n) * sizeof(int32_t)));
         BIPLAN_HIP(hipMemcpyAsync(a.inv, inv[w].data(), size_t(a.n) * sizeof(int32_t), hipMemcpyHostToDevice, p->stream));
         BIPLAN_HIP(hipStreamSynchronize(p->stream));
-        if (opt->evidence) {
+        const bool q2 = opt->evidence && opt->strict_reference && w == 1;      // Evidence_N1 on the group-2 update
+        if (q2 && n1 != n2 && n1 != 1) {
+            p->broadcast_error = 1;
+        } else if (opt->evidence) {
             // common-neighbour counts inside the group (SimRank.py:311-320 on this group's pattern)
             const size_t ev_bytes = size_t((a.n + 31) / 32) * size_t(a.rows_pad) * 32;
             BIPLAN_HIP(pool_hip_alloc((void**)&a.ev, ev_bytes));
-            BIPLAN_HIP(hipMemsetAsync(a.ev, 0, ev_bytes, p->stream));
-            int rc = simrank_evidence_counts_blocked(a.g, 0, a.n, a.ev, a.rows_pad, p->stream);
+            int rc = SIMRANK_OK;
+            if (q2 && n1 == 1 && n2 != 1) {
+                // the 1 x 1 Evidence_N1 broadcasts: the one group-1 node's count (with itself) gates every element
+                const int cnt = rowscale1[0] != 0.f ? (int)std::min<int64_t>(255, nnz) : 0;
+                BIPLAN_HIP(hipMemsetAsync(a.ev, cnt, ev_bytes, p->stream));
+            } else if (q2) {
+                // n1 = n2: element (i, j) of the group-2 update is multiplied by Evidence_N1[i][j], positions in the
+                // caller's order: the counts of the group-1 pattern with its rows taken in THIS group's solver order
+                std::vector<int32_t> rp((size_t)n1 + 1, 0), cl((size_t)std::max<int64_t>(1, nnz));
+                std::vector<float> rs((size_t)n1);
+                for (int64_t r = 0; r < n1; ++r) {
+                    const int32_t src = ord[1][(size_t)r];
+                    const int32_t b = rowptr12[src], e = rowptr12[src + 1];
+                    std::copy(col12 + b, col12 + e, cl.data() + rp[(size_t)r]);
+                    std::sort(cl.data() + rp[(size_t)r], cl.data() + rp[(size_t)r] + (e - b));
+                    rp[(size_t)r + 1] = rp[(size_t)r] + (e - b);
+                    rs[(size_t)r] = rowscale1[src];
+                }
+                simrank_graph* g1 = nullptr;
+                rc = simrank_graph_create(n1, n2, nnz, rp.data(), cl.data(), rs.data(), &g1);
+                if (rc) return fail(rc);
+                hipError_t e = hipMemsetAsync(a.ev, 0, ev_bytes, p->stream);
+                rc = e == hipSuccess ? simrank_evidence_counts_blocked(g1, 0, a.n, a.ev, a.rows_pad, p->stream) : SIMRANK_ERR_HIP;
+                (void)hipStreamSynchronize(p->stream);
+                simrank_graph_destroy(g1);
+            } else {
+                BIPLAN_HIP(hipMemsetAsync(a.ev, 0, ev_bytes, p->stream));
+                rc = simrank_evidence_counts_blocked(a.g, 0, a.n, a.ev, a.rows_pad, p->stream);
+            }
             if (rc) return fail(rc);
             int64_t live = 0, total = 1;
             rc = simrank_evidence_live_segments(a.ev, 32, a.rows_pad, a.n, a.n, &live, &total, p->stream);

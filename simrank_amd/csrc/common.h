@@ -62,20 +62,26 @@ struct Tuning {
     int64_t fuse_min = 3;    // ... a column joins a block's dense set when this many of its rows reference it (2 and 4:
                              // +8 % and +1 % on the leg at pl32768d32)
     int64_t fuse_steps = 8;  // ... and a block keeps its set only when it makes this many 16-column steps
-    int64_t fuse_unit = 1 << 20;  // ... sets of more than this many 64-column groups are cut into units (workgroups whose
-                             // partial sums meet in memory); measured: 64 +3 %, 32 +13 %, so off by default
+    int64_t fuse_unit = 64;  // ... sets of more than this many 64-column groups are cut into units (workgroups whose
+                             // partial sums meet in memory, written through and read past the L1 — round 4; with round 3's
+                             // agent-scope release / acquire pair 64 cost +3 %): pl32768d32 leg 1 5.50 -> 5.20 ms at 64
+                             // (128: 5.34, 32: 5.23, 16: 5.94); 1 << 20 = never
     int64_t fuse_store = 1;  // ... cache policy of its tile stores: 0 plain, 1 nt, 2 sc1 (write through, drop), 3 sc0 sc1
     int64_t fuse_meta_nt = 0; // ... id streams loaded non-temporally
     int64_t fuse_order = 0;  // ... launch order of a panel's units: 0 heaviest first, k > 0: the units with a matrix-core
                              // phase spread over the first 1/k of the order
     int64_t fuse_max_rows = 1 << 20;  // ... operands with more rows than this keep the two-launch leg (N = 65536: 20.4
                              // against 21.8 ms, so practically never)
+    int64_t fuse_cap = 40000;  // fuse = 2: a block whose estimated duration (cycles of one workgroup) exceeds this is cut into
+                             // pieces whose raw sums meet in memory
+    int64_t fuse_wgs = 4;    // fuse = 2: resident workgroups per CU
     int64_t fuse_group = 3;  // ... and up to this many consecutive blocks without a set share a workgroup (1..4)
     int64_t dense_sym = -1;  // dense part in the upper-triangle form of leg 2: 1 yes, 0 no, -1 = when the
                              // dense sets hold at least half of the pattern's entries
 };
 Tuning& tuning();            // the process-wide defaults: simrank_set_tuning writes them, simrank_graph_create
 Tuning tuning_snapshot();    // copies them (under a lock) into the graph it builds; launches read the copy
+
 
 // The arrays of a graph object (CSR, plans): allocated, filled once and freed through these.  A sanitizer
 // build of the HOST logic (make asan: -DSIMRANK_HOST_ONLY, host side only, no GPU needed) keeps them in
@@ -96,6 +102,10 @@ inline hipError_t plan_download(void* h, const void* d, size_t bytes) { return h
 inline void plan_free(void* p) { (void)hipFree(p); }
 #endif
 
+// simrank_graph_create with the knobs given (the plans set some per graph: fp16-held fits take no split blocks)
+int graph_create_with(const Tuning& tun, int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr,
+                      const int32_t* col, const float* rowscale, simrank_graph** out);
+
 // device block pool (api.hip): what simrank_malloc / simrank_free and the plans allocate through
 int pool_alloc(void** dptr, size_t bytes);
 int pool_free(void* ptr);
@@ -105,6 +115,23 @@ inline hipError_t pool_hip_alloc(void** p, size_t bytes) {       // (for call si
     const int rc = pool_alloc(p, bytes);
     return rc == SIMRANK_OK ? hipSuccess : (rc == SIMRANK_ERR_ALLOC ? hipErrorOutOfMemory : hipErrorUnknown);
 }
+
+// planprep.hip: the host-only half of the plans (validation, solver node order, renamed patterns)
+struct PlanPrep {
+    std::vector<int32_t> ord, inv;          // ord[new] = old, inv[old] = new
+    std::vector<int32_t> rp, cl;            // the pattern in the solver's order
+    std::vector<float> rs;
+};
+struct BiPlanPrep {
+    std::vector<int32_t> rowptr21, col21;   // the group-2 pattern (transpose), caller's order
+    std::vector<int32_t> ord[2], inv[2];
+    std::vector<int32_t> rp[2], cl[2];      // group w's pattern with both sides renamed
+    std::vector<float> rs[2];
+};
+int plan_prepare(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* rowscale,
+                 const simrank_plan_options* opt, PlanPrep* out);
+int biplan_prepare(int64_t n1, int64_t n2, int64_t nnz, const int32_t* rowptr12, const int32_t* col12,
+                   const float* rowscale1, const float* rowscale2, const simrank_biplan_options* opt, BiPlanPrep* out);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -178,6 +205,27 @@ struct simrank_fused_plan {
     int32_t* sids32 = nullptr;      //              32-bit ids (-1: no neighbour)
 };
 
+// fused2.hip: leg 1 as one PERSISTENT launch: the same dense sets and id streams, per PIECE of a block (a share of
+// the set's columns + a share of the rows), pulled from per-XCD queues by resident workgroups.
+struct simrank_fused2_plan {
+    int32_t n_items = 0;            // pieces per panel, launch order
+    int32_t n_blocks = 0;
+    int32_t ids16 = 0;
+    int32_t cap_panels = 0;         // panels the partial-sum slots are sized for
+    int64_t n_quads = 0, n_steps = 0, nnz_covered = 0, r_nnz = 0;
+    int32_t* items = nullptr;       // [n_items + 1][16]
+    int32_t n_pslots = 0, n_cslots = 0;
+    float* partials = nullptr;      // [n_pslots][cap_panels][32 x 128]
+    int32_t* tickets = nullptr;     // [n_cslots][cap_panels]
+    uint32_t* heads = nullptr;      // [8][32]
+    uint16_t* dcols16 = nullptr;
+    int32_t* dcols32 = nullptr;
+    uint4* abits = nullptr;
+    int2* gmeta = nullptr;
+    uint16_t* sids16 = nullptr;
+    int32_t* sids32 = nullptr;
+};
+
 namespace simrank {
 constexpr int kFB = 128;          // rows per block of the one-launch plan
 constexpr int kSub = 4;           // blocks a unit without a dense set may hold
@@ -185,6 +233,10 @@ void free_fused_plan(simrank_fused_plan* p);
 int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col, const float* rowscale);
 int launch_fused_trans(const simrank_graph* g, const float* X, int64_t x_rows_pad, int64_t L, float* Y,
                        int64_t y_rows_pad, hipStream_t st);
+void free_fused2_plan(simrank_fused2_plan* p);
+int build_fused2_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col, const float* rowscale);
+int launch_fused2_trans(const simrank_graph* g, const float* X, int64_t x_rows_pad, int64_t L, float* Y,
+                        int64_t y_rows_pad, hipStream_t st);
 struct DenseUse {                   // what the gather kernel needs from a dense launch
     const float* part = nullptr;
     int64_t ldp = 0;
@@ -223,6 +275,7 @@ struct simrank_graph {
     int32_t sym_blocks = 0;
     simrank_dense_plan* dense = nullptr;   // NULL: no block of the pattern is dense enough
     simrank_fused_plan* fused = nullptr;   // leg 1 as one launch (fused.hip); NULL: tuning "fuse" = 0
+    simrank_fused2_plan* fused2 = nullptr; // leg 1 as one persistent launch (fused2.hip); tuning "fuse" = 2
     simrank::Tuning tun;                   // knobs in force when the graph was created (every launch on
                                            // this graph uses these, whatever is set afterwards)
 };

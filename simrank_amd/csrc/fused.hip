@@ -40,6 +40,7 @@
 #include <vector>
 
 #include "common.h"
+#include "fused_dev.h"
 
 namespace simrank {
 
@@ -56,9 +57,6 @@ constexpr int kTS = 132;          // floats per column of the LDS tile (32 colum
 constexpr int kMinUnits = SIMRANK_KMINUNITS;       // units per panel below which blocks are grouped less
 constexpr int kGroupEntries = SIMRANK_KGROUPENTRIES; // gathered entries a unit of several set-less blocks may hold
 constexpr int kMaxRem = SIMRANK_KMAXREM;      // a row whose remainder would be longer sends all its columns to the dense set
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct FusedArgs {
     const float* X;
@@ -87,36 +85,6 @@ struct FusedArgs {
 };
 
 #ifndef SIMRANK_HOST_ONLY          // (the sanitizer build of the host logic has no device code: common.h)
-__device__ __forceinline__ void split3f(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-    const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-    hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-    const float r0 = x0 - __uint_as_float(u0 & 0xFFFF0000u);
-    const float r1 = x1 - __uint_as_float(u1 & 0xFFFF0000u);
-    const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-    mid = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    const float q0 = r0 - __uint_as_float(v0 & 0xFFFF0000u);
-    const float q1 = r1 - __uint_as_float(v1 & 0xFFFF0000u);
-    lo = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
-}
-
-__device__ __forceinline__ bf16x8 frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-    const uint4 v = make_uint4(a, b, c, d);
-    return __builtin_bit_cast(bf16x8, v);
-}
-
-__device__ __forceinline__ float4 ld_seg(__amdgpu_buffer_rsrc_t srd, int id, uint32_t qoff) {
-    typedef unsigned v4u __attribute__((ext_vector_type(4)));
-    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(srd, int(__umul24(uint32_t(id), 128u) + qoff), 0, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-
-// the compiler may not move LDS accesses of this wave across this point (no instruction is emitted)
-__device__ __forceinline__ void wave_lds_order() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 #ifdef SIMRANK_FUSED_STAMPS
 // Diagnostic build only (bash tools/build_variant.sh fst -DSIMRANK_FUSED_STAMPS; tools/fused_stamps.py): the
 // timeline of the workgroups with blockIdx in [g_fst_base, g_fst_base + kFstCap): s_memtime at the phase
@@ -349,27 +317,29 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
         // takes a ticket; the LAST arriver adds the partial sums in unit order (whoever it is: same
         // bits) and goes on to the gather phase, the others are done.  No unit ever waits for another.
         if (unit_nb > 1) {
+            // (round 4: partial sums written THROUGH (sc1) and read past the L1 (sc1) instead of an agent-scope
+            // release / acquire pair around plain accesses — the release wrote back every dirty line of the XCD's
+            // L2, the output tiles of all its workgroups included)
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
             float* mine = p.partials + (size_t(pslot) * p.n_panels + panel) * (32 * kFB);
+            const __amdgpu_buffer_rsrc_t msrd = __builtin_amdgcn_make_buffer_rsrc(mine, 0, 32 * kFB * 4, 0x00020000);
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int x = threadIdx.x + it * 256;      // 1024 float4 = 32 columns x 128 rows
                 const int c = x >> 5, r4 = (x & 31) * 4;
-                *reinterpret_cast<float4*>(mine + c * kFB + r4) = *reinterpret_cast<const float4*>(tile + c * kTS + r4);
+                const float4 v = *reinterpret_cast<const float4*>(tile + c * kTS + r4);
+                v4u o;
+                o.x = __float_as_uint(v.x); o.y = __float_as_uint(v.y); o.z = __float_as_uint(v.z); o.w = __float_as_uint(v.w);
+                __builtin_amdgcn_raw_buffer_store_b128(o, msrd, (c * kFB + r4) * 4, 0, 16);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             int* flag = reinterpret_cast<int*>(bbuf_all);
             if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 int* tk = p.tickets + size_t(cslot) * p.n_panels + panel;
                 const int t = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int last = t == unit_nb - 1;
-                if (last) {
-                    __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
+                if (last) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
                 *flag = last;
             }
             __syncthreads();
@@ -381,8 +351,11 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
                 const int c = x >> 5, r4 = (x & 31) * 4;
                 float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int k = 0; k < unit_nb; ++k) {
-                    const float4 v = *reinterpret_cast<const float4*>(
-                        p.partials + (size_t(first + k) * p.n_panels + panel) * (32 * kFB) + c * kFB + r4);
+                    const float* src = p.partials + (size_t(first + k) * p.n_panels + panel) * (32 * kFB);
+                    const __amdgpu_buffer_rsrc_t ssrd =
+                        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 32 * kFB * 4, 0x00020000);
+                    const v4u w = __builtin_amdgcn_raw_buffer_load_b128(ssrd, (c * kFB + r4) * 4, 0, 16);
+                    const float4 v = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
                     if (k == 0) acc4 = v;
                     else { acc4.x += v.x; acc4.y += v.y; acc4.z += v.z; acc4.w += v.w; }
                 }
@@ -548,7 +521,10 @@ static int upload_vec(T** d, const std::vector<T>& h) {
 
 void free_fused_plan(simrank_fused_plan* p) {
     if (!p) return;
-    plan_free(p->units); (void)hipFree(p->partials); (void)hipFree(p->tickets);
+    plan_free(p->units);
+#ifndef SIMRANK_HOST_ONLY
+    (void)pool_free(p->partials); (void)hipFree(p->tickets);
+#endif
     plan_free(p->dcols16); plan_free(p->dcols32); plan_free(p->abits);
     plan_free(p->gmeta); plan_free(p->sids16); plan_free(p->sids32);
     delete p;
@@ -804,6 +780,23 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
             rc = upload_vec(&pl->sids32, sids);
         }
     }
+#ifndef SIMRANK_HOST_ONLY
+    if (!rc && n_pslots > 0) {
+        // partial sums and tickets of the split blocks for the widest operand a solver hands over (S of the other
+        // node set: max(M, K) columns); a wider one grows them at its first launch
+        const int32_t panels = (int32_t)((std::max<int64_t>(M, K) + 31) / 32);
+        hipError_t e = pool_hip_alloc((void**)&pl->partials, size_t(n_pslots) * panels * 32 * kFB * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&pl->tickets, size_t(n_cslots) * panels * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMemset(pl->tickets, 0, size_t(n_cslots) * panels * sizeof(int32_t));
+        if (e != hipSuccess) {
+            set_error("one-launch plan: partial sums of %d split blocks: %s", n_cslots, hipGetErrorString(e));
+            (void)hipGetLastError();
+            rc = e == hipErrorOutOfMemory ? SIMRANK_ERR_ALLOC : SIMRANK_ERR_HIP;
+        } else {
+            pl->cap_panels = panels;
+        }
+    }
+#endif
     if (rc) {
         free_fused_plan(pl);
         return rc;
@@ -833,11 +826,11 @@ int launch_fused_trans(const simrank_graph* g, const float* X, int64_t x_rows_pa
     a.idx_mask = (int32_t)g->tun.probe_mask;
     a.units = pl->units;
     if (pl->n_pslots > 0 && a.n_panels > pl->cap_panels) {
-        // partial sums and tickets of the split blocks, sized by the widest operand seen so far
+        // (an operand wider than the plan was built for — not what a solver does: grow once)
         SR_HIP(hipStreamSynchronize(st));                  // an earlier launch may still use the old ones
-        (void)hipFree(pl->partials); (void)hipFree(pl->tickets);
+        (void)pool_free(pl->partials); (void)hipFree(pl->tickets);
         pl->partials = nullptr; pl->tickets = nullptr; pl->cap_panels = 0;
-        SR_HIP(hipMalloc((void**)&pl->partials, size_t(pl->n_pslots) * a.n_panels * 32 * kFB * sizeof(float)));
+        SR_HIP(pool_hip_alloc((void**)&pl->partials, size_t(pl->n_pslots) * a.n_panels * 32 * kFB * sizeof(float)));
         SR_HIP(hipMalloc((void**)&pl->tickets, size_t(pl->n_cslots) * a.n_panels * sizeof(int32_t)));
         SR_HIP(hipMemsetAsync(pl->tickets, 0, size_t(pl->n_cslots) * a.n_panels * sizeof(int32_t), st));
         pl->cap_panels = a.n_panels;

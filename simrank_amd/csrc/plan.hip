@@ -108,38 +108,11 @@ int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int
                         const simrank_plan_options* opt, void* stream, simrank_plan** out) {
     SR_REQUIRE(out, "out is NULL");
     *out = nullptr;
-    SR_REQUIRE(opt && rowptr && rowscale && (col || nnz == 0) && n > 0 && nnz >= 0, "bad plan arguments");
-    SR_REQUIRE(n < (int64_t(1) << 24) - 16, "a plan holds at most 2^24 nodes");
-    SR_REQUIRE(rowptr[0] == 0 && rowptr[n] == nnz, "rowptr does not span [0, nnz]");
-    for (int64_t a = 0; a < n; ++a) SR_REQUIRE(rowptr[a + 1] >= rowptr[a], "rowptr not monotone at row %lld", (long long)a);
-    for (int64_t j = 0; j < nnz; ++j) SR_REQUIRE(col[j] >= 0 && col[j] < n, "column index %d out of range", col[j]);
-    if (opt->apriori) {
-        SR_REQUIRE(opt->ld_apriori >= n, "prior: ld %lld < n", (long long)opt->ld_apriori);
-        for (int64_t i = 0; i < n; ++i)
-            for (int64_t j = i + 1; j < n; ++j)
-                SR_REQUIRE(opt->apriori[i * opt->ld_apriori + j] == opt->apriori[j * opt->ld_apriori + i],
-                           "a plan needs a symmetric prior (element %lld, %lld)", (long long)i, (long long)j);
-    }
-    // node order of the solver: ascending row length; ord[new] = old, inv[old] = new
-    std::vector<int32_t> ord((size_t)n), inv((size_t)n);
-    std::iota(ord.begin(), ord.end(), 0);
-    if (opt->reorder)
-        std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) {
-            return rowptr[x + 1] - rowptr[x] < rowptr[y + 1] - rowptr[y];
-        });
-    for (int64_t r = 0; r < n; ++r) inv[(size_t)ord[(size_t)r]] = (int32_t)r;
-    std::vector<int32_t> rp((size_t)n + 1, 0), cl((size_t)std::max<int64_t>(1, nnz));
-    std::vector<float> rs((size_t)n);
-    for (int64_t r = 0; r < n; ++r) {
-        const int32_t a = ord[(size_t)r];
-        const int32_t s = rowptr[a], e = rowptr[a + 1];
-        int32_t* dst = cl.data() + rp[(size_t)r];
-        for (int32_t j = s; j < e; ++j) dst[j - s] = inv[(size_t)col[j]];
-        std::sort(dst, dst + (e - s));
-        for (int32_t j = 1; j < e - s; ++j) SR_REQUIRE(dst[j] != dst[j - 1], "duplicate entry in row %d", a);
-        rp[(size_t)r + 1] = rp[(size_t)r] + (e - s);
-        rs[(size_t)r] = rowscale[a];
-    }
+    PlanPrep pp;
+    int rc = plan_prepare(n, nnz, rowptr, col, rowscale, opt, &pp);     // validation, node order, renamed pattern (planprep.hip)
+    if (rc) return rc;
+    const std::vector<int32_t>& ord = pp.ord;
+    const std::vector<int32_t>& inv = pp.inv;
     simrank_plan* p = new simrank_plan;
     p->n = n;
     p->stream = as_stream(stream);
@@ -152,7 +125,11 @@ int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int
     p->mat_bytes = p->half ? size_t((n + 63) / 64) * size_t(p->rows_pad) * 128
                            : size_t(panels) * size_t(p->rows_pad) * 32 * sizeof(float);
     const size_t prior_bytes = size_t(panels) * size_t(p->rows_pad) * 32 * sizeof(float);
-    int rc = simrank_graph_create(n, n, nnz, rp.data(), cl.data(), rs.data(), &p->g);
+    {
+        Tuning t = tuning_snapshot();
+        if (p->half) t.fuse_unit = int64_t(1) << 20;      // (half.hip runs whole blocks: no units whose sums meet in memory)
+        rc = graph_create_with(t, n, n, nnz, pp.rp.data(), pp.cl.data(), pp.rs.data(), &p->g);
+    }
     auto fail = [&](int code) { simrank_plan_destroy(p); return code; };
     if (rc) return fail(rc);
     if (p->half && !p->g->fused) {

@@ -1,0 +1,116 @@
+// Host-only half of simrank_plan_create / simrank_biplan_create: argument validation, the solver's node
+// order (ascending row length), the renamed CSR patterns, the transposed pattern of the
+// bipartite plans.  No HIP call in here: `make asan` compiles this file for the host and tools/host/
+// host_fuzz.cpp throws malformed inputs at it (non-monotone rowptr, columns out of range or repeated,
+// asymmetric / non-finite priors), expecting SIMRANK_ERR_INVALID and no out-of-bounds read.
+// Replaces nothing of the reference by itself: it is what `_create_graph` (SimRank.py:24-52, :168-200) does to
+// an edge list, restated for callers that hand over CSR arrays.
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "common.h"
+
+namespace simrank {
+
+static int check_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr, const int32_t* col) {
+    SR_REQUIRE(rowptr[0] == 0 && rowptr[n_rows] == nnz, "rowptr does not span [0, nnz]");
+    for (int64_t a = 0; a < n_rows; ++a)
+        SR_REQUIRE(rowptr[a + 1] >= rowptr[a] && rowptr[a + 1] <= nnz, "rowptr not monotone at row %lld", (long long)a);
+    for (int64_t j = 0; j < nnz; ++j) SR_REQUIRE(col[j] >= 0 && col[j] < n_cols, "column index %d out of range", col[j]);
+    return SIMRANK_OK;
+}
+
+static int check_prior(const float* a, int64_t ld, int64_t n, int which, bool half) {
+    if (!a) return SIMRANK_OK;
+    SR_REQUIRE(ld >= n, "prior %d: ld %lld < n", which, (long long)ld);
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = i; j < n; ++j) {
+            const float v = a[i * ld + j];
+            SR_REQUIRE(v == a[j * ld + i], "a plan needs symmetric priors (prior %d, element %lld, %lld)", which, (long long)i,
+                       (long long)j);
+            // (fp16-held matrices store value x 2^14: anything from 4 up, or not finite, leaves fp16's range and
+            // turns into NaN behind the evidence factor)
+            SR_REQUIRE(!half || (std::isfinite(v) && std::fabs(v) < 3.99f),
+                       "storage_fp16 needs finite prior values below 4 in magnitude (element %lld, %lld)", (long long)i,
+                       (long long)j);
+        }
+    return SIMRANK_OK;
+}
+
+// rows of (rowptr, col) taken in the order `ord`, columns renamed by `inv_cols`, sorted; duplicates refused
+static int renamed(int64_t n_rows, const int32_t* rowptr, const int32_t* col, const float* scale,
+                   const std::vector<int32_t>& ord, const std::vector<int32_t>& inv_cols, int64_t nnz, const char* what,
+                   std::vector<int32_t>& rp, std::vector<int32_t>& cl, std::vector<float>& rs) {
+    rp.assign((size_t)n_rows + 1, 0);
+    cl.assign((size_t)std::max<int64_t>(1, nnz), 0);
+    rs.assign((size_t)n_rows, 0.f);
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int32_t a = ord[(size_t)r];
+        const int32_t s = rowptr[a], e = rowptr[a + 1];
+        int32_t* dst = cl.data() + rp[(size_t)r];
+        for (int32_t j = s; j < e; ++j) dst[j - s] = inv_cols[(size_t)col[j]];
+        std::sort(dst, dst + (e - s));
+        for (int32_t j = 1; j < e - s; ++j) SR_REQUIRE(dst[j] != dst[j - 1], "duplicate entry in row %d%s", a, what);
+        rp[(size_t)r + 1] = rp[(size_t)r] + (e - s);
+        rs[(size_t)r] = scale[a];
+    }
+    return SIMRANK_OK;
+}
+
+static void length_order(int64_t n, const int32_t* rowptr, bool reorder, std::vector<int32_t>& ord, std::vector<int32_t>& inv) {
+    ord.resize((size_t)n);
+    inv.resize((size_t)n);
+    std::iota(ord.begin(), ord.end(), 0);
+    if (reorder)
+        std::stable_sort(ord.begin(), ord.end(),
+                         [rowptr](int32_t x, int32_t y) { return rowptr[x + 1] - rowptr[x] < rowptr[y + 1] - rowptr[y]; });
+    for (int64_t r = 0; r < n; ++r) inv[(size_t)ord[(size_t)r]] = (int32_t)r;
+}
+
+int plan_prepare(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* rowscale,
+                 const simrank_plan_options* opt, PlanPrep* out) {
+    SR_REQUIRE(opt && rowptr && rowscale && (col || nnz == 0) && n > 0 && nnz >= 0 && out, "bad plan arguments");
+    SR_REQUIRE(n < (int64_t(1) << 24) - 16, "a plan holds at most 2^24 nodes");
+    int rc = check_csr(n, n, nnz, rowptr, col);
+    if (!rc) rc = check_prior(opt->apriori, opt->ld_apriori, n, 1, opt->storage_fp16 != 0);
+    if (rc) return rc;
+    length_order(n, rowptr, opt->reorder != 0, out->ord, out->inv);
+    return renamed(n, rowptr, col, rowscale, out->ord, out->inv, nnz, "", out->rp, out->cl, out->rs);
+}
+
+int biplan_prepare(int64_t n1, int64_t n2, int64_t nnz, const int32_t* rowptr12, const int32_t* col12,
+                   const float* rowscale1, const float* rowscale2, const simrank_biplan_options* opt, BiPlanPrep* out) {
+    SR_REQUIRE(opt && rowptr12 && rowscale1 && rowscale2 && (col12 || nnz == 0) && n1 > 0 && n2 > 0 && nnz >= 0 && out,
+               "bad plan arguments");
+    SR_REQUIRE(n1 < (int64_t(1) << 24) - 16 && n2 < (int64_t(1) << 24) - 16, "a plan holds at most 2^24 nodes per group");
+    int rc = check_csr(n1, n2, nnz, rowptr12, col12);
+    if (!rc) rc = check_prior(opt->apriori1, opt->ld_apriori1, n1, 1, false);
+    if (!rc) rc = check_prior(opt->apriori2, opt->ld_apriori2, n2, 2, false);
+    if (rc) return rc;
+    // the group-2 pattern: the transpose
+    std::vector<int32_t>& rowptr21 = out->rowptr21;
+    std::vector<int32_t>& col21 = out->col21;
+    rowptr21.assign((size_t)n2 + 1, 0);
+    col21.assign((size_t)std::max<int64_t>(1, nnz), 0);
+    for (int64_t j = 0; j < nnz; ++j) ++rowptr21[(size_t)col12[j] + 1];
+    for (int64_t i = 0; i < n2; ++i) rowptr21[(size_t)i + 1] += rowptr21[(size_t)i];
+    {
+        std::vector<int32_t> fill(rowptr21.begin(), rowptr21.end() - 1);
+        for (int64_t a = 0; a < n1; ++a)
+            for (int32_t j = rowptr12[a]; j < rowptr12[a + 1]; ++j) col21[(size_t)fill[(size_t)col12[j]]++] = (int32_t)a;
+    }
+    const int64_t ns[2] = {n1, n2};
+    const int32_t* rps[2] = {rowptr12, rowptr21.data()};
+    const int32_t* cls[2] = {col12, col21.data()};
+    const float* scales[2] = {rowscale1, rowscale2};
+    for (int w = 0; w < 2; ++w) length_order(ns[w], rps[w], opt->reorder != 0, out->ord[w], out->inv[w]);
+    for (int w = 0; w < 2; ++w) {
+        rc = renamed(ns[w], rps[w], cls[w], scales[w], out->ord[w], out->inv[w ^ 1], nnz, w ? " of group 2" : " of group 1",
+                     out->rp[w], out->cl[w], out->rs[w]);
+        if (rc) return rc;
+    }
+    return SIMRANK_OK;
+}
+
+}  // namespace simrank

@@ -1848,8 +1848,11 @@ static int spmm_impl(const simrank_graph* g, const float* X, int64_t ldx, int64_
     // leg 1 of a panel-blocked update: one launch, matrix cores + gathers on the same panel slice (fused.hip)
     // (measured against the two-launch leg: -13 % at K = 32768 power-law, -10 % Erdos-Renyi, -6 % at K = 65536)
     if (blocked && transpose_out && g->fused && T.fuse && vec_ok && T.dense_terms == 3 && g->n_cols <= T.fuse_max_rows &&
-        (x_rows_pad + 1) * 128 < (int64_t(1) << 31))
+        (x_rows_pad + 1) * 128 < (int64_t(1) << 31)) {
+        if (T.fuse == 2 && g->fused2 && (g->fused2->n_pslots == 0 || (n_cols_x + 31) / 32 <= g->fused2->cap_panels))
+            return launch_fused2_trans(g, X, x_rows_pad, n_cols_x, Y, y_rows_pad, st);
         return launch_fused_trans(g, X, x_rows_pad, n_cols_x, Y, y_rows_pad, st);
+    }
     // the block-dense part goes to the matrix cores first; the gather then runs on the remainder
     // In the upper-triangle form only when the pattern is dense throughout (MovieLens-like: 87 % of
     // the entries in dense sets, leg 2 0.9 -> 0.4 ms): on a power-law pattern the long rows, which

@@ -439,11 +439,13 @@ class Side:
         self.Lm, self.Lk = self.m_hi - self.m_lo, self.k_hi - self.k_lo
         self.mb = -(-self.M // world)
         knobs = {}
+        if spec.storage == "fp16" and hasattr(ops, "get_tuning"):
+            knobs["fuse_unit"] = 1 << 20               # (half.hip runs whole blocks: no units whose sums meet in memory)
         if spec.storage == "fp16" and hasattr(ops, "get_tuning") and ops.get_tuning("fuse_min") == 3:
             # one fp16 MFMA term instead of three bf16 ones, but each operand segment serves 64 columns, so the
             # gathers got cheaper still: the break-even moves up by one (measured: 4 is 3 % faster than 3, 2 is
             # 12 % slower).  Only while the knob is at its default.
-            knobs = {"fuse_min": 4}
+            knobs["fuse_min"] = 4
             if ops.get_tuning("fuse_group") == 3:      # (and groups of four: 7 % faster than three at config 5 here,
                 knobs["fuse_group"] = 4                #  where three is 5 % faster than four in f32)
         self.graph = (ops.graph(csr, spec.rowscale, dense_terms=spec.dense_terms, knobs=knobs) if knobs

@@ -163,7 +163,8 @@ class Plan:
 class BiPlanOptions(C.Structure):              # struct simrank_biplan_options
     _fields_ = [("c1", C.c_float), ("c2", C.c_float), ("lbd1", C.c_float), ("lbd2", C.c_float),
                 ("apriori1", C.c_void_p), ("ld_apriori1", C.c_int64), ("apriori2", C.c_void_p),
-                ("ld_apriori2", C.c_int64), ("evidence", C.c_int32), ("reorder", C.c_int32)]
+                ("ld_apriori2", C.c_int64), ("evidence", C.c_int32), ("reorder", C.c_int32),
+                ("strict_reference", C.c_int32)]
 
 
 class BiPlan:
@@ -172,7 +173,7 @@ class BiPlan:
 
     def __init__(self, ops, csr12: CSR, rowscale1, rowscale2, c1: float = 0.8, c2: float = 0.8,
                  evidence: bool = False, apriori1=None, apriori2=None, lbd1: float = 0.0, lbd2: float = 0.0,
-                 reorder: bool = True):
+                 reorder: bool = True, strict_reference: bool = False):
         self.ops = ops
         rowptr = np.ascontiguousarray(csr12.rowptr, dtype=np.int32)
         col = np.ascontiguousarray(csr12.col, dtype=np.int32)
@@ -184,7 +185,7 @@ class BiPlan:
         opt = BiPlanOptions(c1=c1, c2=c2, lbd1=lbd1, lbd2=lbd2,
                             apriori1=None if a1 is None else a1.ctypes.data, ld_apriori1=0 if a1 is None else a1.shape[1],
                             apriori2=None if a2 is None else a2.ctypes.data, ld_apriori2=0 if a2 is None else a2.shape[1],
-                            evidence=int(evidence), reorder=int(reorder))
+                            evidence=int(evidence), reorder=int(reorder), strict_reference=int(strict_reference))
         h = C.c_void_p()
         with HipOps._knob_lock:
             check(ops.lib.simrank_biplan_create(csr12.n_rows, csr12.n_cols, col.size, rowptr.ctypes.data,

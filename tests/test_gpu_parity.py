@@ -881,15 +881,48 @@ def _csr_and_scales(G12, G21):
     return ingest.CSR(n1, n2, rowptr, cols.astype(np.int32), rs1), rs1, rs2
 
 
-@pytest.mark.parametrize("name", [n for n in golden_names() if n.startswith("BipartiteSimRank_")])
+def _biplan_inputs(g):
+    """CSR of the group-1 pattern and both groups' row values (normalisation x spread for the ++ classes,
+    SimRank.py:396-397) from a golden case's own edge list, as a reference-side binding would pass them."""
+    kw = g.kwargs
+    _, _, _, _, g12, g21 = ingest.bipartite(g.frame, kw.get("weighted", False), kw.get("node_group1_column", "user"),
+                                            kw.get("node_group2_column", "item"), kw.get("weight_column", "weight"))
+    pp = g.cls != "BipartiteSimRank"
+    w1 = ingest.spread(g12) * g12.rowscale if pp else g12.rowscale
+    w2 = ingest.spread(g21) * g21.rowscale if pp else g21.rowscale
+    return g12, w1, w2, pp
+
+
+@pytest.mark.parametrize("name", golden_names("BipartiteSimRank", "BipartiteSimRankPP", "BipartitleAprioriSimRank"))
 def test_biplan_reproduces_the_golden_vectors(ops, name):
-    """create -> run -> result for BipartiteSimRank against the vectors generated from the reference: S1 and S2
-    to 1e-5, the "Converged at iteration k" index exactly, iterations = 0 included; step by step the same."""
+    """create -> run -> result for EVERY bipartite vector generated from the reference — BipartiteSimRank,
+    BipartiteSimRankPP and BipartitleAprioriSimRank with options.strict_reference = 1 (Evidence_N1 on both
+    updates, SimRank.py:420-423, :488-491): S1 and S2 to 1e-5, the "Converged at iteration k" index exactly,
+    iterations = 0 and eps >= 1 included; NumPy's broadcast error for n1 != n2 where the reference raises it
+    (first group-2 update), the 1 x 1 broadcast; step by step the same.  An asymmetric prior is refused."""
+    from simrank_amd._lib import SimRankHipError
     from simrank_amd.engine import BiPlan
     g = Golden(name)
-    csr, rs1, rs2 = _csr_and_scales(g.out["G12"], g.out["G21"])
-    plan = BiPlan(ops, csr, rs1, rs2, c1=g.kwargs.get("C1", 0.8), c2=g.kwargs.get("C2", 0.8))
-    its, eps = g.kwargs.get("iterations", 100), g.kwargs.get("eps", 1e-4)
+    csr, w1, w2, pp = _biplan_inputs(g)
+    kw = g.kwargs
+    pri = dict(apriori1=g.args[0], apriori2=g.args[1], lbd1=kw.get("lbd1", 0.5), lbd2=kw.get("lbd2", 0.5)) if g.args else {}
+    make = lambda: BiPlan(ops, csr, w1, w2, c1=kw.get("C1", 0.8), c2=kw.get("C2", 0.8), evidence=pp,
+                          strict_reference=True, **pri)
+    if name.endswith("_asym"):
+        with pytest.raises(SimRankHipError, match="symmetric"):
+            make()
+        return
+    plan = make()
+    its, eps = kw.get("iterations", 100), kw.get("eps", 1e-4)
+    if g.raises:
+        with pytest.raises(SimRankHipError) as e:
+            plan.run(its, eps)
+        assert g.meta["message"] in str(e.value)
+        with pytest.raises(SimRankHipError, match="broadcast"):
+            plan.step(eps)
+        assert plan.run(0, eps) == (0, None) and plan.run(5, 1.0) == (0, 0)      # (as *_iter0 / *_eps1)
+        plan.free()
+        return
     done, conv = plan.run(its, eps)
     assert (conv if conv is not None else -1) == (g.k if g.k is not None else -1)
     s1, s2 = plan.result()

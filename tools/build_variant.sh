@@ -7,7 +7,7 @@ TAG=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_variants
 mkdir -p $OUT/obj_$TAG
-for f in api spmm dense blockdense fused half plan biplan; do
+for f in api spmm dense blockdense fused fused2 half planprep plan biplan; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -fvisibility=hidden -DSIMRANK_BUILD "$@" \
     -c $ROOT/simrank_amd/csrc/$f.hip -o $OUT/obj_$TAG/$f.o &
 done

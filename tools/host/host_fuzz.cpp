@@ -1,17 +1,21 @@
 // Sanitizer run of the HOST side of libsimrank_hip (make -C simrank_amd/csrc asan): the library's
-// api.hip / blockdense.hip / fused.hip compiled for the host only with -DSIMRANK_HOST_ONLY
+// api.hip / blockdense.hip / fused.hip / fused2.hip / planprep.hip compiled for the host only with -DSIMRANK_HOST_ONLY
 // -fsanitize=address,undefined, so that simrank_graph_create — argument validation, transposed pattern,
 // balanced tiles and launch lists, dense sets (blockdense.hip), the one-launch plan (fused.hip) — runs on
 // random graphs without a GPU, and the plans it builds are checked entry by entry against the CSR:
 //   * tiles: consecutive, never across a multiple of 32, every row once; launch order a permutation;
 //   * dense plan: covered + remainder = nnz, remainder rows ascending and a subset of the row;
 //   * fused plan: every entry of every block is EITHER a pattern bit of the block's dense set OR an id in
-//     exactly one lane group's stream (in ascending order inside its row), row ends and scales as recorded.
+//     exactly one lane group's stream (in ascending order inside its row), row ends and scales as recorded;
+//   * persistent plan (fused2.hip): the same per PIECE of a block, every row owned once, slots consecutive;
+//   * plan inputs (planprep.hip): the node order is a permutation, the renamed patterns are the pattern, the
+//     transpose is the transpose; malformed CSR arrays and priors are refused.
 // Exit code 0 = all graphs passed.  No kernel is launched.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <random>
 #include <set>
@@ -178,6 +182,194 @@ static void check_fused(const simrank_graph* g, const Csr& c) {
     }
 }
 
+// the persistent one-launch plan (fused2.hip): every entry of every block is EITHER a pattern bit of exactly one
+// piece's share of the block's dense set OR an id in exactly one lane group's stream of exactly one piece
+static void check_fused2(const simrank_graph* g, const Csr& c) {
+    const simrank_fused2_plan* pl = g->fused2;
+    if (!pl) return;
+    const int64_t nblk = (c.M + 127) / 128;
+    CHECK(pl->nnz_covered + pl->r_nnz == (int64_t)c.col.size(), "fused2 plan loses entries");
+    std::vector<std::multiset<int32_t>> got((size_t)c.M);
+    std::vector<std::vector<int>> owner((size_t)c.M);
+    const uint32_t* ab = reinterpret_cast<const uint32_t*>(pl->abits);
+    const int32_t* gm = reinterpret_cast<const int32_t*>(pl->gmeta);
+    std::map<int, int> pieces_seen;
+    int expect_pslot = 0, expect_cslot = 0;
+    for (int u = 0; u < pl->n_items; ++u) {
+        const int32_t* it = pl->items + size_t(u) * 16;
+        const int b0 = it[0], q0 = it[1], nq = it[2], gmi = it[3], np = it[4], ps = it[5], cs = it[6], k = it[7];
+        CHECK(b0 >= 0 && b0 < nblk && np >= 1 && np <= 64 && k >= 0 && k < np && nq >= 0 && q0 >= 0 && q0 + nq <= pl->n_quads,
+              "bad item record %d", u);
+        CHECK(pieces_seen[b0]++ == k, "pieces of block %d out of order", b0);
+        if (np > 1) {
+            CHECK(ps == expect_pslot && cs == expect_cslot, "partial slot of item %d: %d (want %d), ticket %d (want %d)", u, ps,
+                  expect_pslot, cs, expect_cslot);
+            ++expect_pslot;
+            if (k == np - 1) ++expect_cslot;
+            if (k > 0) CHECK(pl->items[size_t(u - 1) * 16] == b0, "pieces of a block must be neighbours in the order");
+        } else {
+            CHECK(ps == -1 && cs == -1, "slots on an unsplit block");
+        }
+        for (int qd = q0; qd < q0 + nq; ++qd)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int s = 0; s < 4; ++s) {
+                    const uint32_t w = ab[(size_t(qd) * 64 + lane) * 4 + s];
+                    for (int bit = 0; bit < 32; ++bit)
+                        if (w >> bit & 1) {
+                            const int t = bit >> 3, j = bit & 7, h = lane >> 5, m = lane & 31;
+                            const int row = b0 * 128 + 32 * t + m, kk = 16 * s + 8 * h + j;
+                            CHECK(row < c.M, "pattern bit past the last row");
+                            const int32_t id = pl->ids16 ? (int32_t)pl->dcols16[size_t(qd) * 64 + kk]
+                                                         : pl->dcols32[size_t(qd) * 64 + kk];
+                            got[(size_t)row].insert(id);
+                        }
+                }
+        for (int w = 0; w < 4; ++w) {
+            const int round0 = it[8 + w], rounds = it[12 + w];
+            CHECK(round0 >= 0 && rounds >= 0 && (rounds & 1) == 0, "rounds of a wave must be even");
+            for (int gg = 0; gg < 8; ++gg) {
+                const int32_t* m = gm + (((size_t(gmi) * 4 + w) * 8) + gg) * 8;
+                int f = 0;
+                bool empty_seen = false;
+                for (int kr = 0; kr < 4; ++kr) {
+                    const uint32_t packed = uint32_t(m[2 * kr]);
+                    const int row = int(packed & 255u) == 255 ? -1 : int(packed & 255u);
+                    const int end = (packed >> 8) == 0xFFFFFFu ? -1 : int(packed >> 8);
+                    if (row < 0) continue;
+                    CHECK(row < 128 && b0 * 128 + row < c.M, "row of a lane group out of range");
+                    owner[size_t(b0) * 128 + row].push_back(u);
+                    float sc;
+                    memcpy(&sc, &m[2 * kr + 1], 4);
+                    CHECK(sc == c.scale[size_t(b0) * 128 + row], "row scale");
+                    if (end < 0) { empty_seen = true; continue; }
+                    CHECK(!empty_seen && end > f, "rows without a remainder must come last");
+                    int32_t prev = -1;
+                    for (; f < end; ++f) {
+                        CHECK(f / 8 < rounds, "row runs past the wave's rounds");
+                        const size_t at = (size_t(round0) + f / 8) * 64 + gg * 8 + f % 8;
+                        const int32_t id = pl->ids16 ? (pl->sids16[at] == 0xFFFF ? -1 : (int32_t)pl->sids16[at]) : pl->sids32[at];
+                        CHECK(id > prev, "stream ids of a row not ascending (or a marker inside a row)");
+                        prev = id;
+                        got[size_t(b0) * 128 + row].insert(id);
+                    }
+                }
+                for (; f < 8 * rounds; ++f) {
+                    const size_t at = (size_t(round0) + f / 8) * 64 + gg * 8 + f % 8;
+                    CHECK(pl->ids16 ? pl->sids16[at] == 0xFFFF : pl->sids32[at] < 0, "id past the end of a stream");
+                }
+            }
+        }
+    }
+    CHECK(expect_pslot == pl->n_pslots && expect_cslot == pl->n_cslots, "slot counts");
+    for (int64_t b = 0; b < nblk; ++b) {
+        const int32_t np = pieces_seen[(int)b];
+        CHECK(np >= 1, "block %lld has no item", (long long)b);
+    }
+    for (int64_t a = 0; a < c.M; ++a) {
+        CHECK(owner[(size_t)a].size() == 1, "row %lld owned by %zu lane groups", (long long)a, owner[(size_t)a].size());
+        std::multiset<int32_t> want(c.col.begin() + c.rowptr[a], c.col.begin() + c.rowptr[a + 1]);
+        CHECK(got[(size_t)a] == want, "fused2 row %lld: plan entries differ from the CSR (%zu vs %zu)", (long long)a,
+              got[(size_t)a].size(), want.size());
+    }
+}
+
+// the host half of the plans (planprep.hip): well-formed input gives a permutation and the same pattern under new
+// names; malformed input — rowptr not monotone or not spanning, columns out of range or repeated, a prior that is
+// not symmetric (or not finite / too large for fp16-held matrices) — is SIMRANK_ERR_INVALID, never a wild read
+static void fuzz_plan_inputs(std::mt19937& rng, const Csr& sq, const Csr& rect) {
+    std::uniform_real_distribution<double> u(0, 1);
+    simrank_plan_options opt{};
+    opt.coef = 0.8f;
+    opt.reorder = 1;
+    simrank::PlanPrep pp;
+    const int64_t n = sq.M, nnz = (int64_t)sq.col.size();
+    CHECK(simrank::plan_prepare(n, nnz, sq.rowptr.data(), sq.col.data(), sq.scale.data(), &opt, &pp) == SIMRANK_OK,
+          "plan_prepare: %s", simrank_last_error());
+    {
+        std::vector<int> seen((size_t)n, 0);
+        for (int64_t r = 0; r < n; ++r) {
+            CHECK(pp.ord[r] >= 0 && pp.ord[r] < n && !seen[pp.ord[r]]++ && pp.inv[pp.ord[r]] == r, "node order is not a permutation");
+            CHECK(r == 0 || pp.rp[r] - pp.rp[r - 1] <= pp.rp[r + 1] - pp.rp[r], "rows not in ascending length");
+            std::multiset<int32_t> want, have;
+            for (int32_t j = sq.rowptr[pp.ord[r]]; j < sq.rowptr[pp.ord[r] + 1]; ++j) want.insert(pp.inv[sq.col[j]]);
+            for (int32_t j = pp.rp[r]; j < pp.rp[r + 1]; ++j) have.insert(pp.cl[j]);
+            CHECK(want == have && pp.rs[r] == sq.scale[pp.ord[r]], "renamed row %lld differs", (long long)r);
+        }
+    }
+    if (nnz > 2) {
+        std::vector<int32_t> rp = sq.rowptr, cl = sq.col;
+        cl[nnz / 2] = u(rng) < 0.5 ? (int32_t)n : -1;
+        CHECK(simrank::plan_prepare(n, nnz, rp.data(), cl.data(), sq.scale.data(), &opt, &pp) == SIMRANK_ERR_INVALID, "bad column accepted");
+        cl = sq.col;
+        int64_t a = 0;
+        while (a < n && rp[a + 1] - rp[a] < 2) ++a;
+        if (a < n) {
+            cl[rp[a] + 1] = cl[rp[a]];                           // a repeated column
+            CHECK(simrank::plan_prepare(n, nnz, rp.data(), cl.data(), sq.scale.data(), &opt, &pp) == SIMRANK_ERR_INVALID, "duplicate accepted");
+            cl = sq.col;
+            rp[a + 1] = rp[a] - 1 < 0 ? (int32_t)nnz + 5 : rp[a] - 1;     // not monotone / past the end
+            CHECK(simrank::plan_prepare(n, nnz, rp.data(), cl.data(), sq.scale.data(), &opt, &pp) == SIMRANK_ERR_INVALID, "bad rowptr accepted");
+            rp = sq.rowptr;
+        }
+        rp[n] = (int32_t)nnz - 1;
+        CHECK(simrank::plan_prepare(n, nnz, rp.data(), cl.data(), sq.scale.data(), &opt, &pp) == SIMRANK_ERR_INVALID, "short rowptr accepted");
+    }
+    if (n <= 400) {
+        std::vector<float> prior((size_t)n * n);
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t j = i; j < n; ++j) prior[i * n + j] = prior[j * n + i] = float(u(rng));
+        opt.apriori = prior.data();
+        opt.ld_apriori = n;
+        opt.lbd = 0.3f;
+        CHECK(simrank::plan_prepare(n, nnz, sq.rowptr.data(), sq.col.data(), sq.scale.data(), &opt, &pp) == SIMRANK_OK, "symmetric prior refused");
+        opt.storage_fp16 = 1;
+        CHECK(simrank::plan_prepare(n, nnz, sq.rowptr.data(), sq.col.data(), sq.scale.data(), &opt, &pp) == SIMRANK_OK, "small prior refused for fp16");
+        prior[0] = 4.5f;
+        CHECK(simrank::plan_prepare(n, nnz, sq.rowptr.data(), sq.col.data(), sq.scale.data(), &opt, &pp) == SIMRANK_ERR_INVALID, "prior of 4.5 accepted for fp16");
+        prior[0] = std::numeric_limits<float>::infinity();
+        CHECK(simrank::plan_prepare(n, nnz, sq.rowptr.data(), sq.col.data(), sq.scale.data(), &opt, &pp) == SIMRANK_ERR_INVALID, "infinite prior accepted for fp16");
+        prior[0] = 0.5f;
+        opt.storage_fp16 = 0;
+        if (n > 1) {
+            prior[1] += 0.25f;
+            CHECK(simrank::plan_prepare(n, nnz, sq.rowptr.data(), sq.col.data(), sq.scale.data(), &opt, &pp) == SIMRANK_ERR_INVALID, "asymmetric prior accepted");
+        }
+        opt.ld_apriori = n - 1;
+        CHECK(simrank::plan_prepare(n, nnz, sq.rowptr.data(), sq.col.data(), sq.scale.data(), &opt, &pp) == SIMRANK_ERR_INVALID, "short ld accepted");
+    }
+    // bipartite: the transpose and both renamed patterns
+    simrank_biplan_options bo{};
+    bo.c1 = bo.c2 = 0.8f;
+    bo.reorder = 1;
+    simrank::BiPlanPrep bp;
+    const int64_t n1 = rect.M, n2 = rect.K, z = (int64_t)rect.col.size();
+    std::vector<float> s2((size_t)n2, 0.5f);
+    CHECK(simrank::biplan_prepare(n1, n2, z, rect.rowptr.data(), rect.col.data(), rect.scale.data(), s2.data(), &bo, &bp) == SIMRANK_OK,
+          "biplan_prepare: %s", simrank_last_error());
+    CHECK(bp.rowptr21[n2] == z, "transpose loses entries");
+    for (int64_t i = 0; i < n2; ++i)
+        for (int32_t j = bp.rowptr21[i]; j < bp.rowptr21[i + 1]; ++j) {
+            const int32_t a = bp.col21[j];
+            CHECK(a >= 0 && a < n1 && std::binary_search(rect.col.begin() + rect.rowptr[a], rect.col.begin() + rect.rowptr[a + 1], (int32_t)i),
+                  "transpose entry (%lld, %d) not in the pattern", (long long)i, a);
+        }
+    for (int w = 0; w < 2; ++w) {
+        const int64_t nw = w ? n2 : n1, kw = w ? n1 : n2;
+        CHECK((int64_t)bp.rp[w].size() == nw + 1 && bp.rp[w][nw] == z, "renamed pattern of group %d", w + 1);
+        for (int64_t j = 0; j < z; ++j) CHECK(bp.cl[w][j] >= 0 && bp.cl[w][j] < kw, "renamed column out of range");
+    }
+    if (z > 2) {
+        std::vector<int32_t> cl = rect.col;
+        cl[z / 3] = (int32_t)n2 + 3;
+        CHECK(simrank::biplan_prepare(n1, n2, z, rect.rowptr.data(), cl.data(), rect.scale.data(), s2.data(), &bo, &bp) == SIMRANK_ERR_INVALID,
+              "bipartite: bad column accepted");
+        std::vector<int32_t> rp = rect.rowptr;
+        rp[n1 / 2 + 1] = (int32_t)z + 7;
+        CHECK(simrank::biplan_prepare(n1, n2, z, rp.data(), rect.col.data(), rect.scale.data(), s2.data(), &bo, &bp) == SIMRANK_ERR_INVALID,
+              "bipartite: bad rowptr accepted");
+    }
+}
+
 int main(int argc, char** argv) {
     const int n_graphs = argc > 1 ? atoi(argv[1]) : 60;
     std::mt19937 rng(12345);
@@ -193,6 +385,8 @@ int main(int argc, char** argv) {
         simrank_set_tuning("fuse_unit", it % 3 == 0 ? 4 : 1 << 20);
         simrank_set_tuning("fuse_group", 1 + it % 4);
         simrank_set_tuning("fuse_order", it % 5 == 1 ? 2 : 0);
+        simrank_set_tuning("fuse", it % 2 ? 2 : 1);
+        simrank_set_tuning("fuse_cap", it % 3 == 0 ? 1000 : (it % 3 == 1 ? 3000 : 1 << 30));
         // (every 17th graph has no entries at all: plans of nothing but empty rows)
         Csr c = random_graph(rng, M, K, it % 17 == 16 ? 0.0 : 1 + u(rng) * 12, it % 17 == 16 ? 0 : int(u(rng) * 200),
                              u(rng), it % 2 == 0);
@@ -207,6 +401,11 @@ int main(int argc, char** argv) {
         check_tiles(g, c);
         check_dense(g, c);
         check_fused(g, c);
+        check_fused2(g, c);
+        if (c.M == c.K && it % 4 == 1) {
+            Csr rect = random_graph(rng, 1 + int64_t(u(rng) * 300), 1 + int64_t(u(rng) * 300), 1 + u(rng) * 6, 20, u(rng), false);
+            fuzz_plan_inputs(rng, c, rect);
+        }
         int64_t steps = 0, cov = 0, rem = 0;
         simrank_graph_fused_stats(g, &steps, &cov, &rem);
         CHECK(cov + rem == (int64_t)c.col.size(), "fused stats");

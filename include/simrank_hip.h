@@ -86,6 +86,13 @@ SIMRANK_API int simrank_memcpy_d2d(void* dst_device, const void* src_device, siz
  * side (replaces the DataFrame hand-back of SimRank.py:141, :303). */
 SIMRANK_API int simrank_download_f64(double* dst_host, int64_t ld_dst, const float* src_device,
                          int64_t ld_src, int64_t n_rows, int64_t n_cols, void* stream);
+/* The convergence count of an update without stopping the stream (`_converged`, SimRank.py:54-77, as a caller
+ * that drives the legs itself reads it): _fetch queues the copy of n counters (the simrank_epilogue.n_changed
+ * array) into pinned slot `slot` (0..3) of the current device and records an event behind it; _wait returns their
+ * sum once that copy has landed, while whatever was queued behind the fetch — update k + 1 of the loop at
+ * :129-140, issued before the count of update k is known — keeps running.  One stream per device uses them. */
+SIMRANK_API int simrank_counters_fetch(const unsigned long long* counters, int32_t n, int32_t slot, void* stream);
+SIMRANK_API int simrank_counters_wait(int32_t slot, unsigned long long* sum);
 SIMRANK_API int simrank_stream_create(void** stream);
 SIMRANK_API int simrank_stream_destroy(void* stream);
 SIMRANK_API int simrank_stream_synchronize(void* stream);

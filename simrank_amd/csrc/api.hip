@@ -463,6 +463,56 @@ int simrank_read_counters(const unsigned long long* counters, int32_t n, unsigne
     return SIMRANK_OK;
 }
 
+// The count of an update WITHOUT stopping the stream (the loop of SimRank.py:129-140 as plan.hip runs it, for
+// callers that drive the legs themselves): _fetch queues the copy of the counters into pinned slot `slot` of the
+// current device and records an event behind it, _wait returns their sum once that copy has landed — whatever
+// was queued behind the fetch (update k + 1) keeps running.
+namespace {
+struct CountSlot { unsigned long long* host = nullptr; int32_t cap = 0, n = 0; hipEvent_t ev = nullptr; };
+std::mutex g_count_mutex;
+CountSlot g_count_slots[16][4];
+}  // namespace
+
+int simrank_counters_fetch(const unsigned long long* counters, int32_t n, int32_t slot, void* stream) {
+    SR_REQUIRE(counters && n > 0 && n <= 65536 && slot >= 0 && slot < 4, "bad counter fetch");
+    int dev = 0;
+    SR_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_count_mutex);
+    CountSlot& sl = g_count_slots[dev & 15][slot];
+    if (!sl.ev) SR_HIP(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    if (n > sl.cap) {
+        if (sl.host) (void)hipHostFree(sl.host);
+        sl.host = nullptr;
+        sl.cap = 0;
+        SR_HIP(hipHostMalloc((void**)&sl.host, size_t(n) * sizeof(unsigned long long), hipHostMallocPortable));
+        sl.cap = n;
+    }
+    sl.n = n;
+    SR_HIP(hipMemcpyAsync(sl.host, counters, size_t(n) * sizeof(unsigned long long), hipMemcpyDeviceToHost, as_stream(stream)));
+    SR_HIP(hipEventRecord(sl.ev, as_stream(stream)));
+    return SIMRANK_OK;
+}
+
+int simrank_counters_wait(int32_t slot, unsigned long long* sum) {
+    SR_REQUIRE(sum && slot >= 0 && slot < 4, "bad counter wait");
+    int dev = 0;
+    SR_HIP(hipGetDevice(&dev));
+    hipEvent_t ev;
+    const unsigned long long* host;
+    int32_t n;
+    {
+        std::lock_guard<std::mutex> lock(g_count_mutex);
+        const CountSlot& sl = g_count_slots[dev & 15][slot];
+        SR_REQUIRE(sl.ev && sl.host && sl.n > 0, "counter slot %d was never fetched into", slot);
+        ev = sl.ev; host = sl.host; n = sl.n;
+    }
+    SR_HIP(hipEventSynchronize(ev));
+    unsigned long long total = 0;
+    for (int32_t i = 0; i < n; ++i) total += host[i];
+    *sum = total;
+    return SIMRANK_OK;
+}
+
 int simrank_stream_create(void** stream) {
     SR_REQUIRE(stream, "stream is NULL");
     hipStream_t s;

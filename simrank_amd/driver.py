@@ -884,10 +884,12 @@ class Solver:
         self.events.append((tag, r, a, b))
         return out
 
-    def _update(self, side_idx, in_idx, out_idx, eps):
+    def _update(self, side_idx, in_idx, out_idx, eps, defer=None):
         """One similarity update on every local virtual rank.  Returns 0 when no element moved by more than
         eps and a positive number otherwise — the exact global count of such elements only with
-        ``exact_count`` set (the default short-circuit test stops comparing once one has been found)."""
+        ``exact_count`` set (the default short-circuit test stops comparing once one has been found).
+        ``defer`` (a pinned counter slot, single-rank fused updates only): the count is not read; its copy is
+        queued behind the update and ``ops.wait_changed(defer)`` returns it later (``run``)."""
         sides = self.sides[side_idx]
         hook = self.world.begin_stage if getattr(self.world, "stream_ordered", False) else None
         for r in self.world.local_ranks:
@@ -908,7 +910,10 @@ class Solver:
             self._timed(r, lambda: sides[r].leg2(self.cur[out_idx][r], self.nxt[out_idx][r], eps, mhook),
                         f"leg2.{side_idx}")
             if fused and not device_sum:   # virtual ranks may share one device counter: read it per launch
-                counts.append(self.ops[r].read_changed() if sides[r].Lm else 0)
+                if defer is not None:
+                    self.ops[r].fetch_changed(defer)
+                else:
+                    counts.append(self.ops[r].read_changed() if sides[r].Lm else 0)
         if sides[local[0]].shard_sym:
             # (the convergence counters were read above / are reduced below: the mirrored tiles were
             # counted by the rank that computed them)
@@ -927,7 +932,34 @@ class Solver:
         if device_sum:
             (r,) = local
             return self.world.sum_changed(self.ops[r], bool(sides[r].Lm))
+        if defer is not None:
+            return None
         return self.world.sum_int(counts)
+
+    def _can_defer(self):
+        """The count of an update may be read one update late: one rank, fused (symmetric) updates whose counter
+        this process reads itself, no per-leg timing, an engine with pinned counter slots."""
+        if self.world.size != 1 or len(self.world.local_ranks) != 1 or self.events is not None:
+            return False
+        if getattr(self.world, "stream_ordered", False):
+            return False
+        r = self.world.local_ranks[0]
+        return (hasattr(self.ops[r], "fetch_changed") and all(s[r].symmetric and not s[r].shard_sym and s[r].Lm for s in self.sides))
+
+    def _step_deferred(self, eps, parity):
+        """One loop body queued; -> the pinned slots its counts will land in."""
+        if self.bipartite:
+            self._update(0, 1, 0, eps, defer=2 * parity)
+            self._update(1, 0, 1, eps, defer=2 * parity + 1)
+            return (2 * parity, 2 * parity + 1)
+        self._update(0, 0, 0, eps, defer=2 * parity)
+        return (2 * parity,)
+
+    def _undo_step(self):
+        """Drop the loop body queued last (its results sit in the buffers of the iterates before last)."""
+        for j in range(len(self.sides)):
+            for r in self.world.local_ranks:
+                self.cur[j][r], self.nxt[j][r] = self.nxt[j][r], self.cur[j][r]
 
     def step(self, eps=0.0):
         """One loop body of the reference (both updates for the bipartite classes); the return value as
@@ -944,6 +976,25 @@ class Solver:
         self.reset()
         # test at k = 0 compares S_0 = I with S_-1 = 0: the diagonal differs by 1
         changed = sum(self.n) if 1.0 > eps else 0
+        if iterations > 1 and changed and self._can_defer():
+            # Loop body k + 1 is queued BEFORE the count of body k is read (csrc/plan.hip does the same behind the C
+            # ABI): the device never idles while the host learns whether it may go on; when the count says
+            # "converged" the speculative body is dropped — it wrote the buffers of the iterates before last.
+            o = self.ops[self.world.local_ranks[0]]
+            if on_iteration:
+                on_iteration(0)
+            slots = self._step_deferred(eps, 1)                   # body 1
+            for k in range(1, iterations):
+                nxt_slots = self._step_deferred(eps, (k + 1) & 1)   # body k + 1, speculative
+                if sum(o.wait_changed(s) for s in slots) == 0:
+                    self._undo_step()
+                    if on_converged:
+                        on_converged(k)
+                    return k
+                if on_iteration:
+                    on_iteration(k)
+                slots = nxt_slots
+            return None
         for k in range(iterations):
             if changed == 0:
                 if on_converged:

@@ -655,6 +655,17 @@ class HipOps:
                                              self.stream), "simrank_read_counters")
         return int(total.value)
 
+    def fetch_changed(self, slot: int):
+        """Queue the read-back of the convergence counter into pinned slot ``slot`` (0..3); the stream goes on."""
+        check(self.lib.simrank_counters_fetch(self._counter, CHANGED_SLOTS, int(slot), self.stream),
+              "simrank_counters_fetch")
+
+    def wait_changed(self, slot: int) -> int:
+        """The counter value a ``fetch_changed(slot)`` read: waits for that copy only."""
+        total = C.c_ulonglong(0)
+        check(self.lib.simrank_counters_wait(int(slot), C.byref(total)), "simrank_counters_wait")
+        return int(total.value)
+
     # ---- timing (HIP events on the engine's own stream) ----
     def event(self) -> int:
         e = C.c_void_p()

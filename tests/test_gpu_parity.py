@@ -119,6 +119,56 @@ def test_midsize_against_oracle(kind, cls):
     assert_close(got.values, want["S"])
 
 
+def test_two_different_graphs_back_to_back_on_pooled_blocks():
+    """Blocks of >= 64 MiB (N >= 4096) come back from the library's pool UN-ZEROED: two different graphs of equal N
+    — a power-law SimRank++ (evidence) and an Erdos-Renyi AprioriSimRank (symmetric prior) — fitted one after the
+    other in one process, through ``fit`` and through the C-level plan, each against the oracle's loop
+    (SimRank.py:351-362, :443-454).  A stale byte in a padding row or a reused evidence / prior buffer shows here."""
+    from simrank_amd.engine import HipOps, Plan
+    n, its = 4096, 3
+    rng = np.random.default_rng(5)
+    cases = []
+    for kind in ("pl", "er"):
+        df = synth.powerlaw_directed(n, 16, seed=41) if kind == "pl" else synth.er_directed(n, 0.0025, seed=42)
+        labels, G = O.directed_graph(df)
+        W = O.weight(G)
+        pat = (G > 0).astype(np.float64)
+        E = 1 - 0.5 ** (pat @ pat.T)                       # (= O.evidence: the counts are exact in float64; BLAS instead of an int64 matmul)
+        prior = None
+        if kind == "er":
+            prior = rng.random((n, n))
+            prior = (prior + prior.T) / 2
+        want, _ = O.iterate_directed(W, C=0.8, iterations=its, eps=0.0, E=E, apriori=prior, lbd=0.3 if prior is not None else None)
+        cases.append((kind, df, labels, prior, want))
+    ops = HipOps(0)
+    ops.trim_pool()
+
+    def fit(kind, df, labels, prior, want):
+        if prior is None:
+            got = SRA.SimRankPP().fit(df, iterations=its, eps=0.0, verbose=False)
+        else:
+            got = SRA.AprioriSimRank().fit(df, prior, lbd=0.3, iterations=its, eps=0.0, verbose=False)
+        assert list(got.index) == list(labels)
+        assert_close(got.values, want)
+
+    def plan(kind, df, labels, prior, want):
+        _, csr = ingest.directed(df, False, "from", "to", "weight")
+        pl = Plan(ops, csr, ingest.spread(csr) * csr.rowscale, coef=0.8, evidence=True, apriori=prior, lbd=0.3 if prior is not None else 0.0)
+        pl.run(its, 0.0)
+        got = pl.result()
+        pl.free()
+        # (plan results are in the CSR's node order = ingest's = the oracle's label order)
+        assert_close(got, want)
+
+    fit(*cases[0])
+    assert ops.pool_stats()[1] > 0                         # the first fit's matrices are at rest in the pool
+    fit(*cases[1])
+    plan(*cases[0])
+    plan(*cases[1])
+    fit(*cases[0])
+    plan(*cases[1])
+
+
 def test_midsize_weighted_and_prior_against_oracle():
     df = synth.er_directed(1500, 0.006, seed=13)
     rng = np.random.default_rng(0)

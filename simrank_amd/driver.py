@@ -706,23 +706,42 @@ def resolve_shard_form(make_ops, world, specs, mode, reorder=True):
         world.symmetric_shards = world.size >= HALF_FORM_FROM
         world.form_measured = None
         return
-    times = {}
-    for half in (True, False):
-        world.symmetric_shards = ("force" if single else True) if half else False
-        solver = Solver(make_ops, world, specs, mode, reorder)
-        solver.reset()
-        solver.step(0.0)
-        world.barrier()
-        t0 = time.perf_counter()
-        for _ in range(2):
-            solver.step(0.0)
-        world.barrier()
-        times[half] = world.max_float((time.perf_counter() - t0) / 2)
-        solver.release()
-        del solver
-    world.symmetric_shards = (("force" if single else True) if times[True] < times[False] else False)
-    world.form_measured = {"half_ms": times[True] * 1e3, "full_ms": times[False] * 1e3,
-                           "chosen": "half" if times[True] < times[False] else "full"}
+    times, failed = {}, None
+    try:
+        for half in (True, False):
+            world.symmetric_shards = ("force" if single else True) if half else False
+            solver = None
+            try:
+                solver = Solver(make_ops, world, specs, mode, reorder)
+                solver.reset()
+                solver.step(0.0)
+            except Exception as e:                       # (e.g. out of memory on one rank: every rank must learn of it)
+                failed = e
+            # a rank that failed still joins the collectives its peers are in, with a time no measurement reaches
+            bad = world.max_float(1.0 if failed is not None else 0.0)
+            if bad:
+                if solver is not None:
+                    solver.release()
+                break
+            world.barrier()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                solver.step(0.0)
+            world.barrier()
+            times[half] = world.max_float((time.perf_counter() - t0) / 2)
+            solver.release()
+            del solver
+    finally:
+        if len(times) == 2:
+            world.symmetric_shards = (("force" if single else True) if times[True] < times[False] else False)
+            world.form_measured = {"half_ms": times[True] * 1e3, "full_ms": times[False] * 1e3,
+                                   "chosen": "half" if times[True] < times[False] else "full"}
+        else:
+            # the measurement did not complete on some rank: the rule of thumb, the same on every rank
+            world.symmetric_shards = world.size >= HALF_FORM_FROM
+            world.form_measured = None
+    if failed is not None:
+        raise failed
 
 
 # --------------------------------------------------------------------------------------

@@ -330,7 +330,7 @@ def main():
                     S_in = solver.cur[0][0]
                     scratch = ops.matrix(side.K, side.M, blocked=True)
                     t_probe = {}
-                    for flags in (1, 5):
+                    for flags in (1, 4, 5):
                         gp = ops.graph(side.spec.csr, side.spec.rowscale, knobs={"probe_flags": flags})
                         for _ in range(2):
                             ops.spmm(gp, S_in, scratch, n_cols=side.Lk, transpose_out=True)
@@ -347,9 +347,12 @@ def main():
                     out["roofline_mfma"]["phase_alone"] = {
                         "ms": ph, "achieved": flop / (ph * 1e-3) / 1e12, "unit": "TFLOP/s",
                         "frac": flop / (ph * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
-                        "ms_launch_without_gather_phase": t_probe[1], "ms_launch_with_neither_phase": t_probe[5],
-                        "note": "operand segments come from the real (L2-missing) ids; the phase adds "
-                                "~1.3 ms to the whole launch (DESIGN.md §4.10)"}
+                        "ms_launch_without_gather_phase": t_probe[1], "ms_launch_without_mfma_phase": t_probe[4],
+                        "ms_launch_with_neither_phase": t_probe[5], "ms_launch": l1,
+                        "ms_mfma_phase_adds_to_the_launch": l1 - t_probe[4],
+                        "note": "diagnostic launches (probe_flags 1 / 4 / 5: wrong results, timing only) of the "
+                                "same plan on the same operand; operand segments come from the real "
+                                "(L2-missing) ids (DESIGN.md §4.10)"}
                 except Exception as e:
                     out["roofline_mfma"]["phase_alone"] = {"error": f"{type(e).__name__}: {e}"}
                 finally:
@@ -452,6 +455,8 @@ def main():
                 key = "leg1" if "leg 1" in r.get("kernel", "") else "leg2"
                 if key in rec:
                     r["traffic"] = rec[key]
+                    r["traffic_source"] = ("profiles/pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc "
+                                           f"passes at commit {rec.get('commit', '?')}, NOT measured in this run")
         except Exception:
             pass
 
@@ -523,6 +528,20 @@ def main():
                 "leg1_algorithmic_GBps": leg_bytes(n2, n2, n2, z2, False) / (lt["leg1.0"][0] * 1e-3) / 1e9,
                 "leg2_algorithmic_GBps": leg_bytes(n2, n2, n2, z2, True, triangle=True)
                                          / (lt["leg2.0"][0] * 1e-3) / 1e9}
+            try:
+                # the loop fit() runs (Solver.run: update k + 1 queued before the count of update k is read)
+                s2.events = None
+                s2.run(5, 0.0)
+                ops.synchronize()
+                t0 = time.perf_counter()
+                s2.run(100, 0.0)
+                ops.synchronize()
+                dtf = (time.perf_counter() - t0) / 100
+                out["secondary"]["fit_loop"] = {"value": 1.0 / dtf, "unit": "iterations/s", "ms_per_step": dtf * 1e3,
+                                                "note": "Solver.run, 100 updates, eps = 0: the loop of fit(), count of "
+                                                        "every update read one update late"}
+            except Exception as e:
+                out["secondary"]["fit_loop"] = {"error": f"{type(e).__name__}: {e}"}
             try:
                 # the same loop behind the C ABI (simrank_plan_run: update k + 1 queued before the count of
                 # update k is read, no Python between the launches)
@@ -714,6 +733,37 @@ def main():
                     del res, est
                 walls[name] = best
 
+            df4 = synth.WORKLOADS["pl32768d32"][0]()
+            timed_fit("cfg4_SimRank_pl32768d32_full_handback", SRA.SimRank, df4)
+            try:
+                # the same fit through the C-level plan: create (graph + plans + matrices), run to eps, f64 hand-back
+                from simrank_amd.engine import Plan
+                _, csr4 = ingest.directed(df4, False, "from", "to", "weight")
+                best = None
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    plan = Plan(ops, csr4, coef=0.8)
+                    t1 = time.perf_counter()
+                    done, conv = plan.run(100, 1e-4)
+                    t2 = time.perf_counter()
+                    res4 = plan.result()
+                    t3 = time.perf_counter()
+                    plan.free()
+                    best = dict(fit_wall_s=t3 - t0, create_s=t1 - t0, run_s=t2 - t1, result_f64_s=t3 - t2, converged_at=conv)
+                    del res4
+                walls["cfg4_SimRank_pl32768d32_full_handback_c_plan"] = best
+                csr5p = ingest.directed(synth.WORKLOADS["pl65536"][0](), False, "from", "to", "weight")[1]
+                tc = []
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    plan = Plan(ops, csr5p, ingest.spread(csr5p) * csr5p.rowscale, coef=0.8, evidence=True)
+                    tc.append(time.perf_counter() - t0)
+                    plan.free()
+                walls["cfg5_simrank_plan_create_s"] = {"first": tc[0], "second": tc[1],
+                                                       "note": "N = 65536 SimRank++: graph + plans + evidence counts + three 17 GiB "
+                                                               "matrices; the second call takes them from the library's block pool"}
+            except Exception as e:
+                walls["cfg4_SimRank_pl32768d32_full_handback_c_plan"] = {"error": f"{type(e).__name__}: {e}"}
             df3 = synth.WORKLOADS["ml1m"][0]()
             timed_fit("cfg3_BipartiteSimRankPP_ml1m_full_handback", SRA.BipartiteSimRankPP, df3, strict_reference=False)
             df5 = synth.WORKLOADS["pl65536"][0]()

@@ -783,6 +783,8 @@ int simrank_set_tuning(const char* key, int64_t value) {
     } else if (!strcmp(key, "fuse_max_rows")) {
         SR_REQUIRE(value >= 0, "fuse_max_rows must be >= 0");
         t.fuse_max_rows = value;
+    } else if (!strcmp(key, "fuse_shards")) {
+        t.fuse_shards = value ? 1 : 0;
     } else if (!strcmp(key, "fuse_cap")) {
         SR_REQUIRE(value >= 1000 && value <= (int64_t(1) << 40), "fuse_cap must be >= 1000");
         t.fuse_cap = value;
@@ -823,6 +825,7 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     else if (!strcmp(key, "fuse_unit")) *value = t.fuse_unit;
     else if (!strcmp(key, "fuse_group")) *value = t.fuse_group;
     else if (!strcmp(key, "fuse_cap")) *value = t.fuse_cap;
+    else if (!strcmp(key, "fuse_shards")) *value = t.fuse_shards;
     else if (!strcmp(key, "fuse_wgs")) *value = t.fuse_wgs;
     else if (!strcmp(key, "fuse_max_rows")) *value = t.fuse_max_rows;
     else if (!strcmp(key, "fuse_order")) *value = t.fuse_order;

@@ -75,6 +75,7 @@ struct Tuning {
     int64_t fuse_cap = 40000;  // fuse = 2: a block whose estimated duration (cycles of one workgroup) exceeds this is cut into
                              // pieces whose raw sums meet in memory
     int64_t fuse_wgs = 4;    // fuse = 2: resident workgroups per CU
+    int64_t fuse_shards = 1; // ... also for the row-major column block of a sharded rank (result in the all-to-all's chunks)
     int64_t fuse_group = 3;  // ... and up to this many consecutive blocks without a set share a workgroup (1..4)
     int64_t dense_sym = -1;  // dense part in the upper-triangle form of leg 2: 1 yes, 0 no, -1 = when the
                              // dense sets hold at least half of the pattern's entries
@@ -233,6 +234,10 @@ void free_fused_plan(simrank_fused_plan* p);
 int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col, const float* rowscale);
 int launch_fused_trans(const simrank_graph* g, const float* X, int64_t x_rows_pad, int64_t L, float* Y,
                        int64_t y_rows_pad, hipStream_t st);
+bool fused_rowmajor_fits(const simrank_graph* g, const float* X, int64_t ldx, int64_t L, const float* Y, int64_t t_block,
+                         int64_t t_pad);
+int launch_fused_trans_rowmajor(const simrank_graph* g, const float* X, int64_t ldx, int64_t L, float* Y, int64_t t_block,
+                                int64_t t_pad, hipStream_t st);
 void free_fused2_plan(simrank_fused2_plan* p);
 int build_fused2_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col, const float* rowscale);
 int launch_fused2_trans(const simrank_graph* g, const float* X, int64_t x_rows_pad, int64_t L, float* Y,

@@ -63,6 +63,13 @@ struct FusedArgs {
     float* Y;
     int64_t x_rows_pad, y_rows_pad;
     int64_t L, M;
+    // (round 4: the operand may also be ROW-MAJOR — what a rank of a sharded update holds — and the transposed
+    // result may go out in the chunks an all-to-all between column shards needs, simrank_spmm's t_block layout)
+    int64_t x_panel_stride;   // floats between the slices of consecutive panels (blocked: x_rows_pad * 32, row-major: 32)
+    uint32_t x_pitch;         // bytes between operand rows inside a slice (blocked: 128, row-major: 4 ld)
+    int32_t x_bytes;          // bytes of panel 0's slice the buffer descriptor may read (panel p: minus 128 p when row-major)
+    int32_t y_chunked;        // 1: Y[h n_cols (t_block + t_pad) + c (rows_in_block(h) + t_pad) + (a - h t_block)]
+    int64_t t_block, t_pad;
     int32_t n_panels, n_units, nt;
     int32_t x_sentinel;
     int32_t idx_mask;         // DIAGNOSTIC (tuning "probe_mask"): operand row ids are ANDed with it (wrong results)
@@ -142,9 +149,10 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
     const int g = lane >> 3, q = lane & 7, gbase = lane & ~7;
     const uint32_t qoff = uint32_t(q) * 16u;
 
-    const float* xbase = p.X + (int64_t(panel) * p.x_rows_pad) * 32;
-    const __amdgpu_buffer_rsrc_t srd =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xbase), 0, int(p.x_rows_pad * 128), 0x00020000);
+    const float* xbase = p.X + int64_t(panel) * p.x_panel_stride;
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(xbase), 0, p.x_bytes - (p.x_pitch == 128u ? 0 : panel * 128), 0x00020000);
+    const uint32_t pitch = p.x_pitch;
     const int sent = p.x_sentinel;
 
     const int quad0 = un[1];                                // this unit's quads of the block's dense set
@@ -227,8 +235,8 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
             uint4 aw_b = p.abits[size_t(quad0 + min(q_lo + 1, q_hi - 1)) * 64 + lane];
             struct Terms { uint32_t lo[4], mid[4], hi[4]; };
             auto issue = [&](int ids, int s4, float4& x0, float4& x1) {   // two wave instructions, 8 operand rows each
-                x0 = ld_seg(srd, __shfl(ids, s4 * 16 + g), qoff);
-                x1 = ld_seg(srd, __shfl(ids, s4 * 16 + 8 + g), qoff);
+                x0 = ld_seg_p(srd, __shfl(ids, s4 * 16 + g), pitch, qoff);
+                x1 = ld_seg_p(srd, __shfl(ids, s4 * 16 + 8 + g), pitch, qoff);
             };
             // B fragment through the wave's LDS buffer: [k][n] -> lane (n, h) holds k = 8h .. 8h + 7
             auto stage = [&](const float4& x0, const float4& x1, float (&x)[8]) {
@@ -426,10 +434,20 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
             const int rows_out = max(0, min(32, nrows - 32 * wave));
             const int cols_here = int(min(int64_t(32), p.L - c0));
             if (rows_out > 0 && !(p.probe & 2)) {
-                // panel-blocked Tt: the wave's 32 x 32 tile is 4 KiB contiguous, element (c, r) at c * 32 + r
+                // panel-blocked Tt: the wave's 32 x 32 tile is 4 KiB contiguous, element (c, r) at c * 32 + r;
+                // chunked Tt (a sharded rank): 32 segments of 128 bytes, one per output column, in the chunk of the
+                // row block the rows belong to (a 128-row block never straddles two chunks: t_block % 128 == 0)
+                int cstride = 32;
                 float* base = p.Y + ((int64_t(row0 >> 5) + wave) * p.y_rows_pad + c0) * 32;
+                if (p.y_chunked) {
+                    const int64_t h = row0 / p.t_block;
+                    const int64_t rows_h = min(p.t_block, p.M - h * p.t_block);
+                    cstride = int(rows_h + p.t_pad);
+                    base = p.Y + h * p.L * (p.t_block + p.t_pad) + c0 * cstride + (row0 - h * p.t_block) + 32 * wave;
+                }
                 const float* tw = tile + 32 * wave;
-                const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(base, 0, 4096, 0x00020000);
+                const __amdgpu_buffer_rsrc_t ysrd =
+                    __builtin_amdgcn_make_buffer_rsrc(base, 0, (31 * cstride + 32) * 4, 0x00020000);
                 if ((rows_out & 3) == 0) {
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
@@ -442,7 +460,7 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
                             v4u o;
                             o.x = __float_as_uint(v.x); o.y = __float_as_uint(v.y);
                             o.z = __float_as_uint(v.z); o.w = __float_as_uint(v.w);
-                            const int off = (c * 32 + r4) * 4;
+                            const int off = (c * cstride + r4) * 4;
                             // cache policy of the tile store (aux: 1 = sc0, 2 = nt, 16 = sc1): sc1 writes through
                             // and drops the line, so the output does not take the L2 from the panel's slice
                             switch (p.nt) {
@@ -456,7 +474,7 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
                 } else {
                     for (int x = lane; x < 32 * 32; x += 64) {
                         const int c = x >> 5, r = x & 31;
-                        if (c < cols_here && r < rows_out) base[c * 32 + r] = tw[c * kTS + r];
+                        if (c < cols_here && r < rows_out) base[c * cstride + r] = tw[c * kTS + r];
                     }
                 }
             }
@@ -472,7 +490,7 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
         };
         auto issue8 = [&](int iv, float4 (&v)[8]) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = ld_seg(srd, __shfl(iv, gbase + j), qoff);
+            for (int j = 0; j < 8; ++j) v[j] = ld_seg_p(srd, __shfl(iv, gbase + j), pitch, qoff);
         };
         auto consume = [&](const float4 (&v)[8], int r) {
 #pragma unroll
@@ -805,22 +823,12 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
     return SIMRANK_OK;
 }
 
-// Tt (panel-blocked, y_rows_pad rows per panel) = (diag(rowscale) . A . X)^T, X panel-blocked
-int launch_fused_trans(const simrank_graph* g, const float* X, int64_t x_rows_pad, int64_t L, float* Y,
-                       int64_t y_rows_pad, hipStream_t st) {
+static int launch_fused(const simrank_graph* g, FusedArgs& a, hipStream_t st) {
     simrank_fused_plan* pl = g->fused;
-    SR_REQUIRE(pl, "graph has no fused plan");
-    SR_REQUIRE(aligned16(X) && aligned16(Y), "fused leg needs 16-byte aligned operands");
-    SR_REQUIRE(x_rows_pad >= g->n_cols && (x_rows_pad + 1) * 128 < (int64_t(1) << 31) && x_rows_pad < (int64_t(1) << 24) - 1,
-               "fused leg: operand of %lld rows per panel", (long long)x_rows_pad);
-    FusedArgs a{};
-    a.X = X; a.Y = Y;
-    a.x_rows_pad = x_rows_pad; a.y_rows_pad = y_rows_pad;
-    a.L = L; a.M = g->n_rows;
-    a.n_panels = int32_t((L + 31) / 32);
+    a.M = g->n_rows;
+    a.n_panels = int32_t((a.L + 31) / 32);
     a.n_units = pl->n_units;
     a.nt = (int32_t)(g->tun.stream_nt ? g->tun.fuse_store : 0);
-    a.x_sentinel = (int32_t)x_rows_pad;
     a.probe = (int32_t)g->tun.probe_flags;
     a.meta_nt = (int32_t)g->tun.fuse_meta_nt;
     a.idx_mask = (int32_t)g->tun.probe_mask;
@@ -853,6 +861,7 @@ int launch_fused_trans(const simrank_graph* g, const float* X, int64_t x_rows_pa
     const unsigned lds_pad = 0;
 #endif
 #ifdef SIMRANK_HOST_ONLY
+    (void)lds_pad;
     SR_REQUIRE(false, "host-only build: no kernels");
 #else
     if (pl->ids16)
@@ -862,6 +871,52 @@ int launch_fused_trans(const simrank_graph* g, const float* X, int64_t x_rows_pa
 #endif
     SR_HIP(hipGetLastError());
     return SIMRANK_OK;
+}
+
+// Tt (panel-blocked, y_rows_pad rows per panel) = (diag(rowscale) . A . X)^T, X panel-blocked
+int launch_fused_trans(const simrank_graph* g, const float* X, int64_t x_rows_pad, int64_t L, float* Y,
+                       int64_t y_rows_pad, hipStream_t st) {
+    SR_REQUIRE(g->fused, "graph has no fused plan");
+    SR_REQUIRE(aligned16(X) && aligned16(Y), "fused leg needs 16-byte aligned operands");
+    SR_REQUIRE(x_rows_pad >= g->n_cols && (x_rows_pad + 1) * 128 < (int64_t(1) << 31) && x_rows_pad < (int64_t(1) << 24) - 1,
+               "fused leg: operand of %lld rows per panel", (long long)x_rows_pad);
+    FusedArgs a{};
+    a.X = X; a.Y = Y;
+    a.x_rows_pad = x_rows_pad; a.y_rows_pad = y_rows_pad;
+    a.L = L;
+    a.x_panel_stride = x_rows_pad * 32;
+    a.x_pitch = 128;
+    a.x_bytes = int32_t(x_rows_pad * 128);
+    a.x_sentinel = (int32_t)x_rows_pad;
+    return launch_fused(g, a, st);
+}
+
+// The same leg on a ROW-MAJOR operand (K x L, leading dimension ldx) with the transposed result in the chunked
+// layout of simrank_spmm(transpose_out = 1, t_block, t_pad): what one rank of a column-sharded update runs
+// (its operand is S[:, C_g]; chunk h of the result goes to rank h).  false: the shapes do not fit this path.
+bool fused_rowmajor_fits(const simrank_graph* g, const float* X, int64_t ldx, int64_t L, const float* Y, int64_t t_block,
+                         int64_t t_pad) {
+    const int64_t K = g->n_cols, M = g->n_rows;
+    const int64_t tb = (t_block <= 0 || t_block > M) ? M : t_block;
+    return g->fused && aligned16(X) && aligned16(Y) && ldx % 4 == 0 && ldx * 4 < (int64_t(1) << 24) && ldx >= 32 &&
+           (K + 1) * ldx * 4 < (int64_t(1) << 31) && K < (int64_t(1) << 24) - 1 && L > 0 &&
+           (tb % kFB == 0 || tb == M) && (tb + t_pad) % 4 == 0 && (M - (M - 1) / tb * tb + t_pad) % 4 == 0;
+}
+
+int launch_fused_trans_rowmajor(const simrank_graph* g, const float* X, int64_t ldx, int64_t L, float* Y, int64_t t_block,
+                                int64_t t_pad, hipStream_t st) {
+    SR_REQUIRE(fused_rowmajor_fits(g, X, ldx, L, Y, t_block, t_pad), "fused leg: row-major operand does not fit");
+    FusedArgs a{};
+    a.X = X; a.Y = Y;
+    a.L = L;
+    a.x_panel_stride = 32;
+    a.x_pitch = uint32_t(ldx * 4);
+    a.x_bytes = int32_t((g->n_cols - 1) * ldx * 4 + L * 4);     // (to the last column of the last row: nothing beyond is read)
+    a.x_sentinel = (int32_t)g->n_cols;
+    a.y_chunked = 1;
+    a.t_block = (t_block <= 0 || t_block > g->n_rows) ? g->n_rows : t_block;
+    a.t_pad = t_pad;
+    return launch_fused(g, a, st);
 }
 
 }  // namespace simrank

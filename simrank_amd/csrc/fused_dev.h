@@ -31,6 +31,13 @@ __device__ __forceinline__ float4 ld_seg(__amdgpu_buffer_rsrc_t srd, int id, uin
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+// the same with the row pitch of the operand in bytes (panel-blocked: 128; row-major shards: 4 x ld, below 2^24)
+__device__ __forceinline__ float4 ld_seg_p(__amdgpu_buffer_rsrc_t srd, int id, uint32_t pitch, uint32_t qoff) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(srd, int(__umul24(uint32_t(id), pitch) + qoff), 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 // the compiler may not move LDS accesses of this wave across this point (no instruction is emitted)
 __device__ __forceinline__ void wave_lds_order() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -1853,6 +1853,15 @@ static int spmm_impl(const simrank_graph* g, const float* X, int64_t ldx, int64_
             return launch_fused2_trans(g, X, x_rows_pad, n_cols_x, Y, y_rows_pad, st);
         return launch_fused_trans(g, X, x_rows_pad, n_cols_x, Y, y_rows_pad, st);
     }
+    // ... and of a rank of a sharded update: the same launch on its row-major column block, the result in the
+    // chunks of the all-to-all (round 4; tuning "fuse_shards")
+    if (!blocked && transpose_out && g->fused && T.fuse && T.fuse_shards && vec_ok && T.dense_terms == 3 &&
+        g->n_cols <= T.fuse_max_rows) {
+        // (one block with pitched rows, Y^T[c * ldy + a], is the chunked layout with t_pad = ldy - n_rows)
+        const int64_t tb = a.tstride ? g->n_rows : t_block, tp = a.tstride ? a.tstride - g->n_rows : t_pad;
+        if (fused_rowmajor_fits(g, X, ldx, n_cols_x, Y, tb, tp))
+            return launch_fused_trans_rowmajor(g, X, ldx, n_cols_x, Y, tb, tp, st);
+    }
     // the block-dense part goes to the matrix cores first; the gather then runs on the remainder
     // In the upper-triangle form only when the pattern is dense throughout (MovieLens-like: 87 % of
     // the entries in dense sets, leg 2 0.9 -> 0.4 ms): on a power-law pattern the long rows, which

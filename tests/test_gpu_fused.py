@@ -22,7 +22,7 @@ def ops():
     o = HipOps(0)
     o.set_tuning(fuse_steps=1, fuse_min=2)   # small test graphs: a dense set however few steps it makes
     yield o
-    o.set_tuning(fuse=1, fuse_min=3, fuse_steps=8, fuse_unit=1 << 20, fuse_group=3)
+    o.set_tuning(fuse=1, fuse_min=3, fuse_steps=8, fuse_unit=64, fuse_group=3, fuse_shards=1)
 
 
 @contextlib.contextmanager
@@ -31,7 +31,7 @@ def knobs(ops, **kw):
     try:
         yield
     finally:
-        ops.set_tuning(fuse=1, fuse_min=2, fuse_steps=1, fuse_unit=1 << 20, fuse_group=3)
+        ops.set_tuning(fuse=1, fuse_min=2, fuse_steps=1, fuse_unit=64, fuse_group=3, fuse_shards=1)
 
 
 def put_blocked(ops, a, dtype=np.float32):
@@ -174,3 +174,49 @@ def test_fused_blocks_cut_into_units(ops, unit):
     with knobs(ops, fuse_unit=1 << 20):
         whole = leg1(ops, ops.graph(csr), X, M)
     np.testing.assert_allclose(first, whole, rtol=2e-6, atol=1e-30)
+
+
+@pytest.mark.parametrize("shape,tb,pad", [((1024, 1024, 256), 256, 4), ((1024, 1024, 200), 128, 0), ((640, 900, 96), 0, 0),
+                                          ((2048, 2048, 512), 256, 8), ((1000, 1000, 64), 384, 4)])
+def test_fused_leg1_on_a_sharded_ranks_operand(ops, shape, tb, pad):
+    """Round 4: the one-launch leg on what one rank of a column-sharded update holds — a ROW-MAJOR column block of
+    S (here columns [c0, c0 + L) of a wider matrix) — with the transposed result in the chunks of the all-to-all
+    (simrank_spmm's t_block layout): against float64 NumPy, against the gather kernels the shards ran until round
+    3 (rounding only: fuse_shards = 0), and bit for bit against the same leg on a panel-blocked operand."""
+    M, K, L = shape
+    csr = corner_csr(M, K, seed=M + L, hubs=min(K, 200), p_hub=0.4)
+    rng = np.random.default_rng(6)
+    wide = (rng.random((K, L + 64)) ** 3).astype(np.float32)
+    c0 = 32
+    X = wide[:, c0:c0 + L]
+    want = (dense64(csr) @ X.astype(np.float64)).T                 # L x M
+    xw = ops.matrix(K, L + 64)
+    ops.upload(xw, wide)
+    tbe = tb if tb else M
+    nblk = -(-M // tbe)
+    size = nblk * L * (tbe + pad)
+
+    def run(**kw):
+        with knobs(ops, **kw):
+            g = ops.graph(csr)
+            if tb == 0:                   # one block, pitched rows: Y^T[c * ld + a]
+                y = ops.matrix(L, M)
+                ops.spmm(g, xw, y, n_cols=L, transpose_out=True, x_col0=c0)
+                return ops.download(y)
+            y = ops.matrix(1, size, ld=size)
+            ops.spmm(g, xw, y, n_cols=L, transpose_out=True, t_block=tb, t_pad=pad, x_col0=c0)
+            flat = ops.download(y).ravel()
+        out = np.zeros((L, M), dtype=np.float32)
+        for h in range(nblk):
+            lo, hi = h * tbe, min(M, (h + 1) * tbe)
+            w = hi - lo + pad
+            out[:, lo:hi] = flat[h * L * (tbe + pad): h * L * (tbe + pad) + L * w].reshape(L, w)[:, :hi - lo]
+        return out
+
+    got = run()
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-30)
+    old = run(fuse_shards=0)
+    np.testing.assert_allclose(got, old, rtol=2e-6, atol=1e-30)
+    if tb == 0 or tb % 128 == 0:
+        g = ops.graph(csr)
+        assert np.array_equal(got, leg1(ops, g, X, M))               # the same plan on a panel-blocked copy: same bits

@@ -17,9 +17,11 @@ HALF_ULP = 2.0 ** -11          # relative half-ulp of fp16 for normal numbers
 def ops():
     from simrank_amd.engine import HipOps
     o = HipOps(0)
-    o.set_tuning(fuse_steps=1, fuse_min=2)   # small test graphs: a dense set however few steps it makes
+    # small test graphs: a dense set however few steps it makes; whole blocks (half.hip takes no units whose sums
+    # meet in memory: fits on fp16-held matrices create their graphs that way themselves, driver.Side)
+    o.set_tuning(fuse_steps=1, fuse_min=2, fuse_unit=1 << 20)
     yield o
-    o.set_tuning(fuse=1, fuse_min=3, fuse_steps=8, fuse_unit=1 << 20, fuse_group=3)
+    o.set_tuning(fuse=1, fuse_min=3, fuse_steps=8, fuse_unit=64, fuse_group=3)
 
 
 def put_half(ops, a, scale=1.0):

@@ -71,13 +71,19 @@ def test_logical_shards_are_bitwise_equal_to_one_shard():
     from simrank_amd.engine import HipOps
     df = synth.er_directed(1024, 0.01, seed=1)
     knob = HipOps(0)
-    # P = 1 without the single-rank shortcuts: no upper-triangle leg 2, no one-launch leg 1 (the shards
-    # run the gather kernels of spmm.hip; the one-launch leg sums matrix-core rows in another order)
-    knob.set_tuning(triangle=0, fuse=0)
+    # P = 1 without the single-rank shortcut of leg 2 (no upper triangle); leg 1 is the one-launch leg on one rank
+    # and on every shard (round 4: the same plan on a rank's row-major column block = the same bits)
+    knob.set_tuning(triangle=0)
     try:
         one = SRA.SimRank().fit(df, iterations=6, eps=0, verbose=False, mode="sparse")
     finally:
-        knob.set_tuning(triangle=1, fuse=1)
+        knob.set_tuning(triangle=1)
+    knob.set_tuning(fuse_shards=0)      # (the gather kernels the shards ran until round 3: other summation order)
+    try:
+        old = SRA.SimRank().fit(df, iterations=6, eps=0, verbose=False, mode="sparse", world=LocalWorld(4, symmetric_shards=False))
+    finally:
+        knob.set_tuning(fuse_shards=1)
+    np.testing.assert_allclose(old.values, one.values, rtol=1e-6, atol=1e-30)
     tri = SRA.SimRank().fit(df, iterations=6, eps=0, verbose=False, mode="sparse")
     # mirrored tiles carry the same bits (only the diagonal tiles of the solver's own node
     # order are computed on both sides): nearly all pairs (i, j), (j, i) are bit-equal
@@ -355,7 +361,7 @@ def test_config4_pl32768_eight_shards_bitwise(ops, workload):
     nodes, csr = ingest.directed(df, False, "from", "to", "weight")
     n = csr.n_rows
     rows = [0, 1, n // 3, n // 2 + 7, n - 129, n - 1]
-    ops.set_tuning(triangle=0, fuse=0)   # one rank on the kernels the shards run (no triangle leg 2, no one-launch leg 1)
+    ops.set_tuning(triangle=0)   # one rank on the kernels the shards run (no triangle leg 2; the one-launch leg 1 on both)
     try:
         one = Solver(lambda r: ops, LocalWorld(1), [SideSpec(csr, csr.rowscale, 0.8)], "sparse")
         one.reset()
@@ -364,7 +370,7 @@ def test_config4_pl32768_eight_shards_bitwise(ops, workload):
         want = ops.download_rows(one.cur[0][0], rows)
         one.release()
     finally:
-        ops.set_tuning(triangle=1, fuse=1)
+        ops.set_tuning(triangle=1)
     inv_one = one.inv[0]
     del one
     world = LocalWorld(8, symmetric_shards=False)
@@ -818,15 +824,16 @@ def test_dense_sets_shards_equal_one_shard_bit_for_bit():
     from simrank_amd.engine import HipOps
     df = _dense_corner_graph()
     knob = HipOps(0)
+    # (the dense_tiles + gather path on both sides: one-launch leg off on the single rank AND on the shards)
     knob.set_tuning(triangle=0, fuse=0)
     try:
         one = SRA.SimRank().fit(df, iterations=4, eps=0, verbose=False, mode="sparse")
+        for world in (2, 4):
+            many = SRA.SimRank().fit(df, iterations=4, eps=0, verbose=False, mode="sparse",
+                                     world=LocalWorld(world, symmetric_shards=False))
+            assert np.array_equal(one.values, many.values)
     finally:
         knob.set_tuning(triangle=1, fuse=1)
-    for world in (2, 4):
-        many = SRA.SimRank().fit(df, iterations=4, eps=0, verbose=False, mode="sparse",
-                                 world=LocalWorld(world, symmetric_shards=False))
-        assert np.array_equal(one.values, many.values)
     knob.set_tuning(dense_min=0)
     try:
         plain = SRA.SimRank().fit(df, iterations=4, eps=0, verbose=False, mode="sparse")

@@ -595,11 +595,17 @@ int graph_create_with(const Tuning& tun, int64_t n_rows, int64_t n_cols, int64_t
     }
     for (int64_t i = 0; i < n_cols; ++i) t_rowptr[i + 1] += t_rowptr[i];
     std::vector<int32_t> t_col(std::max<size_t>(1, size_t(nnz)));
+    // t_pos[j]: where entry j = (a, i) of the CSR sits in column i's list of the transposed pattern — the list is
+    // ascending in a, so its part from there on holds exactly the rows b >= a (evidence counts, upper triangle)
+    std::vector<int32_t> t_pos(std::max<size_t>(1, size_t(nnz)), 0);
     {
         std::vector<int32_t> cur(t_rowptr.begin(), t_rowptr.end() - 1);
         for (int64_t a = 0; a < n_rows; ++a)
             if (rowscale[a] > 0.f)
-                for (int32_t j = rowptr[a]; j < rowptr[a + 1]; ++j) t_col[cur[col[j]]++] = (int32_t)a;
+                for (int32_t j = rowptr[a]; j < rowptr[a + 1]; ++j) {
+                    t_pos[size_t(j)] = cur[col[j]];
+                    t_col[cur[col[j]]++] = (int32_t)a;
+                }
     }
     simrank_graph* g = new simrank_graph;
     g->tun = tun;
@@ -654,6 +660,7 @@ int graph_create_with(const Tuning& tun, int64_t n_rows, int64_t n_cols, int64_t
     if (!rc) rc = up((void**)&g->rowscale, rowscale, size_t(n_rows) * 4);
     if (!rc) rc = up((void**)&g->t_rowptr, t_rowptr.data(), size_t(n_cols + 1) * 4);
     if (!rc) rc = up((void**)&g->t_col, t_col.data(), size_t(nnz) * 4);
+    if (!rc) rc = up((void**)&g->t_pos, t_pos.data(), size_t(nnz) * 4);
     if (!rc && g->n_tiles) rc = up((void**)&g->tile_row0, tile_row0.data(), tile_row0.size() * 4);
     if (!rc && g->sym_blocks) rc = up((void**)&g->sym_map, sym_map.data(), sym_map.size() * 4);
     for (int i = 0; i < n_jobs; ++i) {
@@ -687,6 +694,7 @@ int simrank_graph_destroy(simrank_graph* g) {
     plan_free(g->rowscale);
     plan_free(g->t_rowptr);
     plan_free(g->t_col);
+    plan_free(g->t_pos);
     plan_free(g->tile_row0);
     plan_free(g->sym_map);
     free_dense_plan(g->dense);
@@ -783,6 +791,8 @@ int simrank_set_tuning(const char* key, int64_t value) {
     } else if (!strcmp(key, "fuse_max_rows")) {
         SR_REQUIRE(value >= 0, "fuse_max_rows must be >= 0");
         t.fuse_max_rows = value;
+    } else if (!strcmp(key, "ev_tri")) {
+        t.ev_tri = value ? 1 : 0;
     } else if (!strcmp(key, "fuse_shards")) {
         t.fuse_shards = value ? 1 : 0;
     } else if (!strcmp(key, "fuse_cap")) {
@@ -826,6 +836,7 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     else if (!strcmp(key, "fuse_group")) *value = t.fuse_group;
     else if (!strcmp(key, "fuse_cap")) *value = t.fuse_cap;
     else if (!strcmp(key, "fuse_shards")) *value = t.fuse_shards;
+    else if (!strcmp(key, "ev_tri")) *value = t.ev_tri;
     else if (!strcmp(key, "fuse_wgs")) *value = t.fuse_wgs;
     else if (!strcmp(key, "fuse_max_rows")) *value = t.fuse_max_rows;
     else if (!strcmp(key, "fuse_order")) *value = t.fuse_order;

@@ -1614,21 +1614,28 @@ constexpr int kEvThreads = 1024;
 __global__ __launch_bounds__(kEvThreads) void evidence_counts_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ rowscale, const int32_t* __restrict__ t_rowptr,
-    const int32_t* __restrict__ t_col, int64_t M, int64_t col0, int n_cols, uint8_t* out,
-    int64_t ld, int64_t rows_pad, int64_t out_col0, int vec4) {
+    const int32_t* __restrict__ t_col, const int32_t* __restrict__ t_pos, int64_t M, int64_t col0, int n_cols,
+    uint8_t* out, int64_t ld, int64_t rows_pad, int64_t out_col0, int vec4, int tri) {
     extern __shared__ unsigned cnt[];                 // counters of columns 2 w and 2 w + 1 in word w
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int words = (n_cols + 1) >> 1;
-    for (int64_t a = blockIdx.x; a < M; a += gridDim.x) {
-        for (int w = tid; w < words; w += kEvThreads) cnt[w] = 0;
+    // tri (round 4; the whole square block in one pass): the counts are symmetric — common in-neighbours of (a, b)
+    // = of (b, a) — so row a counts the paths to b >= a only (half the LDS atomics, which bound this kernel) and
+    // writes its columns from the 32-column panel of the diagonal on; evidence_mirror_kernel fills the rest.
+    // Rows are taken LONGEST FIRST there (the long rows, late in the solver's order, have the short ranges).
+    for (int64_t it = blockIdx.x; it < M; it += gridDim.x) {
+        const int64_t a = tri ? M - 1 - it : it;
+        const int first = tri ? int(a & ~int64_t(31)) : 0;       // first column this row zeroes, counts from and writes
+        for (int w = (first >> 1) + tid; w < words; w += kEvThreads) cnt[w] = 0;
         __syncthreads();
         if (rowscale[a] > 0.f) {
             const int s = rowptr[a], e = rowptr[a + 1];
             for (int j = s + wave; j < e; j += kEvThreads / 64) {
                 const int i = col[j];
-                const int ts = t_rowptr[i], te = t_rowptr[i + 1];
+                // (tri: column i's list is ascending and holds a itself at t_pos[j]: from there on it is b >= a)
+                const int ts = tri ? t_pos[j] : t_rowptr[i], te = t_rowptr[i + 1];
                 for (int t = ts + lane; t < te; t += 64) {
                     const int64_t c = int64_t(t_col[t]) - col0;
                     if (c >= 0 && c < n_cols) {
@@ -1646,7 +1653,7 @@ __global__ __launch_bounds__(kEvThreads) void evidence_counts_kernel(
         if (vec4) {
             // four columns per thread: two words -> four saturated bytes, one 4-byte store (a panel of the
             // blocked layout and an aligned row-major row both keep 4 consecutive columns together)
-            for (int c4 = tid * 4; c4 < n_cols; c4 += kEvThreads * 4) {
+            for (int c4 = first + tid * 4; c4 < n_cols; c4 += kEvThreads * 4) {
                 const unsigned w0 = cnt[c4 >> 1], w1 = (c4 + 2 < n_cols) ? cnt[(c4 >> 1) + 1] : 0u;
                 const unsigned b0 = min(w0 & 0xFFFFu, 255u), b1 = min(w0 >> 16, 255u);
                 const unsigned b2 = min(w1 & 0xFFFFu, 255u), b3 = min(w1 >> 16, 255u);
@@ -1660,10 +1667,48 @@ __global__ __launch_bounds__(kEvThreads) void evidence_counts_kernel(
                 }
             }
         } else {
-            for (int c = tid; c < n_cols; c += kEvThreads)
+            for (int c = first + tid; c < n_cols; c += kEvThreads)
                 out[elem_at(a, out_col0 + c, ld, rows_pad)] = (uint8_t)min((cnt[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu, 255u);
         }
         __syncthreads();
+    }
+}
+
+// The lower triangle of a square u8 count block from its upper one: 32 x 32 tiles, tile (I, J) with I > J is the
+// transpose of tile (J, I); a tile on the diagonal mirrors itself.  One workgroup of 256 threads per tile: the source
+// tile goes through LDS (coalesced 4-byte loads and stores on both sides, either layout).
+__global__ __launch_bounds__(256) void evidence_mirror_kernel(uint8_t* cnt, int64_t n, int64_t ld, int64_t rows_pad) {
+    __shared__ unsigned char t[32][36];
+    const int64_t w = blockIdx.x;
+    int64_t I = (int64_t)((sqrt(8.0 * double(w) + 1.0) - 1.0) * 0.5);
+    while (I * (I + 1) / 2 > w) --I;
+    while ((I + 1) * (I + 2) / 2 <= w) ++I;
+    const int64_t J = w - I * (I + 1) / 2;                        // I >= J
+    const int tid = threadIdx.x, r = tid >> 3, q = tid & 7;       // row r of the tile, bytes 4 q .. 4 q + 3
+    // source tile (J, I): rows 32 J + r, columns 32 I + 4 q ..
+    {
+        const int64_t row = 32 * J + r, c = 32 * I + 4 * q;
+        unsigned v = 0;
+        if (row < n) {
+            const uint8_t* src = cnt + elem_at(row, c, ld, rows_pad);
+            if (c + 4 <= n && ((reinterpret_cast<uintptr_t>(src) & 3) == 0)) v = *reinterpret_cast<const unsigned*>(src);
+            else for (int k = 0; k < 4; ++k) if (c + k < n) v |= unsigned(src[k]) << (8 * k);
+        }
+        *reinterpret_cast<unsigned*>(&t[r][4 * q]) = v;
+    }
+    __syncthreads();
+    // destination tile (I, J): row 32 I + r, columns 32 J + 4 q .. = source (column r, rows 4 q ..)
+    const int64_t row = 32 * I + r, c = 32 * J + 4 * q;
+    if (row >= n) return;
+    uint8_t* dst = cnt + elem_at(row, c, ld, rows_pad);
+    unsigned char b[4];
+    for (int k = 0; k < 4; ++k) b[k] = t[4 * q + k][r];
+    if (I == J)                                                   // on the diagonal: only what lies left of it
+        for (int k = 0; k < 4; ++k) if (4 * q + k >= r) b[k] = t[r][4 * q + k];
+    if (c + 4 <= n && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0)) {
+        *reinterpret_cast<unsigned*>(dst) = unsigned(b[0]) | unsigned(b[1]) << 8 | unsigned(b[2]) << 16 | unsigned(b[3]) << 24;
+    } else {
+        for (int k = 0; k < 4; ++k) if (c + k < n) dst[k] = b[k];
     }
 }
 
@@ -2221,6 +2266,9 @@ static int evidence_counts_impl(const simrank_graph* g, int64_t col0, int64_t n_
     // 4-byte stores need the block's first column, the pass boundaries (multiples of 65536) and the row
     // pitch to be multiples of 4 (the blocked layout: always, out_col0 being a multiple of 4)
     const int vec4 = (reinterpret_cast<uintptr_t>(counts) % 4 == 0) && (rows_pad ? true : ld % 4 == 0);
+    // the whole square in one pass: upper triangle + mirror (tuning "ev_tri"; column blocks of sharded ranks and
+    // blocks of more than 65536 columns take every path)
+    const int tri = (g->tun.ev_tri && col0 == 0 && n_cols == g->n_rows && n_cols <= kEvChunk) ? 1 : 0;
     for (int64_t c = 0; c < n_cols; c += kEvChunk) {
         const int nc = (int)std::min<int64_t>(kEvChunk, n_cols - c);
         const size_t lds = size_t((nc + 1) / 2) * 4;
@@ -2229,7 +2277,14 @@ static int evidence_counts_impl(const simrank_graph* g, int64_t col0, int64_t n_
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(evidence_counts_kernel, dim3(grid), dim3(kEvThreads), lds,
                            as_stream(stream), g->rowptr, g->col, g->rowscale, g->t_rowptr,
-                           g->t_col, g->n_rows, col0 + c, nc, counts, ld, rows_pad, c, vec4);
+                           g->t_col, g->t_pos, g->n_rows, col0 + c, nc, counts, ld, rows_pad, c, vec4, tri);
+        SR_HIP(hipGetLastError());
+    }
+    if (tri) {
+        const int64_t T = (g->n_rows + 31) / 32, tiles = T * (T + 1) / 2;
+        SR_REQUIRE(tiles < (int64_t(1) << 31), "evidence mirror: %lld tiles", (long long)tiles);
+        hipLaunchKernelGGL(evidence_mirror_kernel, dim3((unsigned)tiles), dim3(256), 0, as_stream(stream), counts,
+                           g->n_rows, ld, rows_pad);
         SR_HIP(hipGetLastError());
     }
     return SIMRANK_OK;

@@ -173,6 +173,30 @@ def test_evidence_counts_exact_and_saturating(ops):
         np.testing.assert_array_equal(ops.download(out), want[:, c0:c0 + L])
 
 
+@pytest.mark.parametrize("M,K,blocked", [(180, 400, False), (257, 90, True), (1000, 1000, True), (33, 500, True),
+                                         (2048, 3000, True), (1, 5, False)])
+def test_evidence_counts_upper_triangle_and_mirror(ops, M, K, blocked):
+    """Round 4: a whole square block of counts is computed as its upper triangle (row a counts the paths to b >= a:
+    half the LDS atomics) and mirrored by a second kernel — bit-equal to the exact counts, either layout, sizes off
+    the 32-grid, rows without weight, saturation (`_cal_Evidence`, SimRank.py:311-320)."""
+    csr = random_csr(M, K, 9, seed=M + K, heavy={0: min(K, 400), M // 2: min(K, 300)} if M > 2 else ())
+    live = sp.diags((csr.rowscale.astype(np.float32) > 0).astype(np.float64)) @ sp.csr_matrix(
+        (np.ones(csr.col.size), csr.col, csr.rowptr), shape=(M, K))
+    want = np.minimum((live @ live.T).toarray(), 255).astype(np.uint8)
+    got = {}
+    for tri in (1, 0):
+        ops.set_tuning(ev_tri=tri)
+        try:
+            g = ops.graph(csr)
+            out = ops.matrix(M, M, np.uint8, blocked=True) if blocked else ops.matrix(M, M, np.uint8)
+            ops.evidence_counts(g, 0, out)
+            got[tri] = ops.download(out)
+        finally:
+            ops.set_tuning(ev_tri=1)
+    np.testing.assert_array_equal(got[1], want)
+    np.testing.assert_array_equal(got[0], want)
+
+
 def test_densify(ops):
     csr = random_csr(150, 90, 10, seed=3)
     g = ops.graph(csr)

@@ -56,6 +56,6 @@ rec["_note"] = ("HBM-side bytes per launch from rocprofv3 PMC (tools/gpu_profile
                 "rounds 1-2: gather kernel of the remainder + dense_tiles); leg2 = gather kernel, upper-triangle "
                 "form, timed exact-count form only (bench.py --exact-only).")
 rec[key] = {"leg1": g1 + d, "leg2": g2, "leg1_parts": {"gather": g1, "dense_tiles": d},
-            "source": os.path.basename(out_dir.rstrip("/"))}
+            "source": os.path.basename(out_dir.rstrip("/")), "commit": os.environ.get("PMC_COMMIT", "?")}
 json.dump(rec, open(path, "w"), indent=1)
 print(json.dumps(rec[key], indent=1))

@@ -791,6 +791,9 @@ int simrank_set_tuning(const char* key, int64_t value) {
     } else if (!strcmp(key, "fuse_max_rows")) {
         SR_REQUIRE(value >= 0, "fuse_max_rows must be >= 0");
         t.fuse_max_rows = value;
+    } else if (!strcmp(key, "fuse_rows")) {
+        SR_REQUIRE(value >= 64 && value <= (int64_t(1) << 40), "fuse_rows must be >= 64");
+        t.fuse_rows = value;
     } else if (!strcmp(key, "ev_tri")) {
         t.ev_tri = value ? 1 : 0;
     } else if (!strcmp(key, "fuse_shards")) {
@@ -837,6 +840,7 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     else if (!strcmp(key, "fuse_cap")) *value = t.fuse_cap;
     else if (!strcmp(key, "fuse_shards")) *value = t.fuse_shards;
     else if (!strcmp(key, "ev_tri")) *value = t.ev_tri;
+    else if (!strcmp(key, "fuse_rows")) *value = t.fuse_rows;
     else if (!strcmp(key, "fuse_wgs")) *value = t.fuse_wgs;
     else if (!strcmp(key, "fuse_max_rows")) *value = t.fuse_max_rows;
     else if (!strcmp(key, "fuse_order")) *value = t.fuse_order;

@@ -63,10 +63,12 @@ struct Tuning {
     int64_t fuse_min = 3;    // ... a column joins a block's dense set when this many of its rows reference it (2 and 4:
                              // +8 % and +1 % on the leg at pl32768d32)
     int64_t fuse_steps = 8;  // ... and a block keeps its set only when it makes this many 16-column steps
-    int64_t fuse_unit = 64;  // ... sets of more than this many 64-column groups are cut into units (workgroups whose
+    int64_t fuse_unit = 48;  // ... sets of more than this many 64-column groups are cut into units (workgroups whose
                              // partial sums meet in memory, written through and read past the L1 — round 4; with round 3's
                              // agent-scope release / acquire pair 64 cost +3 %): pl32768d32 leg 1 5.50 -> 5.20 ms at 64
-                             // (128: 5.34, 32: 5.23, 16: 5.94); 1 << 20 = never
+                             // (128: 5.34, 32: 5.23, 16: 5.94); with the gather units of fuse_rows 48 -> 5.0 ms; 1 << 20 = never
+    int64_t fuse_rows = 8192; // ... and a block whose gathered remainder exceeds this many entries is cut into gather units
+                             // (every n-th row of its descending remainder order each), split blocks only when fuse_unit is on
     int64_t fuse_store = 1;  // ... cache policy of its tile stores: 0 plain, 1 nt, 2 sc1 (write through, drop), 3 sc0 sc1
     int64_t fuse_meta_nt = 0; // ... id streams loaded non-temporally
     int64_t fuse_order = 0;  // ... launch order of a panel's units: 0 heaviest first, k > 0: the units with a matrix-core

@@ -75,6 +75,7 @@ struct FusedArgs {
     int32_t idx_mask;         // DIAGNOSTIC (tuning "probe_mask"): operand row ids are ANDed with it (wrong results)
     int32_t meta_nt;          // the id streams are loaded non-temporally (they are re-read once per panel)
     int32_t probe;            // DIAGNOSTIC (tuning "probe_flags"): 1 no gather phase, 2 no stores, 4 no MFMA phase
+    const float* rowscale;    // [M] (the last arriver of a split block scales the rows)
     const int32_t* units;     // [n_units][32]: first block, first quad (absolute), quads, index among the block's
                               // units, units of the block, partial-sum slot (-1: none), counter slot, block has a
                               // set, blocks of the unit (1..4; > 1 only without a set), then per wave: first round
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
     };
     {   // lane (g, q): row q & 3 of lane group g, blocks q >> 2 and 2 + (q >> 2) of the unit
         const int sbA = q >> 2, sbB = 2 + (q >> 2);
-        const int2* src = p.gmeta + ((size_t(b0) * 4 + wave) * 8 + g) * 4 + (q & 3);
+        const int2* src = p.gmeta + ((size_t(un[29]) * 4 + wave) * 8 + g) * 4 + (q & 3);
         int2* dst = gm_lds + (wave * 8 + g) * 4 + (q & 3);
         const int2 none = make_int2(int(0xFFFFFFFFu), 0);
         const int2 a = sbA < n_sub ? src[size_t(sbA) * 4 * 8 * 4] : none;
@@ -320,58 +321,17 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
                 __syncthreads();
             }
         }
-        // ------------------------------------------------------------ 2b. blocks cut into several units
-        // (a workgroup must not outlive its panel's turn in the L2): every unit publishes its sums and
-        // takes a ticket; the LAST arriver adds the partial sums in unit order (whoever it is: same
-        // bits) and goes on to the gather phase, the others are done.  No unit ever waits for another.
-        if (unit_nb > 1) {
-            // (round 4: partial sums written THROUGH (sc1) and read past the L1 (sc1) instead of an agent-scope
-            // release / acquire pair around plain accesses — the release wrote back every dirty line of the XCD's
-            // L2, the output tiles of all its workgroups included)
-            typedef unsigned v4u __attribute__((ext_vector_type(4)));
-            float* mine = p.partials + (size_t(pslot) * p.n_panels + panel) * (32 * kFB);
-            const __amdgpu_buffer_rsrc_t msrd = __builtin_amdgcn_make_buffer_rsrc(mine, 0, 32 * kFB * 4, 0x00020000);
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int x = threadIdx.x + it * 256;      // 1024 float4 = 32 columns x 128 rows
-                const int c = x >> 5, r4 = (x & 31) * 4;
-                const float4 v = *reinterpret_cast<const float4*>(tile + c * kTS + r4);
-                v4u o;
-                o.x = __float_as_uint(v.x); o.y = __float_as_uint(v.y); o.z = __float_as_uint(v.z); o.w = __float_as_uint(v.w);
-                __builtin_amdgcn_raw_buffer_store_b128(o, msrd, (c * kFB + r4) * 4, 0, 16);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            int* flag = reinterpret_cast<int*>(bbuf_all);
-            if (threadIdx.x == 0) {
-                int* tk = p.tickets + size_t(cslot) * p.n_panels + panel;
-                const int t = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int last = t == unit_nb - 1;
-                if (last) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-                *flag = last;
-            }
-            __syncthreads();
-            if (!*flag) return;
-            const int first = pslot - unit_k;                // the block's units own consecutive slots
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int x = threadIdx.x + it * 256;
-                const int c = x >> 5, r4 = (x & 31) * 4;
-                float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int k = 0; k < unit_nb; ++k) {
-                    const float* src = p.partials + (size_t(first + k) * p.n_panels + panel) * (32 * kFB);
-                    const __amdgpu_buffer_rsrc_t ssrd =
-                        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 32 * kFB * 4, 0x00020000);
-                    const v4u w = __builtin_amdgcn_raw_buffer_load_b128(ssrd, (c * kFB + r4) * 4, 0, 16);
-                    const float4 v = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
-                    if (k == 0) acc4 = v;
-                    else { acc4.x += v.x; acc4.y += v.y; acc4.z += v.z; acc4.w += v.w; }
-                }
-                *reinterpret_cast<float4*>(tile + c * kTS + r4) = acc4;
-            }
-            __syncthreads();
-        }
     }
+    // (round 4) a block cut into units: matrix-core units (a share of the set's columns, no rows) and gather units (a
+    // share of the rows, no columns of the set) all leave RAW sums in their tile and publish it after the gather
+    // phase (step 4b); a gather unit's tile starts as zeros
+    const bool split_unit = un[30] != 0;
+    if (split_unit && nq == 0) {
+        for (int x4 = threadIdx.x; x4 < 32 * kTS / 4; x4 += 256)
+            reinterpret_cast<float4*>(tile)[x4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+    }
+    const bool has_d = has_set || split_unit;                 // the tile holds something before the rows are emitted
 
     FST(2);
     // ---------------------------------------------------------------- 3. gather phase (the remainder)
@@ -403,10 +363,10 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
         int krow = 0;                                         // rows of the lane group finished in this block
         auto emit = [&](const int3& m, const float4& sv) {
             if (m.x >= 0) {
-                const float sc = __int_as_float(m.y);
+                const float sc = split_unit ? 1.0f : __int_as_float(m.y);     // (a split block is scaled by its last arriver)
                 float* tp = tile + (4 * q) * kTS + m.x;
-                const float d0 = has_set ? tp[0] : 0.f, d1 = has_set ? tp[kTS] : 0.f;
-                const float d2 = has_set ? tp[2 * kTS] : 0.f, d3 = has_set ? tp[3 * kTS] : 0.f;
+                const float d0 = has_d ? tp[0] : 0.f, d1 = has_d ? tp[kTS] : 0.f;
+                const float d2 = has_d ? tp[2 * kTS] : 0.f, d3 = has_d ? tp[3 * kTS] : 0.f;
                 tp[0] = (sv.x + d0) * sc;
                 tp[kTS] = (sv.y + d1) * sc;
                 tp[2 * kTS] = (sv.z + d2) * sc;
@@ -428,8 +388,65 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
             for (int k = krow; k < 4; ++k) emit(unpack(gmp[sb * 128 + k]), make_float4(0.f, 0.f, 0.f, 0.f));
             FST(3);
             __syncthreads();
-            // ------------------------------------------------------------ 4. transposed store
             const int row0 = (b0 + sb) * kFB;
+            // ------------------------------------------------------------ 4b. the units of a split block meet in memory
+            // (a workgroup must not outlive its panel's turn in the L2): every unit publishes its raw sums — written
+            // THROUGH (sc1) and read past the L1 (sc1): round 3's agent-scope release / acquire pair around plain
+            // accesses wrote back every dirty line of the XCD's L2 — and takes a ticket; the LAST arriver adds them in
+            // unit order (whoever it is: same bits), scales the rows and stores the tile, the others are done.
+            // No unit ever waits for another.
+            if (unit_nb > 1) {
+                typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                float* mine = p.partials + (size_t(pslot) * p.n_panels + panel) * (32 * kFB);
+                const __amdgpu_buffer_rsrc_t msrd = __builtin_amdgcn_make_buffer_rsrc(mine, 0, 32 * kFB * 4, 0x00020000);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int x = threadIdx.x + it * 256;      // 1024 float4 = 32 columns x 128 rows
+                    const int c = x >> 5, r4 = (x & 31) * 4;
+                    const float4 v = *reinterpret_cast<const float4*>(tile + c * kTS + r4);
+                    v4u o;
+                    o.x = __float_as_uint(v.x); o.y = __float_as_uint(v.y); o.z = __float_as_uint(v.z); o.w = __float_as_uint(v.w);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, msrd, (c * kFB + r4) * 4, 0, 16);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                int* flag = reinterpret_cast<int*>(bbuf_all);
+                if (threadIdx.x == 0) {
+                    int* tk = p.tickets + size_t(cslot) * p.n_panels + panel;
+                    const int t = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int last = t == unit_nb - 1;
+                    if (last) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                    *flag = last;
+                }
+                __syncthreads();
+                if (!*flag) {
+                    sb = n_sub;                                  // (nothing left to do for this unit)
+                    return;
+                }
+                const int first = pslot - unit_k;                // the block's units own consecutive slots
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int x = threadIdx.x + it * 256;
+                    const int c = x >> 5, r4 = (x & 31) * 4;
+                    float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int k = 0; k < unit_nb; ++k) {
+                        const float* src = p.partials + (size_t(first + k) * p.n_panels + panel) * (32 * kFB);
+                        const __amdgpu_buffer_rsrc_t ssrd =
+                            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 32 * kFB * 4, 0x00020000);
+                        const v4u w = __builtin_amdgcn_raw_buffer_load_b128(ssrd, (c * kFB + r4) * 4, 0, 16);
+                        const float4 v = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+                        if (k == 0) acc4 = v;
+                        else { acc4.x += v.x; acc4.y += v.y; acc4.z += v.z; acc4.w += v.w; }
+                    }
+                    float scv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) scv[j] = row0 + r4 + j < p.M ? p.rowscale[row0 + r4 + j] : 0.f;
+                    acc4.x *= scv[0]; acc4.y *= scv[1]; acc4.z *= scv[2]; acc4.w *= scv[3];
+                    *reinterpret_cast<float4*>(tile + c * kTS + r4) = acc4;
+                }
+                __syncthreads();
+            }
+            // ------------------------------------------------------------ 4. transposed store
             const int nrows = int(min(int64_t(kFB), p.M - row0));
             const int rows_out = max(0, min(32, nrows - 32 * wave));
             const int cols_here = int(min(int64_t(32), p.L - c0));
@@ -569,11 +586,14 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
     std::vector<int32_t> dcols;                       // padded to 64 per block
     std::vector<uint32_t> abits;                      // [quad][lane][4 steps]
     // per block and wave: its rounds (64 ids each) and its lane groups' rows; laid out per unit below
-    std::vector<std::vector<int32_t>> blk_sids(size_t(nblk) * 4);
-    std::vector<int32_t> blk_gmeta(size_t(nblk) * 32 * 4 * 2, 0);
+    std::vector<std::vector<int32_t>> blk_sids((size_t(nblk) + size_t(kSub)) * 4);
+    std::vector<int32_t> blk_gmeta((size_t(nblk) + size_t(kSub)) * 32 * 4 * 2, int32_t(0xFFFFFFFFu));
+    std::fill(blk_gmeta.begin(), blk_gmeta.begin() + size_t(nblk) * 32 * 4 * 2, 0);
     std::vector<uint16_t> cnt(size_t(K), 0);
     std::vector<int32_t> kpos(size_t(K), -1), touched, set;
     std::vector<int64_t> cost(size_t(nblk), 0), blk_rem(size_t(nblk), 0);
+    std::vector<int32_t> blk_ng(size_t(nblk), 0), blk_gslot(size_t(nblk), 0);   // split blocks: gather units, slot of gather unit 1
+    size_t extra_gm = 0;
     std::vector<int32_t> rem[kFB];
     int64_t covered = 0, steps_total = 0, r_nnz = 0;
     for (int64_t b = 0; b < nblk; ++b) {
@@ -631,53 +651,77 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
         int order[kFB];
         std::iota(order, order + nr, 0);
         std::stable_sort(order, order + nr, [&](int x, int y) { return rem[x].size() > rem[y].size(); });
-        // 32 lane groups x 4 rows: longest row first, to the group with the smallest total that has room
-        int grp_rows[32][4], grp_n[32];
-        int64_t grp_tot[32];
-        for (int i = 0; i < 32; ++i) { grp_n[i] = 0; grp_tot[i] = 0; }
-        for (int i = 0; i < nr; ++i) {
-            int best = -1;
-            for (int gi = 0; gi < 32; ++gi)
-                if (grp_n[gi] < 4 && (best < 0 || grp_tot[gi] < grp_tot[best])) best = gi;
-            grp_rows[best][grp_n[best]++] = order[i];
-            grp_tot[best] += (int64_t)rem[order[i]].size();
-        }
-        // groups by total, dealt to the waves in turn: every wave gets the same mix
-        int gorder[32];
-        std::iota(gorder, gorder + 32, 0);
-        std::stable_sort(gorder, gorder + 32, [&](int x, int y) { return grp_tot[x] > grp_tot[y]; });
-        int64_t slots_block = 0;
-        for (int w = 0; w < 4; ++w) {
-            int64_t longest = 0;
-            for (int gg = 0; gg < 8; ++gg) longest = std::max(longest, grp_tot[gorder[gg * 4 + w]]);
-            const int rounds = (int)((longest + 7) / 8);
-            std::vector<int32_t>& sids = blk_sids[size_t(b) * 4 + size_t(w)];
-            const size_t base = 0;
-            sids.assign(size_t(rounds) * 64, -1);
-            for (int gg = 0; gg < 8; ++gg) {
-                const int gi = gorder[gg * 4 + w];
-                int32_t* gm = &blk_gmeta[((size_t(b) * 4 + size_t(w)) * 8 + size_t(gg)) * 8];
-                int f = 0;
-                for (int k = 0; k < 4; ++k) {
-                    if (k < grp_n[gi]) {
-                        const int rr = grp_rows[gi][k];
-                        for (int32_t id : rem[rr]) {
-                            sids[base + size_t(f >> 3) * 64 + size_t(gg) * 8 + size_t(f & 7)] = id;
-                            ++f;
+        // Gather units of the block (round 4).  A block whose set is cut into units (fuse_unit) or whose remainder
+        // exceeds fuse_rows entries is SPLIT: its matrix-core units and its gather units (each owning every n-th
+        // row of the descending remainder order) all publish raw sums, the last arriver adds and scales them.
+        // An unsplit block is one unit doing both phases, as before.
+        const int64_t unit_q0 = std::max<int64_t>(4, g->tun.fuse_unit);
+        const bool may_split = unit_q0 < (int64_t(1) << 20);
+        const int n_m = nq > 0 ? (int)std::max<int64_t>(1, (nq + unit_q0 - 1) / unit_q0) : 0;
+        int n_g = 1;
+        if (may_split) n_g = (int)std::min<int64_t>(32, std::max<int64_t>(1, (blk_rem[size_t(b)] + g->tun.fuse_rows - 1) / g->tun.fuse_rows));
+        const bool split = may_split && (n_m > 1 || n_g > 1);
+        if (!split) n_g = 1;
+        blk_ng[size_t(b)] = split ? n_g : 0;
+        for (int gu = 0; gu < n_g; ++gu) {
+            // this gather unit's rows: every n_g-th of the descending order
+            int prow[kFB], pn = 0;
+            for (int i = gu; i < nr; i += n_g) prow[pn++] = order[i];
+            // 32 lane groups x 4 rows: longest row first, to the group with the smallest total that has room
+            int grp_rows[32][4], grp_n[32];
+            int64_t grp_tot[32];
+            for (int i = 0; i < 32; ++i) { grp_n[i] = 0; grp_tot[i] = 0; }
+            for (int i = 0; i < pn; ++i) {
+                int best = -1;
+                for (int gi = 0; gi < 32; ++gi)
+                    if (grp_n[gi] < 4 && (best < 0 || grp_tot[gi] < grp_tot[best])) best = gi;
+                grp_rows[best][grp_n[best]++] = prow[i];
+                grp_tot[best] += (int64_t)rem[prow[i]].size();
+            }
+            // groups by total, dealt to the waves in turn: every wave gets the same mix
+            int gorder[32];
+            std::iota(gorder, gorder + 32, 0);
+            std::stable_sort(gorder, gorder + 32, [&](int x, int y) { return grp_tot[x] > grp_tot[y]; });
+            // where this unit's row records and streams live: gather unit 0 of a block keeps the block's own slot
+            const size_t slot = gu == 0 ? size_t(b) : size_t(nblk) + size_t(kSub) + extra_gm++;
+            if (gu > 0) {
+                blk_gmeta.resize((slot + 1) * 32 * 4 * 2, 0);
+                blk_sids.resize((slot + 1) * 4);
+            }
+            if (gu == 1) blk_gslot[size_t(b)] = (int32_t)slot;      // (gather units 1 .. of a block own consecutive slots)
+            int64_t slots_block = 0;
+            for (int w = 0; w < 4; ++w) {
+                int64_t longest = 0;
+                for (int gg = 0; gg < 8; ++gg) longest = std::max(longest, grp_tot[gorder[gg * 4 + w]]);
+                const int rounds = (int)((longest + 7) / 8);
+                std::vector<int32_t>& sids = blk_sids[slot * 4 + size_t(w)];
+                const size_t base = 0;
+                sids.assign(size_t(rounds) * 64, -1);
+                for (int gg = 0; gg < 8; ++gg) {
+                    const int gi = gorder[gg * 4 + w];
+                    int32_t* gm = &blk_gmeta[((slot * 4 + size_t(w)) * 8 + size_t(gg)) * 8];
+                    int f = 0;
+                    for (int k = 0; k < 4; ++k) {
+                        if (k < grp_n[gi]) {
+                            const int rr = grp_rows[gi][k];
+                            for (int32_t id : rem[rr]) {
+                                sids[base + size_t(f >> 3) * 64 + size_t(gg) * 8 + size_t(f & 7)] = id;
+                                ++f;
+                            }
+                            // (an empty row never ends a stream slot: no end)
+                            const uint32_t end = rem[rr].empty() ? 0xFFFFFFu : uint32_t(f);
+                            gm[2 * k] = int32_t(end << 8 | uint32_t(rr));
+                            const float sc = rowscale[size_t(lo + rr)];
+                            memcpy(&gm[2 * k + 1], &sc, 4);
+                        } else {
+                            gm[2 * k] = int32_t(0xFFFFFFFFu);
                         }
-                        // (an empty row never ends a stream slot: no end)
-                        const uint32_t end = rem[rr].empty() ? 0xFFFFFFu : uint32_t(f);
-                        gm[2 * k] = int32_t(end << 8 | uint32_t(rr));
-                        const float sc = rowscale[size_t(lo + rr)];
-                        memcpy(&gm[2 * k + 1], &sc, 4);
-                    } else {
-                        gm[2 * k] = int32_t(0xFFFFFFFFu);
                     }
                 }
+                slots_block += longest;
             }
-            slots_block += longest;
+            if (gu == 0) cost[size_t(b)] = int64_t((U + 15) / 16) * 24 + slots_block * 20 + 100;
         }
-        cost[size_t(b)] = int64_t((U + 15) / 16) * 24 + slots_block * 20 + 100;
         for (int32_t c : touched) { cnt[c] = 0; kpos[c] = -1; }
     }
     // Units (one workgroup per unit and panel).  A block whose set has more than fuse_unit quads is cut
@@ -686,7 +730,7 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
     // first gathers ... barrier -> store) would outweigh their gathers — so up to fuse_group consecutive
     // ones share a unit, their rounds one stream per wave.  Launch order by cost, heaviest first.
     const int64_t unit_q = std::max<int64_t>(4, g->tun.fuse_unit);
-    struct Unit { int32_t b0, nsub, q0, nq, k, nb; int64_t cost; };
+    struct Unit { int32_t b0, nsub, q0, nq, k, nb; int64_t cost; int32_t gslot, split; };
     std::vector<Unit> ulist;
     // (a panel should offer an XCD more workgroups than it has slots — 32 CUs x 4 — or several panels are
     // in flight at once and share its L2: with too few units the grouping is halved; N = 8192, 64 blocks:
@@ -695,24 +739,33 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
         ulist.clear();
         for (int64_t b = 0; b < nblk;) {
             const int32_t q0 = blk_quad0[size_t(b)], nqb = blk_quad0[size_t(b) + 1] - q0;
-            if (nqb > 0) {
-                const int32_t nb = (int32_t)std::max<int64_t>(1, (nqb + unit_q - 1) / unit_q);
-                for (int32_t k = 0; k < nb; ++k) {
-                    const int32_t lo = (int32_t)(int64_t(nqb) * k / nb), hi = (int32_t)(int64_t(nqb) * (k + 1) / nb);
-                    ulist.push_back({(int32_t)b, 1, q0 + lo, hi - lo, k, nb, cost[size_t(b)]});
+            if (blk_ng[size_t(b)] > 0) {
+                // a split block: matrix-core units (no rows) and gather units (no columns of the set); the slot
+                // behind the last block holds no rows at all
+                const int32_t n_m = nqb > 0 ? (int32_t)std::max<int64_t>(1, (nqb + unit_q - 1) / unit_q) : 0;
+                const int32_t n_g = blk_ng[size_t(b)], nb = n_m + n_g;
+                for (int32_t k = 0; k < n_m; ++k) {
+                    const int32_t lo = (int32_t)(int64_t(nqb) * k / n_m), hi = (int32_t)(int64_t(nqb) * (k + 1) / n_m);
+                    ulist.push_back({(int32_t)b, 1, q0 + lo, hi - lo, k, nb, cost[size_t(b)], (int32_t)nblk, 1});
                 }
+                for (int32_t k = 0; k < n_g; ++k)
+                    ulist.push_back({(int32_t)b, 1, q0, 0, n_m + k, nb, cost[size_t(b)],
+                                     k == 0 ? (int32_t)b : blk_gslot[size_t(b)] + (k - 1), 1});
+                ++b;
+            } else if (nqb > 0) {
+                ulist.push_back({(int32_t)b, 1, q0, nqb, 0, 1, cost[size_t(b)], (int32_t)b, 0});
                 ++b;
             } else {
                 // (at most kGroupEntries gathered entries per unit: blocks of an Erdos-Renyi pattern — every
                 // row its 32 entries, no set — are work enough alone; four of them in one workgroup left half
                 // of an XCD's workgroup slots empty: leg 1 +47 % at N = 32768, mean degree 32)
                 int64_t e = b + 1, c = cost[size_t(b)], entries = blk_rem[size_t(b)];
-                while (e < nblk && e - b < group && blk_quad0[size_t(e) + 1] == blk_quad0[size_t(e)] &&
+                while (e < nblk && e - b < group && blk_quad0[size_t(e) + 1] == blk_quad0[size_t(e)] && blk_ng[size_t(e)] == 0 &&
                        entries + blk_rem[size_t(e)] <= kGroupEntries) {
                     entries += blk_rem[size_t(e)];
                     c += cost[size_t(e++)];
                 }
-                ulist.push_back({(int32_t)b, (int32_t)(e - b), q0, 0, 0, 1, c});
+                ulist.push_back({(int32_t)b, (int32_t)(e - b), q0, 0, 0, 1, c, (int32_t)b, 0});
                 b = e;
             }
         }
@@ -726,7 +779,7 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
         // instead of all in front: a CU then holds matrix-core work and gather work at the same time
         // (the two phases use different pipes), not one kind after the other.  A block's units stay together.
         std::vector<Unit> heavy, light, mixed;
-        for (const Unit& u : ulist) (u.nq > 0 ? heavy : light).push_back(u);
+        for (const Unit& u : ulist) ((u.nq > 0 || u.split) ? heavy : light).push_back(u);
         const size_t span = std::max(heavy.size(), std::min(ulist.size(), ulist.size() / size_t(g->tun.fuse_order)));
         size_t hi = 0, li = 0;
         for (size_t pos = 0; pos < ulist.size(); ++pos) {
@@ -747,6 +800,8 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
         rec[5] = -1; rec[6] = -1;
         rec[7] = u.nq > 0 ? 1 : 0;
         rec[8] = u.nsub;
+        rec[29] = u.gslot;                          // where the unit's row records live (an unsplit block: its own slot)
+        rec[30] = u.split;
         if (u.nb > 1) {
             // the units of a block are neighbours in the list (same cost, ordered by k): consecutive slots
             if (u.k == 0) { rec[5] = n_pslots; rec[6] = n_cslots; }
@@ -759,7 +814,7 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
             int32_t rounds = 0;
             for (int sb = 0; sb < kSub; ++sb) {
                 if (sb < u.nsub) {
-                    const std::vector<int32_t>& bs = blk_sids[size_t(u.b0 + sb) * 4 + size_t(w)];
+                    const std::vector<int32_t>& bs = blk_sids[size_t(u.gslot + sb) * 4 + size_t(w)];
                     sids.insert(sids.end(), bs.begin(), bs.end());
                     rounds += (int32_t)(bs.size() / 64);
                 }
@@ -833,6 +888,7 @@ static int launch_fused(const simrank_graph* g, FusedArgs& a, hipStream_t st) {
     a.meta_nt = (int32_t)g->tun.fuse_meta_nt;
     a.idx_mask = (int32_t)g->tun.probe_mask;
     a.units = pl->units;
+    a.rowscale = g->rowscale;
     if (pl->n_pslots > 0 && a.n_panels > pl->cap_panels) {
         // (an operand wider than the plan was built for — not what a solver does: grow once)
         SR_HIP(hipStreamSynchronize(st));                  // an earlier launch may still use the old ones

@@ -22,7 +22,7 @@ def ops():
     o = HipOps(0)
     o.set_tuning(fuse_steps=1, fuse_min=2)   # small test graphs: a dense set however few steps it makes
     yield o
-    o.set_tuning(fuse=1, fuse_min=3, fuse_steps=8, fuse_unit=64, fuse_group=3, fuse_shards=1)
+    o.set_tuning(fuse=1, fuse_min=3, fuse_steps=8, fuse_unit=48, fuse_group=3, fuse_shards=1, fuse_rows=8192)
 
 
 @contextlib.contextmanager
@@ -31,7 +31,7 @@ def knobs(ops, **kw):
     try:
         yield
     finally:
-        ops.set_tuning(fuse=1, fuse_min=2, fuse_steps=1, fuse_unit=64, fuse_group=3, fuse_shards=1)
+        ops.set_tuning(fuse=1, fuse_min=2, fuse_steps=1, fuse_unit=48, fuse_group=3, fuse_shards=1, fuse_rows=8192)
 
 
 def put_blocked(ops, a, dtype=np.float32):
@@ -144,12 +144,37 @@ def test_fused_randomized(ops, seed):
                          avg=int(rng.integers(1, 12)))
     X = (rng.random((K, L)) ** 2).astype(np.float32)
     with knobs(ops, fuse_min=int(rng.integers(2, 6)), fuse_steps=int(rng.choice([0, 1, 3, 8])),
-               fuse_unit=int(rng.choice([4, 8, 32])), fuse_group=int(rng.integers(1, 5))):
+               fuse_unit=int(rng.choice([4, 8, 32, 1 << 20])), fuse_group=int(rng.integers(1, 5)),
+               fuse_rows=int(rng.choice([64, 300, 2000, 8192]))):
         g = ops.graph(csr)
         got = leg1(ops, g, X, M)
         steps, cov, rem = ops.fused_stats(g)
         assert cov + rem == csr.nnz
     np.testing.assert_allclose(got, (dense64(csr) @ X.astype(np.float64)).T, rtol=RTOL, atol=1e-30)
+
+
+@pytest.mark.parametrize("rows", [64, 500, 8192])
+def test_fused_gather_units(ops, rows):
+    """Round 4: a block whose remainder exceeds fuse_rows entries is cut into gather units (every n-th row of its
+    descending remainder order each) beside the matrix-core units of its set; all publish raw sums, the last arriver
+    adds them in unit order and scales the rows: same values whatever the cut, same bits launch after launch."""
+    M, K, L = 520, 3000, 130
+    csr = corner_csr(M, K, seed=11, hubs=1500, p_hub=0.3, avg=30)
+    X = np.random.default_rng(12).random((K, L)).astype(np.float32)
+    want = (dense64(csr) @ X.astype(np.float64)).T
+    with knobs(ops, fuse_rows=rows, fuse_unit=8, fuse_min=4):
+        g = ops.graph(csr)
+        first = leg1(ops, g, X, M)
+        for _ in range(3):
+            assert np.array_equal(first, leg1(ops, g, X, M))
+    np.testing.assert_allclose(first, want, rtol=RTOL, atol=1e-30)
+    with knobs(ops, fuse_unit=1 << 20, fuse_min=4):
+        whole = leg1(ops, ops.graph(csr), X, M)
+    np.testing.assert_allclose(first, whole, rtol=2e-6, atol=1e-30)
+    # without any dense set: gather units only
+    with knobs(ops, fuse_rows=rows, fuse_min=100):
+        got = leg1(ops, ops.graph(csr), X, M)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-30)
 
 
 @pytest.mark.parametrize("unit", [4, 6, 32])

@@ -106,7 +106,7 @@ static void check_fused(const simrank_graph* g, const Csr& c) {
     const int64_t nblk = (c.M + 127) / 128;
     CHECK(pl->nnz_covered + pl->r_nnz == (int64_t)c.col.size(), "fused plan loses entries");
     std::vector<std::multiset<int32_t>> got((size_t)c.M);
-    std::vector<int> seen_block((size_t)nblk, 0);
+    std::vector<int> seen_block((size_t)nblk, 0), owners((size_t)c.M, 0);
     const uint32_t* ab = reinterpret_cast<const uint32_t*>(pl->abits);
     const int32_t* gm = reinterpret_cast<const int32_t*>(pl->gmeta);
     std::map<int, int> units_of, quads_of;
@@ -114,7 +114,7 @@ static void check_fused(const simrank_graph* g, const Csr& c) {
         const int32_t* un = pl->units + size_t(u) * 32;
         const int b0 = un[0], q0 = un[1], nq = un[2], k = un[3], nb = un[4], nsub = un[8];
         CHECK(b0 >= 0 && b0 + nsub <= nblk && nsub >= 1 && nsub <= 4 && k >= 0 && k < nb, "bad unit record");
-        CHECK((nq > 0) == (un[7] != 0) && (nsub == 1 || nq == 0), "unit kinds mixed up");
+        CHECK((nq > 0) == (un[7] != 0) && (nsub == 1 || nq == 0) && (nsub == 1 || nb == 1), "unit kinds mixed up");
         CHECK((nb > 1) == (un[5] >= 0) && (nb > 1) == (un[6] >= 0), "partial slots");
         units_of[b0] += 1;
         // dense part: pattern bits -> entries
@@ -132,16 +132,21 @@ static void check_fused(const simrank_graph* g, const Csr& c) {
                             got[(size_t)row].insert(id);
                         }
                 }
-        if (k != nb - 1) continue;                            // the gather streams belong to the whole block: once
+        // gather streams: an unsplit block's unit holds them all; of a split block (round 4) every unit holds the rows
+        // recorded in ITS slot of the row records (matrix-core units: none), every row in exactly one unit
+        const int gslot = un[29], split = un[30];
+        CHECK((split != 0) == (nb > 1), "split flag of unit %d", u);
+        CHECK(gslot >= 0, "row-record slot of unit %d", u);
         for (int sb = 0; sb < nsub; ++sb) {
             const int b = b0 + sb;
-            CHECK(!seen_block[(size_t)b]++, "block %d gathered twice", b);
+            if (!split) CHECK(!seen_block[(size_t)b]++, "block %d gathered twice", b);
+            else if (k == nb - 1) ++seen_block[(size_t)b];
             for (int w = 0; w < 4; ++w) {
                 const int32_t* wm = un + 9 + w * 5;
                 const int r_lo = sb ? wm[sb] : 0, r_hi = wm[1 + sb];
                 CHECK(r_hi >= r_lo, "round counts not monotone");
                 for (int gg = 0; gg < 8; ++gg) {
-                    const int32_t* m = gm + (((size_t(b) * 4 + w) * 8) + gg) * 8;
+                    const int32_t* m = gm + (((size_t(gslot + sb) * 4 + w) * 8) + gg) * 8;
                     int f = 0;
                     bool empty_seen = false;
                     for (int kr = 0; kr < 4; ++kr) {
@@ -149,7 +154,9 @@ static void check_fused(const simrank_graph* g, const Csr& c) {
                         const int row = int(packed & 255u) == 255 ? -1 : int(packed & 255u);
                         const int end = (packed >> 8) == 0xFFFFFFu ? -1 : int(packed >> 8);
                         if (row < 0) continue;
+                        CHECK(nq == 0 || !split, "a matrix-core unit of a split block owns a row");
                         CHECK(row < 128 && b * 128 + row < c.M, "row of a lane group out of range");
+                        ++owners[size_t(b) * 128 + row];
                         float sc;
                         memcpy(&sc, &m[2 * kr + 1], 4);
                         CHECK(sc == c.scale[size_t(b) * 128 + row], "row scale");
@@ -174,6 +181,7 @@ static void check_fused(const simrank_graph* g, const Csr& c) {
             }
         }
     }
+    for (int64_t a = 0; a < c.M; ++a) CHECK(owners[(size_t)a] == 1, "row %lld owned by %d lane groups", (long long)a, owners[(size_t)a]);
     for (int64_t b = 0; b < nblk; ++b) CHECK(seen_block[(size_t)b] == 1, "block %lld not gathered", (long long)b);
     for (int64_t a = 0; a < c.M; ++a) {
         std::multiset<int32_t> want(c.col.begin() + c.rowptr[a], c.col.begin() + c.rowptr[a + 1]);
@@ -382,7 +390,8 @@ int main(int argc, char** argv) {
         simrank_set_tuning("dense_cols", it % 2 ? 16 : 64);
         simrank_set_tuning("fuse_min", 2 + it % 3);
         simrank_set_tuning("fuse_steps", (it % 4) * 3);
-        simrank_set_tuning("fuse_unit", it % 3 == 0 ? 4 : 1 << 20);
+        simrank_set_tuning("fuse_unit", it % 3 == 0 ? 4 : (it % 3 == 1 ? 64 : 1 << 20));
+        simrank_set_tuning("fuse_rows", it % 4 == 0 ? 64 : (it % 4 == 1 ? 700 : 8192));
         simrank_set_tuning("fuse_group", 1 + it % 4);
         simrank_set_tuning("fuse_order", it % 5 == 1 ? 2 : 0);
         simrank_set_tuning("fuse", it % 2 ? 2 : 1);

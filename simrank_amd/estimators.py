@@ -51,7 +51,11 @@ def _precision(dense_precision, storage_precision="f32"):
     ``fit(storage_precision=...)``: "f32" (default), or "fp16": the similarity matrices and the
     intermediate product are HELD in fp16 (f32 sums and epilogue, one rounding per stored value; one GPU,
     gather mode, symmetric iterates) — half the bytes and half the gathered lines per update, the
-    reduced-precision mode that pays on config 5; NOT within the parity bar either."""
+    reduced-precision mode that pays on config 5; NOT within the parity bar either.  In that mode the
+    convergence test is NOT the reference's `_converged` (SimRank.py:54-77): an element counts as moved only
+    when it moved by more than eps + half an fp16 spacing at its stored value, so ``converged_at`` and the
+    number of updates are not comparable with the reference's (the loop usually ends one or two updates
+    later on SimRank++ matrices, much later on matrices full of values above 1/8)."""
     if dense_precision not in _DENSE_TERMS:
         raise ValueError(f"dense_precision must be one of {sorted(_DENSE_TERMS)}, not {dense_precision!r}")
     if storage_precision not in ("f32", "fp16"):

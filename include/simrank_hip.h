@@ -331,6 +331,14 @@ SIMRANK_API int simrank_spmm_blocked_h16(const simrank_graph* g, const void* X, 
 SIMRANK_API int simrank_widen_blocked_h16(const void* src, int64_t src_rows_pad, float* dst,
                                           int64_t dst_rows_pad, int64_t n_rows, int64_t n_cols,
                                           float scale, void* stream);
+/* Flat conversions f32 <-> fp16 (value x scale, nearest even, saturating at fp16's largest finite value): the WIRE
+ * format of a sharded update's exchange buffers — the transposed product of SimRank.py:139's first `.dot` on its way to
+ * the rank that needs it, and the mirrored tiles of the second — when the caller trades precision for link bytes
+ * (driver: TorchWorld(exchange_precision="fp16"); the kernels on both sides stay f32; outside the 1e-5 parity bar,
+ * never the default).  n elements (16 bytes per lane where both operands are 16-byte aligned), scale a power of two in
+ * 1 .. 32768. */
+SIMRANK_API int simrank_narrow_h16(const float* src_device, void* dst_device_fp16, int64_t n, float scale, void* stream);
+SIMRANK_API int simrank_widen_h16(const void* src_device_fp16, float* dst_device, int64_t n, float scale, void* stream);
 
 /* ---- dense MFMA path (second `.dot(G.T)` of SimRank.py:139 when W really is dense) -- */
 /* Wd[a*ld + i] = rowscale[a] where (a,i) is stored, 0 elsewhere */

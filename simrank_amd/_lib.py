@@ -97,6 +97,8 @@ PROTOTYPES = {
     "simrank_fill_identity_blocked_h16": [_vp, _i64, _i64, _i64, _i64, C.c_float, _vp],
     "simrank_spmm_blocked_h16": [_vp, _vp, _i64, _i64, _vp, _i64, _i32, C.POINTER(Epilogue), _i64, C.c_float, _vp],
     "simrank_widen_blocked_h16": [_vp, _i64, _vp, _i64, _i64, _i64, C.c_float, _vp],
+    "simrank_narrow_h16": [_vp, _vp, _i64, C.c_float, _vp],
+    "simrank_widen_h16": [_vp, _vp, _i64, C.c_float, _vp],
     "simrank_epilogue_apply_blocked": [_vp, _vp, _i64, _i64, _i64, C.POINTER(Epilogue), _vp],
     "simrank_topk_rows_blocked": [_vp, _i64, _i64, _i64, _i64, _vp, _i32, _i32, _vp, _vp, _vp],
     "simrank_evidence_counts_blocked": [_vp, _i64, _i64, _vp, _i64, _vp],

@@ -602,6 +602,36 @@ __global__ __launch_bounds__(256) void half_widen_kernel(const uint16_t* __restr
         d[1] = make_float4(o[4] * inv_scale, o[5] * inv_scale, o[6] * inv_scale, o[7] * inv_scale);
     }
 }
+// flat conversions, 8 elements per thread (the tail element by element); saturating: a value beyond fp16's range
+// becomes the largest finite fp16, not an infinity the receiver would turn into NaN behind a zero evidence factor
+__global__ __launch_bounds__(256) void flat_narrow_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst,
+                                                          int64_t n, float scale, int vec) {
+    const int64_t n8 = vec ? n >> 3 : 0;
+    auto cv = [scale](float v) { return fminf(fmaxf(v * scale, -65504.f), 65504.f); };
+    for (int64_t t = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; t < n8; t += int64_t(gridDim.x) * blockDim.x) {
+        const float4 a = reinterpret_cast<const float4*>(src)[2 * t], b = reinterpret_cast<const float4*>(src)[2 * t + 1];
+        v4u o;
+        o.x = pack2(cv(a.x), cv(a.y)); o.y = pack2(cv(a.z), cv(a.w));
+        o.z = pack2(cv(b.x), cv(b.y)); o.w = pack2(cv(b.z), cv(b.w));
+        reinterpret_cast<v4u*>(dst)[t] = o;
+    }
+    for (int64_t i = 8 * n8 + blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+        dst[i] = __builtin_bit_cast(uint16_t, _Float16(cv(src[i])));
+}
+
+__global__ __launch_bounds__(256) void flat_widen_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst,
+                                                         int64_t n, float inv_scale, int vec) {
+    const int64_t n8 = vec ? n >> 3 : 0;
+    for (int64_t t = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; t < n8; t += int64_t(gridDim.x) * blockDim.x) {
+        const v4u v = reinterpret_cast<const v4u*>(src)[t];
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        add8(o, v);
+        reinterpret_cast<float4*>(dst)[2 * t] = make_float4(o[0] * inv_scale, o[1] * inv_scale, o[2] * inv_scale, o[3] * inv_scale);
+        reinterpret_cast<float4*>(dst)[2 * t + 1] = make_float4(o[4] * inv_scale, o[5] * inv_scale, o[6] * inv_scale, o[7] * inv_scale);
+    }
+    for (int64_t i = 8 * n8 + blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+        dst[i] = half_bits_to_float(src[i]) * inv_scale;
+}
 #endif  // SIMRANK_HOST_ONLY
 
 }  // namespace simrank
@@ -642,6 +672,39 @@ int simrank_widen_blocked_h16(const void* src, int64_t src_rows_pad, float* dst,
     const int grid = (int)std::min<int64_t>((total + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(half_widen_kernel, dim3(grid), dim3(256), 0, as_stream(stream), (const uint16_t*)src,
                        src_rows_pad, dst, dst_rows_pad, n_rows, p64, p32, 1.0f / scale);
+#endif
+    SR_HIP(hipGetLastError());
+    return SIMRANK_OK;
+}
+
+// Flat f32 <-> fp16 conversions (value x scale, round to nearest even, saturating): the WIRE format of a sharded
+// update's exchange buffers (driver: exchange_precision = "fp16") — the kernels on both sides stay f32.
+int simrank_narrow_h16(const float* src, void* dst, int64_t n, float scale, void* stream) {
+    SR_REQUIRE(power_of_two_scale(scale), "scale must be a power of two in 1 .. 32768");
+    SR_REQUIRE(n >= 0 && (n == 0 || (src && dst)), "bad arguments");
+    SR_REQUIRE(reinterpret_cast<uintptr_t>(src) % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 2 == 0, "misaligned operands");
+#ifndef SIMRANK_HOST_ONLY
+    if (n > 0) {
+        const int vec = aligned16(src) && aligned16(dst);        // (16 bytes per lane where both sides allow it)
+        const int grid = (int)std::min<int64_t>(((n + 7) / 8 + 255) / 256, 256 * 32);
+        hipLaunchKernelGGL(flat_narrow_kernel, dim3(grid), dim3(256), 0, as_stream(stream), src, (uint16_t*)dst, n, scale, vec);
+    }
+#endif
+    SR_HIP(hipGetLastError());
+    return SIMRANK_OK;
+}
+
+int simrank_widen_h16(const void* src, float* dst, int64_t n, float scale, void* stream) {
+    SR_REQUIRE(power_of_two_scale(scale), "scale must be a power of two in 1 .. 32768");
+    SR_REQUIRE(n >= 0 && (n == 0 || (src && dst)), "bad arguments");
+    SR_REQUIRE(reinterpret_cast<uintptr_t>(src) % 2 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0, "misaligned operands");
+#ifndef SIMRANK_HOST_ONLY
+    if (n > 0) {
+        const int vec = aligned16(src) && aligned16(dst);
+        const int grid = (int)std::min<int64_t>(((n + 7) / 8 + 255) / 256, 256 * 32);
+        hipLaunchKernelGGL(flat_widen_kernel, dim3(grid), dim3(256), 0, as_stream(stream), (const uint16_t*)src, dst, n,
+                           1.0f / scale, vec);
+    }
 #endif
     SR_HIP(hipGetLastError());
     return SIMRANK_OK;

@@ -61,6 +61,32 @@ class Xfer:
                                 # in_splits, out_splits, event); None = one all-to-all
     send_t: object = None      # torch views of send / recv (TorchWorld)
     recv_t: object = None
+    wire: object = None        # fp16 shadows of the two (exchange_precision="fp16")
+
+
+class Wire:
+    """fp16 shadows of one pair of exchange buffers (``exchange_precision="fp16"``): what the kernels wrote in f32 is
+    narrowed (value x 2^14, nearest even, saturating) into ``send_h`` right before a collective moves it, and what
+    arrives in ``recv_h`` is widened into the f32 buffer the next leg reads.  Half the bytes on the links; the
+    transposed product (and the mirrored tiles of the half form) take one fp16 rounding per update — outside the
+    1e-5 parity bar, never the default."""
+
+    def __init__(self, ops, send_t, recv_t):
+        self.ops, self.send_t, self.recv_t = ops, send_t, recv_t
+        self.send_h = ops.exchange_buffer_h(send_t.numel())
+        self.recv_h = ops.exchange_buffer_h(recv_t.numel())
+
+    def pack(self, off, n):
+        self.ops.narrow_t(self.send_t, self.send_h, off, n)
+
+    def unpack(self, off, n):
+        self.ops.widen_t(self.recv_h, self.recv_t, off, n)
+
+
+def _wire_view(t):
+    """fp16 tensors travel as bytes (every backend moves those; split sizes double)."""
+    import torch
+    return t.view(torch.uint8)
 
 
 def row_pad(block_rows: int) -> int:
@@ -128,11 +154,17 @@ def permute_columns(csr: CSR, perm: np.ndarray) -> CSR:
 class LocalWorld:
     """P virtual ranks inside this process (P = 1 is the ordinary single-GPU case)."""
 
-    def __init__(self, size: int = 1, symmetric_shards: bool = True, leg2_stages: int = 1):
+    def __init__(self, size: int = 1, symmetric_shards: bool = True, leg2_stages: int = 1,
+                 exchange_precision: str = "f32"):
         """``symmetric_shards``: sharded symmetric updates run leg 2 in its half form when the node
         count allows it (``Side.shard_sym``); False keeps the full form, whose results are bit-equal
         to a single rank's full form.  ``leg2_stages``: the half-form leg 2 (and its exchange) cut into
-        that many stages of column tiles, as ``TorchWorld`` does to overlap the second all-to-all."""
+        that many stages of column tiles, as ``TorchWorld`` does to overlap the second all-to-all.
+        ``exchange_precision``: "fp16" rounds what the virtual ranks hand each other the way ``TorchWorld``'s fp16
+        wire format does (no bytes to save here: this is how that mode's arithmetic is tested on one GPU)."""
+        if exchange_precision not in ("f32", "fp16"):
+            raise ValueError("exchange_precision must be 'f32' or 'fp16'")
+        self.exchange_precision = exchange_precision
         self.size = int(size)
         self.local_ranks = list(range(self.size))
         self.is_root = True
@@ -144,6 +176,9 @@ class LocalWorld:
         """All-to-all of the transposed tiles between the virtual ranks (device copies)."""
         if self.size == 1:
             return                               # recv aliases send
+        if self.exchange_precision == "fp16":
+            for src in parts:
+                src.ops.round_trip_h16(src.send, self.size * src.ncols * (src.mb + src.pad))
         for src in parts:
             for dst in parts:
                 w = dst.nrows + src.pad          # padded row of a chunk
@@ -155,6 +190,9 @@ class LocalWorld:
     def exchange_mirrors(self, sides):
         """All-to-all of the packed mirrored tiles of a half-form leg 2 (equal chunks; stage by stage when
         the leg was cut: a stage's range of every chunk sits together, ``Side.sh_stages``)."""
+        if self.exchange_precision == "fp16":
+            for sd in sides:
+                sd.ops.round_trip_h16(sd.sh_send, self.size * sd.sh_chunk)
         for st in sides[0].sh_stages or [dict(off=0, chunk=sides[0].sh_chunk)]:
             n = 4 * st["chunk"]
             for src in sides:
@@ -184,7 +222,8 @@ class TorchWorld:
     GPU box; "gloo" in the CPU tests)."""
 
     def __init__(self, group=None, stages: int = 0, stage_single_rank: bool = False,
-                 handback: str = "root", symmetric_shards="auto", measure_single_rank: bool = False):
+                 handback: str = "root", symmetric_shards="auto", measure_single_rank: bool = False,
+                 exchange_precision: str = "f32"):
         """``stages``: leg 1 is cut into that many column slices, each exchanged by its own
         all_to_all_single as soon as its kernel has finished, so the transfers over xGMI overlap
         the remaining leg-1 kernels (1 = one exchange after the whole leg; 0 = by the width of a
@@ -203,6 +242,13 @@ class TorchWorld:
         import torch.distributed as dist
         if handback not in ("root", "all"):
             raise ValueError("handback must be 'root' or 'all'")
+        if exchange_precision not in ("f32", "fp16"):
+            raise ValueError("exchange_precision must be 'f32' or 'fp16'")
+        # "fp16": both all-to-alls move fp16 (value x 2^14) instead of f32 — HALF the bytes on the xGMI links, where
+        # the exchanges, not the kernels, set the pace of a sharded update from N = 65536 on; the
+        # kernels on both sides stay f32, the transposed product takes one fp16 rounding per update: outside the
+        # 1e-5 parity bar, never the default (BASELINE config 5's "reduced precision" on the links)
+        self.exchange_precision = exchange_precision
         self.handback = handback
         self.dist = dist
         self.group = group
@@ -232,6 +278,21 @@ class TorchWorld:
             return False
         return self.dist.get_backend(self.group) == "nccl"
 
+    def _a2a(self, wire, recv_t, send_t, roff, rn, soff, sn, out_splits=None, in_splits=None, async_op=False):
+        """all_to_all_single of send_t[soff:soff+sn] into recv_t[roff:roff+rn], through the fp16 wire buffers when
+        there are any.  -> (work or None, what to run once the data has arrived)."""
+        if wire is None:
+            w = self.dist.all_to_all_single(recv_t[roff:roff + rn], send_t[soff:soff + sn], out_splits, in_splits,
+                                            group=self.group, async_op=async_op)
+            return w, None
+        wire.pack(soff, sn)
+        if not self.stream_ordered:
+            wire.ops.synchronize()                # (the collective reads the fp16 buffer from another stream / the host)
+        twice = lambda v: None if v is None else [2 * int(e) for e in v]
+        w = self.dist.all_to_all_single(_wire_view(wire.recv_h[roff:roff + rn]), _wire_view(wire.send_h[soff:soff + sn]),
+                                        twice(out_splits), twice(in_splits), group=self.group, async_op=async_op)
+        return w, (lambda: wire.unpack(roff, rn))
+
     def begin_stage(self, x, st):
         """Stream-ordered pipeline: called right after the kernels of one stage of leg 1 were
         queued.  The all-to-all of that stage is issued at once; RCCL's stream waits for what is
@@ -240,10 +301,9 @@ class TorchWorld:
         # every rank joins every stage's collective, also with all-zero splits (a rank that owns an
         # empty block at small N): skipping it on local data would leave the peers waiting
         with torch.cuda.stream(x.ops.torch_stream()):
-            st["work"] = self.dist.all_to_all_single(
-                x.recv_t[st["recv_off"]:st["recv_off"] + sum(st["out_splits"])],
-                x.send_t[st["send_off"]:st["send_off"] + sum(st["in_splits"])],
-                st["out_splits"], st["in_splits"], group=self.group, async_op=True)
+            st["work"], st["post"] = self._a2a(x.wire, x.recv_t, x.send_t, st["recv_off"], sum(st["out_splits"]),
+                                               st["send_off"], sum(st["in_splits"]), st["out_splits"], st["in_splits"],
+                                               async_op=True)
 
     def exchange(self, parts):
         (x,) = parts
@@ -253,35 +313,41 @@ class TorchWorld:
                 if x.stages is not None:
                     for st in x.stages:               # issued by begin_stage during leg 1
                         w = st.pop("work", None)
+                        post = st.pop("post", None)
                         if w is not None:
                             w.wait()                  # the engine's stream waits, not the host
+                        if post is not None:
+                            post()
                     return
                 span = lambda n, h: partition(n, self.size, h)[1] - partition(n, self.size, h)[0]
                 in_splits = [x.ncols * (span(x.row_dim, h) + x.pad) for h in range(self.size)]
                 out_splits = [span(x.col_dim, h) * (x.nrows + x.pad) for h in range(self.size)]
-                self.dist.all_to_all_single(x.recv_t[:sum(out_splits)], x.send_t[:sum(in_splits)],
-                                            out_splits, in_splits, group=self.group)
+                _, post = self._a2a(x.wire, x.recv_t, x.send_t, 0, sum(out_splits), 0, sum(in_splits), out_splits, in_splits)
+                if post is not None:
+                    post()
             return
         if x.stages is not None:
             works = []
             for st in x.stages:
                 x.ops.event_synchronize(st["event"])      # this slice's kernel has finished
                 # (zero-size splits are legal; every rank must issue every stage's collective)
-                works.append(self.dist.all_to_all_single(
-                    x.recv_t[st["recv_off"]:st["recv_off"] + sum(st["out_splits"])],
-                    x.send_t[st["send_off"]:st["send_off"] + sum(st["in_splits"])],
-                    st["out_splits"], st["in_splits"], group=self.group, async_op=True))
-            for w in works:
+                works.append(self._a2a(x.wire, x.recv_t, x.send_t, st["recv_off"], sum(st["out_splits"]), st["send_off"],
+                                       sum(st["in_splits"]), st["out_splits"], st["in_splits"], async_op=True))
+            for w, _ in works:
                 w.wait()
             x.ops.collective_done()
+            for _, post in works:
+                if post is not None:
+                    post()
             return
         x.ops.synchronize()                      # the producing leg finished on the engine's stream
         span = lambda n, h: partition(n, self.size, h)[1] - partition(n, self.size, h)[0]
         in_splits = [x.ncols * (span(x.row_dim, h) + x.pad) for h in range(self.size)]
         out_splits = [span(x.col_dim, h) * (x.nrows + x.pad) for h in range(self.size)]
-        self.dist.all_to_all_single(x.recv_t[:sum(out_splits)], x.send_t[:sum(in_splits)],
-                                    out_splits, in_splits, group=self.group)
+        _, post = self._a2a(x.wire, x.recv_t, x.send_t, 0, sum(out_splits), 0, sum(in_splits), out_splits, in_splits)
         x.ops.collective_done()
+        if post is not None:
+            post()
 
     def begin_mirror_stage(self, sd, st):
         """Stream-ordered pipeline of exchange 2: called right after the kernel of one stage of the half-form
@@ -289,9 +355,8 @@ class TorchWorld:
         import torch
         n = self.size * st["chunk"]
         with torch.cuda.stream(sd.ops.torch_stream()):
-            st["work"] = self.dist.all_to_all_single(sd.sh_recv_t[st["off"]:st["off"] + n],
-                                                     sd.sh_send_t[st["off"]:st["off"] + n],
-                                                     group=self.group, async_op=True)
+            st["work"], st["post"] = self._a2a(sd.sh_wire, sd.sh_recv_t, sd.sh_send_t, st["off"], n, st["off"], n,
+                                               async_op=True)
 
     def exchange_mirrors(self, sides):
         """All-to-all of the packed mirrored tiles of a half-form leg 2: equal chunks, the one a
@@ -304,26 +369,34 @@ class TorchWorld:
             import torch
             with torch.cuda.stream(sd.ops.torch_stream()):
                 if stages is None:
-                    self.dist.all_to_all_single(sd.sh_recv_t, sd.sh_send_t, group=self.group)
+                    _, post = self._a2a(sd.sh_wire, sd.sh_recv_t, sd.sh_send_t, 0, sd.sh_recv_t.numel(), 0,
+                                        sd.sh_send_t.numel())
+                    if post is not None:
+                        post()
                     return
                 for st in stages:
-                    w = st.pop("work", None)
+                    w, post = st.pop("work", None), st.pop("post", None)
                     if w is None:                      # (not issued during the leg)
                         n = self.size * st["chunk"]
-                        w = self.dist.all_to_all_single(sd.sh_recv_t[st["off"]:st["off"] + n],
-                                                        sd.sh_send_t[st["off"]:st["off"] + n],
-                                                        group=self.group, async_op=True)
+                        w, post = self._a2a(sd.sh_wire, sd.sh_recv_t, sd.sh_send_t, st["off"], n, st["off"], n,
+                                            async_op=True)
                     w.wait()                           # the engine's stream waits, not the host
+                    if post is not None:
+                        post()
             return
         sd.ops.synchronize()
+        posts = []
         if stages is None:
-            self.dist.all_to_all_single(sd.sh_recv_t, sd.sh_send_t, group=self.group)
+            posts.append(self._a2a(sd.sh_wire, sd.sh_recv_t, sd.sh_send_t, 0, sd.sh_recv_t.numel(), 0,
+                                   sd.sh_send_t.numel())[1])
         else:
             for st in stages:
                 n = self.size * st["chunk"]
-                self.dist.all_to_all_single(sd.sh_recv_t[st["off"]:st["off"] + n],
-                                            sd.sh_send_t[st["off"]:st["off"] + n], group=self.group)
+                posts.append(self._a2a(sd.sh_wire, sd.sh_recv_t, sd.sh_send_t, st["off"], n, st["off"], n)[1])
         sd.ops.collective_done()
+        for post in posts:
+            if post is not None:
+                post()
 
     def sum_changed(self, ops, active=True):
         """Global convergence count of the update just queued, stream-ordered: the striped
@@ -425,8 +498,11 @@ class SideSpec:
 
 class Side:
     def __init__(self, ops, spec: SideSpec, rank: int, world: int, mode: str, torch_buffers: bool,
-                 stages: int = 1, blocked: bool = False, shard_symmetric: bool = True, leg2_stages: int = 1):
+                 stages: int = 1, blocked: bool = False, shard_symmetric: bool = True, leg2_stages: int = 1,
+                 wire_fp16: bool = False):
         self.ops, self.spec, self.rank, self.world, self.mode = ops, spec, rank, world, mode
+        self.wire_fp16 = bool(wire_fp16) and torch_buffers       # fp16 shadows of the exchange buffers (TorchWorld)
+        self.sh_wire = None
         self.blocked = blocked         # single rank, gather legs: every matrix panel-blocked
         self.sdtype = np.float16 if spec.storage == "fp16" else np.float32    # S and the transposed product
         csr = spec.csr
@@ -489,6 +565,8 @@ class Side:
                 self.sh_recv_t = ops.exchange_buffer(world * self.sh_chunk)
                 self.sh_send = ops.matrix(world, self.sh_chunk, ld=self.sh_chunk, external=self.sh_send_t)
                 self.sh_recv = ops.matrix(world, self.sh_chunk, ld=self.sh_chunk, external=self.sh_recv_t)
+                if self.wire_fp16:
+                    self.sh_wire = Wire(ops, self.sh_send_t, self.sh_recv_t)
             else:
                 self.sh_send = ops.matrix(world, self.sh_chunk, ld=self.sh_chunk)
                 self.sh_recv = ops.matrix(world, self.sh_chunk, ld=self.sh_chunk)
@@ -561,6 +639,8 @@ class Side:
             x.recv_t = o.exchange_buffer(col_dim * recv_ld)
             x.send = o.matrix(max(1, ncols), send_ld, ld=send_ld, external=x.send_t)
             x.recv = o.matrix(col_dim, self.Lm, ld=recv_ld, external=x.recv_t)
+            if self.wire_fp16:
+                x.wire = Wire(o, x.send_t, x.recv_t)
         else:
             x.send = o.matrix(max(1, ncols), send_ld, ld=send_ld)
             x.recv = o.matrix(col_dim, self.Lm, ld=recv_ld)
@@ -841,7 +921,8 @@ class Solver:
         self.sdtype = np.float16 if self.storage == "fp16" else np.float32
         self.sides = [{r: Side(self.ops[r], sp, r, world.size, self.mode, torch_buffers,
                                getattr(world, "stages", 1), self.blocked,
-                               getattr(world, "symmetric_shards", True), getattr(world, "leg2_stages", 1))
+                               getattr(world, "symmetric_shards", True), getattr(world, "leg2_stages", 1),
+                               getattr(world, "exchange_precision", "f32") == "fp16")
                        for r in world.local_ranks} for sp in specs]
         # similarity matrices: index j -> size n_j; S_j is n_j x (block of n_j), ping-pong
         if self.bipartite:

@@ -301,6 +301,37 @@ class HipOps:
         import torch
         return torch.empty(max(1, n_floats), dtype=torch.float32, device=f"cuda:{self.device}")
 
+    def exchange_buffer_h(self, n: int):
+        """Flat float16 buffer: the wire format of an exchange (driver: exchange_precision="fp16")."""
+        import torch
+        return torch.empty(max(8, n), dtype=torch.float16, device=f"cuda:{self.device}")
+
+    WIRE_SCALE = 16384.0        # what values on the wire are multiplied by (as fp16-held matrices: similarities of a
+                                # large sparse graph lie mostly below fp16's normal range)
+
+    def narrow_t(self, src_t, dst_t, off: int, n: int):
+        """dst_t[off:off+n] (float16 tensor) = src_t[off:off+n] (float32 tensor) x WIRE_SCALE, on the engine's stream."""
+        if n:
+            check(self.lib.simrank_narrow_h16(C.c_void_p(src_t.data_ptr() + 4 * off), C.c_void_p(dst_t.data_ptr() + 2 * off),
+                                              int(n), C.c_float(self.WIRE_SCALE), self.stream), "simrank_narrow_h16")
+
+    def widen_t(self, src_t, dst_t, off: int, n: int):
+        """dst_t[off:off+n] (float32) = src_t[off:off+n] (float16) / WIRE_SCALE, on the engine's stream."""
+        if n:
+            check(self.lib.simrank_widen_h16(C.c_void_p(src_t.data_ptr() + 2 * off), C.c_void_p(dst_t.data_ptr() + 4 * off),
+                                             int(n), C.c_float(self.WIRE_SCALE), self.stream), "simrank_widen_h16")
+
+    def round_trip_h16(self, m: "Matrix", n: int):
+        """The first n floats of ``m`` as they would arrive over an fp16 wire (virtual ranks: no wire to save bytes on)."""
+        if n:
+            tmp = self._malloc(2 * n + 16)
+            check(self.lib.simrank_narrow_h16(C.c_void_p(m.ptr), C.c_void_p(tmp), int(n), C.c_float(self.WIRE_SCALE),
+                                              self.stream), "simrank_narrow_h16")
+            check(self.lib.simrank_widen_h16(C.c_void_p(tmp), C.c_void_p(m.ptr), int(n), C.c_float(self.WIRE_SCALE),
+                                             self.stream), "simrank_widen_h16")
+            self.lib.simrank_stream_synchronize(self.stream)
+            self._free(tmp)
+
     def copy_bytes(self, dst_ptr: int, src_ptr: int, nbytes: int):
         if nbytes:
             check(self.lib.simrank_memcpy_d2d(C.c_void_p(dst_ptr), C.c_void_p(src_ptr), nbytes,

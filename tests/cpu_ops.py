@@ -66,6 +66,23 @@ class NumpyOps:
         import torch
         return torch.full((max(1, n_floats),), 7.0, dtype=torch.float32)
 
+    WIRE_SCALE = 16384.0
+
+    def exchange_buffer_h(self, n):
+        import torch
+        return torch.full((max(8, n),), 3.0, dtype=torch.float16)
+
+    def narrow_t(self, src_t, dst_t, off, n):
+        v = np.clip(src_t.numpy()[off:off + n].astype(np.float64) * self.WIRE_SCALE, -65504.0, 65504.0)
+        dst_t.numpy()[off:off + n] = v.astype(np.float16)
+
+    def widen_t(self, src_t, dst_t, off, n):
+        dst_t.numpy()[off:off + n] = (src_t.numpy()[off:off + n].astype(np.float32) / np.float32(self.WIRE_SCALE))
+
+    def round_trip_h16(self, m, n):
+        v = np.clip(m.flat[:n].astype(np.float64) * self.WIRE_SCALE, -65504.0, 65504.0).astype(np.float16)
+        m.flat[:n] = v.astype(np.float32) / np.float32(self.WIRE_SCALE)
+
     def _locate(self, ptr):
         base = ptr & ~((1 << 40) - 1)
         return self._buffers[base], ptr - base

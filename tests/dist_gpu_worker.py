@@ -61,6 +61,23 @@ def main():
                                                        symmetric_shards="force"))
             assert all(sd.shard_sym for sd in made[-1].sides[0].values())
             np.testing.assert_allclose(got.values, want.values, rtol=2e-6, atol=1e-30)
+        # the fp16 wire (exchange_precision="fp16"): simrank_narrow_h16 -> all_to_all_single of the fp16 bytes ->
+        # simrank_widen_h16, all on the engine's stream; same roundings as the in-process emulation of that wire
+        P = dist.get_world_size()
+        for stages, form in ((1, "force"), (2, "force"), (2, False)):
+            emu = SRA.SimRankPP().fit(df, iterations=4, eps=0, verbose=False, mode="sparse",
+                                      world=LocalWorld(P, symmetric_shards=bool(form), exchange_precision="fp16"))
+            got = SRA.SimRankPP().fit(df, iterations=4, eps=0, verbose=False, mode="sparse",
+                                      world=TorchWorld(stages=stages, stage_single_rank=True, handback="all",
+                                                       symmetric_shards=form, exchange_precision="fp16"))
+            assert made[-1].sides[0][rank].x1.wire is not None
+            big = want.values > 1e-6
+            rel = np.abs(got.values - want.values)[big] / want.values[big]
+            assert rel.max() < 4e-3, rel.max()
+            if P > 1 or stages > 1:             # (one rank, one stage: the rank's buffers alias, nothing travels)
+                assert rel.max() > 1e-7, rel.max()
+            if P > 1:                           # (the emulation of one rank has no wire either)
+                np.testing.assert_allclose(got.values, emu.values, rtol=1e-5, atol=1e-9)
     finally:
         drv.Solver.__init__ = orig
     # the measured choice between the two forms of leg 2 (driver.resolve_shard_form): both solvers, the barriers

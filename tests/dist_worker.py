@@ -41,6 +41,36 @@ def main(argv):
         assert any(c[0] == "spmm_shard" for c in ops.calls) and any(c[0] == "shard_unpack" for c in ops.calls)
         assert list(got.index) == list(want.index)
         np.testing.assert_allclose(got.values, want.values, rtol=2e-5, atol=1e-30)
+    for name in [n for n in names if n.startswith("wire:")]:
+        # exchange_precision="fp16": both all-to-alls (exchange 1 staged or not, the mirrors of the half form) move
+        # fp16 values (as bytes); the result is the f32 wire's to a few fp16 roundings, and it is what LocalWorld's emulation
+        # of the same wire gives (same roundings of the same values)
+        import simrank_amd.SimRank as SRA
+        from simrank_amd import synth
+        from simrank_amd.driver import LocalWorld
+        cls = name.split(":")[1]
+        P = dist.get_world_size()
+        frame = synth.powerlaw_directed((256 if stages > 1 else 64) * P, 5, 3)
+        kw = dict(weighted=True) if cls.endswith("PP") else {}
+        for half in (True, False):
+            one = NumpyOps()
+            exact = getattr(SRA, cls)().fit(frame, verbose=False, world=LocalWorld(1), mode="sparse", iterations=6, eps=0,
+                                            _ops_factory=lambda r: one, **kw)
+            emu_ops = NumpyOps()
+            emu = getattr(SRA, cls)().fit(frame, verbose=False, mode="sparse", iterations=6, eps=0,
+                                          world=LocalWorld(P, symmetric_shards=half, exchange_precision="fp16"),
+                                          _ops_factory=lambda r: emu_ops, **kw)
+            ops = NumpyOps()
+            got = getattr(SRA, cls)().fit(frame, verbose=False, mode="sparse", iterations=6, eps=0,
+                                          _ops_factory=lambda r: ops,
+                                          world=TorchWorld(stages=stages, handback="all", symmetric_shards=half,
+                                                           exchange_precision="fp16"), **kw)
+            assert list(got.index) == list(exact.index)
+            big = exact.values > 1e-6
+            rel = np.abs(got.values - exact.values)[big] / exact.values[big]
+            assert 1e-7 < rel.max() < 4e-3, rel.max()          # really rounded, and only by a few fp16 roundings
+            if stages == 1:
+                np.testing.assert_allclose(got.values, emu.values, rtol=1e-6, atol=1e-12)
     for name in [n for n in names if n.startswith("auto:")]:
         # TorchWorld(symmetric_shards="auto") with the measurement forced on a small graph: both forms are
         # timed, every rank adopts the same one, the result is the one-rank result either way
@@ -62,7 +92,7 @@ def main(argv):
         assert len(set(votes)) == 1, votes                   # same numbers, same decision on every rank
         np.testing.assert_allclose(got.values, want.values, rtol=2e-5, atol=1e-30)
         drv.MEASURE_FORM_FROM_N = 4096
-    names = [n for n in names if not n.startswith("half:") and not n.startswith("auto:")]
+    names = [n for n in names if not n.startswith("half:") and not n.startswith("auto:") and not n.startswith("wire:")]
     for name in names:
         g = Golden(name)
         ops = NumpyOps()

@@ -77,3 +77,19 @@ def test_shard_form_is_measured_and_agreed_over_gloo():
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     for r in range(2):
         assert f"RANK {r} ok" in p.stdout
+
+
+@pytest.mark.parametrize("world,stages", [(2, 1), (3, 2)])
+def test_fp16_wire_over_gloo(world, stages):
+    """TorchWorld(exchange_precision="fp16"): the exchange buffers travel as fp16 (half the link bytes), the kernels
+    stay f32 — full and half form, staged and not; the result is the f32 wire's to a few fp16 roundings and equals
+    LocalWorld's emulation of the same wire."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"),
+           str(stages), "wire:SimRank", "wire:SimRankPP"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    for r in range(world):
+        assert f"RANK {r} ok" in p.stdout

@@ -340,3 +340,79 @@ def test_graph_without_entries_on_half_storage(ops):
     ops.spmm(g, yt, y, epilogue=dict(coef=0.8, previous=x, eps=1e-4, set_diag=True, symmetric=True))
     assert np.array_equal(ops.download(y), np.eye(n, dtype=np.float32))
     assert ops.read_changed() > 0
+
+
+# ---- the fp16 WIRE format of the sharded exchanges (f32 kernels, fp16 on the links) ----
+
+def test_wire_narrow_widen_bits(ops):
+    """simrank_narrow_h16 / simrank_widen_h16: value x 2^14, nearest even, saturating at the largest finite fp16;
+    bit-equal to NumPy's float16 conversion of the same scaled floats — at aligned and unaligned offsets, with
+    tails shorter than a vector.  (Raw device pointers: torch's own HIP runtime is not brought up inside this
+    process — the torch-tensor wrappers HipOps.narrow_t / widen_t make the same two calls.)"""
+    import ctypes as C
+    from simrank_amd._lib import check
+    lib, st = ops.lib, ops.stream
+    rng = np.random.default_rng(5)
+    n = 100_003
+    a = (rng.random(n) ** 6).astype(np.float32)            # most values far below 1, as similarities are
+    a[:8] = [0.0, 1.0, 3.99, 4.5, 2.0 ** -39, 2.0 ** -40, 65504.0 / 16384 + 1e-3, 1e30]
+    scaled = np.clip(a.astype(np.float64) * 16384.0, -65504.0, 65504.0).astype(np.float32)
+    want = scaled.astype(np.float16)
+    assert np.isfinite(want.astype(np.float32)).all()       # saturated, never an infinity
+    src, dst, back = ops._malloc(4 * n), ops._malloc(2 * n), ops._malloc(4 * n)
+    scale = C.c_float(16384.0)
+    try:
+        check(lib.simrank_memcpy_h2d(src, a.ctypes.data, a.nbytes, st), "h2d")
+        for off, cnt in ((0, n), (3, 77), (8, 4096), (5, n - 5), (16, 7)):
+            check(lib.simrank_memset(C.c_void_p(dst), 0, 2 * n, st), "memset")
+            check(lib.simrank_narrow_h16(C.c_void_p(src + 4 * off), C.c_void_p(dst + 2 * off), cnt, scale, st), "narrow")
+            got = np.empty(n, dtype=np.uint16)
+            check(lib.simrank_memcpy_d2h(got.ctypes.data, dst, got.nbytes, st), "d2h")
+            assert np.array_equal(got[off:off + cnt], want[off:off + cnt].view(np.uint16)), (off, cnt)
+            assert not got[:off].any() and not got[off + cnt:].any()
+            check(lib.simrank_memset(C.c_void_p(back), 0xFF, 4 * n, st), "memset")
+            check(lib.simrank_widen_h16(C.c_void_p(dst + 2 * off), C.c_void_p(back + 4 * off), cnt, scale, st), "widen")
+            b = np.empty(n, dtype=np.float32)
+            check(lib.simrank_memcpy_d2h(b.ctypes.data, back, b.nbytes, st), "d2h")
+            assert np.array_equal(b[off:off + cnt], want[off:off + cnt].astype(np.float32) / np.float32(16384.0))
+            assert (b[:off].view(np.uint32) == 0xFFFFFFFF).all() and (b[off + cnt:].view(np.uint32) == 0xFFFFFFFF).all()
+    finally:
+        for ptr in (src, dst, back):
+            ops._free(ptr)
+
+
+def test_wire_refuses_bad_scale_and_alignment(ops):
+    import ctypes as C
+    lib, st = ops.lib, ops.stream
+    src, dst = ops._malloc(256), ops._malloc(128)
+    try:
+        rc = lib.simrank_narrow_h16(C.c_void_p(src), C.c_void_p(dst), 64, C.c_float(3.0), st)
+        assert rc != 0 and b"power of two" in lib.simrank_last_error()
+        rc = lib.simrank_widen_h16(C.c_void_p(dst + 1), C.c_void_p(src), 8, C.c_float(16384.0), st)
+        assert rc != 0 and b"misaligned" in lib.simrank_last_error()
+        assert lib.simrank_narrow_h16(None, None, 0, C.c_float(16384.0), st) == 0
+    finally:
+        ops._free(src)
+        ops._free(dst)
+
+
+@pytest.mark.parametrize("cls,half", [("SimRank", True), ("SimRank", False), ("SimRankPP", True)])
+def test_fp16_wire_on_virtual_ranks(cls, half):
+    """LocalWorld(P, exchange_precision="fp16") rounds what the ranks hand each other exactly as TorchWorld's fp16
+    wire does (tests/test_distributed_gloo.py pins the two against each other on CPU): against the f32 wire the
+    result moves by a few fp16 roundings per update and no more."""
+    import simrank_amd.SimRank as SRA
+    from simrank_amd import synth
+    from simrank_amd.driver import LocalWorld
+    df = synth.powerlaw_directed(1024, 8, seed=4)
+    kw = dict(weighted=True) if cls.endswith("PP") else {}
+    exact = getattr(SRA, cls)().fit(df, iterations=6, eps=0, verbose=False, mode="sparse",
+                                    world=LocalWorld(4, symmetric_shards=half), **kw)
+    wire = getattr(SRA, cls)().fit(df, iterations=6, eps=0, verbose=False, mode="sparse",
+                                   world=LocalWorld(4, symmetric_shards=half, exchange_precision="fp16"), **kw)
+    assert list(wire.index) == list(exact.index)
+    big = exact.values > 1e-6
+    rel = np.abs(wire.values - exact.values)[big] / exact.values[big]
+    assert 1e-7 < rel.max() < 4e-3, rel.max()
+    assert np.abs(wire.values - exact.values).max() < 1e-3
+    assert np.array_equal(np.diag(wire.values), np.diag(exact.values))

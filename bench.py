@@ -159,6 +159,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL on the GPUs (the measurement); gloo = CPU rehearsal of the launch "
                          "path with the NumPy test double (tests only)")
+    ap.add_argument("--exchange-precision", default="f32", choices=["f32", "fp16"],
+                    help="wire format of the all-to-alls of a sharded run: f32 = exact (default, the parity path); "
+                         "fp16 = value x 2^14 in fp16 on the links, f32 kernels (half the link bytes, one fp16 "
+                         "rounding per update: outside the 1e-5 bar, reported as such)")
     ap.add_argument("--force-dist", action="store_true",
                     help="use the torch.distributed world even with one rank (exercises RCCL)")
     args = ap.parse_args()
@@ -190,7 +194,8 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world_size)
         form = {"auto": "auto", "half": True, "full": False}[args.shard_form]
-        world = TorchWorld(stages=args.stages, stage_single_rank=args.force_dist, symmetric_shards=form)
+        world = TorchWorld(stages=args.stages, stage_single_rank=args.force_dist, symmetric_shards=form,
+                           exchange_precision=args.exchange_precision)
     else:
         world = LocalWorld(1)
 
@@ -278,7 +283,9 @@ def main():
                    "sharding": f"S column-sharded over {world_size} rank(s), all-to-all per update"
                                + (f" in {side_stages} overlapped stage(s)" if use_dist else "")
                                + ("; leg 2 in its half form (tiles i <= j per rank, mirrored tiles in a second "
-                                  "half-size all-to-all)" if getattr(side, "shard_sym", False) else "")},
+                                  "half-size all-to-all)" if getattr(side, "shard_sym", False) else "")
+                               + ("; fp16 WIRE format (reduced precision on the links, outside the parity bar)"
+                                  if use_dist and args.exchange_precision == "fp16" else "")},
     }
     if use_dist and getattr(world, "form_measured", None):
         out["shard_form_measured"] = world.form_measured      # both forms of leg 2 timed on this node's links

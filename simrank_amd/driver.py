@@ -20,6 +20,7 @@ single GPU that is available, bit-for-bit against P = 1).
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, replace
 
 import numpy as np
@@ -27,6 +28,11 @@ import numpy as np
 from .ingest import CSR, partition, relabel
 
 PAD_MIN_ROWS, PAD_MULTIPLE = 1024, 256   # when exchanged chunk rows get padded (row_pad)
+# by how many floats (whole 128-byte lines).  Three lines, not one: with ONE line the row stride is 2^k + 1 lines and the
+# channel hash of the memory system (XOR of address fields) still sends the rows of a panel to few channels — a rank's
+# leg 1 at P = 8 on pl32768d32: 1.04 ms unpadded, 0.80 with one line, 0.63 with three or five
+# (profiles/r04_shard_leg1_probe.log; SIMRANK_ROW_PAD / SIMRANK_PITCH_PAD are the measurement knobs)
+ROW_PAD = int(os.environ.get("SIMRANK_ROW_PAD", "96"))
 RESTRICT_BELOW = 0.5     # SimRank++: leg 2 skips evidence-dead 32-column segments when fewer than this
                          # fraction of them is live (ER N=8192: 0.24 live; the power-law graphs: 0.9)
 HALF_FORM_FROM = 8      # TorchWorld(symmetric_shards="auto") when nothing is measured: half-form leg 2 from this many ranks on
@@ -93,9 +99,9 @@ def row_pad(block_rows: int) -> int:
     """Padding of the rows of an exchanged chunk.  A chunk row has `rows of the receiving
     rank` floats and becomes a row of the receiver's gather operand; when that length is a
     large power-of-two multiple, consecutive rows of a panel fall on the same L2 channels
-    and sets, so 32 floats (one 128-byte line) are appended.  Every rank derives it from the
+    and sets, so ``ROW_PAD`` floats (three 128-byte lines) are appended.  Every rank derives it from the
     full block size, so senders and receivers agree."""
-    return 32 if block_rows >= PAD_MIN_ROWS and block_rows % PAD_MULTIPLE == 0 else 0
+    return ROW_PAD if block_rows >= PAD_MIN_ROWS and block_rows % PAD_MULTIPLE == 0 else 0
 
 
 def auto_stages(k_dim: int, world: int) -> int:

@@ -257,7 +257,7 @@ class HipOps:
         else:
             self.stream = C.c_void_p(stream)
         self._counter = self._malloc(8 * CHANGED_SLOTS)
-        self.pitch_pad = 32
+        self.pitch_pad = int(os.environ.get("SIMRANK_PITCH_PAD", "96"))
 
     # ---- memory ----
     # hipMalloc maps a 17 GiB matrix in 0.4-0.5 s (profiles/r03_setup_before_pool.log: 1.6-2.0 s of a config-5

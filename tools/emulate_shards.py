@@ -18,7 +18,7 @@ n = csr.n_rows
 import itertools
 huges = [int(x) for x in os.environ.get('HUGE', '512').split(',')]
 dmins = [int(x) for x in os.environ.get('DMIN', '4').split(',')]
-for huge, dmin, P in itertools.product(huges, dmins, (1, 8) if len(huges) > 1 else (1, 2, 4, 8)):
+for huge, dmin, P in itertools.product(huges, dmins, (1, 8) if len(huges) > 1 else [int(v) for v in os.environ.get('PS', '1,2,4,8').split(',')]):
     for half, st2 in (((False, 1),) if P == 1 else ((False, 1), (True, 1), (True, int(os.environ.get("LEG2_STAGES", "2"))))):
         ops.set_tuning(huge=huge, dense_min=dmin)
         s = Solver(lambda r: ops, LocalWorld(P, symmetric_shards=half, leg2_stages=st2),

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define SIMRANK_ABI_VERSION 4
+#define SIMRANK_ABI_VERSION 5
 #define SIMRANK_CHANGED_SLOTS 1024
 
 #if defined(__GNUC__)
@@ -456,6 +456,72 @@ SIMRANK_API int simrank_biplan_run(simrank_biplan* p, int32_t iterations, double
                                    int32_t* converged_at);
 SIMRANK_API int simrank_biplan_result_f64(simrank_biplan* p, int32_t group, double* dst, int64_t ld);
 SIMRANK_API int simrank_biplan_destroy(simrank_biplan* p);
+
+/* ---- SHARDED PLAN: the same loop with S split by COLUMN BLOCK over `world` GPUs, one process per GPU
+ *      ("step(...) includes K10 when P>1"; the loop of SimRank.py:129-140, :351-362, :443-454 — the
+ *      reference has no counterpart, it is one NumPy process).  Every rank holds the whole (small) graph and the
+ *      N x N/P column block of S it owns; one update is
+ *          leg 1   (W.S_block)^T, stored straight into the chunks of the all-to-all        [first .dot of :139]
+ *          exchange 1   all-to-all of the chunks (in `stages` slices, each leaving while the next is computed)
+ *          leg 2   W.(received operand) with the fused epilogue and the convergence count  [second .dot, :140, :74]
+ *                  full form: every 32 x 32 tile; half form: tiles i <= j only, the transposed tiles i < j go to the
+ *                  ranks that own them in a second, half-size all-to-all (exchange 2) and are put in place
+ *          count   summed over the ranks on the device (all-reduce), read by every rank
+ *      A COMMUNICATOR carries the exchanges: RCCL (loaded with dlopen at the first use: `librccl.so.1`, or what the
+ *      environment variable SIMRANK_RCCL_LIB names; ncclSend / ncclRecv groups on a stream of their own, ordered
+ *      against the kernels by events), or an IN-PROCESS GROUP of `world` virtual ranks on one device whose exchanges
+ *      are device copies (tests, and the per-rank kernel times of DESIGN.md §5 on the one GPU available).
+ *      The entry points that move data between ranks take ALL of this process's plans: one in a multi-process world,
+ *      the `world` plans of an in-process group (which then advance in lockstep on one stream).
+ *      Nodes: ascending row length, dealt to the shards in runs of 128 in the half form (as driver.dealt_order).
+ *      Results: simrank_shardplan_block_f64 = the rank's columns (all n rows, caller's row order) + their node ids by
+ *      simrank_shardplan_columns; simrank_shardplan_result_f64 assembles the whole matrix on rank `root`.
+ *      Only symmetric iterates (SimRank, SimRank++, symmetric priors); f32. */
+typedef struct simrank_comm simrank_comm;
+#define SIMRANK_COMM_ID_BYTES 128
+/* rank 0 makes an id, the host program hands its bytes to every rank (its own job: MPI, a file, a socket), every rank
+ * creates its communicator from it (collective: returns when all `world` ranks have called) */
+SIMRANK_API int simrank_comm_unique_id(void* id_bytes);
+SIMRANK_API int simrank_comm_create(const void* id_bytes, int32_t rank, int32_t world, simrank_comm** out);
+/* an RCCL communicator the host program already has (ncclComm_t; not destroyed with the handle) */
+SIMRANK_API int simrank_comm_adopt(void* rccl_comm, int32_t rank, int32_t world, simrank_comm** out);
+/* `world` virtual ranks inside this process, on the current device: out[0 .. world) */
+SIMRANK_API int simrank_comm_local_group(int32_t world, simrank_comm** out);
+SIMRANK_API int simrank_comm_destroy(simrank_comm* c);
+
+typedef struct simrank_shardplan simrank_shardplan;
+typedef struct simrank_shardplan_options {
+    float coef;                 /* C */
+    float lbd;                  /* prior blend (used when apriori != NULL) */
+    const float* apriori;       /* HOST n x n row-major symmetric prior (the same on every rank), or NULL */
+    int64_t ld_apriori;
+    int32_t evidence;           /* 1: SimRank++ evidence factor */
+    int32_t reorder;            /* 1: ascending-row-length node order (dealt to the shards in the half form) */
+    int32_t leg2_form;          /* 0 full, 1 half (needs n % (32 world) == 0), -1: half from 8 ranks on where it applies */
+    int32_t stages;             /* exchange 1 in that many overlapped stages (0: by the width of a rank's block) */
+    int32_t wire_fp16;          /* 1: the exchanges move fp16 x 2^14 (half the link bytes, f32 kernels, one fp16 rounding
+                                   of the transposed product per update: outside the parity bar); 0 (default): f32 */
+    int32_t reserved;           /* 0 */
+} simrank_shardplan_options;
+SIMRANK_API int simrank_shardplan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                                         const float* rowscale, const simrank_shardplan_options* options,
+                                         simrank_comm* comm, void* stream, simrank_shardplan** out);
+SIMRANK_API int simrank_shardplan_reset(simrank_shardplan* const* plans, int32_t n_local);
+/* one update on every rank; n_changed (may be NULL) = the count over ALL ranks */
+SIMRANK_API int simrank_shardplan_step(simrank_shardplan* const* plans, int32_t n_local, double eps, int32_t exact_count,
+                                       int64_t* n_changed);
+/* the reference loop, update k + 1 queued before the count of update k is read; every rank returns the same numbers */
+SIMRANK_API int simrank_shardplan_run(simrank_shardplan* const* plans, int32_t n_local, int32_t iterations, double eps,
+                                      int32_t* updates_done, int32_t* converged_at);
+/* dst[i][j] (HOST, n x n_cols_of_the_rank) = S[caller's node i][the rank's column j]; ids[j] = caller's id of column j */
+SIMRANK_API int simrank_shardplan_block_f64(simrank_shardplan* p, double* dst, int64_t ld);
+SIMRANK_API int simrank_shardplan_columns(const simrank_shardplan* p, int32_t* ids);
+/* the whole matrix in the caller's order on rank `root` (dst ignored elsewhere); collective */
+SIMRANK_API int simrank_shardplan_result_f64(simrank_shardplan* const* plans, int32_t n_local, int32_t root, double* dst,
+                                             int64_t ld);
+SIMRANK_API int simrank_shardplan_info(const simrank_shardplan* p, int64_t* n, int64_t* col_lo, int64_t* col_hi,
+                                       int32_t* half_form, int32_t* stages, int32_t* updates);
+SIMRANK_API int simrank_shardplan_destroy(simrank_shardplan* p);
 
 /* ---- tuning knobs (measurement harness; defaults are the tuned values).  simrank_set_tuning
  *      changes the process-wide DEFAULTS; simrank_graph_create copies them into the graph it

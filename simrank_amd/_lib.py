@@ -119,6 +119,21 @@ PROTOTYPES = {
     "simrank_plan_result_f64": [_vp, _vp, _i64],
     "simrank_plan_info": [_vp, C.POINTER(_i64), C.POINTER(C.c_int32), C.POINTER(_vp)],
     "simrank_plan_destroy": [_vp],
+    "simrank_comm_unique_id": [_vp],
+    "simrank_comm_create": [_vp, C.c_int32, C.c_int32, C.POINTER(_vp)],
+    "simrank_comm_adopt": [_vp, C.c_int32, C.c_int32, C.POINTER(_vp)],
+    "simrank_comm_local_group": [C.c_int32, C.POINTER(_vp)],
+    "simrank_comm_destroy": [_vp],
+    "simrank_shardplan_create": [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)],
+    "simrank_shardplan_reset": [C.POINTER(_vp), C.c_int32],
+    "simrank_shardplan_step": [C.POINTER(_vp), C.c_int32, C.c_double, C.c_int32, C.POINTER(_i64)],
+    "simrank_shardplan_run": [C.POINTER(_vp), C.c_int32, C.c_int32, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    "simrank_shardplan_block_f64": [_vp, _vp, _i64],
+    "simrank_shardplan_columns": [_vp, _vp],
+    "simrank_shardplan_result_f64": [C.POINTER(_vp), C.c_int32, C.c_int32, _vp, _i64],
+    "simrank_shardplan_info": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_int32),
+                               C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    "simrank_shardplan_destroy": [_vp],
     "simrank_set_tuning": [C.c_char_p, _i64],
     "simrank_get_tuning": [C.c_char_p, C.POINTER(_i64)],
 }
@@ -142,7 +157,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError = symbol missing from the .so
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
-    if lib.simrank_abi_version() != 4:
+    if lib.simrank_abi_version() != 5:
         raise ImportError("libsimrank_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -134,6 +134,10 @@ struct BiPlanPrep {
 };
 int plan_prepare(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* rowscale,
                  const simrank_plan_options* opt, PlanPrep* out);
+// the sharded plan's host half: the single plan's, plus the ascending order DEALT to `deal` shards in runs of 128 (32)
+// nodes when n divides evenly (driver.dealt_order); deal <= 1: plain ascending order
+int shard_prepare(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* rowscale,
+                  const float* apriori, int64_t ld_apriori, bool reorder, int32_t deal, PlanPrep* out);
 int biplan_prepare(int64_t n1, int64_t n2, int64_t nnz, const int32_t* rowptr12, const int32_t* col12,
                    const float* rowscale1, const float* rowscale2, const simrank_biplan_options* opt, BiPlanPrep* out);
 

@@ -79,6 +79,29 @@ int plan_prepare(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* c
     return renamed(n, rowptr, col, rowscale, out->ord, out->inv, nnz, "", out->rp, out->cl, out->rs);
 }
 
+int shard_prepare(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* rowscale,
+                  const float* apriori, int64_t ld_apriori, bool reorder, int32_t deal, PlanPrep* out) {
+    SR_REQUIRE(rowptr && rowscale && (col || nnz == 0) && n > 0 && nnz >= 0 && out, "bad plan arguments");
+    SR_REQUIRE(n < (int64_t(1) << 24) - 16, "a plan holds at most 2^24 nodes");
+    int rc = check_csr(n, n, nnz, rowptr, col);
+    if (!rc) rc = check_prior(apriori, ld_apriori, n, 1, false);
+    if (rc) return rc;
+    length_order(n, rowptr, reorder, out->ord, out->inv);
+    if (reorder && deal > 1 && n % (32 * int64_t(deal)) == 0) {
+        // tile t of the ascending order goes to shard t mod deal: every shard the same mix of short and long rows,
+        // ascending inside (what halves every rank's gathers in the half-form leg 2)
+        const int64_t unit = n % (128 * int64_t(deal)) == 0 ? 128 : 32, per = n / (unit * deal);
+        std::vector<int32_t> dealt((size_t)n);
+        for (int64_t b = 0; b < per; ++b)
+            for (int64_t w = 0; w < deal; ++w)
+                for (int64_t i = 0; i < unit; ++i)
+                    dealt[(size_t)((w * per + b) * unit + i)] = out->ord[(size_t)((b * deal + w) * unit + i)];
+        out->ord.swap(dealt);
+        for (int64_t r = 0; r < n; ++r) out->inv[(size_t)out->ord[(size_t)r]] = (int32_t)r;
+    }
+    return renamed(n, rowptr, col, rowscale, out->ord, out->inv, nnz, "", out->rp, out->cl, out->rs);
+}
+
 int biplan_prepare(int64_t n1, int64_t n2, int64_t nnz, const int32_t* rowptr12, const int32_t* col12,
                    const float* rowscale1, const float* rowscale2, const simrank_biplan_options* opt, BiPlanPrep* out) {
     SR_REQUIRE(opt && rowptr12 && rowscale1 && rowscale2 && (col12 || nnz == 0) && n1 > 0 && n2 > 0 && nnz >= 0 && out,

@@ -1,0 +1,771 @@
+// K10 behind the C ABI ("step(...) includes K10 when P>1"): the loop of SimRank.fit with S split by
+// COLUMN BLOCK over `world` GPUs, one process per GPU, for callers that bind the library directly.  The reference
+// (SimRank.py:129-140, :351-362, :443-454) is one NumPy process and has no counterpart; what one update computes is
+// its two `.dot`s, `C *`, `Evidence *`, the prior blend, `fill_diagonal` and the test of `_converged` (:74).
+//
+// One update of a rank (driver.Side / driver.Solver._update do the same over torch.distributed):
+//   leg 1       simrank_spmm(transpose_out, t_block = mb, t_pad): (W . S_block)^T straight into the chunks of the
+//               all-to-all, one launch per STAGE (a slice of the rank's columns)
+//   exchange 1  per stage: chunk h of the slice goes to rank h; what arrives from rank h lands at the rows of the
+//               leg-2 operand that rank's columns own — consecutive rows, so no renaming of the graph is needed
+//               (all_to_all_single could not scatter like that; ncclSend / ncclRecv groups can).  RCCL runs on a
+//               stream of its own: it waits for the stage's kernel by an event and moves the slice while the next
+//               stage computes; leg 2 waits for the last stage.
+//   leg 2       full form: simrank_spmm with the fused epilogue; half form: simrank_spmm_shard (tiles i <= j), then
+//   exchange 2  the packed mirrored tiles, equal chunks, and simrank_shard_unpack puts them in place
+//   count       the striped counters summed over the ranks on the device (ncclAllReduce), copied to pinned memory;
+//               simrank_shardplan_run queues update k + 1 before it reads the count of update k, like the single plan
+//
+// A communicator is RCCL (dlopen, so the library does not depend on it) or an in-process group of virtual ranks on
+// one device whose exchanges are device copies — how every line of this file but the RCCL calls themselves is tested
+// on the one GPU available (tests/test_gpu_shardplan.py: bit-equal to one rank in the full form).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+static_assert(sizeof(ncclUniqueId) == SIMRANK_COMM_ID_BYTES, "RCCL's unique id is SIMRANK_COMM_ID_BYTES long");
+
+namespace simrank {
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+static Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* name = std::getenv("SIMRANK_RCCL_LIB");
+        for (const char* cand : {name, "librccl.so.1", "librccl.so"}) {
+            if (!cand || !*cand) continue;
+            r.lib = dlopen(cand, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) return;
+        auto sym = [](const char* s) { return dlsym(r.lib, s); };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv &&
+               r.AllReduce && r.GetErrorString;
+    });
+    return &r;
+}
+
+#define SR_RCCL(call)                                                                          \
+    do {                                                                                       \
+        ncclResult_t r_ = (call);                                                              \
+        if (r_ != ncclSuccess) {                                                               \
+            ::simrank::set_error("%s failed: %s (%s:%d)", #call, rccl()->GetErrorString(r_), __FILE__, __LINE__); \
+            return SIMRANK_ERR_HIP;                                                            \
+        }                                                                                      \
+    } while (0)
+
+struct LocalGroup {
+    int32_t world = 0;
+    int32_t alive = 0;
+};
+
+constexpr float kWireScale = 16384.0f;       // what values on an fp16 wire are multiplied by (engine.HipOps.WIRE_SCALE)
+
+static int64_t env_pad(const char* name) {
+    const char* v = std::getenv(name);
+    const int64_t p = v && *v ? std::atoll(v) : 96;      // three 128-byte lines ("The row pitch")
+    return p < 0 ? 0 : p / 4 * 4;
+}
+// leading dimension of a row-major block of `cols` elements of `elem` bytes (engine.HipOps.pitch)
+static int64_t pitch(int64_t cols, int64_t elem) {
+    const int64_t unit = 16 / elem;
+    int64_t ld = (std::max<int64_t>(cols, 1) + unit - 1) / unit * unit;
+    if (ld >= 4096 && (ld & (ld - 1)) == 0) ld += env_pad("SIMRANK_PITCH_PAD");
+    return ld;
+}
+static int64_t row_pad(int64_t block_rows) {             // driver.row_pad
+    return block_rows >= 1024 && block_rows % 256 == 0 ? env_pad("SIMRANK_ROW_PAD") / 32 * 32 : 0;
+}
+static void part(int64_t n, int32_t world, int32_t rank, int64_t* lo, int64_t* hi) {      // ingest.partition
+    const int64_t b = (n + world - 1) / world;
+    *lo = std::min<int64_t>(n, rank * b);
+    *hi = std::min<int64_t>(n, *lo + b);
+}
+static int64_t span(int64_t n, int32_t world, int32_t rank) {
+    int64_t lo, hi;
+    part(n, world, rank, &lo, &hi);
+    return hi - lo;
+}
+// driver.stage_widths: equal pieces rounded up to whole 32-column panels, the last one shorter or empty
+static int64_t stage_width(int64_t n_cols, int32_t n_stages, int32_t s) {
+    int64_t q = (n_cols + n_stages - 1) / n_stages;
+    q = (q + 31) / 32 * 32;
+    return std::max<int64_t>(0, std::min<int64_t>(q, n_cols - s * q));
+}
+static int64_t stage_col0(int64_t n_cols, int32_t n_stages, int32_t s) {
+    int64_t c = 0;
+    for (int32_t t = 0; t < s; ++t) c += stage_width(n_cols, n_stages, t);
+    return c;
+}
+
+}  // namespace simrank
+
+struct simrank_comm {
+    int32_t rank = 0, world = 1;
+    simrank::LocalGroup* group = nullptr;    // in-process group, or
+    ncclComm_t nccl = nullptr;               // RCCL
+    bool owned = false;
+};
+
+struct simrank_shardplan {
+    simrank_comm* comm = nullptr;
+    int32_t rank = 0, world = 1;
+    int64_t n = 0, mb = 0, m_lo = 0, m_hi = 0, Lm = 0;
+    int64_t ld = 0, pad = 0, send_ld = 0, recv_ld = 0, ld_ev = 0;
+    simrank_graph* g = nullptr;
+    float* S[2] = {nullptr, nullptr};       // the rank's column block of the iterate, row-major n x Lm, ping-pong
+    float* send = nullptr;                  // exchange 1: Lm columns x (n + world pad) floats, chunked per stage
+    float* recv = nullptr;                  //             the leg-2 operand, n rows x (Lm + pad)
+    float* sh_send = nullptr;               // exchange 2 (half form): world chunks of packed mirrored tiles
+    float* sh_recv = nullptr;
+    int64_t sh_chunk = 0;
+    uint16_t* wire[4] = {nullptr, nullptr, nullptr, nullptr};   // fp16 shadows of send / recv / sh_send / sh_recv
+    uint8_t* ev = nullptr;
+    float* prior = nullptr;
+    int32_t* inv = nullptr;                 // device: position of caller's node i in the solver's order
+    std::vector<int32_t> ord;               // host: ord[position] = caller's node
+    unsigned long long* counters = nullptr;
+    unsigned long long* host_counters[2] = {nullptr, nullptr};
+    hipEvent_t counted[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr;
+    hipStream_t xstream = nullptr;          // RCCL's stream for exchange 1 (stages overlap the kernels)
+    std::vector<hipEvent_t> staged;         // [n_stages] "this stage's kernel is done" + [1] "all stages have arrived"
+    float coef = 0.8f, lbd = 0.f;
+    int32_t restrict_support = 0, half_form = 0, n_stages = 1, wire_fp16 = 0;
+    int cur = 0;
+    int32_t updates = 0;
+};
+
+namespace simrank {
+
+// ---- one all-to-all: what every local plan sends to / receives from every rank (element counts) ----
+struct Route {
+    std::vector<const float*> sp;
+    std::vector<float*> rp;
+    std::vector<int64_t> sn, rn;
+    const float* send_base = nullptr;       // the f32 buffers the pieces lie in, and their fp16 shadows (wire_fp16)
+    float* recv_base = nullptr;
+    uint16_t* send_h = nullptr;
+    uint16_t* recv_h = nullptr;
+    explicit Route(int32_t world) : sp(world, nullptr), rp(world, nullptr), sn(world, 0), rn(world, 0) {}
+};
+
+static int all_to_all(simrank_shardplan* const* plans, int32_t n_local, std::vector<Route>& routes, hipStream_t st) {
+    simrank_shardplan* p0 = plans[0];
+    const int32_t P = p0->world;
+    const bool wire = p0->wire_fp16 != 0;
+    // fp16 wire: narrow every outgoing piece into the shadow at the same element offset
+    if (wire)
+        for (int32_t i = 0; i < n_local; ++i)
+            for (int32_t h = 0; h < P; ++h) {
+                Route& r = routes[i];
+                if (!r.sn[h]) continue;
+                const int rc = simrank_narrow_h16(r.sp[h], r.send_h + (r.sp[h] - r.send_base), r.sn[h], kWireScale, st);
+                if (rc) return rc;
+            }
+    const size_t elem = wire ? 2 : 4;
+    auto src_of = [&](Route& r, int32_t h) -> const void* {
+        return wire ? (const void*)(r.send_h + (r.sp[h] - r.send_base)) : (const void*)r.sp[h];
+    };
+    auto dst_of = [&](Route& r, int32_t h) -> void* {
+        return wire ? (void*)(r.recv_h + (r.rp[h] - r.recv_base)) : (void*)r.rp[h];
+    };
+    if (p0->comm->group) {
+        for (int32_t s = 0; s < P; ++s)
+            for (int32_t d = 0; d < P; ++d) {
+                const int64_t cnt = routes[s].sn[d];
+                SR_REQUIRE(cnt == routes[d].rn[s], "ranks %d and %d disagree about a chunk (%lld / %lld elements)", s, d,
+                           (long long)cnt, (long long)routes[d].rn[s]);
+                if (cnt)
+                    SR_HIP(hipMemcpyAsync(dst_of(routes[d], s), src_of(routes[s], d), size_t(cnt) * elem,
+                                          hipMemcpyDeviceToDevice, st));
+            }
+    } else {
+        Rccl* R = rccl();
+        Route& r = routes[0];
+        const int32_t me = p0->rank;
+        if (r.sn[me]) {                      // the chunk a rank addresses to itself never touches the fabric
+            SR_REQUIRE(r.sn[me] == r.rn[me], "own chunk: %lld / %lld elements", (long long)r.sn[me], (long long)r.rn[me]);
+            SR_HIP(hipMemcpyAsync(dst_of(r, me), src_of(r, me), size_t(r.sn[me]) * elem, hipMemcpyDeviceToDevice, st));
+        }
+        const ncclDataType_t dt = wire ? ncclHalf : ncclFloat;
+        SR_RCCL(R->GroupStart());
+        for (int32_t h = 0; h < P; ++h) {
+            if (h == me) continue;
+            if (r.sn[h]) SR_RCCL(R->Send(src_of(r, h), size_t(r.sn[h]), dt, h, p0->comm->nccl, st));
+            if (r.rn[h]) SR_RCCL(R->Recv(dst_of(r, h), size_t(r.rn[h]), dt, h, p0->comm->nccl, st));
+        }
+        SR_RCCL(R->GroupEnd());
+    }
+    if (wire)
+        for (int32_t i = 0; i < n_local; ++i)
+            for (int32_t h = 0; h < P; ++h) {
+                Route& r = routes[i];
+                if (!r.rn[h]) continue;
+                const int rc = simrank_widen_h16(r.recv_h + (r.rp[h] - r.recv_base), r.rp[h], r.rn[h], kWireScale, st);
+                if (rc) return rc;
+            }
+    return SIMRANK_OK;
+}
+
+static int check_group(simrank_shardplan* const* plans, int32_t n_local) {
+    SR_REQUIRE(plans && n_local >= 1 && plans[0], "no plans");
+    simrank_shardplan* p0 = plans[0];
+    if (p0->comm->group) {
+        SR_REQUIRE(n_local == p0->world, "an in-process group advances all its %d plans together (%d given)", p0->world, n_local);
+        for (int32_t i = 0; i < n_local; ++i)
+            SR_REQUIRE(plans[i] && plans[i]->comm->group == p0->comm->group && plans[i]->rank == i &&
+                           plans[i]->stream == p0->stream && plans[i]->n == p0->n &&
+                           plans[i]->half_form == p0->half_form && plans[i]->n_stages == p0->n_stages &&
+                           plans[i]->wire_fp16 == p0->wire_fp16,
+                       "plans[%d] is not rank %d of the same in-process group, stream and options", i, i);
+    } else {
+        SR_REQUIRE(n_local == 1, "a process of a multi-process world holds one plan");
+    }
+    return SIMRANK_OK;
+}
+
+static void fill_epilogue(simrank_shardplan* p, double eps, int32_t exact_count, simrank_epilogue* ep) {
+    *ep = simrank_epilogue{};
+    ep->coef = p->coef;
+    ep->lbd = p->lbd;
+    ep->evidence = p->ev;
+    ep->ld_evidence = p->ld_ev;
+    ep->apriori = p->prior;
+    ep->ld_apriori = p->ld;
+    ep->previous = p->S[p->cur];
+    ep->ld_previous = p->ld;
+    ep->eps = eps;
+    ep->n_changed = p->counters;
+    ep->diag_col0 = p->m_lo;
+    ep->set_diag = 1;
+    ep->symmetric = 0;
+    ep->restrict_support = p->restrict_support;
+    ep->count_any = exact_count ? 0 : 1;
+}
+
+// One update on every local plan, queued; its count lands in pinned slot `slot` of every plan.
+static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, int32_t exact_count, int slot) {
+    simrank_shardplan* p0 = plans[0];
+    const int32_t P = p0->world, S = p0->n_stages;
+    const bool local = p0->comm->group != nullptr;
+    hipStream_t xs = local ? p0->stream : p0->xstream;
+    // leg 1 + exchange 1, stage by stage
+    for (int32_t s = 0; s < S; ++s) {
+        std::vector<Route> routes(n_local, Route(P));
+        for (int32_t i = 0; i < n_local; ++i) {
+            simrank_shardplan* p = plans[i];
+            const int64_t w = stage_width(p->Lm, S, s), c0 = stage_col0(p->Lm, S, s);
+            const int64_t send_off = c0 * p->send_ld;
+            if (w) {
+                const int rc = simrank_spmm(p->g, p->S[p->cur] + c0, p->ld, w, p->send + send_off, 0, 1, p->mb, p->pad,
+                                            nullptr, p->stream);
+                if (rc) return rc;
+            }
+            Route& r = routes[i];
+            r.send_base = p->send; r.recv_base = p->recv;
+            r.send_h = p->wire[0]; r.recv_h = p->wire[1];
+            for (int32_t h = 0; h < P; ++h) {
+                r.sp[h] = p->send + send_off + int64_t(h) * w * (p->mb + p->pad);
+                r.sn[h] = w * (span(p->n, P, h) + p->pad);
+                int64_t k_lo, k_hi;
+                part(p->n, P, h, &k_lo, &k_hi);
+                const int64_t wh = stage_width(k_hi - k_lo, S, s), ch = stage_col0(k_hi - k_lo, S, s);
+                r.rp[h] = p->recv + (k_lo + ch) * p->recv_ld;
+                r.rn[h] = wh * p->recv_ld;
+                if (!p->Lm) r.rn[h] = 0;                 // (a rank without columns receives rows of zero length)
+            }
+            if (!local) {                                // RCCL's stream waits for this stage's kernel only
+                SR_HIP(hipEventRecord(p->staged[s], p->stream));
+                SR_HIP(hipStreamWaitEvent(xs, p->staged[s], 0));
+            }
+        }
+        const int rc = all_to_all(plans, n_local, routes, xs);
+        if (rc) return rc;
+    }
+    // every RCCL call of this communicator is issued on ITS stream, in one order; `hop` makes one stream wait for the other
+    auto hop = [&](hipStream_t from, hipStream_t to, hipEvent_t ev) -> int {
+        if (from == to) return SIMRANK_OK;
+        SR_HIP(hipEventRecord(ev, from));
+        SR_HIP(hipStreamWaitEvent(to, ev, 0));
+        return SIMRANK_OK;
+    };
+    int rc = local ? SIMRANK_OK : hop(xs, p0->stream, p0->staged[S]);      // leg 2 reads what the last stage delivered
+    if (rc) return rc;
+    // leg 2 with the fused epilogue and count
+    for (int32_t i = 0; i < n_local; ++i) {
+        simrank_shardplan* p = plans[i];
+        simrank_epilogue ep;
+        fill_epilogue(p, eps, exact_count, &ep);
+        if (!p->Lm) {
+            SR_HIP(hipMemsetAsync(p->counters, 0, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS, p->stream));
+        } else if (p->half_form) {
+            rc = simrank_spmm_shard(p->g, p->recv, p->recv_ld, p->S[p->cur ^ 1], p->ld, &ep, p->rank, P, p->sh_send,
+                                    p->sh_chunk, p->stream);
+        } else {
+            rc = simrank_spmm(p->g, p->recv, p->recv_ld, p->Lm, p->S[p->cur ^ 1], p->ld, 0, 0, 0, &ep, p->stream);
+        }
+        if (rc) return rc;
+    }
+    if (!local) {
+        rc = hop(p0->stream, xs, p0->staged[0]);
+        if (rc) return rc;
+        if (P > 1)                                       // the count of the whole update, on every rank
+            SR_RCCL(rccl()->AllReduce(p0->counters, p0->counters, SIMRANK_CHANGED_SLOTS, ncclUint64, ncclSum,
+                                      p0->comm->nccl, xs));
+    }
+    if (p0->half_form) {
+        // exchange 2: the packed mirrored tiles (the chunk a rank addresses to itself is empty: stored in place)
+        std::vector<Route> routes(n_local, Route(P));
+        for (int32_t i = 0; i < n_local; ++i) {
+            simrank_shardplan* p = plans[i];
+            Route& r = routes[i];
+            r.send_base = p->sh_send; r.recv_base = p->sh_recv;
+            r.send_h = p->wire[2]; r.recv_h = p->wire[3];
+            for (int32_t h = 0; h < P; ++h) {
+                r.sp[h] = p->sh_send + int64_t(h) * p->sh_chunk;
+                r.rp[h] = p->sh_recv + int64_t(h) * p->sh_chunk;
+                r.sn[h] = r.rn[h] = h == p->rank ? 0 : p->sh_chunk;
+            }
+        }
+        rc = all_to_all(plans, n_local, routes, xs);
+        if (rc) return rc;
+    }
+    if (!local) {
+        rc = hop(xs, p0->stream, p0->staged[S]);
+        if (rc) return rc;
+    }
+    for (int32_t i = 0; i < n_local; ++i) {
+        simrank_shardplan* p = plans[i];
+        SR_HIP(hipMemcpyAsync(p->host_counters[slot], p->counters, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS,
+                              hipMemcpyDeviceToHost, p->stream));
+        SR_HIP(hipEventRecord(p->counted[slot], p->stream));
+        if (p->half_form) {
+            rc = simrank_shard_unpack(p->S[p->cur ^ 1], p->ld, p->sh_recv, p->sh_chunk, p->rank, P, p->n, p->stream);
+            if (rc) return rc;
+        }
+    }
+    return SIMRANK_OK;
+}
+
+// the count of the update that used `slot`, over all ranks; waits for that update only
+static int read_count(simrank_shardplan* const* plans, int32_t n_local, int slot, unsigned long long* sum) {
+    unsigned long long t = 0;
+    for (int32_t i = 0; i < n_local; ++i) {
+        SR_HIP(hipEventSynchronize(plans[i]->counted[slot]));
+        for (int k = 0; k < SIMRANK_CHANGED_SLOTS; ++k) t += plans[i]->host_counters[slot][k];
+    }
+    *sum = t;
+    return SIMRANK_OK;
+}
+
+static void flip(simrank_shardplan* const* plans, int32_t n_local) {
+    for (int32_t i = 0; i < n_local; ++i) plans[i]->cur ^= 1;
+}
+
+// the rank's block with its rows in the caller's order, on the device (in the idle ping-pong partner)
+static int block_rows_in_callers_order(simrank_shardplan* p, float** out) {
+    float* tmp = p->S[p->cur ^ 1];
+    if (p->Lm) {
+        const int rc = simrank_permute(p->S[p->cur], p->ld, tmp, p->ld, p->n, p->Lm, p->inv, nullptr, 4, p->stream);
+        if (rc) return rc;
+    }
+    *out = tmp;
+    return SIMRANK_OK;
+}
+
+}  // namespace simrank
+
+using namespace simrank;
+
+extern "C" {
+
+int simrank_comm_unique_id(void* id_bytes) {
+    SR_REQUIRE(id_bytes, "id is NULL");
+    Rccl* R = rccl();
+    SR_REQUIRE(R->ok, "RCCL could not be loaded (librccl.so.1; set SIMRANK_RCCL_LIB)");
+    ncclUniqueId id;
+    SR_RCCL(R->GetUniqueId(&id));
+    std::memcpy(id_bytes, &id, sizeof id);
+    return SIMRANK_OK;
+}
+
+int simrank_comm_create(const void* id_bytes, int32_t rank, int32_t world, simrank_comm** out) {
+    SR_REQUIRE(id_bytes && out && world >= 1 && rank >= 0 && rank < world, "bad communicator arguments");
+    *out = nullptr;
+    Rccl* R = rccl();
+    SR_REQUIRE(R->ok, "RCCL could not be loaded (librccl.so.1; set SIMRANK_RCCL_LIB)");
+    ncclUniqueId id;
+    std::memcpy(&id, id_bytes, sizeof id);
+    ncclComm_t c = nullptr;
+    SR_RCCL(R->CommInitRank(&c, world, id, rank));
+    simrank_comm* k = new simrank_comm;
+    k->rank = rank; k->world = world; k->nccl = c; k->owned = true;
+    *out = k;
+    return SIMRANK_OK;
+}
+
+int simrank_comm_adopt(void* rccl_comm, int32_t rank, int32_t world, simrank_comm** out) {
+    SR_REQUIRE(rccl_comm && out && world >= 1 && rank >= 0 && rank < world, "bad communicator arguments");
+    SR_REQUIRE(rccl()->ok, "RCCL could not be loaded (librccl.so.1; set SIMRANK_RCCL_LIB)");
+    simrank_comm* k = new simrank_comm;
+    k->rank = rank; k->world = world; k->nccl = (ncclComm_t)rccl_comm; k->owned = false;
+    *out = k;
+    return SIMRANK_OK;
+}
+
+int simrank_comm_local_group(int32_t world, simrank_comm** out) {
+    SR_REQUIRE(out && world >= 1 && world <= 64, "an in-process group has 1 .. 64 ranks");
+    LocalGroup* g = new LocalGroup;
+    g->world = world;
+    g->alive = world;
+    for (int32_t r = 0; r < world; ++r) {
+        simrank_comm* k = new simrank_comm;
+        k->rank = r; k->world = world; k->group = g;
+        out[r] = k;
+    }
+    return SIMRANK_OK;
+}
+
+int simrank_comm_destroy(simrank_comm* c) {
+    if (!c) return SIMRANK_OK;
+    if (c->group && --c->group->alive == 0) delete c->group;
+    if (c->nccl && c->owned) (void)rccl()->CommDestroy(c->nccl);
+    delete c;
+    return SIMRANK_OK;
+}
+
+int simrank_shardplan_destroy(simrank_shardplan* p) {
+    if (!p) return SIMRANK_OK;
+    if (p->xstream) (void)hipStreamSynchronize(p->xstream);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    for (void* b : {(void*)p->S[0], (void*)p->S[1], (void*)p->send, (void*)p->recv, (void*)p->sh_send, (void*)p->sh_recv,
+                    (void*)p->wire[0], (void*)p->wire[1], (void*)p->wire[2], (void*)p->wire[3], (void*)p->ev,
+                    (void*)p->prior, (void*)p->inv, (void*)p->counters})
+        (void)pool_free(b);
+    for (int i = 0; i < 2; ++i) {
+        if (p->host_counters[i]) (void)hipHostFree(p->host_counters[i]);
+        if (p->counted[i]) (void)hipEventDestroy(p->counted[i]);
+    }
+    for (hipEvent_t e : p->staged) (void)hipEventDestroy(e);
+    if (p->xstream) (void)hipStreamDestroy(p->xstream);
+    simrank_graph_destroy(p->g);
+    delete p;
+    return SIMRANK_OK;
+}
+
+int simrank_shardplan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* rowscale,
+                             const simrank_shardplan_options* opt, simrank_comm* comm, void* stream,
+                             simrank_shardplan** out) {
+    SR_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    SR_REQUIRE(opt && comm, "options / communicator missing");
+    const int32_t P = comm->world;
+    SR_REQUIRE(opt->leg2_form >= -1 && opt->leg2_form <= 1 && opt->stages >= 0 && opt->stages <= 64, "bad options");
+    const bool fits_half = P > 1 && n % (32 * int64_t(P)) == 0;
+    SR_REQUIRE(opt->leg2_form != 1 || fits_half || (P == 1 && n % 32 == 0),
+               "the half form of leg 2 needs n to be a multiple of 32 x ranks");
+    const bool half = opt->leg2_form == 1 || (opt->leg2_form == -1 && fits_half && P >= 8);
+    PlanPrep pp;
+    int rc = shard_prepare(n, nnz, rowptr, col, rowscale, opt->apriori, opt->ld_apriori, opt->reorder != 0, half ? P : 1, &pp);
+    if (rc) return rc;
+    simrank_shardplan* p = new simrank_shardplan;
+    p->comm = comm; p->rank = comm->rank; p->world = P;
+    p->n = n;
+    p->stream = as_stream(stream);
+    p->coef = opt->coef; p->lbd = opt->lbd;
+    p->half_form = half ? 1 : 0;
+    p->wire_fp16 = opt->wire_fp16 ? 1 : 0;
+    p->mb = (n + P - 1) / P;
+    part(n, P, p->rank, &p->m_lo, &p->m_hi);
+    p->Lm = p->m_hi - p->m_lo;
+    p->ld = pitch(p->Lm, 4);
+    p->ld_ev = pitch(p->Lm, 1);
+    p->pad = row_pad(p->mb);
+    p->send_ld = int64_t(P) * (p->mb + p->pad);          // (>= n + P pad: only the last chunk can be short)
+    p->recv_ld = std::max<int64_t>(1, p->Lm + p->pad);
+    // stages of exchange 1: by the width of the LARGEST block, so every rank takes the same number (driver.auto_stages)
+    p->n_stages = opt->stages > 0 ? opt->stages : int32_t(std::max<int64_t>(1, std::min<int64_t>(4, p->mb / 2048)));
+    p->ord = pp.ord;
+    auto fail = [&](int code) { simrank_shardplan_destroy(p); return code; };
+    rc = simrank_graph_create(n, n, nnz, pp.rp.data(), pp.cl.data(), pp.rs.data(), &p->g);
+    if (rc) return fail(rc);
+#define SP_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (void)hipGetLastError();                                                              \
+            return fail(e_ == hipErrorOutOfMemory ? SIMRANK_ERR_ALLOC : SIMRANK_ERR_HIP);         \
+        }                                                                                         \
+    } while (0)
+    auto dev = [&](void** b, size_t bytes) -> hipError_t {
+        hipError_t e = pool_hip_alloc(b, std::max<size_t>(bytes, 16));
+        if (e == hipSuccess) e = hipMemsetAsync(*b, 0, std::max<size_t>(bytes, 16), p->stream);
+        return e;
+    };
+    const size_t blk = size_t(n) * size_t(p->ld) * 4;
+    SP_HIP(dev((void**)&p->S[0], blk));
+    SP_HIP(dev((void**)&p->S[1], blk));
+    const size_t send_floats = size_t(std::max<int64_t>(1, p->Lm)) * size_t(p->send_ld);
+    const size_t recv_floats = size_t(n) * size_t(p->recv_ld);
+    SP_HIP(dev((void**)&p->send, send_floats * 4));
+    SP_HIP(dev((void**)&p->recv, recv_floats * 4));
+    if (p->wire_fp16) {
+        SP_HIP(dev((void**)&p->wire[0], send_floats * 2));
+        SP_HIP(dev((void**)&p->wire[1], recv_floats * 2));
+    }
+    if (p->half_form) {
+        const int64_t t = p->mb / 32;
+        p->sh_chunk = std::max<int64_t>(1, t * (t - 1) / 2 * 1024);
+        const size_t sh = size_t(P) * size_t(p->sh_chunk);
+        SP_HIP(dev((void**)&p->sh_send, sh * 4));
+        SP_HIP(dev((void**)&p->sh_recv, sh * 4));
+        if (p->wire_fp16) {
+            SP_HIP(dev((void**)&p->wire[2], sh * 2));
+            SP_HIP(dev((void**)&p->wire[3], sh * 2));
+        }
+    }
+    SP_HIP(dev((void**)&p->counters, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS));
+    for (int i = 0; i < 2; ++i) {
+        SP_HIP(hipHostMalloc((void**)&p->host_counters[i], sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS, hipHostMallocPortable));
+        SP_HIP(hipEventCreateWithFlags(&p->counted[i], hipEventDisableTiming));
+    }
+    if (!comm->group) {
+        SP_HIP(hipStreamCreateWithFlags(&p->xstream, hipStreamNonBlocking));
+        p->staged.resize(size_t(p->n_stages) + 1, nullptr);
+        for (hipEvent_t& e : p->staged) SP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    SP_HIP(dev((void**)&p->inv, size_t(n) * 4));
+    SP_HIP(hipMemcpyAsync(p->inv, pp.inv.data(), size_t(n) * 4, hipMemcpyHostToDevice, p->stream));
+    SP_HIP(hipStreamSynchronize(p->stream));             // (pp.inv is a host vector about to go away)
+    if (opt->evidence && p->Lm) {
+        // common in-neighbour counts of the rank's columns (SimRank.py:311-320), 1 - 2^-count in the epilogue
+        SP_HIP(dev((void**)&p->ev, size_t(n) * size_t(p->ld_ev)));
+        rc = simrank_evidence_counts(p->g, p->m_lo, p->Lm, p->ev, p->ld_ev, p->stream);
+        if (rc) return fail(rc);
+        int64_t live = 0, total = 1;
+        rc = simrank_evidence_live_segments(p->ev, p->ld_ev, 0, n, p->Lm, &live, &total, p->stream);
+        if (rc) return fail(rc);
+        p->restrict_support = 2 * live < total ? 1 : 0;
+    }
+    if (opt->apriori && p->Lm) {
+        // the rank's columns of the prior in the solver's order: block[i][j] = A[ord[i]][ord[m_lo + j]]
+        std::vector<float> host(size_t(n) * size_t(p->ld), 0.f);
+        for (int64_t i = 0; i < n; ++i) {
+            const float* src = opt->apriori + int64_t(pp.ord[(size_t)i]) * opt->ld_apriori;
+            float* dst = host.data() + i * p->ld;
+            for (int64_t j = 0; j < p->Lm; ++j) dst[j] = src[pp.ord[(size_t)(p->m_lo + j)]];
+        }
+        SP_HIP(dev((void**)&p->prior, blk));
+        SP_HIP(hipMemcpyAsync(p->prior, host.data(), blk, hipMemcpyHostToDevice, p->stream));
+        SP_HIP(hipStreamSynchronize(p->stream));
+    }
+#undef SP_HIP
+    if (p->Lm) {
+        rc = simrank_fill_identity(p->S[0], n, p->Lm, p->ld, p->m_lo, p->stream);
+        if (rc) return fail(rc);
+    }
+    *out = p;
+    return SIMRANK_OK;
+}
+
+int simrank_shardplan_reset(simrank_shardplan* const* plans, int32_t n_local) {
+    int rc = check_group(plans, n_local);
+    if (rc) return rc;
+    for (int32_t i = 0; i < n_local; ++i) {
+        simrank_shardplan* p = plans[i];
+        p->cur = 0;
+        p->updates = 0;
+        if (p->Lm) {
+            rc = simrank_fill_identity(p->S[0], p->n, p->Lm, p->ld, p->m_lo, p->stream);
+            if (rc) return rc;
+        }
+    }
+    return SIMRANK_OK;
+}
+
+int simrank_shardplan_step(simrank_shardplan* const* plans, int32_t n_local, double eps, int32_t exact_count,
+                           int64_t* n_changed) {
+    int rc = check_group(plans, n_local);
+    if (rc) return rc;
+    rc = update(plans, n_local, eps, exact_count, 0);
+    if (rc) return rc;
+    flip(plans, n_local);
+    for (int32_t i = 0; i < n_local; ++i) ++plans[i]->updates;
+    if (n_changed) {
+        unsigned long long c = 0;
+        rc = read_count(plans, n_local, 0, &c);
+        if (rc) return rc;
+        *n_changed = (int64_t)c;
+    }
+    return SIMRANK_OK;
+}
+
+int simrank_shardplan_run(simrank_shardplan* const* plans, int32_t n_local, int32_t iterations, double eps,
+                          int32_t* updates_done, int32_t* converged_at) {
+    int rc = check_group(plans, n_local);
+    if (rc) return rc;
+    SR_REQUIRE(iterations >= 0, "iterations < 0");
+    rc = simrank_shardplan_reset(plans, n_local);
+    if (rc) return rc;
+    int32_t conv = -1, done = 0;
+    if (iterations > 0 && !(1.0 > eps)) {
+        conv = 0;           // loop index 0 compares S_0 = I with the zero matrix: "converged" unless 1 > eps
+    } else if (iterations > 0) {
+        rc = update(plans, n_local, eps, 0, 1);
+        if (rc) return rc;
+        for (int32_t k = 1;; ++k) {
+            flip(plans, n_local);                    // S[cur] = result of update k
+            done = k;
+            if (k == iterations) break;              // the reference makes no test after its last update
+            rc = update(plans, n_local, eps, 0, (k + 1) & 1);      // update k + 1, speculative
+            if (rc) return rc;
+            unsigned long long c = 0;
+            rc = read_count(plans, n_local, k & 1, &c);           // the same number on every rank
+            if (rc) return rc;
+            if (c == 0) {                            // converged at loop index k; the speculative update is dropped
+                conv = k;
+                break;
+            }
+        }
+    }
+    for (int32_t i = 0; i < n_local; ++i) {
+        SR_HIP(hipStreamSynchronize(plans[i]->stream));
+        if (plans[i]->xstream) SR_HIP(hipStreamSynchronize(plans[i]->xstream));
+        plans[i]->updates = done;
+    }
+    if (updates_done) *updates_done = done;
+    if (converged_at) *converged_at = conv;
+    return SIMRANK_OK;
+}
+
+int simrank_shardplan_block_f64(simrank_shardplan* p, double* dst, int64_t ld) {
+    SR_REQUIRE(p && (dst || !p->Lm) && ld >= p->Lm, "bad result arguments");
+    if (!p->Lm) return SIMRANK_OK;
+    float* tmp = nullptr;
+    int rc = block_rows_in_callers_order(p, &tmp);
+    if (!rc) rc = simrank_download_f64(dst, ld, tmp, p->ld, p->n, p->Lm, p->stream);
+    return rc;
+}
+
+int simrank_shardplan_columns(const simrank_shardplan* p, int32_t* ids) {
+    SR_REQUIRE(p && (ids || !p->Lm), "bad arguments");
+    for (int64_t j = 0; j < p->Lm; ++j) ids[j] = p->ord[(size_t)(p->m_lo + j)];
+    return SIMRANK_OK;
+}
+
+int simrank_shardplan_result_f64(simrank_shardplan* const* plans, int32_t n_local, int32_t root, double* dst, int64_t ld) {
+    int rc = check_group(plans, n_local);
+    if (rc) return rc;
+    simrank_shardplan* p0 = plans[0];
+    const int32_t P = p0->world;
+    const int64_t n = p0->n;
+    SR_REQUIRE(root >= 0 && root < P, "root out of range");
+    const bool local = p0->comm->group != nullptr;
+    const bool i_am_root = local || p0->rank == root;
+    SR_REQUIRE(!i_am_root || (dst && ld >= n), "bad result arguments");
+    auto scatter = [&](const std::vector<double>& blockv, int64_t lo, int64_t width) {
+        for (int64_t i = 0; i < n; ++i) {
+            const double* src = blockv.data() + i * width;
+            double* row = dst + i * ld;
+            for (int64_t j = 0; j < width; ++j) row[p0->ord[(size_t)(lo + j)]] = src[j];
+        }
+    };
+    if (local) {
+        for (int32_t i = 0; i < n_local; ++i) {
+            simrank_shardplan* p = plans[i];
+            if (!p->Lm) continue;
+            std::vector<double> host(size_t(n) * size_t(p->Lm));
+            rc = simrank_shardplan_block_f64(p, host.data(), p->Lm);
+            if (rc) return rc;
+            scatter(host, p->m_lo, p->Lm);
+        }
+        return SIMRANK_OK;
+    }
+    Rccl* R = rccl();
+    float* mine = nullptr;
+    rc = block_rows_in_callers_order(p0, &mine);
+    if (rc) return rc;
+    // (the communicator's calls all go to its own stream; the hand-back is not overlapped with anything)
+    SR_HIP(hipStreamSynchronize(p0->stream));
+    hipStream_t xs = p0->xstream;
+    if (!i_am_root) {
+        if (p0->Lm) SR_RCCL(R->Send(mine, size_t(n) * size_t(p0->ld), ncclFloat, root, p0->comm->nccl, xs));
+        SR_HIP(hipStreamSynchronize(xs));
+        return SIMRANK_OK;
+    }
+    float* scratch = nullptr;
+    const int64_t ld_max = pitch(p0->mb, 4);
+    hipError_t e = pool_hip_alloc((void**)&scratch, size_t(n) * size_t(ld_max) * 4);
+    if (e != hipSuccess) {
+        set_error("simrank_shardplan_result_f64: %s", hipGetErrorString(e));
+        return SIMRANK_ERR_ALLOC;
+    }
+    for (int32_t h = 0; h < P && !rc; ++h) {
+        int64_t lo, hi;
+        part(n, P, h, &lo, &hi);
+        const int64_t w = hi - lo, ldh = pitch(w, 4);
+        if (!w) continue;
+        const float* src = mine;
+        if (h != root) {
+            ncclResult_t r = R->Recv(scratch, size_t(n) * size_t(ldh), ncclFloat, h, p0->comm->nccl, xs);
+            if (r != ncclSuccess || hipStreamSynchronize(xs) != hipSuccess) {
+                set_error("ncclRecv failed: %s", R->GetErrorString(r));
+                rc = SIMRANK_ERR_HIP;
+                break;
+            }
+            src = scratch;
+        }
+        std::vector<double> host(size_t(n) * size_t(w));
+        rc = simrank_download_f64(host.data(), w, src, ldh, n, w, p0->stream);
+        if (!rc) scatter(host, lo, w);
+    }
+    (void)hipStreamSynchronize(p0->stream);
+    (void)pool_free(scratch);
+    return rc;
+}
+
+int simrank_shardplan_info(const simrank_shardplan* p, int64_t* n, int64_t* col_lo, int64_t* col_hi, int32_t* half_form,
+                           int32_t* stages, int32_t* updates) {
+    SR_REQUIRE(p, "plan is NULL");
+    if (n) *n = p->n;
+    if (col_lo) *col_lo = p->m_lo;
+    if (col_hi) *col_hi = p->m_hi;
+    if (half_form) *half_form = p->half_form;
+    if (stages) *stages = p->n_stages;
+    if (updates) *updates = p->updates;
+    return SIMRANK_OK;
+}
+
+}  // extern "C"

@@ -160,6 +160,118 @@ class Plan:
             pass
 
 
+class ShardPlanOptions(C.Structure):           # struct simrank_shardplan_options
+    _fields_ = [("coef", C.c_float), ("lbd", C.c_float), ("apriori", C.c_void_p), ("ld_apriori", C.c_int64),
+                ("evidence", C.c_int32), ("reorder", C.c_int32), ("leg2_form", C.c_int32), ("stages", C.c_int32),
+                ("wire_fp16", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ShardPlans:
+    """This process's share of a SHARDED fit behind the C ABI (simrank_shardplan_*: K10, S split by column block over
+    ``world`` ranks): ONE plan when ``comm`` is an RCCL communicator of a multi-process world (``rccl_comm``), or all
+    ``world`` plans of an in-process group of virtual ranks on this device (``comm=None``: the exchanges are device
+    copies — tests and single-GPU emulation).  ``run`` / ``step`` / ``result`` are collective."""
+
+    def __init__(self, ops, csr: CSR, rowscale=None, world: int = 1, comm=None, coef: float = 0.8, evidence: bool = False,
+                 apriori=None, lbd: float = 0.0, reorder: bool = True, leg2_form: int = -1, stages: int = 0,
+                 wire_fp16: bool = False):
+        self.ops, self.n = ops, csr.n_rows
+        lib = ops.lib
+        rs = np.ascontiguousarray(csr.rowscale if rowscale is None else rowscale, dtype=np.float32)
+        rowptr = np.ascontiguousarray(csr.rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(csr.col, dtype=np.int32)
+        ap = None if apriori is None else np.ascontiguousarray(apriori, dtype=np.float32)
+        opt = ShardPlanOptions(coef=coef, lbd=lbd, apriori=None if ap is None else ap.ctypes.data,
+                               ld_apriori=0 if ap is None else ap.shape[1], evidence=int(evidence), reorder=int(reorder),
+                               leg2_form=int(leg2_form), stages=int(stages), wire_fp16=int(wire_fp16), reserved=0)
+        self.own_comms = comm is None
+        if comm is None:
+            arr = (C.c_void_p * world)()
+            check(lib.simrank_comm_local_group(int(world), arr), "simrank_comm_local_group")
+            self.comms = [C.c_void_p(arr[r]) for r in range(world)]
+        else:
+            self.comms = [comm]
+        self.plans = []
+        with HipOps._knob_lock:
+            for c in self.comms:
+                h = C.c_void_p()
+                check(lib.simrank_shardplan_create(csr.n_rows, col.size, rowptr.ctypes.data,
+                                                   col.ctypes.data if col.size else None, rs.ctypes.data, C.byref(opt),
+                                                   c, ops.stream, C.byref(h)), "simrank_shardplan_create")
+                self.plans.append(h)
+        self._arr = (C.c_void_p * len(self.plans))(*[h.value for h in self.plans])
+
+    @staticmethod
+    def rccl_unique_id(lib) -> bytes:
+        buf = C.create_string_buffer(128)
+        check(lib.simrank_comm_unique_id(buf), "simrank_comm_unique_id")
+        return buf.raw
+
+    @staticmethod
+    def rccl_comm(lib, unique_id: bytes, rank: int, world: int):
+        h = C.c_void_p()
+        check(lib.simrank_comm_create(C.c_char_p(unique_id), int(rank), int(world), C.byref(h)), "simrank_comm_create")
+        return h
+
+    def info(self, i: int = 0) -> dict:
+        n, lo, hi = C.c_int64(), C.c_int64(), C.c_int64()
+        half, stages, updates = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.ops.lib.simrank_shardplan_info(self.plans[i], C.byref(n), C.byref(lo), C.byref(hi), C.byref(half),
+                                                  C.byref(stages), C.byref(updates)), "simrank_shardplan_info")
+        return dict(n=n.value, col_lo=lo.value, col_hi=hi.value, half_form=bool(half.value), stages=stages.value,
+                    updates=updates.value)
+
+    def reset(self):
+        check(self.ops.lib.simrank_shardplan_reset(self._arr, len(self.plans)), "simrank_shardplan_reset")
+
+    def step(self, eps: float, exact_count: bool = True) -> int:
+        c = C.c_int64(0)
+        check(self.ops.lib.simrank_shardplan_step(self._arr, len(self.plans), float(eps), int(exact_count), C.byref(c)),
+              "simrank_shardplan_step")
+        return c.value
+
+    def run(self, iterations: int, eps: float):
+        """-> (updates applied, loop index at which the convergence test passed or None); the same on every rank."""
+        done, conv = C.c_int32(0), C.c_int32(-1)
+        check(self.ops.lib.simrank_shardplan_run(self._arr, len(self.plans), int(iterations), float(eps), C.byref(done),
+                                                 C.byref(conv)), "simrank_shardplan_run")
+        return done.value, (None if conv.value < 0 else conv.value)
+
+    def block(self, i: int = 0):
+        """(float64 [n, columns of plan i] in the caller's row order, the caller's node ids of those columns)."""
+        inf = self.info(i)
+        w = inf["col_hi"] - inf["col_lo"]
+        out = np.empty((self.n, w), dtype=np.float64)
+        ids = np.empty(w, dtype=np.int32)
+        check(self.ops.lib.simrank_shardplan_block_f64(self.plans[i], out.ctypes.data, max(1, w)), "simrank_shardplan_block_f64")
+        check(self.ops.lib.simrank_shardplan_columns(self.plans[i], ids.ctypes.data), "simrank_shardplan_columns")
+        return out, ids
+
+    def result(self, root: int = 0, i_am_root: bool = True):
+        """The whole matrix (float64, caller's order) on rank ``root``; None elsewhere.  Collective."""
+        out = np.empty((self.n, self.n), dtype=np.float64) if i_am_root else None
+        check(self.ops.lib.simrank_shardplan_result_f64(self._arr, len(self.plans), int(root),
+                                                        out.ctypes.data if out is not None else None, self.n),
+              "simrank_shardplan_result_f64")
+        return out
+
+    def free(self):
+        lib = self.ops.lib
+        for h in self.plans:
+            lib.simrank_shardplan_destroy(h)
+        self.plans = []
+        if self.own_comms:
+            for c in self.comms:
+                lib.simrank_comm_destroy(c)
+        self.comms = []
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class BiPlanOptions(C.Structure):              # struct simrank_biplan_options
     _fields_ = [("c1", C.c_float), ("c2", C.c_float), ("lbd1", C.c_float), ("lbd2", C.c_float),
                 ("apriori1", C.c_void_p), ("ld_apriori1", C.c_int64), ("apriori2", C.c_void_p),

@@ -1,0 +1,65 @@
+"""Worker of tests/test_gpu_shardplan.py: one rank of an RCCL world driving `simrank_shardplan_*` through ctypes — no
+torch in this process (the library loads RCCL itself).  Rank 0 writes the communicator id to a file the other ranks
+wait for (the host program's job in a real deployment: MPI, a socket, a file)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world = int(os.environ["SHARD_RANK"]), int(os.environ["SHARD_WORLD"])
+    idfile = os.environ["SHARD_ID_FILE"]
+    from simrank_amd import _lib, ingest, synth
+    from simrank_amd.engine import HipOps, Plan, ShardPlans
+    ops = HipOps(rank % max(1, _lib.device_count()))
+    if rank == 0:
+        uid = ShardPlans.rccl_unique_id(ops.lib)
+        with open(idfile + ".tmp", "wb") as f:
+            f.write(uid)
+        os.replace(idfile + ".tmp", idfile)
+    else:
+        t0 = time.time()
+        while not os.path.exists(idfile):
+            if time.time() - t0 > 120:
+                raise SystemExit("no communicator id")
+            time.sleep(0.05)
+        uid = open(idfile, "rb").read()
+    comm = ShardPlans.rccl_comm(ops.lib, uid, rank, world)
+    n = 1024 * world
+    df = synth.powerlaw_directed(n, 10, seed=6)
+    _, csr = ingest.directed(df, False, "from", "to", "weight")
+    scale = ingest.spread(csr) * csr.rowscale
+    one = Plan(ops, csr, rowscale=scale, evidence=True)
+    want_done, want_conv = one.run(30, 1e-4)
+    want = one.result()
+    one.free()
+    for form, stages, wire in ((0, 1, False), (0, 3, False), (1, 2, False), (0, 2, True)):
+        sp = ShardPlans(ops, csr, rowscale=scale, world=world, comm=comm, evidence=True, leg2_form=form, stages=stages,
+                        wire_fp16=wire)
+        done, conv = sp.run(30, 1e-4)
+        got = sp.result(root=0, i_am_root=rank == 0)
+        if wire:
+            if rank == 0:
+                big = want > 1e-6
+                assert (np.abs(got - want)[big] / want[big]).max() < 5e-3
+        else:
+            assert (done, conv) == (want_done, want_conv), (done, conv, want_done, want_conv)
+            if rank == 0:
+                np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-30)
+        blk, ids = sp.block(0)
+        if rank == 0:
+            assert np.array_equal(got[:, ids], blk)
+        c = sp.step(0.0, exact_count=True)
+        assert c > 0
+        sp.free()
+    ops.lib.simrank_comm_destroy(comm)
+    print("SHARDPLAN RCCL ok", flush=True)
+
+
+if __name__ == "__main__":
+    main()

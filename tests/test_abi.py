@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_string():
     lib = _lib.load()
-    assert lib.simrank_abi_version() == 4
+    assert lib.simrank_abi_version() == 5
     rc = lib.simrank_set_tuning(b"no_such_knob", 1)
     assert rc == -1 and b"no_such_knob" in lib.simrank_last_error()
     assert lib.simrank_set_tuning(b"panel", 48) == -1
@@ -91,11 +91,19 @@ int main(void) {
     simrank_epilogue ep;
     memset(&ep, 0, sizeof ep);
     ep.coef = 0.8f;
-    if (simrank_abi_version() != 4) return 1;
+    if (simrank_abi_version() != SIMRANK_ABI_VERSION) return 1;
     if (simrank_graph_create(0, 4, 0, NULL, NULL, NULL, &g) != SIMRANK_ERR_INVALID) return 2;
     if (simrank_spmm_shard(NULL, NULL, 0, NULL, 0, &ep, 0, 2, NULL, 0, NULL) != SIMRANK_ERR_INVALID) return 3;
     if (simrank_shard_unpack(NULL, 0, NULL, 0, 0, 2, 64, NULL) != SIMRANK_ERR_INVALID) return 4;
     if (!strlen(simrank_last_error())) return 5;
+    {   /* the sharded plan's entry points: argument checks only */
+        simrank_shardplan* sp = NULL;
+        simrank_shardplan_options so;
+        memset(&so, 0, sizeof so);
+        if (simrank_shardplan_create(4, 0, NULL, NULL, NULL, &so, NULL, NULL, &sp) != SIMRANK_ERR_INVALID) return 6;
+        if (simrank_shardplan_step(NULL, 0, 0.0, 1, NULL) != SIMRANK_ERR_INVALID) return 7;
+        if (simrank_comm_local_group(0, NULL) != SIMRANK_ERR_INVALID) return 8;
+    }
     printf("abi %d ok\n", simrank_abi_version());
     return 0;
 }
@@ -107,4 +115,4 @@ int main(void) {
                         capture_output=True, text=True)
     assert cc.returncode == 0, cc.stderr
     run = subprocess.run([str(exe)], capture_output=True, text=True)
-    assert run.returncode == 0 and "abi 4 ok" in run.stdout, (run.returncode, run.stdout, run.stderr)
+    assert run.returncode == 0 and "abi 5 ok" in run.stdout, (run.returncode, run.stdout, run.stderr)

@@ -1,0 +1,218 @@
+"""K10 behind the C ABI on a real MI355X: `simrank_shardplan_*` (csrc/shardplan.hip) — the loop of SimRank.py:129-140,
+:351-362, :443-454 with S split by column block over `world` ranks.  On the one GPU of the box the ranks are an
+IN-PROCESS GROUP (exchanges = device copies) for every world size, and ONE rank of a real RCCL world (own process, no
+torch) for the RCCL calls themselves; two GPUs, where visible, run a real two-rank world.  Checked against the golden
+vectors of the reference, the single-rank plan, and — bit for bit in the full form — the Python driver's sharded path,
+which makes the same launches over torch.distributed."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import simrank_amd.SimRank as SRA
+from oracle import simrank_oracle as O
+from simrank_amd import ingest, synth
+from simrank_amd.driver import LocalWorld
+from tests.conftest import Golden
+from tests.helpers import RTOL, assert_close
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from simrank_amd.engine import HipOps
+    return HipOps(0)
+
+
+def golden_csr(g):
+    G = g.out["G"]
+    n = len(G)
+    rows, cols = np.nonzero(G)
+    rowptr = np.zeros(n + 1, np.int32)
+    np.cumsum(np.bincount(rows, minlength=n), out=rowptr[1:])
+    scale = np.zeros(n)
+    scale[rows] = G[rows, cols]
+    return ingest.CSR(n, n, rowptr, cols.astype(np.int32), scale)
+
+
+def assembled(sp):
+    """The whole matrix from the ranks' blocks (what a host program of a multi-process world would do)."""
+    out = np.full((sp.n, sp.n), np.nan)
+    for i in range(len(sp.plans)):
+        blk, ids = sp.block(i)
+        out[:, ids] = blk
+    return out
+
+
+@pytest.mark.parametrize("world,form,stages", [(1, 0, 1), (2, 0, 1), (3, 0, 2), (4, 0, 1), (4, 1, 1), (2, 1, 3), (5, 0, 1)])
+@pytest.mark.parametrize("name", ["SimRank_er128", "SimRankPP_er128", "SimRank_toy5", "SimRankPP_bts300"])
+def test_shardplan_reproduces_the_golden_vectors(ops, name, world, form, stages):
+    """create -> run -> result on `world` virtual ranks against the vectors generated from the reference: S to 1e-5,
+    the "Converged at iteration k" index exactly; uneven and EMPTY blocks (toy5 on 3..5 ranks), both forms of leg 2,
+    exchange 1 in stages."""
+    from simrank_amd.engine import ShardPlans
+    g = Golden(name)
+    csr = golden_csr(g)
+    if form == 1 and csr.n_rows % (32 * world):
+        pytest.skip("the half form needs n % (32 x ranks) == 0")
+    sp = ShardPlans(ops, csr, world=world, coef=g.kwargs.get("C", 0.8), evidence=name.startswith("SimRankPP"),
+                    leg2_form=form, stages=stages)
+    assert sp.info()["half_form"] == bool(form) and sp.info()["stages"] == stages
+    done, conv = sp.run(g.kwargs.get("iterations", 100), g.kwargs.get("eps", 1e-4))
+    assert (conv if conv is not None else -1) == (g.k if g.k is not None else -1)
+    full = sp.result()
+    assert_close(full, g.out["S"])
+    assert np.array_equal(full, assembled(sp))                   # root's gather == the blocks put together
+    # step by step with the exact count: the passing test is the first zero count
+    sp.reset()
+    eps = g.kwargs.get("eps", 1e-4)
+    counts = [sp.step(eps, exact_count=True) for _ in range(done)]
+    if conv is not None and done:
+        assert counts[-1] == 0 and all(c > 0 for c in counts[:-1])
+    assert_close(sp.result(), g.out["S"])
+    assert sp.run(0, 1e-4) == (0, None)
+    np.testing.assert_array_equal(sp.result(), np.eye(csr.n_rows))
+    assert sp.run(5, 1.0) == (0, 0)
+    sp.free()
+
+
+@pytest.mark.parametrize("pp", [False, True])
+def test_shardplan_full_form_is_the_python_drivers_bits(ops, pp):
+    """The C choreography makes the launches driver.Side makes (same graph, node order, chunk layout, pads): in the
+    full form, unstaged, the result is BIT-EQUAL to `fit(world=LocalWorld(P, symmetric_shards=False))` — and so to a
+    single rank's full form; the half form agrees with the driver's half form bit for bit as well (same dealt order),
+    and with one rank to rounding."""
+    from simrank_amd.engine import ShardPlans
+    df = synth.powerlaw_directed(2048, 12, seed=8)
+    _, csr = ingest.directed(df, False, "from", "to", "weight")
+    cls = SRA.SimRankPP if pp else SRA.SimRank
+    scale = ingest.spread(csr) * csr.rowscale if pp else csr.rowscale
+    for world in (2, 4, 8):
+        want = cls().fit(df, iterations=5, eps=0, verbose=False, mode="sparse", world=LocalWorld(world, symmetric_shards=False))
+        sp = ShardPlans(ops, csr, rowscale=scale, world=world, evidence=pp, leg2_form=0, stages=1)
+        assert sp.run(5, 0.0) == (5, None)
+        got = sp.result()
+        sp.free()
+        assert np.array_equal(got, want.values), world
+        want_half = cls().fit(df, iterations=5, eps=0, verbose=False, mode="sparse", world=LocalWorld(world))
+        sp = ShardPlans(ops, csr, rowscale=scale, world=world, evidence=pp, leg2_form=1, stages=1)
+        assert sp.info()["half_form"]
+        sp.run(5, 0.0)
+        half = sp.result()
+        sp.free()
+        assert np.array_equal(half, want_half.values), world
+        np.testing.assert_allclose(half, got, rtol=2e-6, atol=1e-30)
+        # exchange 1 in stages: whole panels per slice, the same plan: same values
+        sp = ShardPlans(ops, csr, rowscale=scale, world=world, evidence=pp, leg2_form=0, stages=3)
+        sp.run(5, 0.0)
+        staged = sp.result()
+        sp.free()
+        np.testing.assert_allclose(staged, got, rtol=2e-6, atol=1e-30)
+
+
+def test_shardplan_with_a_prior_against_the_oracle(ops):
+    """AprioriSimRank's loop (SimRank.py:443-454) on four virtual ranks: symmetric prior, evidence, nodes dealt inside,
+    results in the caller's order; an asymmetric prior is refused."""
+    from simrank_amd._lib import SimRankHipError
+    from simrank_amd.engine import ShardPlans
+    df = synth.powerlaw_directed(640, 9, seed=5)
+    _, csr = ingest.directed(df, False, "from", "to", "weight")
+    rng = np.random.default_rng(2)
+    A = rng.random((csr.n_rows, csr.n_rows))
+    A = (A + A.T) / 2
+    G = csr.dense()
+    want_S, want_k = O.iterate_directed(G, C=0.7, iterations=100, eps=1e-4, E=O.evidence(G),
+                                        apriori=A.astype(np.float32).astype(np.float64), lbd=0.3)
+    for form in (0, 1):
+        sp = ShardPlans(ops, csr, world=4, coef=0.7, evidence=True, apriori=A, lbd=0.3, leg2_form=form)
+        done, conv = sp.run(100, 1e-4)
+        assert conv == want_k
+        assert_close(sp.result(), want_S)
+        sp.free()
+    A[3, 5] += 0.5
+    with pytest.raises(SimRankHipError, match="symmetric"):
+        ShardPlans(ops, csr, world=2, apriori=A, lbd=0.3)
+
+
+def test_shardplan_fp16_wire(ops):
+    """options.wire_fp16: the exchanges move fp16 x 2^14 — the same roundings as the Python driver's
+    `exchange_precision="fp16"` (bit-equal to it in the full form), a few fp16 spacings from the f32 wire."""
+    from simrank_amd.engine import ShardPlans
+    df = synth.powerlaw_directed(1024, 8, seed=4)
+    _, csr = ingest.directed(df, False, "from", "to", "weight")
+    exact = SRA.SimRank().fit(df, iterations=6, eps=0, verbose=False, mode="sparse",
+                              world=LocalWorld(4, symmetric_shards=False))
+    emu = SRA.SimRank().fit(df, iterations=6, eps=0, verbose=False, mode="sparse",
+                            world=LocalWorld(4, symmetric_shards=False, exchange_precision="fp16"))
+    sp = ShardPlans(ops, csr, world=4, leg2_form=0, stages=1, wire_fp16=True)
+    sp.run(6, 0.0)
+    got = sp.result()
+    sp.free()
+    assert np.array_equal(got, emu.values)
+    big = exact.values > 1e-6
+    rel = np.abs(got - exact.values)[big] / exact.values[big]
+    assert 1e-7 < rel.max() < 4e-3
+    sp = ShardPlans(ops, csr, world=4, leg2_form=1, stages=2, wire_fp16=True)
+    sp.run(6, 0.0)
+    half = sp.result()
+    sp.free()
+    rel = np.abs(half - exact.values)[big] / exact.values[big]
+    assert 1e-7 < rel.max() < 4e-3
+
+
+def test_shardplan_refuses_what_it_cannot_run(ops):
+    from simrank_amd._lib import SimRankHipError
+    from simrank_amd.engine import ShardPlans
+    import ctypes as C
+    df = synth.powerlaw_directed(100, 5, seed=1)
+    _, csr = ingest.directed(df, False, "from", "to", "weight")
+    with pytest.raises(SimRankHipError, match="multiple of 32"):
+        ShardPlans(ops, csr, world=2, leg2_form=1)
+    sp = ShardPlans(ops, csr, world=3)
+    one = (C.c_void_p * 1)(sp.plans[0].value)
+    assert ops.lib.simrank_shardplan_step(one, 1, 0.0, 1, None) != 0        # a group advances all its plans together
+    assert b"in-process group" in ops.lib.simrank_last_error()
+    sp.free()
+    bad = ingest.CSR(csr.n_rows, csr.n_cols, csr.rowptr[::-1].copy(), csr.col, csr.rowscale)
+    with pytest.raises(SimRankHipError):
+        ShardPlans(ops, bad, world=2)
+
+
+def _run_workers(n_ranks, tmp_path):
+    idfile = tmp_path / "rccl_id.bin"
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, SHARD_RANK=str(r), SHARD_WORLD=str(n_ranks), SHARD_ID_FILE=str(idfile),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_rccl_worker.py")], env=env,
+                                      cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, err = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, out, err))
+    return outs
+
+
+def test_shardplan_over_rccl_one_rank(tmp_path):
+    """The RCCL communicator itself (dlopen, ncclCommInitRank, the send / receive groups on their own stream, the
+    all-reduce of the count) in a process of its own without torch: a world of one rank on the one GPU."""
+    (rc, out, err), = _run_workers(1, tmp_path)
+    assert rc == 0 and "SHARDPLAN RCCL ok" in out, out[-3000:] + err[-3000:]
+
+
+def test_shardplan_over_rccl_two_ranks(tmp_path):
+    """A real two-rank world (one process per GPU, the all-to-alls over xGMI); skipped on the one-GPU box."""
+    from simrank_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    outs = _run_workers(2, tmp_path)
+    assert all(rc == 0 and "SHARDPLAN RCCL ok" in out for rc, out, err in outs), [o[1][-2000:] + o[2][-2000:] for o in outs]

@@ -345,6 +345,32 @@ static void fuzz_plan_inputs(std::mt19937& rng, const Csr& sq, const Csr& rect) 
         opt.ld_apriori = n - 1;
         CHECK(simrank::plan_prepare(n, nnz, sq.rowptr.data(), sq.col.data(), sq.scale.data(), &opt, &pp) == SIMRANK_ERR_INVALID, "short ld accepted");
     }
+    // the sharded plan's node order: a permutation whatever the shard count; dealt in runs when n divides evenly, each
+    // shard's rows ascending; malformed input refused
+    for (int32_t deal : {1, 2, 3, 8}) {
+        simrank::PlanPrep sp;
+        CHECK(simrank::shard_prepare(n, nnz, sq.rowptr.data(), sq.col.data(), sq.scale.data(), nullptr, 0, true, deal, &sp) == SIMRANK_OK,
+              "shard_prepare: %s", simrank_last_error());
+        std::vector<int> seen((size_t)n, 0);
+        for (int64_t r = 0; r < n; ++r)
+            CHECK(sp.ord[r] >= 0 && sp.ord[r] < n && !seen[sp.ord[r]]++ && sp.inv[sp.ord[r]] == r, "dealt order is not a permutation");
+        CHECK(sp.rp[n] == nnz, "dealt pattern loses entries");
+        const bool dealt = deal > 1 && n % (32 * int64_t(deal)) == 0;
+        const int64_t per = dealt ? n / deal : n;
+        for (int64_t r = 1; r < n; ++r)
+            CHECK(r % per == 0 || sp.rp[r] - sp.rp[r - 1] <= sp.rp[r + 1] - sp.rp[r], "rows of a shard not in ascending length");
+        if (dealt) {                               // every shard holds the same mix: shard totals within one run of rows
+            std::vector<int64_t> tot((size_t)deal, 0);
+            for (int64_t r = 0; r < n; ++r) tot[(size_t)(r / per)] += sp.rp[r + 1] - sp.rp[r];
+            for (int32_t w = 1; w < deal; ++w) CHECK(tot[w] >= tot[w - 1], "later shards must not be lighter (dealt ascending)");
+        }
+        if (nnz > 2) {
+            std::vector<int32_t> cl = sq.col;
+            cl[nnz / 2] = (int32_t)n;
+            CHECK(simrank::shard_prepare(n, nnz, sq.rowptr.data(), cl.data(), sq.scale.data(), nullptr, 0, true, deal, &sp) == SIMRANK_ERR_INVALID,
+                  "shard_prepare accepted a bad column");
+        }
+    }
     // bipartite: the transpose and both renamed patterns
     simrank_biplan_options bo{};
     bo.c1 = bo.c2 = 0.8f;

@@ -476,7 +476,7 @@ SIMRANK_API int simrank_biplan_destroy(simrank_biplan* p);
  *      Nodes: ascending row length, dealt to the shards in runs of 128 in the half form (as driver.dealt_order).
  *      Results: simrank_shardplan_block_f64 = the rank's columns (all n rows, caller's row order) + their node ids by
  *      simrank_shardplan_columns; simrank_shardplan_result_f64 assembles the whole matrix on rank `root`.
- *      Only symmetric iterates (SimRank, SimRank++, symmetric priors); f32. */
+ *      Only symmetric iterates (SimRank, SimRank++, symmetric priors); f32, or fp16-held matrices (options.storage_fp16). */
 typedef struct simrank_comm simrank_comm;
 #define SIMRANK_COMM_ID_BYTES 128
 /* rank 0 makes an id, the host program hands its bytes to every rank (its own job: MPI, a file, a socket), every rank
@@ -501,7 +501,10 @@ typedef struct simrank_shardplan_options {
     int32_t stages;             /* exchange 1 in that many overlapped stages (0: by the width of a rank's block) */
     int32_t wire_fp16;          /* 1: the exchanges move fp16 x 2^14 (half the link bytes, f32 kernels, one fp16 rounding
                                    of the transposed product per update: outside the parity bar); 0 (default): f32 */
-    int32_t reserved;           /* 0 */
+    int32_t storage_fp16;       /* 1: S, the transposed product and the leg-2 operand HELD in fp16 on 64-column panels ("FP16
+                                   STORAGE" above; BASELINE config 5 in its stated form: reduced precision AND shards): half the
+                                   kernel bytes and half the link bytes; needs n % (64 world) == 0, leg 2 in its full form,
+                                   no prior; outside the parity bar, the convergence index is not reference-comparable */
 } simrank_shardplan_options;
 SIMRANK_API int simrank_shardplan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col,
                                          const float* rowscale, const simrank_shardplan_options* options,

@@ -75,6 +75,8 @@ struct HalfArgs {
     int64_t prev_rows_pad;
     unsigned long long* n_changed;
     int32_t set_diag, count_any;
+    int32_t full;              // leg 2 of a SHARDED update: every element of the n_rows x L column block (no triangle, no
+    int32_t col0;              // mirror image); col0 = global index of the block's column 0 (diagonal: row == col0 + column)
 };
 
 #ifndef SIMRANK_HOST_ONLY
@@ -119,7 +121,8 @@ __device__ __forceinline__ float half_bits_to_float(uint32_t bits16) {
 #ifndef SIMRANK_HALF_LB2
 #define SIMRANK_HALF_LB2 3      // ... of leg 2
 #endif
-template <bool IDS16, bool SYM, bool PRIOR>
+// FULL: leg 2 of one rank of a sharded update — the whole column block, each element once, no mirror image
+template <bool IDS16, bool SYM, bool PRIOR, bool FULL = false>
 __global__ __launch_bounds__(256, SYM ? SIMRANK_HALF_LB2 : SIMRANK_HALF_LB1) void half_leg_kernel(const HalfArgs p) {
     // [row][column] of the block's result: a lane group finishes a row with two 16-byte writes per lane; the
     // strided reads are left to the transposed store, which runs with all lanes
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256, SYM ? SIMRANK_HALF_LB2 : SIMRANK_HALF_LB1) voi
     const int g = lane >> 3, q = lane & 7, gbase = lane & ~7;
     const uint32_t qoff = uint32_t(q) * 16u;
     int n_sub = un[8];
-    if constexpr (SYM) {
+    if constexpr (SYM && !FULL) {
         // blocks whose first row lies right of the panel's last column have nothing in the upper triangle
         const int64_t last_c = (p.L < c0 + 64 ? p.L : c0 + 64) - 1;
         int k = 0;
@@ -363,6 +366,7 @@ __global__ __launch_bounds__(256, SYM ? SIMRANK_HALF_LB2 : SIMRANK_HALF_LB1) voi
                 // that holds 16 gathers in flight).
                 const int cb = int(c0) + 8 * q;                // first of this lane's columns
                 const int Lc = int(p.L);
+                constexpr bool full = FULL;                    // (sharded leg 2: the whole block, each element once)
                 const bool check = p.prev && !(p.count_any && seen);
                 const uint32_t half32 = uint32_t(q >> 2), o32 = uint32_t(8 * q) & 31u;
                 const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(256, SYM ? SIMRANK_HALF_LB2 : SIMRANK_HALF_LB1) voi
                     for (int it = 0; it < RB; ++it) {
                         const int r = 32 * wave + 8 * (RB * pair + it) + g;
                         const int a = row0 + r;
-                        const bool on = r < nrows && a <= cb + 7 && cb < Lc;
+                        const bool on = r < nrows && (full || a <= cb + 7) && cb < Lc;
                         // (rows that are off load from an offset past the descriptor's end: zeros, no branch)
                         const uint32_t off = on ? uint32_t(a) : 0x7FFFFFF0u / 256u;
                         evw[it] = __builtin_amdgcn_raw_buffer_load_b64(esrd, int(off * 32u + ev_off), 0, 2);
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(256, SYM ? SIMRANK_HALF_LB2 : SIMRANK_HALF_LB1) voi
                     for (int it = 0; it < RB; ++it) {
                         const int r = 32 * wave + 8 * (RB * pair + it) + g;
                         const int a = row0 + r;
-                        const bool on = r < nrows && a <= cb + 7 && cb < Lc;
+                        const bool on = r < nrows && (full || a <= cb + 7) && cb < Lc;
                         if (on) {
                             float4* tp = reinterpret_cast<float4*>(tile + r * kHR + 8 * q);
                             const float4 t0 = tp[0], t1 = tp[1];
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(256, SYM ? SIMRANK_HALF_LB2 : SIMRANK_HALF_LB1) voi
                                 for (int i = 0; i < 8; ++i) o[i] = keep * o[i] + (p.lbd * p.scale) * pr[i];
                             }
                             if (p.set_diag) {
-                                const int d = a - cb;
+                                const int d = a - cb - (FULL ? p.col0 : 0);
 #pragma unroll
                                 for (int i = 0; i < 8; ++i)
                                     if (d == i) o[i] = p.scale;
@@ -455,20 +459,20 @@ __global__ __launch_bounds__(256, SYM ? SIMRANK_HALF_LB2 : SIMRANK_HALF_LB1) voi
                                     const float ov = half_bits_to_float(ob);
                                     const float hu = __builtin_ldexpf(1.0f, max(int((ob >> 10) & 31u), 1) - 26);
                                     const int c = cb + i;
-                                    const bool counts = c >= a && c < Lc;
+                                    const bool counts = (full || c >= a) && c < Lc;
                                     changed += (counts && fabs(double(o[i]) - double(ov)) > p.eps + double(hu))
-                                                   ? (c > a ? 2u : 1u) : 0u;
+                                                   ? (c > a && !full ? 2u : 1u) : 0u;
                                 }
                             }
                             tp[0] = make_float4(nvs[0], nvs[1], nvs[2], nvs[3]);
                             tp[1] = make_float4(nvs[4], nvs[5], nvs[6], nvs[7]);
                             const int yoff = int(uint32_t(a) * 128u + qoff);
-                            if (a <= cb && cb + 7 < Lc) {
+                            if ((full || a <= cb) && cb + 7 < Lc) {
                                 __builtin_amdgcn_raw_buffer_store_b128(out, ysrd, yoff, 0, 2);
                             } else {
 #pragma unroll
                                 for (int i = 0; i < 8; ++i)
-                                    if (cb + i >= a && cb + i < Lc)
+                                    if ((full || cb + i >= a) && cb + i < Lc)
                                         __builtin_amdgcn_raw_buffer_store_b16(
                                             (unsigned short)((ow[i >> 1] >> (16 * (i & 1))) & 0xFFFFu), ysrd, yoff + 2 * i, 0, 0);
                             }
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(256, SYM ? SIMRANK_HALF_LB2 : SIMRANK_HALF_LB1) voi
             // ------------------------------------------------------------ 4. transposed store
             // wave w: rows 64 (w >> 1) .. + 63 of the block (one 64-column panel of the output), columns
             // 32 (w & 1) .. + 31 of this panel (32 consecutive rows of the output) = 4 KiB contiguous
-            {
+            if constexpr (!(SYM && FULL)) {
                 const int ap = wave >> 1, cw = wave & 1;
                 const int rows_here = nrows - 64 * ap;                 // rows of the block in this output panel
                 if (rows_here > 0) {
@@ -736,8 +740,14 @@ int simrank_spmm_blocked_h16(const simrank_graph* g, const void* X, int64_t x_ro
     a.dcols16 = pl->dcols16; a.dcols32 = pl->dcols32; a.abits = pl->abits;
     a.gmeta = pl->gmeta; a.sids16 = pl->sids16; a.sids32 = pl->sids32;
     if (ep) {
-        SR_REQUIRE(ep->symmetric && n_cols_x == g->n_rows && ep->diag_col0 == 0,
-                   "fp16 storage: leg 2 is the symmetric single-rank form only");
+        // symmetric = 1: one rank holds the whole matrix (upper triangle + mirror image); symmetric = 0: the column block
+        // [diag_col0, diag_col0 + n_cols_x) of one rank of a sharded update, every element computed (csrc/shardplan.hip)
+        SR_REQUIRE(ep->symmetric ? (n_cols_x == g->n_rows && ep->diag_col0 == 0)
+                                 : (ep->diag_col0 >= 0 && ep->diag_col0 + n_cols_x <= g->n_rows),
+                   "fp16 storage: leg 2 is the symmetric single-rank form, or a column block of a sharded update");
+        SR_REQUIRE(ep->symmetric || !ep->apriori, "fp16 storage: a sharded leg 2 takes no prior");
+        a.full = ep->symmetric ? 0 : 1;
+        a.col0 = (int32_t)ep->diag_col0;
         a.coef = ep->coef; a.lbd = ep->lbd; a.eps = ep->eps * double(scale);
         a.scale = scale;
         a.ev = ep->evidence; a.ap = ep->apriori;
@@ -759,7 +769,10 @@ int simrank_spmm_blocked_h16(const simrank_graph* g, const void* X, int64_t x_ro
 #define SR_HALF(SYM, PRI) \
     do { if (pl->ids16) hipLaunchKernelGGL((half_leg_kernel<true, SYM, PRI>), dim3((unsigned)grid), dim3(256), 0, st, a); \
          else hipLaunchKernelGGL((half_leg_kernel<false, SYM, PRI>), dim3((unsigned)grid), dim3(256), 0, st, a); } while (0)
-    if (ep && a.ap) SR_HALF(true, true);
+    if (ep && a.full) {
+        if (pl->ids16) hipLaunchKernelGGL((half_leg_kernel<true, true, false, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((half_leg_kernel<false, true, false, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    } else if (ep && a.ap) SR_HALF(true, true);
     else if (ep) SR_HALF(true, false);
     else SR_HALF(false, false);
 #undef SR_HALF

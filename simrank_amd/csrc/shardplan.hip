@@ -89,6 +89,7 @@ struct LocalGroup {
     int32_t alive = 0;
 };
 
+constexpr float kHalfScale = 16384.0f;       // what fp16-held matrices are scaled by (include/simrank_hip.h, SCALE)
 constexpr float kWireScale = 16384.0f;       // what values on an fp16 wire are multiplied by (engine.HipOps.WIRE_SCALE)
 
 static int64_t env_pad(const char* name) {
@@ -117,14 +118,14 @@ static int64_t span(int64_t n, int32_t world, int32_t rank) {
     return hi - lo;
 }
 // driver.stage_widths: equal pieces rounded up to whole 32-column panels, the last one shorter or empty
-static int64_t stage_width(int64_t n_cols, int32_t n_stages, int32_t s) {
+static int64_t stage_width(int64_t n_cols, int32_t n_stages, int32_t s, int32_t align = 32) {
     int64_t q = (n_cols + n_stages - 1) / n_stages;
-    q = (q + 31) / 32 * 32;
+    q = (q + align - 1) / align * align;
     return std::max<int64_t>(0, std::min<int64_t>(q, n_cols - s * q));
 }
-static int64_t stage_col0(int64_t n_cols, int32_t n_stages, int32_t s) {
+static int64_t stage_col0(int64_t n_cols, int32_t n_stages, int32_t s, int32_t align = 32) {
     int64_t c = 0;
-    for (int32_t t = 0; t < s; ++t) c += stage_width(n_cols, n_stages, t);
+    for (int32_t t = 0; t < s; ++t) c += stage_width(n_cols, n_stages, t, align);
     return c;
 }
 
@@ -160,6 +161,11 @@ struct simrank_shardplan {
     hipStream_t stream = nullptr;
     hipStream_t xstream = nullptr;          // RCCL's stream for exchange 1 (stages overlap the kernels)
     std::vector<hipEvent_t> staged;         // [n_stages] "this stage's kernel is done" + [1] "all stages have arrived"
+    // storage_fp16: S, the transposed product and the leg-2 operand HELD in fp16 on 64-column panels (half.hip):
+    // S[] = n rows x Lm columns, `send` = Lm rows x n columns (what leg 1 stores), `recv` = n rows x Lm columns
+    int32_t half = 0;
+    int64_t rows_pad = 0, rows_pad_t = 0;   // padded rows of an n-row / an Lm-row panel
+    float* hand[2] = {nullptr, nullptr};    // hand-back scratch of an fp16 plan: f32 panel-blocked, f32 row-major
     float coef = 0.8f, lbd = 0.f;
     int32_t restrict_support = 0, half_form = 0, n_stages = 1, wire_fp16 = 0;
     int cur = 0;
@@ -168,73 +174,84 @@ struct simrank_shardplan {
 
 namespace simrank {
 
-// ---- one all-to-all: what every local plan sends to / receives from every rank (element counts) ----
+// ---- one all-to-all: what every local plan sends to / receives from every rank, as lists of pieces (element counts;
+// rank s's i-th piece for rank d is rank d's i-th piece from rank s) ----
+struct Piece {
+    char* ptr;
+    int64_t n;
+};
 struct Route {
-    std::vector<const float*> sp;
-    std::vector<float*> rp;
-    std::vector<int64_t> sn, rn;
+    std::vector<std::vector<Piece>> out, in;          // [peer][piece]
     const float* send_base = nullptr;       // the f32 buffers the pieces lie in, and their fp16 shadows (wire_fp16)
     float* recv_base = nullptr;
     uint16_t* send_h = nullptr;
     uint16_t* recv_h = nullptr;
-    explicit Route(int32_t world) : sp(world, nullptr), rp(world, nullptr), sn(world, 0), rn(world, 0) {}
+    explicit Route(int32_t world) : out(world), in(world) {}
+    void add_out(int32_t h, const void* ptr, int64_t n) { if (n) out[h].push_back(Piece{(char*)const_cast<void*>(ptr), n}); }
+    void add_in(int32_t h, void* ptr, int64_t n) { if (n) in[h].push_back(Piece{(char*)ptr, n}); }
 };
 
-static int all_to_all(simrank_shardplan* const* plans, int32_t n_local, std::vector<Route>& routes, hipStream_t st) {
+// elem: bytes per element of the buffers (4: f32 — narrowed to fp16 on the way when the plan's wire is fp16; 2: fp16-held)
+static int all_to_all(simrank_shardplan* const* plans, int32_t n_local, std::vector<Route>& routes, hipStream_t st, int elem) {
     simrank_shardplan* p0 = plans[0];
     const int32_t P = p0->world;
-    const bool wire = p0->wire_fp16 != 0;
+    const bool wire = p0->wire_fp16 != 0 && elem == 4;
     // fp16 wire: narrow every outgoing piece into the shadow at the same element offset
     if (wire)
         for (int32_t i = 0; i < n_local; ++i)
-            for (int32_t h = 0; h < P; ++h) {
-                Route& r = routes[i];
-                if (!r.sn[h]) continue;
-                const int rc = simrank_narrow_h16(r.sp[h], r.send_h + (r.sp[h] - r.send_base), r.sn[h], kWireScale, st);
-                if (rc) return rc;
-            }
-    const size_t elem = wire ? 2 : 4;
-    auto src_of = [&](Route& r, int32_t h) -> const void* {
-        return wire ? (const void*)(r.send_h + (r.sp[h] - r.send_base)) : (const void*)r.sp[h];
+            for (int32_t h = 0; h < P; ++h)
+                for (const Piece& pc : routes[i].out[h]) {
+                    const float* src = (const float*)pc.ptr;
+                    const int rc = simrank_narrow_h16(src, routes[i].send_h + (src - routes[i].send_base), pc.n, kWireScale, st);
+                    if (rc) return rc;
+                }
+    const size_t bytes = wire ? 2 : size_t(elem);
+    auto src_of = [&](Route& r, const Piece& pc) -> const void* {
+        return wire ? (const void*)(r.send_h + ((const float*)pc.ptr - r.send_base)) : (const void*)pc.ptr;
     };
-    auto dst_of = [&](Route& r, int32_t h) -> void* {
-        return wire ? (void*)(r.recv_h + (r.rp[h] - r.recv_base)) : (void*)r.rp[h];
+    auto dst_of = [&](Route& r, const Piece& pc) -> void* {
+        return wire ? (void*)(r.recv_h + ((float*)pc.ptr - r.recv_base)) : (void*)pc.ptr;
+    };
+    auto matched = [&](const std::vector<Piece>& a, const std::vector<Piece>& b) {
+        if (a.size() != b.size()) return false;
+        for (size_t i = 0; i < a.size(); ++i)
+            if (a[i].n != b[i].n) return false;
+        return true;
     };
     if (p0->comm->group) {
         for (int32_t s = 0; s < P; ++s)
             for (int32_t d = 0; d < P; ++d) {
-                const int64_t cnt = routes[s].sn[d];
-                SR_REQUIRE(cnt == routes[d].rn[s], "ranks %d and %d disagree about a chunk (%lld / %lld elements)", s, d,
-                           (long long)cnt, (long long)routes[d].rn[s]);
-                if (cnt)
-                    SR_HIP(hipMemcpyAsync(dst_of(routes[d], s), src_of(routes[s], d), size_t(cnt) * elem,
-                                          hipMemcpyDeviceToDevice, st));
+                SR_REQUIRE(matched(routes[s].out[d], routes[d].in[s]), "ranks %d and %d disagree about their chunks", s, d);
+                for (size_t i = 0; i < routes[s].out[d].size(); ++i)
+                    SR_HIP(hipMemcpyAsync(dst_of(routes[d], routes[d].in[s][i]), src_of(routes[s], routes[s].out[d][i]),
+                                          size_t(routes[s].out[d][i].n) * bytes, hipMemcpyDeviceToDevice, st));
             }
     } else {
         Rccl* R = rccl();
         Route& r = routes[0];
         const int32_t me = p0->rank;
-        if (r.sn[me]) {                      // the chunk a rank addresses to itself never touches the fabric
-            SR_REQUIRE(r.sn[me] == r.rn[me], "own chunk: %lld / %lld elements", (long long)r.sn[me], (long long)r.rn[me]);
-            SR_HIP(hipMemcpyAsync(dst_of(r, me), src_of(r, me), size_t(r.sn[me]) * elem, hipMemcpyDeviceToDevice, st));
-        }
-        const ncclDataType_t dt = wire ? ncclHalf : ncclFloat;
+        // the chunk a rank addresses to itself never touches the fabric
+        SR_REQUIRE(matched(r.out[me], r.in[me]), "own chunk: pieces differ");
+        for (size_t i = 0; i < r.out[me].size(); ++i)
+            SR_HIP(hipMemcpyAsync(dst_of(r, r.in[me][i]), src_of(r, r.out[me][i]), size_t(r.out[me][i].n) * bytes,
+                                  hipMemcpyDeviceToDevice, st));
+        const ncclDataType_t dt = bytes == 2 ? ncclHalf : ncclFloat;
         SR_RCCL(R->GroupStart());
         for (int32_t h = 0; h < P; ++h) {
             if (h == me) continue;
-            if (r.sn[h]) SR_RCCL(R->Send(src_of(r, h), size_t(r.sn[h]), dt, h, p0->comm->nccl, st));
-            if (r.rn[h]) SR_RCCL(R->Recv(dst_of(r, h), size_t(r.rn[h]), dt, h, p0->comm->nccl, st));
+            for (const Piece& pc : r.out[h]) SR_RCCL(R->Send(src_of(r, pc), size_t(pc.n), dt, h, p0->comm->nccl, st));
+            for (const Piece& pc : r.in[h]) SR_RCCL(R->Recv(dst_of(r, pc), size_t(pc.n), dt, h, p0->comm->nccl, st));
         }
         SR_RCCL(R->GroupEnd());
     }
     if (wire)
         for (int32_t i = 0; i < n_local; ++i)
-            for (int32_t h = 0; h < P; ++h) {
-                Route& r = routes[i];
-                if (!r.rn[h]) continue;
-                const int rc = simrank_widen_h16(r.recv_h + (r.rp[h] - r.recv_base), r.rp[h], r.rn[h], kWireScale, st);
-                if (rc) return rc;
-            }
+            for (int32_t h = 0; h < P; ++h)
+                for (const Piece& pc : routes[i].in[h]) {
+                    float* dst = (float*)pc.ptr;
+                    const int rc = simrank_widen_h16(routes[i].recv_h + (dst - routes[i].recv_base), dst, pc.n, kWireScale, st);
+                    if (rc) return rc;
+                }
     return SIMRANK_OK;
 }
 
@@ -247,7 +264,7 @@ static int check_group(simrank_shardplan* const* plans, int32_t n_local) {
             SR_REQUIRE(plans[i] && plans[i]->comm->group == p0->comm->group && plans[i]->rank == i &&
                            plans[i]->stream == p0->stream && plans[i]->n == p0->n &&
                            plans[i]->half_form == p0->half_form && plans[i]->n_stages == p0->n_stages &&
-                           plans[i]->wire_fp16 == p0->wire_fp16,
+                           plans[i]->wire_fp16 == p0->wire_fp16 && plans[i]->half == p0->half,
                        "plans[%d] is not rank %d of the same in-process group, stream and options", i, i);
     } else {
         SR_REQUIRE(n_local == 1, "a process of a multi-process world holds one plan");
@@ -270,6 +287,7 @@ static void fill_epilogue(simrank_shardplan* p, double eps, int32_t exact_count,
     ep->diag_col0 = p->m_lo;
     ep->set_diag = 1;
     ep->symmetric = 0;
+    if (p->half) ep->ld_evidence = ep->ld_apriori = ep->ld_previous = 0;      // (panel-blocked: the padded rows say it all)
     ep->restrict_support = p->restrict_support;
     ep->count_any = exact_count ? 0 : 1;
 }
@@ -281,36 +299,56 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
     const bool local = p0->comm->group != nullptr;
     hipStream_t xs = local ? p0->stream : p0->xstream;
     // leg 1 + exchange 1, stage by stage
+    const int32_t walign = p0->half ? 64 : 32;            // stage widths: whole panels of the operand
     for (int32_t s = 0; s < S; ++s) {
         std::vector<Route> routes(n_local, Route(P));
         for (int32_t i = 0; i < n_local; ++i) {
             simrank_shardplan* p = plans[i];
-            const int64_t w = stage_width(p->Lm, S, s), c0 = stage_col0(p->Lm, S, s);
-            const int64_t send_off = c0 * p->send_ld;
-            if (w) {
-                const int rc = simrank_spmm(p->g, p->S[p->cur] + c0, p->ld, w, p->send + send_off, 0, 1, p->mb, p->pad,
-                                            nullptr, p->stream);
-                if (rc) return rc;
-            }
+            const int64_t w = stage_width(p->Lm, S, s, walign), c0 = stage_col0(p->Lm, S, s, walign);
             Route& r = routes[i];
-            r.send_base = p->send; r.recv_base = p->recv;
-            r.send_h = p->wire[0]; r.recv_h = p->wire[1];
-            for (int32_t h = 0; h < P; ++h) {
-                r.sp[h] = p->send + send_off + int64_t(h) * w * (p->mb + p->pad);
-                r.sn[h] = w * (span(p->n, P, h) + p->pad);
-                int64_t k_lo, k_hi;
-                part(p->n, P, h, &k_lo, &k_hi);
-                const int64_t wh = stage_width(k_hi - k_lo, S, s), ch = stage_col0(k_hi - k_lo, S, s);
-                r.rp[h] = p->recv + (k_lo + ch) * p->recv_ld;
-                r.rn[h] = wh * p->recv_ld;
-                if (!p->Lm) r.rn[h] = 0;                 // (a rank without columns receives rows of zero length)
+            if (p->half) {
+                // fp16-held: leg 1 stores rows [c0, c0 + w) of every 64-column panel of (W.S_block)^T (Lm rows x n
+                // columns); the panels of rank h's columns go to rank h and land, panel by panel, at the rows of its
+                // leg-2 operand this rank's columns own
+                uint16_t* T = reinterpret_cast<uint16_t*>(p->send);
+                uint16_t* X2 = reinterpret_cast<uint16_t*>(p->recv);
+                if (w) {
+                    const int rc = simrank_spmm_blocked_h16(p->g, reinterpret_cast<uint16_t*>(p->S[p->cur]) + (c0 / 64) * p->rows_pad * 64,
+                                                            p->rows_pad, w, T + c0 * 64, p->rows_pad_t, 1, nullptr, 0,
+                                                            kHalfScale, p->stream);
+                    if (rc) return rc;
+                }
+                for (int32_t h = 0; h < P; ++h) {
+                    int64_t lo, hi;
+                    part(p->n, P, h, &lo, &hi);
+                    for (int64_t pn = lo / 64; pn < hi / 64; ++pn) r.add_out(h, T + (pn * p->rows_pad_t + c0) * 64, w * 64);
+                    const int64_t wh = stage_width(hi - lo, S, s, walign), ch = stage_col0(hi - lo, S, s, walign);
+                    for (int64_t pn = 0; pn < p->Lm / 64; ++pn) r.add_in(h, X2 + (pn * p->rows_pad + lo + ch) * 64, wh * 64);
+                }
+            } else {
+                const int64_t send_off = c0 * p->send_ld;
+                if (w) {
+                    const int rc = simrank_spmm(p->g, p->S[p->cur] + c0, p->ld, w, p->send + send_off, 0, 1, p->mb, p->pad,
+                                                nullptr, p->stream);
+                    if (rc) return rc;
+                }
+                r.send_base = p->send; r.recv_base = p->recv;
+                r.send_h = p->wire[0]; r.recv_h = p->wire[1];
+                for (int32_t h = 0; h < P; ++h) {
+                    r.add_out(h, p->send + send_off + int64_t(h) * w * (p->mb + p->pad), w * (span(p->n, P, h) + p->pad));
+                    int64_t k_lo, k_hi;
+                    part(p->n, P, h, &k_lo, &k_hi);
+                    const int64_t wh = stage_width(k_hi - k_lo, S, s, walign), ch = stage_col0(k_hi - k_lo, S, s, walign);
+                    // (a rank without columns receives rows of zero length)
+                    r.add_in(h, p->recv + (k_lo + ch) * p->recv_ld, p->Lm ? wh * p->recv_ld : 0);
+                }
             }
             if (!local) {                                // RCCL's stream waits for this stage's kernel only
                 SR_HIP(hipEventRecord(p->staged[s], p->stream));
                 SR_HIP(hipStreamWaitEvent(xs, p->staged[s], 0));
             }
         }
-        const int rc = all_to_all(plans, n_local, routes, xs);
+        const int rc = all_to_all(plans, n_local, routes, xs, p0->half ? 2 : 4);
         if (rc) return rc;
     }
     // every RCCL call of this communicator is issued on ITS stream, in one order; `hop` makes one stream wait for the other
@@ -329,6 +367,9 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
         fill_epilogue(p, eps, exact_count, &ep);
         if (!p->Lm) {
             SR_HIP(hipMemsetAsync(p->counters, 0, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS, p->stream));
+        } else if (p->half) {
+            rc = simrank_spmm_blocked_h16(p->g, p->recv, p->rows_pad, p->Lm, p->S[p->cur ^ 1], p->rows_pad, 0, &ep, p->rows_pad,
+                                          kHalfScale, p->stream);
         } else if (p->half_form) {
             rc = simrank_spmm_shard(p->g, p->recv, p->recv_ld, p->S[p->cur ^ 1], p->ld, &ep, p->rank, P, p->sh_send,
                                     p->sh_chunk, p->stream);
@@ -353,12 +394,12 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
             r.send_base = p->sh_send; r.recv_base = p->sh_recv;
             r.send_h = p->wire[2]; r.recv_h = p->wire[3];
             for (int32_t h = 0; h < P; ++h) {
-                r.sp[h] = p->sh_send + int64_t(h) * p->sh_chunk;
-                r.rp[h] = p->sh_recv + int64_t(h) * p->sh_chunk;
-                r.sn[h] = r.rn[h] = h == p->rank ? 0 : p->sh_chunk;
+                if (h == p->rank) continue;
+                r.add_out(h, p->sh_send + int64_t(h) * p->sh_chunk, p->sh_chunk);
+                r.add_in(h, p->sh_recv + int64_t(h) * p->sh_chunk, p->sh_chunk);
             }
         }
-        rc = all_to_all(plans, n_local, routes, xs);
+        rc = all_to_all(plans, n_local, routes, xs, 4);
         if (rc) return rc;
     }
     if (!local) {
@@ -395,6 +436,16 @@ static void flip(simrank_shardplan* const* plans, int32_t n_local) {
 
 // the rank's block with its rows in the caller's order, on the device (in the idle ping-pong partner)
 static int block_rows_in_callers_order(simrank_shardplan* p, float** out) {
+    if (p->half) {
+        // fp16-held: widen into an f32 panel-blocked scratch copy, then out of that layout and the solver's row order
+        const size_t wide = size_t((p->Lm + 31) / 32) * size_t(p->rows_pad) * 32 * 4, rowm = size_t(p->n) * size_t(p->ld) * 4;
+        if (!p->hand[0]) SR_HIP(pool_hip_alloc((void**)&p->hand[0], wide));
+        if (!p->hand[1]) SR_HIP(pool_hip_alloc((void**)&p->hand[1], rowm));
+        int rc = simrank_widen_blocked_h16(p->S[p->cur], p->rows_pad, p->hand[0], p->rows_pad, p->n, p->Lm, kHalfScale, p->stream);
+        if (!rc) rc = simrank_permute_layout(p->hand[0], 32, p->rows_pad, p->hand[1], p->ld, 0, p->n, p->Lm, p->inv, nullptr, 4, p->stream);
+        *out = p->hand[1];
+        return rc;
+    }
     float* tmp = p->S[p->cur ^ 1];
     if (p->Lm) {
         const int rc = simrank_permute(p->S[p->cur], p->ld, tmp, p->ld, p->n, p->Lm, p->inv, nullptr, 4, p->stream);
@@ -471,7 +522,7 @@ int simrank_shardplan_destroy(simrank_shardplan* p) {
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     for (void* b : {(void*)p->S[0], (void*)p->S[1], (void*)p->send, (void*)p->recv, (void*)p->sh_send, (void*)p->sh_recv,
                     (void*)p->wire[0], (void*)p->wire[1], (void*)p->wire[2], (void*)p->wire[3], (void*)p->ev,
-                    (void*)p->prior, (void*)p->inv, (void*)p->counters})
+                    (void*)p->prior, (void*)p->inv, (void*)p->counters, (void*)p->hand[0], (void*)p->hand[1]})
         (void)pool_free(b);
     for (int i = 0; i < 2; ++i) {
         if (p->host_counters[i]) (void)hipHostFree(p->host_counters[i]);
@@ -495,7 +546,12 @@ int simrank_shardplan_create(int64_t n, int64_t nnz, const int32_t* rowptr, cons
     const bool fits_half = P > 1 && n % (32 * int64_t(P)) == 0;
     SR_REQUIRE(opt->leg2_form != 1 || fits_half || (P == 1 && n % 32 == 0),
                "the half form of leg 2 needs n to be a multiple of 32 x ranks");
-    const bool half = opt->leg2_form == 1 || (opt->leg2_form == -1 && fits_half && P >= 8);
+    const bool fp16 = opt->storage_fp16 != 0;
+    // fp16-held matrices (half.hip): every block whole 64-column panels, leg 2 in its full form, no prior, no fp16 wire
+    // (the exchange moves the fp16 values themselves)
+    SR_REQUIRE(!fp16 || (n % (64 * int64_t(P)) == 0 && opt->leg2_form != 1 && !opt->apriori && !opt->wire_fp16),
+               "storage_fp16 on shards needs n %% (64 x ranks) == 0, leg 2 in its full form, no prior and the f32 wire option off");
+    const bool half = !fp16 && (opt->leg2_form == 1 || (opt->leg2_form == -1 && fits_half && P >= 8));
     PlanPrep pp;
     int rc = shard_prepare(n, nnz, rowptr, col, rowscale, opt->apriori, opt->ld_apriori, opt->reorder != 0, half ? P : 1, &pp);
     if (rc) return rc;
@@ -518,8 +574,19 @@ int simrank_shardplan_create(int64_t n, int64_t nnz, const int32_t* rowptr, cons
     p->n_stages = opt->stages > 0 ? opt->stages : int32_t(std::max<int64_t>(1, std::min<int64_t>(4, p->mb / 2048)));
     p->ord = pp.ord;
     auto fail = [&](int code) { simrank_shardplan_destroy(p); return code; };
-    rc = simrank_graph_create(n, n, nnz, pp.rp.data(), pp.cl.data(), pp.rs.data(), &p->g);
+    p->half = fp16 ? 1 : 0;
+    p->rows_pad = (n + 7) / 8 * 8 + 8;
+    p->rows_pad_t = (p->Lm + 7) / 8 * 8 + 8;
+    {
+        Tuning t = tuning_snapshot();
+        if (fp16) t.fuse_unit = int64_t(1) << 20;        // (half.hip runs whole blocks: no units whose sums meet in memory)
+        rc = graph_create_with(t, n, n, nnz, pp.rp.data(), pp.cl.data(), pp.rs.data(), &p->g);
+    }
     if (rc) return fail(rc);
+    if (fp16 && !p->g->fused) {
+        set_error("storage_fp16 needs the one-launch plan (tuning fuse = 1) and a graph that has one");
+        return fail(SIMRANK_ERR_INVALID);
+    }
 #define SP_HIP(call)                                                                              \
     do {                                                                                          \
         hipError_t e_ = (call);                                                                   \
@@ -534,13 +601,18 @@ int simrank_shardplan_create(int64_t n, int64_t nnz, const int32_t* rowptr, cons
         if (e == hipSuccess) e = hipMemsetAsync(*b, 0, std::max<size_t>(bytes, 16), p->stream);
         return e;
     };
-    const size_t blk = size_t(n) * size_t(p->ld) * 4;
+    const size_t blk = fp16 ? size_t(p->Lm / 64) * size_t(p->rows_pad) * 128 : size_t(n) * size_t(p->ld) * 4;
     SP_HIP(dev((void**)&p->S[0], blk));
     SP_HIP(dev((void**)&p->S[1], blk));
     const size_t send_floats = size_t(std::max<int64_t>(1, p->Lm)) * size_t(p->send_ld);
     const size_t recv_floats = size_t(n) * size_t(p->recv_ld);
-    SP_HIP(dev((void**)&p->send, send_floats * 4));
-    SP_HIP(dev((void**)&p->recv, recv_floats * 4));
+    if (fp16) {
+        SP_HIP(dev((void**)&p->send, size_t(n / 64) * size_t(p->rows_pad_t) * 128));      // (W.S_block)^T: Lm rows x n columns
+        SP_HIP(dev((void**)&p->recv, blk));                                                // leg-2 operand: n rows x Lm columns
+    } else {
+        SP_HIP(dev((void**)&p->send, send_floats * 4));
+        SP_HIP(dev((void**)&p->recv, recv_floats * 4));
+    }
     if (p->wire_fp16) {
         SP_HIP(dev((void**)&p->wire[0], send_floats * 2));
         SP_HIP(dev((void**)&p->wire[1], recv_floats * 2));
@@ -571,13 +643,19 @@ int simrank_shardplan_create(int64_t n, int64_t nnz, const int32_t* rowptr, cons
     SP_HIP(hipStreamSynchronize(p->stream));             // (pp.inv is a host vector about to go away)
     if (opt->evidence && p->Lm) {
         // common in-neighbour counts of the rank's columns (SimRank.py:311-320), 1 - 2^-count in the epilogue
-        SP_HIP(dev((void**)&p->ev, size_t(n) * size_t(p->ld_ev)));
-        rc = simrank_evidence_counts(p->g, p->m_lo, p->Lm, p->ev, p->ld_ev, p->stream);
-        if (rc) return fail(rc);
-        int64_t live = 0, total = 1;
-        rc = simrank_evidence_live_segments(p->ev, p->ld_ev, 0, n, p->Lm, &live, &total, p->stream);
-        if (rc) return fail(rc);
-        p->restrict_support = 2 * live < total ? 1 : 0;
+        if (fp16) {                                      // (32-column panels of n padded rows, as the single plan's)
+            SP_HIP(dev((void**)&p->ev, size_t((p->Lm + 31) / 32) * size_t(p->rows_pad) * 32));
+            rc = simrank_evidence_counts_blocked(p->g, p->m_lo, p->Lm, p->ev, p->rows_pad, p->stream);
+            if (rc) return fail(rc);
+        } else {
+            SP_HIP(dev((void**)&p->ev, size_t(n) * size_t(p->ld_ev)));
+            rc = simrank_evidence_counts(p->g, p->m_lo, p->Lm, p->ev, p->ld_ev, p->stream);
+            if (rc) return fail(rc);
+            int64_t live = 0, total = 1;
+            rc = simrank_evidence_live_segments(p->ev, p->ld_ev, 0, n, p->Lm, &live, &total, p->stream);
+            if (rc) return fail(rc);
+            p->restrict_support = 2 * live < total ? 1 : 0;
+        }
     }
     if (opt->apriori && p->Lm) {
         // the rank's columns of the prior in the solver's order: block[i][j] = A[ord[i]][ord[m_lo + j]]
@@ -593,7 +671,8 @@ int simrank_shardplan_create(int64_t n, int64_t nnz, const int32_t* rowptr, cons
     }
 #undef SP_HIP
     if (p->Lm) {
-        rc = simrank_fill_identity(p->S[0], n, p->Lm, p->ld, p->m_lo, p->stream);
+        rc = fp16 ? simrank_fill_identity_blocked_h16(p->S[0], n, p->Lm, p->rows_pad, p->m_lo, kHalfScale, p->stream)
+                  : simrank_fill_identity(p->S[0], n, p->Lm, p->ld, p->m_lo, p->stream);
         if (rc) return fail(rc);
     }
     *out = p;
@@ -608,7 +687,8 @@ int simrank_shardplan_reset(simrank_shardplan* const* plans, int32_t n_local) {
         p->cur = 0;
         p->updates = 0;
         if (p->Lm) {
-            rc = simrank_fill_identity(p->S[0], p->n, p->Lm, p->ld, p->m_lo, p->stream);
+            rc = p->half ? simrank_fill_identity_blocked_h16(p->S[0], p->n, p->Lm, p->rows_pad, p->m_lo, kHalfScale, p->stream)
+                         : simrank_fill_identity(p->S[0], p->n, p->Lm, p->ld, p->m_lo, p->stream);
             if (rc) return rc;
         }
     }

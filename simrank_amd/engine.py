@@ -163,7 +163,7 @@ class Plan:
 class ShardPlanOptions(C.Structure):           # struct simrank_shardplan_options
     _fields_ = [("coef", C.c_float), ("lbd", C.c_float), ("apriori", C.c_void_p), ("ld_apriori", C.c_int64),
                 ("evidence", C.c_int32), ("reorder", C.c_int32), ("leg2_form", C.c_int32), ("stages", C.c_int32),
-                ("wire_fp16", C.c_int32), ("reserved", C.c_int32)]
+                ("wire_fp16", C.c_int32), ("storage_fp16", C.c_int32)]
 
 
 class ShardPlans:
@@ -174,7 +174,9 @@ class ShardPlans:
 
     def __init__(self, ops, csr: CSR, rowscale=None, world: int = 1, comm=None, coef: float = 0.8, evidence: bool = False,
                  apriori=None, lbd: float = 0.0, reorder: bool = True, leg2_form: int = -1, stages: int = 0,
-                 wire_fp16: bool = False):
+                 wire_fp16: bool = False, storage: str = "f32"):
+        """``storage="fp16"``: matrices held in fp16 on every rank (config 5's reduced precision on shards)."""
+        assert storage in ("f32", "fp16")
         self.ops, self.n = ops, csr.n_rows
         lib = ops.lib
         rs = np.ascontiguousarray(csr.rowscale if rowscale is None else rowscale, dtype=np.float32)
@@ -183,7 +185,8 @@ class ShardPlans:
         ap = None if apriori is None else np.ascontiguousarray(apriori, dtype=np.float32)
         opt = ShardPlanOptions(coef=coef, lbd=lbd, apriori=None if ap is None else ap.ctypes.data,
                                ld_apriori=0 if ap is None else ap.shape[1], evidence=int(evidence), reorder=int(reorder),
-                               leg2_form=int(leg2_form), stages=int(stages), wire_fp16=int(wire_fp16), reserved=0)
+                               leg2_form=int(leg2_form), stages=int(stages), wire_fp16=int(wire_fp16),
+                               storage_fp16=int(storage == "fp16"))
         self.own_comms = comm is None
         if comm is None:
             arr = (C.c_void_p * world)()

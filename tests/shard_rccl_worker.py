@@ -57,6 +57,14 @@ def main():
         c = sp.step(0.0, exact_count=True)
         assert c > 0
         sp.free()
+    # fp16-held matrices on the ranks (config 5's reduced precision on shards): against the f32 result
+    sp = ShardPlans(ops, csr, rowscale=scale, world=world, comm=comm, evidence=True, stages=2, storage="fp16")
+    done, conv = sp.run(30, 1e-4)
+    got = sp.result(root=0, i_am_root=rank == 0)
+    assert conv is not None and conv >= want_conv - 1
+    if rank == 0:
+        assert np.abs(got - want).max() < 1e-4 * 0.8 / 0.2 + 6e-4
+    sp.free()
     ops.lib.simrank_comm_destroy(comm)
     print("SHARDPLAN RCCL ok", flush=True)
 

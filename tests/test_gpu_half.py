@@ -189,8 +189,49 @@ def test_half_storage_needs_what_it_says(ops):
     g = ops.graph(csr)
     with pytest.raises(SimRankHipError, match="leg 1"):
         ops.spmm(g, x, y)                                       # neither transposed nor an epilogue
-    with pytest.raises(SimRankHipError, match="symmetric single-rank"):
-        ops.spmm(g, x, y, epilogue=dict(coef=0.8, symmetric=False))
+    with pytest.raises(SimRankHipError, match="column block of a sharded update"):
+        ops.spmm(g, x, y, epilogue=dict(coef=0.8, symmetric=False, diag_col0=8))     # columns 8 .. 207 of 200
+    with pytest.raises(SimRankHipError, match="no prior"):
+        ops.spmm(g, x, y, epilogue=dict(coef=0.8, symmetric=False, apriori=put_blocked(ops, np.zeros((200, 200), np.float32))))
+
+
+@pytest.mark.parametrize("n,col0,L", [(520, 128, 192), (1000, 0, 64), (1000, 936, 64), (2100, 640, 130), (200, 64, 136)])
+@pytest.mark.parametrize("variant", ["plain", "evidence-scaled"])
+def test_leg2_full_form_on_a_column_block(ops, n, col0, L, variant):
+    """Leg 2 of one rank of a SHARDED update on fp16-held matrices (csrc/shardplan.hip, storage_fp16): the column block
+    [col0, col0 + L) of S' — every element computed once (no triangle, no mirror image), the diagonal where
+    row == col0 + column, each moved element counted once."""
+    scale = 16384.0 if variant.endswith("-scaled") else 1.0
+    csr = corner_csr(n, n, seed=n + L, hubs=min(n, 120))
+    rng = np.random.default_rng(n + col0)
+    W = dense64(csr)
+    Tt = (rng.random((n, L)) ** 4 / (4096.0 if scale > 1 else 1.0) * scale).astype(np.float16).astype(np.float64) / scale
+    counts = rng.integers(0, 6, size=(n, L)).astype(np.uint8) if variant.startswith("evidence") else None
+    want = 0.8 * (W @ Tt)
+    if counts is not None:
+        want = want * (1.0 - 0.5 ** counts.astype(np.float64))
+    want[np.arange(col0, col0 + L), np.arange(L)] = 1.0
+    prev = (rng.random((n, L)) ** 4 / (4096.0 if scale > 1 else 1.0) * scale).astype(np.float16).astype(np.float64) / scale
+    g = ops.graph(csr)
+    y = ops.matrix(n, L, np.float16, blocked=True)
+    y.scale = scale
+    ep = dict(coef=0.8, previous=put_half(ops, prev, scale), eps=1e-3, set_diag=True, symmetric=False, diag_col0=col0,
+              evidence=None if counts is None else put_blocked(ops, counts, np.uint8))
+    ops.spmm(g, put_half(ops, Tt, scale), y, epilogue=ep)
+    got = ops.download(y)
+    changed = ops.read_changed()
+    close_to_rounded(got, want, scale=scale)
+    assert np.all(got[np.arange(col0, col0 + L), np.arange(L)] == 1.0)
+    e16 = np.where(prev == 0, 1, np.maximum(np.frexp(prev * scale)[1] + 14, 1))      # (frexp(0) has exponent 0)
+    tol = 1e-3 + np.ldexp(1.0, e16 - 26) / scale
+    move = np.abs(want - prev)
+    # (bracketed: the device's f32 sums of up to a few hundred terms are not the float64 ones)
+    lo, hi = int((move > tol + 4e-5 * want + 1e-7).sum()), int((move > tol - 4e-5 * want - 1e-7).sum())
+    assert lo <= changed <= hi, (lo, changed, hi)
+    ep["previous"] = put_half(ops, got, scale)
+    ep["eps"] = 1e-6 / scale
+    ops.spmm(g, put_half(ops, Tt, scale), y, epilogue=ep)
+    assert ops.read_changed() == 0 and np.array_equal(ops.download(y), got)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -164,6 +164,41 @@ def test_shardplan_fp16_wire(ops):
     assert 1e-7 < rel.max() < 4e-3
 
 
+@pytest.mark.parametrize("pp", [False, True])
+@pytest.mark.parametrize("world,stages", [(1, 1), (2, 1), (4, 3), (8, 2)])
+def test_shardplan_with_half_storage_against_the_oracle(ops, pp, world, stages):
+    """options.storage_fp16: BASELINE config 5 in its stated form — reduced precision AND shards.  Every rank holds its
+    block, the transposed product and the leg-2 operand in fp16 (half.hip on a column block: leg 2 in its full form), the
+    exchange moves the fp16 panels themselves.  Against the float64 oracle with the bars of the single-rank fp16 tests
+    (tests/test_gpu_half.py: two roundings per update, damped by the contraction), and against the single-rank fp16 plan
+    to a few fp16 spacings (same kernels; the triangle + mirror form there, the full form here)."""
+    from simrank_amd.engine import Plan, ShardPlans
+    df = synth.powerlaw_directed(2048, 24, seed=12)
+    _, csr = ingest.directed(df, False, "from", "to", "weight")
+    scale = ingest.spread(csr) * csr.rowscale if pp else csr.rowscale
+    want = (O.fit_simrank_pp if pp else O.fit_simrank)(df, verbose=False, iterations=10, eps=1e-30)
+    sp = ShardPlans(ops, csr, rowscale=scale, world=world, evidence=pp, storage="fp16", stages=stages, leg2_form=0)
+    assert sp.run(10, 1e-30) == (10, None)
+    a, b = sp.result(), want["S"]
+    assert np.array_equal(a, assembled(sp))
+    sp.free()
+    assert np.all(np.diag(a) == 1.0)
+    err = np.abs(a - b)
+    rel = err[b > 0] / b[b > 0]
+    assert err.max() < 6e-4 and rel.max() < 2.5e-3 and np.median(rel) < 4e-4, (err.max(), rel.max(), np.median(rel))
+    one = Plan(ops, csr, rowscale=scale, evidence=pp, storage="fp16")
+    one.run(10, 1e-30)
+    np.testing.assert_allclose(a, one.result(), rtol=8 * 2.0 ** -11, atol=1e-7)
+    one.free()
+    # to eps = 1e-4: may end later than the reference, never earlier by more than one update (tests/test_gpu_half.py)
+    want = (O.fit_simrank_pp if pp else O.fit_simrank)(df, verbose=False)
+    sp = ShardPlans(ops, csr, rowscale=scale, world=world, evidence=pp, storage="fp16", stages=stages)
+    done, conv = sp.run(100, 1e-4)
+    assert conv is not None and conv >= want["k"] - 1
+    assert np.abs(sp.result() - want["S"]).max() < 1e-4 * 0.8 / 0.2 + 6e-4
+    sp.free()
+
+
 def test_shardplan_refuses_what_it_cannot_run(ops):
     from simrank_amd._lib import SimRankHipError
     from simrank_amd.engine import ShardPlans
@@ -172,6 +207,8 @@ def test_shardplan_refuses_what_it_cannot_run(ops):
     _, csr = ingest.directed(df, False, "from", "to", "weight")
     with pytest.raises(SimRankHipError, match="multiple of 32"):
         ShardPlans(ops, csr, world=2, leg2_form=1)
+    with pytest.raises(SimRankHipError, match="storage_fp16 on shards"):
+        ShardPlans(ops, csr, world=2, storage="fp16")                       # 100 nodes: not whole 64-column panels per rank
     sp = ShardPlans(ops, csr, world=3)
     one = (C.c_void_p * 1)(sp.plans[0].value)
     assert ops.lib.simrank_shardplan_step(one, 1, 0.0, 1, None) != 0        # a group advances all its plans together

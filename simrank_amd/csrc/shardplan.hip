@@ -176,9 +176,10 @@ namespace simrank {
 
 // ---- one all-to-all: what every local plan sends to / receives from every rank, as lists of pieces (element counts;
 // rank s's i-th piece for rank d is rank d's i-th piece from rank s) ----
-struct Piece {
+struct Piece {               // `reps` runs of n elements, `stride` elements apart (the panels of a blocked matrix)
     char* ptr;
     int64_t n;
+    int64_t reps, stride;
 };
 struct Route {
     std::vector<std::vector<Piece>> out, in;          // [peer][piece]
@@ -187,8 +188,12 @@ struct Route {
     uint16_t* send_h = nullptr;
     uint16_t* recv_h = nullptr;
     explicit Route(int32_t world) : out(world), in(world) {}
-    void add_out(int32_t h, const void* ptr, int64_t n) { if (n) out[h].push_back(Piece{(char*)const_cast<void*>(ptr), n}); }
-    void add_in(int32_t h, void* ptr, int64_t n) { if (n) in[h].push_back(Piece{(char*)ptr, n}); }
+    void add_out(int32_t h, const void* ptr, int64_t n, int64_t reps = 1, int64_t stride = 0) {
+        if (n && reps) out[h].push_back(Piece{(char*)const_cast<void*>(ptr), n, reps, stride});
+    }
+    void add_in(int32_t h, void* ptr, int64_t n, int64_t reps = 1, int64_t stride = 0) {
+        if (n && reps) in[h].push_back(Piece{(char*)ptr, n, reps, stride});
+    }
 };
 
 // elem: bytes per element of the buffers (4: f32 — narrowed to fp16 on the way when the plan's wire is fp16; 2: fp16-held)
@@ -215,16 +220,23 @@ static int all_to_all(simrank_shardplan* const* plans, int32_t n_local, std::vec
     auto matched = [&](const std::vector<Piece>& a, const std::vector<Piece>& b) {
         if (a.size() != b.size()) return false;
         for (size_t i = 0; i < a.size(); ++i)
-            if (a[i].n != b[i].n) return false;
+            if (a[i].n != b[i].n || a[i].reps != b[i].reps) return false;
         return true;
     };
     if (p0->comm->group) {
         for (int32_t s = 0; s < P; ++s)
             for (int32_t d = 0; d < P; ++d) {
                 SR_REQUIRE(matched(routes[s].out[d], routes[d].in[s]), "ranks %d and %d disagree about their chunks", s, d);
-                for (size_t i = 0; i < routes[s].out[d].size(); ++i)
-                    SR_HIP(hipMemcpyAsync(dst_of(routes[d], routes[d].in[s][i]), src_of(routes[s], routes[s].out[d][i]),
-                                          size_t(routes[s].out[d][i].n) * bytes, hipMemcpyDeviceToDevice, st));
+                for (size_t i = 0; i < routes[s].out[d].size(); ++i) {
+                    const Piece& a = routes[s].out[d][i];
+                    const Piece& b = routes[d].in[s][i];
+                    if (a.reps == 1)
+                        SR_HIP(hipMemcpyAsync(dst_of(routes[d], b), src_of(routes[s], a), size_t(a.n) * bytes,
+                                              hipMemcpyDeviceToDevice, st));
+                    else                                 // (one strided copy for all the panels of a chunk)
+                        SR_HIP(hipMemcpy2DAsync(b.ptr, size_t(b.stride) * bytes, a.ptr, size_t(a.stride) * bytes,
+                                                size_t(a.n) * bytes, size_t(a.reps), hipMemcpyDeviceToDevice, st));
+                }
             }
     } else {
         Rccl* R = rccl();
@@ -232,15 +244,29 @@ static int all_to_all(simrank_shardplan* const* plans, int32_t n_local, std::vec
         const int32_t me = p0->rank;
         // the chunk a rank addresses to itself never touches the fabric
         SR_REQUIRE(matched(r.out[me], r.in[me]), "own chunk: pieces differ");
-        for (size_t i = 0; i < r.out[me].size(); ++i)
-            SR_HIP(hipMemcpyAsync(dst_of(r, r.in[me][i]), src_of(r, r.out[me][i]), size_t(r.out[me][i].n) * bytes,
-                                  hipMemcpyDeviceToDevice, st));
+        for (size_t i = 0; i < r.out[me].size(); ++i) {
+            const Piece& a = r.out[me][i];
+            const Piece& b = r.in[me][i];
+            if (a.reps == 1)
+                SR_HIP(hipMemcpyAsync(dst_of(r, b), src_of(r, a), size_t(a.n) * bytes, hipMemcpyDeviceToDevice, st));
+            else
+                SR_HIP(hipMemcpy2DAsync(b.ptr, size_t(b.stride) * bytes, a.ptr, size_t(a.stride) * bytes, size_t(a.n) * bytes,
+                                        size_t(a.reps), hipMemcpyDeviceToDevice, st));
+        }
         const ncclDataType_t dt = bytes == 2 ? ncclHalf : ncclFloat;
         SR_RCCL(R->GroupStart());
         for (int32_t h = 0; h < P; ++h) {
             if (h == me) continue;
-            for (const Piece& pc : r.out[h]) SR_RCCL(R->Send(src_of(r, pc), size_t(pc.n), dt, h, p0->comm->nccl, st));
-            for (const Piece& pc : r.in[h]) SR_RCCL(R->Recv(dst_of(r, pc), size_t(pc.n), dt, h, p0->comm->nccl, st));
+            // (a strided piece = one send / receive per panel: each is a contiguous run of >= 0.5 MB at the sizes this mode
+            // is for, and lands where leg 2 reads it — no staging copy on either side)
+            for (const Piece& pc : r.out[h])
+                for (int64_t k = 0; k < pc.reps; ++k)
+                    SR_RCCL(R->Send(pc.reps == 1 ? src_of(r, pc) : (const void*)(pc.ptr + size_t(k) * size_t(pc.stride) * bytes),
+                                    size_t(pc.n), dt, h, p0->comm->nccl, st));
+            for (const Piece& pc : r.in[h])
+                for (int64_t k = 0; k < pc.reps; ++k)
+                    SR_RCCL(R->Recv(pc.reps == 1 ? dst_of(r, pc) : (void*)(pc.ptr + size_t(k) * size_t(pc.stride) * bytes),
+                                    size_t(pc.n), dt, h, p0->comm->nccl, st));
         }
         SR_RCCL(R->GroupEnd());
     }
@@ -321,9 +347,9 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
                 for (int32_t h = 0; h < P; ++h) {
                     int64_t lo, hi;
                     part(p->n, P, h, &lo, &hi);
-                    for (int64_t pn = lo / 64; pn < hi / 64; ++pn) r.add_out(h, T + (pn * p->rows_pad_t + c0) * 64, w * 64);
+                    r.add_out(h, T + ((lo / 64) * p->rows_pad_t + c0) * 64, w * 64, (hi - lo) / 64, p->rows_pad_t * 64);
                     const int64_t wh = stage_width(hi - lo, S, s, walign), ch = stage_col0(hi - lo, S, s, walign);
-                    for (int64_t pn = 0; pn < p->Lm / 64; ++pn) r.add_in(h, X2 + (pn * p->rows_pad + lo + ch) * 64, wh * 64);
+                    r.add_in(h, X2 + (lo + ch) * 64, wh * 64, p->Lm / 64, p->rows_pad * 64);
                 }
             } else {
                 const int64_t send_off = c0 * p->send_ld;

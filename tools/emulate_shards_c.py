@@ -19,6 +19,27 @@ w = sys.argv[1] if len(sys.argv) > 1 else "pl32768d32"
 df = synth.WORKLOADS[w][0]()
 _, csr = ingest.directed(df, False, "from", "to", "weight")
 n = csr.n_rows
+pp = os.environ.get("PP") == "1"                 # SimRank++ (evidence, spread weights): config 5's class
+scale = ingest.spread(csr) * csr.rowscale if pp else csr.rowscale
+if os.environ.get("STORAGE") == "fp16":
+    # fp16-held matrices on every rank (options.storage_fp16; the Python driver has no such sharded mode): timing only,
+    # next to the f32 plan of the same form
+    for P in [int(v) for v in os.environ.get("PS", "8").split(",")]:
+        for storage in ("f32", "fp16"):
+            sp = ShardPlans(ops, csr, rowscale=scale, world=P, evidence=pp, leg2_form=0, stages=1, storage=storage)
+            sp.step(0.0)
+            ops.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                sp.step(0.0, exact_count=False)
+            ops.synchronize()
+            ms = (time.perf_counter() - t0) / 3 * 1e3
+            sp.free()
+            per = n * (n // P) * (2 if storage == "fp16" else 4) * (P - 1) / P / 2**20
+            print(f"{w}{' SimRank++' if pp else ''} P={P} {storage} matrices, leg 2 in its full form: C loop {ms / P:.3f} ms per rank "
+                  f"and update ({ms:.2f} ms for the {P} virtual ranks, device copies included); exchange payload per rank "
+                  f"{per:.0f} MiB", flush=True)
+    sys.exit(0)
 for P in [int(v) for v in os.environ.get("PS", "8,4").split(",")]:
     for form in (0, 1):
         sp = ShardPlans(ops, csr, world=P, leg2_form=form, stages=1)

@@ -737,7 +737,11 @@ def main():
                             frame.values                         # (the similarity frames are the hand-back)
                     dt = time.perf_counter() - t0
                     best = dict(fit_wall_s=dt, converged_at=est.converged_at)
-                    del res, est
+                    # (every reference to the N x N host frame goes BEFORE the next call is timed: unmapping 8.6 GB takes
+                    # 0.4 s, and the loop variable kept the first call's frame alive into the second call's timed region —
+                    # the 0.68 s this line showed for config 4 until round 4; profiles/r04_fit_breakdown_cfg4.log)
+                    frame = None
+                    del res, est, frame
                 walls[name] = best
 
             df4 = synth.WORKLOADS["pl32768d32"][0]()

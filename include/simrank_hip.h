@@ -386,7 +386,7 @@ SIMRANK_API int simrank_dense_part(const simrank_graph* g, const float* X, int64
  *      n x n row-major, must be symmetric).  simrank_plan_run is the reference loop: at most
  *      `iterations` updates, stopping at loop index k when no element moved by more than eps
  *      (converged_at = k, exactly the "Converged at iteration k" of SimRank.py:132; -1 when the loop ran
- *      out); update k + 1 is queued before the count of update k is read.  simrank_plan_step is one
+ *      out); below 16384 nodes update k + 1 is queued before the count of update k is read.  simrank_plan_step is one
  *      update with its count; simrank_plan_result(_f64) hands S back in the caller's node order
  *      (device row-major f32 / host f64: SimRank.py:141).  One plan per host thread; all work goes to the
  *      stream given at creation. */
@@ -513,7 +513,8 @@ SIMRANK_API int simrank_shardplan_reset(simrank_shardplan* const* plans, int32_t
 /* one update on every rank; n_changed (may be NULL) = the count over ALL ranks */
 SIMRANK_API int simrank_shardplan_step(simrank_shardplan* const* plans, int32_t n_local, double eps, int32_t exact_count,
                                        int64_t* n_changed);
-/* the reference loop, update k + 1 queued before the count of update k is read; every rank returns the same numbers */
+/* the reference loop (while a rank's update is short, update k + 1 is queued before the count of update k is read); every
+ * rank returns the same numbers */
 SIMRANK_API int simrank_shardplan_run(simrank_shardplan* const* plans, int32_t n_local, int32_t iterations, double eps,
                                       int32_t* updates_done, int32_t* converged_at);
 /* dst[i][j] (HOST, n x n_cols_of_the_rank) = S[caller's node i][the rank's column j]; ids[j] = caller's id of column j */

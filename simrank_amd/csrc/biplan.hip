@@ -300,9 +300,13 @@ int simrank_biplan_run(simrank_biplan* p, int32_t iterations, double eps, int32_
             if (k == iterations) break;                  // the reference makes no test after its last iteration
             // iteration k + 1 is queued before the counts of iteration k are known; if they say "converged" it is
             // not adopted: it wrote the buffers of the iterates before last, the current ones are untouched
+            // (small graphs only, common.h kSpeculateBelow: a long iteration is queued once its predecessor's counts are known)
+            const bool spec = std::max(p->s[0].n, p->s[1].n) < kSpeculateBelow;
             const int c1_cur = p->s[0].cur, c2_cur = p->s[1].cur;
-            rc = iteration(p, eps, 0, (k + 1) & 1);
-            if (rc) return rc;
+            if (spec) {
+                rc = iteration(p, eps, 0, (k + 1) & 1);
+                if (rc) return rc;
+            }
             unsigned long long c1 = 0, c2 = 0;
             rc = read_counts(p, k & 1, &c1, &c2);
             if (rc) return rc;
@@ -312,6 +316,10 @@ int simrank_biplan_run(simrank_biplan* p, int32_t iterations, double eps, int32_
                 p->s[0].cur = c1_cur;
                 p->s[1].cur = c2_cur;
                 break;
+            }
+            if (!spec) {
+                rc = iteration(p, eps, 0, (k + 1) & 1);
+                if (rc) return rc;
             }
         }
     }

@@ -141,6 +141,11 @@ int shard_prepare(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* 
 int biplan_prepare(int64_t n1, int64_t n2, int64_t nnz, const int32_t* rowptr12, const int32_t* col12,
                    const float* rowscale1, const float* rowscale2, const simrank_biplan_options* opt, BiPlanPrep* out);
 
+// The run loops queue update k + 1 BEFORE they read the count of update k only while an update is short (small graphs:
+// the host round trip per update is what they save); from this many nodes on an update takes milliseconds, the round trip
+// is noise, and the speculative update would just be 1 / k of the fit thrown away (config 5: 27 ms of 140).
+constexpr int64_t kSpeculateBelow = 16384;
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

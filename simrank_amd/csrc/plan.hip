@@ -7,7 +7,8 @@
 //         new = E * C * W.S.W^T (+ lbd A); diag <- 1
 //
 // as two launches per update (leg 1: fused_trans_kernel, leg 2: upper-triangle gather with the fused
-// epilogue and count), with update k + 1 queued BEFORE the count of update k is read: the host never
+// epilogue and count), with update k + 1 queued BEFORE the count of update k is read (graphs below 16384 nodes,
+// where an update is short; common.h kSpeculateBelow): the host never
 // leaves the device idle to learn whether it may go on, and when the count says "converged" the
 // speculative update is simply not adopted (it wrote the buffer of the iterate before last).
 // Python's driver.Solver does the same choreography for every world size; this is the single-rank case
@@ -241,14 +242,22 @@ int simrank_plan_run(simrank_plan* p, int32_t iterations, double eps, int32_t* u
             if (k == iterations) break;              // the reference makes no test after its last update
             // loop index k tests the count of update k and, if it may go on, runs update k + 1 — which is
             // queued NOW, before the count is known (it reads S[cur], writes the buffer of the iterate before)
-            rc = leg_pair(p, eps, 0, (k + 1) & 1);
-            if (rc) return rc;
+            // (small graphs only, common.h kSpeculateBelow: a long update is queued once its predecessor's count is known)
+            const bool spec = p->n < kSpeculateBelow;
+            if (spec) {
+                rc = leg_pair(p, eps, 0, (k + 1) & 1);
+                if (rc) return rc;
+            }
             unsigned long long c = 0;
             rc = read_count(p, k & 1, &c);           // waits for update k only
             if (rc) return rc;
             if (c == 0) {                            // converged at loop index k: k updates applied; the
                 conv = k;                            // speculative one is not adopted
                 break;
+            }
+            if (!spec) {
+                rc = leg_pair(p, eps, 0, (k + 1) & 1);
+                if (rc) return rc;
             }
         }
     }

@@ -755,14 +755,23 @@ int simrank_shardplan_run(simrank_shardplan* const* plans, int32_t n_local, int3
             flip(plans, n_local);                    // S[cur] = result of update k
             done = k;
             if (k == iterations) break;              // the reference makes no test after its last update
-            rc = update(plans, n_local, eps, 0, (k + 1) & 1);      // update k + 1, speculative
-            if (rc) return rc;
+            // update k + 1 goes out before the count of update k is known only while a rank's update is short (common.h
+            // kSpeculateBelow, on the rows a rank computes per leg: n / ranks columns of n rows)
+            const bool spec = plans[0]->n / std::max(1, plans[0]->world / 2) < kSpeculateBelow;
+            if (spec) {
+                rc = update(plans, n_local, eps, 0, (k + 1) & 1);
+                if (rc) return rc;
+            }
             unsigned long long c = 0;
             rc = read_count(plans, n_local, k & 1, &c);           // the same number on every rank
             if (rc) return rc;
-            if (c == 0) {                            // converged at loop index k; the speculative update is dropped
+            if (c == 0) {                            // converged at loop index k; a speculative update is dropped
                 conv = k;
                 break;
+            }
+            if (!spec) {
+                rc = update(plans, n_local, eps, 0, (k + 1) & 1);
+                if (rc) return rc;
             }
         }
     }

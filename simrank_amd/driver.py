@@ -37,6 +37,7 @@ RESTRICT_BELOW = 0.5     # SimRank++: leg 2 skips evidence-dead 32-column segmen
                          # fraction of them is live (ER N=8192: 0.24 live; the power-law graphs: 0.9)
 HALF_FORM_FROM = 8      # TorchWorld(symmetric_shards="auto") when nothing is measured: half-form leg 2 from this many ranks on
 MEASURE_FORM_FROM_N = 4096   # ... with at least this many nodes (and > 1 rank) both forms are TIMED and the faster one taken
+SPECULATE_BELOW_N = 16384   # run() queues loop body k + 1 before reading the count of body k only below this many nodes
 DEAL_UNIT = 128         # nodes are dealt to the shards in runs of this many (dealt_order)
 STAGE_ALIGN = 32         # stage widths of a pipelined exchange are multiples of this (panels)
 
@@ -1047,6 +1048,8 @@ class Solver:
         this process reads itself, no per-leg timing, an engine with pinned counter slots."""
         if self.world.size != 1 or len(self.world.local_ranks) != 1 or self.events is not None:
             return False
+        if max(self.n) >= SPECULATE_BELOW_N:
+            return False          # (an update takes milliseconds: the round trip is noise, a dropped update is not)
         if getattr(self.world, "stream_ordered", False):
             return False
         r = self.world.local_ranks[0]

@@ -523,6 +523,11 @@ SIMRANK_API int simrank_shardplan_columns(const simrank_shardplan* p, int32_t* i
 /* the whole matrix in the caller's order on rank `root` (dst ignored elsewhere); collective */
 SIMRANK_API int simrank_shardplan_result_f64(simrank_shardplan* const* plans, int32_t n_local, int32_t root, double* dst,
                                              int64_t ld);
+/* the k most similar nodes of every node on rank `root` (HOST int32 / float [n][k], caller's ids, largest first, ties by the
+ * lower id, -1 / 0 where a row has fewer): every rank selects among its own columns on the device, n k values per rank cross
+ * the links and PCIe instead of n^2 — the hand-back config 5 is meant for (its dense result is 34 GB of float64); collective */
+SIMRANK_API int simrank_shardplan_topk(simrank_shardplan* const* plans, int32_t n_local, int32_t root, int32_t k,
+                                       int32_t exclude_diag, int32_t* idx_host, float* val_host);
 SIMRANK_API int simrank_shardplan_info(const simrank_shardplan* p, int64_t* n, int64_t* col_lo, int64_t* col_hi,
                                        int32_t* half_form, int32_t* stages, int32_t* updates);
 SIMRANK_API int simrank_shardplan_destroy(simrank_shardplan* p);

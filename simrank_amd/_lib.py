@@ -131,6 +131,7 @@ PROTOTYPES = {
     "simrank_shardplan_block_f64": [_vp, _vp, _i64],
     "simrank_shardplan_columns": [_vp, _vp],
     "simrank_shardplan_result_f64": [C.POINTER(_vp), C.c_int32, C.c_int32, _vp, _i64],
+    "simrank_shardplan_topk": [C.POINTER(_vp), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp],
     "simrank_shardplan_info": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_int32),
                                C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "simrank_shardplan_destroy": [_vp],

@@ -871,6 +871,123 @@ int simrank_shardplan_result_f64(simrank_shardplan* const* plans, int32_t n_loca
     return rc;
 }
 
+int simrank_shardplan_topk(simrank_shardplan* const* plans, int32_t n_local, int32_t root, int32_t k, int32_t exclude_diag,
+                           int32_t* idx_host, float* val_host) {
+    int rc = check_group(plans, n_local);
+    if (rc) return rc;
+    simrank_shardplan* p0 = plans[0];
+    const int32_t P = p0->world;
+    const int64_t n = p0->n;
+    SR_REQUIRE(root >= 0 && root < P && k > 0 && k <= 1024, "bad top-k arguments");
+    const bool local = p0->comm->group != nullptr;
+    const bool i_am_root = local || p0->rank == root;
+    SR_REQUIRE(!i_am_root || (idx_host && val_host), "bad top-k arguments");
+    // every rank: the k best of ITS columns for every row (rows in the solver's order, ids = the caller's); root: merge
+    auto kk_of = [&](int32_t h) { return (int32_t)std::min<int64_t>(k, span(n, P, h)); };
+    std::vector<std::vector<int32_t>> cand_idx(P);
+    std::vector<std::vector<float>> cand_val(P);
+    Rccl* R = local ? nullptr : rccl();
+    for (int32_t i = 0; i < n_local; ++i) {
+        simrank_shardplan* p = plans[i];
+        const int32_t kk = kk_of(p->rank);
+        if (!kk) continue;
+        int32_t* ids_dev = nullptr;
+        int32_t* idx_dev = nullptr;
+        float* val_dev = nullptr;
+        hipError_t e = pool_hip_alloc((void**)&ids_dev, size_t(p->Lm) * 4);
+        if (e == hipSuccess) e = pool_hip_alloc((void**)&idx_dev, size_t(n) * kk * 4);
+        if (e == hipSuccess) e = pool_hip_alloc((void**)&val_dev, size_t(n) * kk * 4);
+        if (e == hipSuccess) e = hipMemcpyAsync(ids_dev, p->ord.data() + p->m_lo, size_t(p->Lm) * 4, hipMemcpyHostToDevice, p->stream);
+        const float* src = p->S[p->cur];
+        if (e == hipSuccess && p->half) {                // fp16-held: an f32 row-major copy in the solver's row order
+            const size_t wide = size_t((p->Lm + 31) / 32) * size_t(p->rows_pad) * 32 * 4, rowm = size_t(n) * size_t(p->ld) * 4;
+            if (!p->hand[0]) e = pool_hip_alloc((void**)&p->hand[0], wide);
+            if (e == hipSuccess && !p->hand[1]) e = pool_hip_alloc((void**)&p->hand[1], rowm);
+            if (e == hipSuccess) {
+                rc = simrank_widen_blocked_h16(p->S[p->cur], p->rows_pad, p->hand[0], p->rows_pad, n, p->Lm, kHalfScale, p->stream);
+                if (!rc) rc = simrank_permute_layout(p->hand[0], 32, p->rows_pad, p->hand[1], p->ld, 0, n, p->Lm, nullptr, nullptr, 4, p->stream);
+                src = p->hand[1];
+            }
+        }
+        if (e == hipSuccess && !rc)
+            rc = simrank_topk_rows_ids(src, p->ld, n, p->Lm, p->m_lo, ids_dev, kk, exclude_diag, idx_dev, val_dev, p->stream);
+        if (e == hipSuccess && !rc) {
+            if (i_am_root) {
+                cand_idx[p->rank].resize(size_t(n) * kk);
+                cand_val[p->rank].resize(size_t(n) * kk);
+                e = hipMemcpyAsync(cand_idx[p->rank].data(), idx_dev, size_t(n) * kk * 4, hipMemcpyDeviceToHost, p->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(cand_val[p->rank].data(), val_dev, size_t(n) * kk * 4, hipMemcpyDeviceToHost, p->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+            } else {
+                e = hipStreamSynchronize(p->stream);
+                ncclResult_t r1 = R->Send(idx_dev, size_t(n) * kk, ncclInt32, root, p->comm->nccl, p->xstream);
+                ncclResult_t r2 = r1 == ncclSuccess ? R->Send(val_dev, size_t(n) * kk, ncclFloat, root, p->comm->nccl, p->xstream) : r1;
+                if (r2 != ncclSuccess) { set_error("ncclSend failed: %s", R->GetErrorString(r2)); rc = SIMRANK_ERR_HIP; }
+                if (e == hipSuccess) e = hipStreamSynchronize(p->xstream);
+            }
+        } else {
+            (void)hipStreamSynchronize(p->stream);
+        }
+        (void)pool_free(ids_dev); (void)pool_free(idx_dev); (void)pool_free(val_dev);
+        if (e != hipSuccess) {
+            set_error("simrank_shardplan_topk: %s", hipGetErrorString(e));
+            (void)hipGetLastError();
+            return SIMRANK_ERR_HIP;
+        }
+        if (rc) return rc;
+    }
+    if (!i_am_root) return SIMRANK_OK;
+    if (!local) {                                        // the other ranks' candidates
+        for (int32_t h = 0; h < P; ++h) {
+            const int32_t kk = kk_of(h);
+            if (h == root || !kk) continue;
+            int32_t* idx_dev = nullptr;
+            float* val_dev = nullptr;
+            hipError_t e = pool_hip_alloc((void**)&idx_dev, size_t(n) * kk * 4);
+            if (e == hipSuccess) e = pool_hip_alloc((void**)&val_dev, size_t(n) * kk * 4);
+            if (e == hipSuccess) {
+                ncclResult_t r1 = R->Recv(idx_dev, size_t(n) * kk, ncclInt32, h, p0->comm->nccl, p0->xstream);
+                ncclResult_t r2 = r1 == ncclSuccess ? R->Recv(val_dev, size_t(n) * kk, ncclFloat, h, p0->comm->nccl, p0->xstream) : r1;
+                if (r2 != ncclSuccess) { set_error("ncclRecv failed: %s", R->GetErrorString(r2)); rc = SIMRANK_ERR_HIP; }
+                cand_idx[h].resize(size_t(n) * kk);
+                cand_val[h].resize(size_t(n) * kk);
+                if (!rc) e = hipMemcpyAsync(cand_idx[h].data(), idx_dev, size_t(n) * kk * 4, hipMemcpyDeviceToHost, p0->xstream);
+                if (!rc && e == hipSuccess) e = hipMemcpyAsync(cand_val[h].data(), val_dev, size_t(n) * kk * 4, hipMemcpyDeviceToHost, p0->xstream);
+                if (e == hipSuccess) e = hipStreamSynchronize(p0->xstream);
+            }
+            (void)pool_free(idx_dev); (void)pool_free(val_dev);
+            if (e != hipSuccess) {
+                set_error("simrank_shardplan_topk: %s", hipGetErrorString(e));
+                return SIMRANK_ERR_HIP;
+            }
+            if (rc) return rc;
+        }
+    }
+    // merge: largest first, ties by the lower id; row r of the solver's order is the caller's node ord[r]
+    std::vector<std::pair<float, int32_t>> row;
+    for (int64_t r = 0; r < n; ++r) {
+        row.clear();
+        for (int32_t h = 0; h < P; ++h) {
+            const int32_t kk = kk_of(h);
+            for (int32_t j = 0; j < kk; ++j) {
+                const int32_t id = cand_idx[h][size_t(r) * kk + j];
+                if (id >= 0) row.emplace_back(cand_val[h][size_t(r) * kk + j], id);
+            }
+        }
+        const size_t take = std::min<size_t>(size_t(k), row.size());
+        std::partial_sort(row.begin(), row.begin() + take, row.end(), [](const std::pair<float, int32_t>& a, const std::pair<float, int32_t>& b) {
+            return a.first > b.first || (a.first == b.first && a.second < b.second);
+        });
+        int32_t* io = idx_host + int64_t(p0->ord[(size_t)r]) * k;
+        float* vo = val_host + int64_t(p0->ord[(size_t)r]) * k;
+        for (int32_t j = 0; j < k; ++j) {
+            io[j] = size_t(j) < take ? row[j].second : -1;
+            vo[j] = size_t(j) < take ? row[j].first : 0.f;
+        }
+    }
+    return SIMRANK_OK;
+}
+
 int simrank_shardplan_info(const simrank_shardplan* p, int64_t* n, int64_t* col_lo, int64_t* col_hi, int32_t* half_form,
                            int32_t* stages, int32_t* updates) {
     SR_REQUIRE(p, "plan is NULL");

@@ -258,6 +258,15 @@ class ShardPlans:
               "simrank_shardplan_result_f64")
         return out
 
+    def topk(self, k: int, exclude_diag: bool = True, root: int = 0, i_am_root: bool = True):
+        """(ids int32 [n, k], values float32 [n, k]) on rank ``root``: the k most similar nodes of every node.  Collective."""
+        idx = np.empty((self.n, k), dtype=np.int32) if i_am_root else None
+        val = np.empty((self.n, k), dtype=np.float32) if i_am_root else None
+        check(self.ops.lib.simrank_shardplan_topk(self._arr, len(self.plans), int(root), int(k), int(exclude_diag),
+                                                  idx.ctypes.data if i_am_root else None,
+                                                  val.ctypes.data if i_am_root else None), "simrank_shardplan_topk")
+        return idx, val
+
     def free(self):
         lib = self.ops.lib
         for h in self.plans:

@@ -57,6 +57,17 @@ def main():
         c = sp.step(0.0, exact_count=True)
         assert c > 0
         sp.free()
+    # top-k hand-back: every rank's candidates meet on rank 0
+    sp = ShardPlans(ops, csr, rowscale=scale, world=world, comm=comm, evidence=True)
+    sp.run(5, 0.0)
+    full = sp.result(root=0, i_am_root=rank == 0)
+    idx, val = sp.topk(6, root=0, i_am_root=rank == 0)
+    sp.free()
+    if rank == 0:
+        for a in range(0, n, 37):
+            cand = np.array([c for c in range(n) if c != a])
+            order = cand[np.lexsort((cand, -full[a, cand]))][:6]
+            assert list(idx[a]) == list(order), a
     # fp16-held matrices on the ranks (config 5's reduced precision on shards): against the f32 result
     sp = ShardPlans(ops, csr, rowscale=scale, world=world, comm=comm, evidence=True, stages=2, storage="fp16")
     done, conv = sp.run(30, 1e-4)

@@ -199,6 +199,31 @@ def test_shardplan_with_half_storage_against_the_oracle(ops, pp, world, stages):
     sp.free()
 
 
+@pytest.mark.parametrize("storage,world,form", [("f32", 3, 0), ("f32", 4, 1), ("fp16", 2, 0), ("f32", 1, 0)])
+def test_shardplan_topk_in_the_callers_ids(ops, storage, world, form):
+    """simrank_shardplan_topk: every rank selects among its own columns, root merges — ids and tie order the caller's,
+    against a sort of the dense result the same plans hand back."""
+    from simrank_amd.engine import ShardPlans
+    n_want = 640 if storage == "fp16" or form else 600
+    df = synth.powerlaw_directed(n_want, 7, seed=9)
+    _, csr = ingest.directed(df, False, "from", "to", "weight")
+    if (storage == "fp16" and csr.n_rows % (64 * world)) or (form and csr.n_rows % (32 * world)):
+        pytest.skip("size does not fit the mode")
+    sp = ShardPlans(ops, csr, world=world, coef=0.8, evidence=True, leg2_form=form, storage=storage)
+    sp.run(6, 1e-30)
+    S = sp.result()
+    idx, val = sp.topk(7)
+    big, _ = sp.topk(5, exclude_diag=False)
+    sp.free()
+    n = csr.n_rows
+    for a in range(n):
+        cand = np.array([c for c in range(n) if c != a])
+        order = cand[np.lexsort((cand, -S[a, cand]))][:7]
+        assert list(idx[a]) == list(order), a
+        np.testing.assert_array_equal(val[a].astype(np.float64), S[a, order])
+        assert big[a][0] == a                       # the node itself (similarity 1) when the diagonal is not excluded
+
+
 def test_shardplan_refuses_what_it_cannot_run(ops):
     from simrank_amd._lib import SimRankHipError
     from simrank_amd.engine import ShardPlans

@@ -49,8 +49,10 @@ def _precision(dense_precision, storage_precision="f32"):
     (operand split into three bf16 terms); "fp16" rounds its operand to one fp16 term — BASELINE.json
     config 5's reduced-precision dense leg: faster, NOT within the 1e-5 parity bar.
     ``fit(storage_precision=...)``: "f32" (default), or "fp16": the similarity matrices and the
-    intermediate product are HELD in fp16 (f32 sums and epilogue, one rounding per stored value; one GPU,
-    gather mode, symmetric iterates) — half the bytes and half the gathered lines per update, the
+    intermediate product are HELD in fp16 (f32 sums and epilogue, one rounding per stored value; gather
+    mode, symmetric iterates; one GPU — or, for SimRank / SimRank++ without a prior, the ranks of a
+    ``LocalWorld(P)`` / RCCL ``TorchWorld``: ``cshard.py``, the sharded loop behind the C ABI) — half the
+    bytes and half the gathered lines per update (and half the bytes on the links), the
     reduced-precision mode that pays on config 5; NOT within the parity bar either.  In that mode the
     convergence test is NOT the reference's `_converged` (SimRank.py:54-77): an element counts as moved only
     when it moved by more than eps + half an fp16 spacing at its stored value, so ``converged_at`` and the
@@ -76,6 +78,13 @@ def _make_solver(ops_factory, device, world, specs, mode):
     terms = _DENSE_TERMS[dense]
     if terms != 3 or storage != "f32":
         specs = [dataclasses.replace(s, dense_terms=terms, storage=storage) for s in specs]
+    if storage == "fp16" and (world.size > 1 or not isinstance(world, LocalWorld)):
+        # fp16-held matrices on SHARDS: the sharded loop behind the C ABI (csrc/shardplan.hip) — config 5 as stated
+        from . import cshard
+        why = cshard.applies(world, specs, mode)
+        if why:
+            raise ValueError("storage_precision='fp16' on several ranks: " + why)
+        return cshard.CShardSolver(factory, world, specs[0])
     return Solver(factory, world, specs, mode)
 
 
@@ -417,7 +426,7 @@ def _lazy_evidence(world, solver, j, csr):
     exact).  With every shard in this process the counts come back from the device; in a
     multi-process world a lazy read must not be a collective (only some ranks may read
     it), so it is recomputed from the CSR."""
-    if isinstance(world, LocalWorld):
+    if isinstance(world, LocalWorld) and hasattr(solver, "evidence"):
         return lambda: solver.evidence(j)
     return lambda: _host_evidence(csr)
 

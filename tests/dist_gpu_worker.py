@@ -89,6 +89,17 @@ def main():
     assert m and m["half_ms"] > 0 and m["full_ms"] > 0 and m["chosen"] in ("half", "full"), m
     np.testing.assert_allclose(got.values, want.values, rtol=2e-6, atol=1e-30)
     drv.MEASURE_FORM_FROM_N = 4096
+    # fp16-held matrices on the ranks of an RCCL world through the class surface (simrank_amd/cshard.py: the sharded loop
+    # behind the C ABI on the library's own communicator, made from an id broadcast through torch.distributed)
+    from oracle import simrank_oracle as O
+    df = synth.powerlaw_directed(1024 * dist.get_world_size(), 16, seed=9)
+    want = O.fit_simrank_pp(df, verbose=False)
+    est = SRA.SimRankPP()
+    got = est.fit(df, verbose=False, storage_precision="fp16", world=TorchWorld(handback="all"))
+    assert est.converged_at is not None and est.converged_at >= want["k"] - 1
+    assert np.abs(got.values - want["S"]).max() < 1e-4 * 0.8 / 0.2 + 6e-4
+    top = SRA.SimRankPP().fit(df, verbose=False, storage_precision="fp16", world=TorchWorld(), top_k=3)
+    assert len(top) == 3 * len(got)                   # every rank gets the top-k frame
     dist.barrier()
     print("RCCL WORLD ok", flush=True)
     dist.destroy_process_group()

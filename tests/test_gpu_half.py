@@ -274,6 +274,50 @@ def test_fit_with_half_storage_against_the_oracle(cls):
     assert np.abs(got.values - want["S"]).max() < 1e-4 * 0.8 / 0.2 + 6e-4
 
 
+@pytest.mark.parametrize("cls", ["SimRank", "SimRankPP"])
+def test_fit_with_half_storage_on_virtual_ranks(cls):
+    """BASELINE config 5 in its stated form through the reference's class surface: `fit(storage_precision="fp16",
+    world=LocalWorld(4))` runs the sharded loop behind the C ABI on fp16-held matrices (simrank_amd/cshard.py) — the
+    bars of the single-rank mode against the float64 oracle, the dense and the top-k hand-back, the console text of
+    the reference's loop."""
+    import io
+    from contextlib import redirect_stdout
+    import simrank_amd.SimRank as SRA
+    from oracle import simrank_oracle as O
+    from simrank_amd import synth
+    from simrank_amd.driver import LocalWorld
+    df = synth.powerlaw_directed(2048, 24, seed=12)
+    oracle = O.fit_simrank if cls == "SimRank" else O.fit_simrank_pp
+    want = oracle(df, verbose=False, iterations=10, eps=1e-30)
+    est = getattr(SRA, cls)()
+    got = est.fit(df, verbose=False, storage_precision="fp16", iterations=10, eps=1e-30, world=LocalWorld(4))
+    assert list(got.index) == want["labels"] and est.engine_mode == "sparse"
+    a, b = got.values, want["S"]
+    assert np.all(np.diag(a) == 1.0)
+    err = np.abs(a - b)
+    rel = err[b > 0] / b[b > 0]
+    assert err.max() < 6e-4 and rel.max() < 2.5e-3 and np.median(rel) < 4e-4, (err.max(), rel.max(), np.median(rel))
+    # to eps, with the reference's console text; top-k hand-back
+    want = oracle(df, verbose=False)
+    est = getattr(SRA, cls)()
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        top = est.fit(df, verbose=True, storage_precision="fp16", world=LocalWorld(8), top_k=5)
+    assert est.converged_at is not None and est.converged_at >= want["k"] - 1
+    assert f"Converged at iteration {est.converged_at}" in buf.getvalue() and "Start iterating..." in buf.getvalue()
+    assert len(top) == 5 * 2048 and set(top.columns) == {"node", "rank", "neighbor", "similarity"}
+    full = getattr(SRA, cls)().fit(df, verbose=False, storage_precision="fp16", world=LocalWorld(8))
+    first = top[top["rank"] == 1].set_index("node")
+    for node in list(full.index[:50]):
+        row = full.loc[node].drop(node)
+        assert first.loc[node, "similarity"] == np.float32(row.max())
+    if cls == "SimRankPP":
+        assert est.Evidence.shape == (2048, 2048)          # (lazy attribute: from the CSR on the host in this mode)
+    with pytest.raises(ValueError, match="multiple of"):
+        getattr(SRA, cls)().fit(synth.powerlaw_directed(300, 5, seed=1), verbose=False, storage_precision="fp16",
+                                world=LocalWorld(2))
+
+
 def test_half_storage_is_refused_where_it_does_not_exist():
     import simrank_amd.SimRank as SRA
     from simrank_amd import synth

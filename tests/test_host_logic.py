@@ -369,8 +369,20 @@ def test_storage_precision_is_validated_on_the_host():
         SRA.SimRank().fit(df, verbose=False, storage_precision="bf16", _ops_factory=lambda r: NumpyOps())
     with pytest.raises(ValueError, match="storage_precision='fp16' needs"):
         SRA.SimRank().fit(df, verbose=False, storage_precision="fp16", _ops_factory=lambda r: NumpyOps())
-    with pytest.raises(ValueError, match="storage_precision='fp16' needs"):
+    # several ranks: the sharded loop behind the C ABI takes the mode (simrank_amd/cshard.py) — where its conditions
+    # hold (whole 64-column panels per rank, one symmetric side, no prior) and the engine is the HIP one
+    with pytest.raises(ValueError, match="on several ranks: .* multiple of 128"):
         SRA.SimRank().fit(df, verbose=False, storage_precision="fp16", world=LocalWorld(2),
                           _ops_factory=lambda r: NumpyOps())
+    ring = pd.DataFrame({"from": np.arange(128), "to": (np.arange(128) + 1) % 128, "weight": np.ones(128)})
+    with pytest.raises(ValueError, match="storage_precision='fp16' needs the HIP engine"):
+        SRA.SimRank().fit(ring, verbose=False, storage_precision="fp16", world=LocalWorld(2),
+                          _ops_factory=lambda r: NumpyOps())
+    with pytest.raises(ValueError, match="on several ranks: a prior"):
+        SRA.AprioriSimRank().fit(ring, np.eye(128), verbose=False, storage_precision="fp16", world=LocalWorld(2),
+                                 _ops_factory=lambda r: NumpyOps())
+    with pytest.raises(ValueError, match="on several ranks: the bipartite classes"):
+        SRA.BipartiteSimRank().fit(pd.DataFrame({"user": [0, 1], "item": [0, 1], "weight": [1.0, 1.0]}), verbose=False,
+                                   storage_precision="fp16", world=LocalWorld(2), _ops_factory=lambda r: NumpyOps())
     ok = SRA.SimRank().fit(df, verbose=False, storage_precision="f32", _ops_factory=lambda r: NumpyOps())
     assert ok.shape == (4, 4)

@@ -955,7 +955,7 @@ bool fused_rowmajor_fits(const simrank_graph* g, const float* X, int64_t ldx, in
     const int64_t K = g->n_cols, M = g->n_rows;
     const int64_t tb = (t_block <= 0 || t_block > M) ? M : t_block;
     return g->fused && aligned16(X) && aligned16(Y) && ldx % 4 == 0 && ldx * 4 < (int64_t(1) << 24) && ldx >= 32 &&
-           (K + 1) * ldx * 4 < (int64_t(1) << 31) && K < (int64_t(1) << 24) - 1 && L > 0 &&
+           (K + 1) * ldx * 4 < (int64_t(1) << 32) && K < (int64_t(1) << 24) - 1 && L > 0 &&
            (tb % kFB == 0 || tb == M) && (tb + t_pad) % 4 == 0 && (M - (M - 1) / tb * tb + t_pad) % 4 == 0;
 }
 
@@ -967,7 +967,9 @@ int launch_fused_trans_rowmajor(const simrank_graph* g, const float* X, int64_t 
     a.L = L;
     a.x_panel_stride = 32;
     a.x_pitch = uint32_t(ldx * 4);
-    a.x_bytes = int32_t((g->n_cols - 1) * ldx * 4 + L * 4);     // (to the last column of the last row: nothing beyond is read)
+    // (to the last column of the last row: nothing beyond is read.  The descriptor's byte count and the offsets
+    // id x pitch are UNSIGNED 32-bit quantities: a rank's block may span up to 4 GiB — config 5 on eight ranks is 2.2)
+    a.x_bytes = int32_t(uint32_t((g->n_cols - 1) * ldx * 4 + L * 4));
     a.x_sentinel = (int32_t)g->n_cols;
     a.y_chunked = 1;
     a.t_block = (t_block <= 0 || t_block > g->n_rows) ? g->n_rows : t_block;

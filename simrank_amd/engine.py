@@ -39,7 +39,7 @@ class Matrix:
         if self.blocked:
             assert external is None and ld is None
             # (+8 rows: panels are not a power of two apart, and every panel starts 16-byte aligned)
-            self.rows_pad = -(-max(1, self.rows) // 8) * 8 + 8
+            self.rows_pad = -(-max(1, self.rows) // 8) * 8 + BLOCK_PAD_ROWS
             self.ld = 64 if self.dtype == np.float16 else 32
             self.panels = -(-max(1, self.cols) // self.ld)
             self.nbytes = self.panels * self.rows_pad * self.ld * self.dtype.itemsize
@@ -351,6 +351,10 @@ class BiPlan:
             self.free()
         except Exception:
             pass
+
+
+# rows appended to every panel of a panel-blocked matrix (panels are then not a power of two apart); a measurement knob
+BLOCK_PAD_ROWS = int(os.environ.get("SIMRANK_BLOCK_PAD_ROWS", "8")) // 8 * 8 or 8
 
 
 class HipOps:

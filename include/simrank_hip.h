@@ -549,7 +549,8 @@ SIMRANK_API int simrank_shardplan_destroy(simrank_shardplan* p);
  *      "dense_min" / "dense_cols"  selection of the block-dense part (see above); dense_min 0 = off
  *      "fuse" / "fuse_min" / "fuse_steps"  leg 1 of a panel-blocked update as one launch (see above): a
  *                 column joins a 128-row block's dense set when fuse_min (3) of its rows reference it, a
- *                 block keeps its set when it makes fuse_steps (8) 16-column steps; fuse 0 = the
+ *                 block keeps its set when it makes fuse_steps 16-column steps (default -1: 20 while a panel's
+ *                 operand slice fits the XCD's L2, i.e. up to 32768 operand rows, 8 beyond); fuse 0 = the
  *                 dense_tiles + gather launches of round 2
  *      "fuse_max_rows" operands with more rows than this (default 2^20: never) keep the two-launch leg 1
  *      "fuse_group" up to this many (1..4, default 3) consecutive blocks without a set share a workgroup

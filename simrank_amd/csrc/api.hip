@@ -808,8 +808,11 @@ int simrank_set_tuning(const char* key, int64_t value) {
         SR_REQUIRE(value >= 1 && value <= 4, "fuse_group must be 1 .. 4");
         t.fuse_group = value;
     } else if (!strcmp(key, "fuse_steps")) {
-        SR_REQUIRE(value >= 0 && value <= (1 << 20), "fuse_steps must be >= 0");
+        SR_REQUIRE(value >= -1 && value <= (1 << 20), "fuse_steps must be >= 0, or -1 (by the operand's size)");
         t.fuse_steps = value;
+    } else if (!strcmp(key, "fuse_dens")) {
+        SR_REQUIRE(value >= 0 && value <= (1 << 20), "fuse_dens must be >= 0");
+        t.fuse_dens = value;
     } else if (!strcmp(key, "dense_cols")) {
         SR_REQUIRE(value >= 1 && value <= (1 << 20), "dense_cols must be >= 1");
         t.dense_cols = value;
@@ -835,6 +838,7 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     else if (!strcmp(key, "fuse")) *value = t.fuse;
     else if (!strcmp(key, "fuse_min")) *value = t.fuse_min;
     else if (!strcmp(key, "fuse_steps")) *value = t.fuse_steps;
+    else if (!strcmp(key, "fuse_dens")) *value = t.fuse_dens;
     else if (!strcmp(key, "fuse_unit")) *value = t.fuse_unit;
     else if (!strcmp(key, "fuse_group")) *value = t.fuse_group;
     else if (!strcmp(key, "fuse_cap")) *value = t.fuse_cap;

@@ -62,7 +62,9 @@ struct Tuning {
                              // same workgroup on the same L2-resident panel slice; 0 = dense_tiles + gather3 launches
     int64_t fuse_min = 3;    // ... a column joins a block's dense set when this many of its rows reference it (2 and 4:
                              // +8 % and +1 % on the leg at pl32768d32)
-    int64_t fuse_steps = 8;  // ... and a block keeps its set only when it makes this many 16-column steps
+    int64_t fuse_steps = -1; // ... and a block keeps its set only when it makes this many 16-column steps; -1: by the size
+                             // of a panel's operand slice (fuse_min_steps below)
+    int64_t fuse_dens = 0;   // ... or (> 0) when it makes at least 4 and covers this many entries per step
     int64_t fuse_unit = 48;  // ... sets of more than this many 64-column groups are cut into units (workgroups whose
                              // partial sums meet in memory, written through and read past the L1 — round 4; with round 3's
                              // agent-scope release / acquire pair 64 cost +3 %): pl32768d32 leg 1 5.50 -> 5.20 ms at 64
@@ -140,6 +142,16 @@ int shard_prepare(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* 
                   const float* apriori, int64_t ld_apriori, bool reorder, int32_t deal, PlanPrep* out);
 int biplan_prepare(int64_t n1, int64_t n2, int64_t nnz, const int32_t* rowptr12, const int32_t* col12,
                    const float* rowscale1, const float* rowscale2, const simrank_biplan_options* opt, BiPlanPrep* out);
+
+// How many 16-column steps a block's dense set must make to be kept.  A short matrix-core phase costs a workgroup more in
+// fixed work (pattern table, tile hand-over, barriers) than its few shared columns save in gathers — unless the gathers
+// are expensive: once a panel's operand slice (K rows x 128 bytes) no longer fits the XCD's 4 MiB L2, more of them miss
+// and the break-even moves to smaller sets.  Measured after the round-4 split into matrix-core and gather units
+// (profiles/r04_fuse_steps_sweep.log): K = 32768: 20 steps 4.81 ms against 4.97 with 8 (pl32768d32), 4.27 / 4.33 (pl32768);
+// K = 65536 (pl65536): 8 steps 18.2 ms against 18.5 with 20.
+inline int64_t fuse_min_steps(const Tuning& t, int64_t K) {
+    return t.fuse_steps >= 0 ? t.fuse_steps : (K * 128 > (int64_t(4) << 20) ? 8 : 20);
+}
 
 // The run loops queue update k + 1 BEFORE they read the count of update k only while an update is short (small graphs:
 // the host round trip per update is what they save); from this many nodes on an update takes milliseconds, the round trip

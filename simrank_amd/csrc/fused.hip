@@ -579,7 +579,7 @@ void free_fused_plan(simrank_fused_plan* p) {
 int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col, const float* rowscale) {
     const int64_t M = g->n_rows, K = g->n_cols;
     const int64_t thr = std::max<int64_t>(2, g->tun.fuse_min);
-    const int64_t min_steps = std::max<int64_t>(0, g->tun.fuse_steps);
+    const int64_t min_steps = fuse_min_steps(g->tun, g->n_cols);
     const int64_t nblk = (M + kFB - 1) / kFB;
     const bool ids16 = K < 65535;
     std::vector<int32_t> blk_quad0(size_t(nblk) + 1, 0);
@@ -604,9 +604,18 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
             if (cnt[col[j]]++ == 0) touched.push_back(col[j]);
         for (int32_t c : touched)
             if (cnt[c] >= thr) { set.push_back(c); kpos[c] = 0; }
-        if ((int64_t)(set.size() + 15) / 16 < min_steps) {
-            for (int32_t c : set) kpos[c] = -1;
-            set.clear();
+        {
+            const int64_t steps = (int64_t)(set.size() + 15) / 16;
+            bool keep = steps >= min_steps;
+            if (!keep && g->tun.fuse_dens > 0 && steps >= 4) {      // a short set that is dense all the same
+                int64_t cov = 0;
+                for (int32_t c : set) cov += cnt[c];
+                keep = cov >= g->tun.fuse_dens * steps;
+            }
+            if (!keep) {
+                for (int32_t c : set) kpos[c] = -1;
+                set.clear();
+            }
         }
         // rows that would keep a long remainder go to the matrix cores whole
         for (int64_t a = lo; a < hi; ++a) {

@@ -610,7 +610,7 @@ int build_fused2_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* co
     (void)rowscale;
     const int64_t M = g->n_rows, K = g->n_cols;
     const int64_t thr = std::max<int64_t>(2, g->tun.fuse_min);
-    const int64_t min_steps = std::max<int64_t>(0, g->tun.fuse_steps);
+    const int64_t min_steps = fuse_min_steps(g->tun, g->n_cols);
     const int64_t nblk = (M + kFB - 1) / kFB;
     const bool ids16 = K < 65535;
     const double c_step = 200.0;          // cycles per 16-column step of a workgroup (4 waves side by side)

@@ -22,7 +22,7 @@ def ops():
     o = HipOps(0)
     o.set_tuning(fuse_steps=1, fuse_min=2)   # small test graphs: a dense set however few steps it makes
     yield o
-    o.set_tuning(fuse=1, fuse_min=3, fuse_steps=8, fuse_unit=48, fuse_group=3, fuse_shards=1, fuse_rows=8192)
+    o.set_tuning(fuse=1, fuse_min=3, fuse_steps=-1, fuse_unit=48, fuse_group=3, fuse_shards=1, fuse_rows=8192)
 
 
 @contextlib.contextmanager

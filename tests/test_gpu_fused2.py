@@ -13,7 +13,7 @@ from tests.test_gpu_kernels import corner_csr, dense64, random_csr
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-5
-DEFAULTS = dict(fuse=1, fuse_min=3, fuse_steps=8, fuse_unit=48, fuse_group=3, fuse_cap=40000, fuse_wgs=4)
+DEFAULTS = dict(fuse=1, fuse_min=3, fuse_steps=-1, fuse_unit=48, fuse_group=3, fuse_cap=40000, fuse_wgs=4)
 
 
 @pytest.fixture(scope="module")

@@ -1,11 +1,11 @@
 #!/bin/bash
-# dense sets: size rule (fuse_steps) against a density rule (fuse_dens entries per step) on three graphs
-out=gpurun_out/r04_fuse_dens_sweep.log
+# after the size rule of the dense sets: the unit sizes again
+out=gpurun_out/r04_units_sweep2.log
 : > $out
-for w in pl32768d32 pl32768 "pl65536 --pp"; do
-  for cfg in "fuse_steps=8" "fuse_steps=20" "fuse_steps=20,fuse_dens=64" "fuse_steps=20,fuse_dens=80" "fuse_steps=20,fuse_dens=96" "fuse_steps=20,fuse_dens=128" "fuse_steps=32,fuse_dens=96" "fuse_steps=1000,fuse_dens=80" "fuse_steps=1000,fuse_dens=112"; do
-    echo -n "$w: " >> $out
-    timeout -k 10 200 python tools/leg_only.py --workload $w --steps 4 --set $cfg >> $out 2>&1 || exit 1
-  done
-done
+for fu in 24 32 48 64 96; do for fr in 6000 8192 12000; do
+  timeout -k 10 200 python tools/leg_only.py --workload pl32768d32 --steps 5 --set fuse_unit=$fu,fuse_rows=$fr >> $out 2>&1 || exit 1
+done; done
+for fs in 20 28; do for fg in 2 3 4; do
+  timeout -k 10 200 python tools/leg_only.py --workload pl32768d32 --steps 5 --set fuse_steps=$fs,fuse_group=$fg >> $out 2>&1 || exit 1
+done; done
 cat $out

@@ -804,6 +804,48 @@ def main():
         except Exception as e:
             out["fit_wall"] = {"error": f"{type(e).__name__}: {e}"}
 
+    if not args.no_extras and world_size == 1 and gpu and solver.mode == "sparse" and n % 512 == 0:
+        # what ONE rank of an 8-rank world spends in kernels on this graph (north_star's configs 4 and 5 are 8-GPU
+        # configurations; no multi-GPU node is needed to time a rank's launches): LocalWorld(8) runs the eight shards one
+        # after another on this GPU with the exchanges done by device copies — nothing here is a multi-GPU measurement
+        try:
+            type(ops).trim_pool()
+            emu = {}
+            sh = Solver(lambda r: ops, LocalWorld(8), [make_spec(csr, args.pp)], "sparse")
+            sh.reset()
+            sh.step(0.0)
+            sh.enable_timing()
+            for _ in range(3):
+                sh.step(0.0)
+            lt = sh.leg_times()
+            side8 = sh.sides[0][0]
+            emu["python_driver_f32"] = {
+                "leg2_form": "half" if side8.shard_sym else "full",
+                "leg1_ms": lt["leg1.0"][0], "leg2_ms": lt["leg2.0"][0], "unpack_ms": lt.get("unpack.0", (0.0, 0))[0],
+                "kernels_per_rank_ms": lt["leg1.0"][0] + lt["leg2.0"][0] + lt.get("unpack.0", (0.0, 0))[0],
+                "exchange_payload_per_rank_MiB": (4.0 * n * n / 8 * 7 / 8 + (4.0 * side8.sh_chunk * 7 if side8.shard_sym else 0)) / 2**20}
+            sh.release()
+            del sh
+            from simrank_amd.engine import ShardPlans
+            spec8 = make_spec(csr, args.pp)
+            for label, kw in (("c_loop_f32_half_form", dict(leg2_form=1)), ("c_loop_fp16_held_full_form", dict(storage="fp16"))):
+                sp = ShardPlans(ops, csr, rowscale=spec8.rowscale, world=8, coef=coef, evidence=args.pp, stages=1, **kw)
+                sp.step(0.0)
+                ops.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    sp.step(0.0, exact_count=False)
+                ops.synchronize()
+                emu[label] = {"per_rank_ms_device_copies_included": (time.perf_counter() - t0) / 3 / 8 * 1e3}
+                sp.free()
+            emu["note"] = ("eight virtual ranks on ONE GPU, run one after another (driver.LocalWorld / simrank_comm_local_group): a "
+                           "rank's kernel time, not a multi-GPU measurement; single rank on this box: "
+                           f"{out['ms_per_step']:.2f} ms per step")
+            out["shards_emulated_p8"] = emu
+            type(ops).trim_pool()
+        except Exception as e:
+            out["shards_emulated_p8"] = {"error": f"{type(e).__name__}: {e}"}
+
     if not args.no_extras and world_size == 1 and solver.mode == "sparse" and n <= 32768:
         # BASELINE.json's literal recipe — sparse leg 1, dense f32 MFMA GEMM for leg 2 —
         # measured on the same workload so the dispatch decision is a number, not a claim

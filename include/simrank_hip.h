@@ -476,7 +476,10 @@ SIMRANK_API int simrank_biplan_destroy(simrank_biplan* p);
  *      Nodes: ascending row length, dealt to the shards in runs of 128 in the half form (as driver.dealt_order).
  *      Results: simrank_shardplan_block_f64 = the rank's columns (all n rows, caller's row order) + their node ids by
  *      simrank_shardplan_columns; simrank_shardplan_result_f64 assembles the whole matrix on rank `root`.
- *      Only symmetric iterates (SimRank, SimRank++, symmetric priors); f32, or fp16-held matrices (options.storage_fp16). */
+ *      Only symmetric iterates (SimRank, SimRank++, symmetric priors); f32, or fp16-held matrices (options.storage_fp16).
+ *      Lifetime: destroy the plans before their communicator.  Failure: these calls are collectives — a rank whose call
+ *      fails (out of memory, a bad argument the others did not pass) leaves its peers waiting inside RCCL, as in any
+ *      RCCL program; the host program owns that failure mode (validate on every rank before, tear the job down after). */
 typedef struct simrank_comm simrank_comm;
 #define SIMRANK_COMM_ID_BYTES 128
 /* rank 0 makes an id, the host program hands its bytes to every rank (its own job: MPI, a file, a socket), every rank

@@ -14,6 +14,7 @@
 // Python's driver.Solver does the same choreography for every world size; this is the single-rank case
 // for callers that bind the library directly (examples/reference_hip_stub.py).
 #include <algorithm>
+#include <cstring>
 #include <numeric>
 #include <vector>
 
@@ -28,6 +29,8 @@ struct simrank_plan {
     uint8_t* ev = nullptr;                    // evidence counts (SimRank++), panel-blocked u8
     float* prior = nullptr;                   // panel-blocked, solver order
     int32_t* inv = nullptr;                   // device: position of caller's node i in the solver's order
+    int32_t* ord_dev = nullptr;               // device: caller's node at position r (ids of the columns, top-k)
+    std::vector<int32_t> ord;                 // host copy
     unsigned long long* counters = nullptr;   // device, SIMRANK_CHANGED_SLOTS
     unsigned long long* host_counters[2] = {nullptr, nullptr};   // pinned; update u lands in slot u & 1
     hipEvent_t counted[2] = {nullptr, nullptr};
@@ -95,7 +98,7 @@ int simrank_plan_destroy(simrank_plan* p) {
     if (!p) return SIMRANK_OK;
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     (void)pool_free(p->S[0]); (void)pool_free(p->S[1]); (void)pool_free(p->Tt); (void)pool_free(p->ev);
-    (void)pool_free(p->prior); (void)pool_free(p->inv); (void)pool_free(p->counters);
+    (void)pool_free(p->prior); (void)pool_free(p->inv); (void)pool_free(p->ord_dev); (void)pool_free(p->counters);
     for (int i = 0; i < 2; ++i) {
         if (p->host_counters[i]) (void)hipHostFree(p->host_counters[i]);
         if (p->counted[i]) (void)hipEventDestroy(p->counted[i]);
@@ -157,6 +160,9 @@ int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int
     }
     PLAN_HIP(pool_hip_alloc((void**)&p->inv, size_t(n) * sizeof(int32_t)));
     PLAN_HIP(hipMemcpyAsync(p->inv, inv.data(), size_t(n) * sizeof(int32_t), hipMemcpyHostToDevice, p->stream));
+    p->ord = ord;
+    PLAN_HIP(pool_hip_alloc((void**)&p->ord_dev, size_t(n) * sizeof(int32_t)));
+    PLAN_HIP(hipMemcpyAsync(p->ord_dev, p->ord.data(), size_t(n) * sizeof(int32_t), hipMemcpyHostToDevice, p->stream));
     PLAN_HIP(hipStreamSynchronize(p->stream));          // (inv is a host vector about to go away)
     if (opt->evidence) {
         // common in-neighbour counts of the pattern (SimRank.py:311-320), 1 - 2^-count in the epilogue
@@ -299,32 +305,51 @@ int simrank_plan_result_f64(simrank_plan* p, double* dst, int64_t ld) {
 
 int simrank_plan_topk(simrank_plan* p, int32_t k, int32_t exclude_diag, int32_t* idx_host, float* val_host) {
     SR_REQUIRE(p && idx_host && val_host && k > 0 && k <= 1024, "bad top-k arguments");
-    // S in the caller's node order as a row-major device copy (as simrank_plan_result), the selection there,
-    // and 2 x n x k values across PCIe instead of n^2 (ids = the caller's, ties by the lower id)
-    const int64_t n = p->n, ldt = (n + 3) / 4 * 4;
-    float* rowm = nullptr;
+    // The selection runs on the plan's own panel-blocked matrix in the solver's order (one pass, eight rows per wave;
+    // fp16-held: on its f32 copy), reporting the caller's ids; the rows go back into the caller's order on the host —
+    // 2 x n x k values across PCIe instead of n^2, and no n^2 copy on the device either.
+    const int64_t n = p->n;
+    const size_t wide_bytes = size_t((n + 31) / 32) * size_t(p->rows_pad) * 32 * sizeof(float);
+    float* wide = nullptr;
     int32_t* idx_dev = nullptr;
     float* val_dev = nullptr;
-    hipError_t e = pool_hip_alloc((void**)&rowm, size_t(n) * size_t(ldt) * sizeof(float));
+    hipError_t e = hipSuccess;
+    int rc = SIMRANK_OK;
+    if (p->half) {
+        e = pool_hip_alloc((void**)&wide, wide_bytes);
+        if (e == hipSuccess)
+            rc = simrank_widen_blocked_h16(p->S[p->cur], p->rows_pad, wide, p->rows_pad, n, n, kHalfScale, p->stream);
+    }
     if (e == hipSuccess) e = pool_hip_alloc((void**)&idx_dev, size_t(n) * size_t(k) * sizeof(int32_t));
     if (e == hipSuccess) e = pool_hip_alloc((void**)&val_dev, size_t(n) * size_t(k) * sizeof(float));
-    int rc = SIMRANK_OK;
-    if (e == hipSuccess) rc = simrank_plan_result(p, rowm, ldt);
+    std::vector<int32_t> idx_s;
+    std::vector<float> val_s;
+    if (e == hipSuccess && !rc) {
+        // (the diagonal of the solver's order is the diagonal of the caller's: position r against position r)
+        rc = simrank_topk_rows_blocked(p->half ? wide : p->S[p->cur], p->rows_pad, n, n, 0, p->ord_dev, k, exclude_diag, idx_dev,
+                                       val_dev, p->stream);
+        idx_s.resize(size_t(n) * size_t(k));
+        val_s.resize(size_t(n) * size_t(k));
+    }
     if (e == hipSuccess && !rc)
-        rc = simrank_topk_rows(rowm, ldt, n, n, 0, k, exclude_diag, idx_dev, val_dev, p->stream);
+        e = hipMemcpyAsync(idx_s.data(), idx_dev, size_t(n) * size_t(k) * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream);
     if (e == hipSuccess && !rc)
-        e = hipMemcpyAsync(idx_host, idx_dev, size_t(n) * size_t(k) * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream);
-    if (e == hipSuccess && !rc)
-        e = hipMemcpyAsync(val_host, val_dev, size_t(n) * size_t(k) * sizeof(float), hipMemcpyDeviceToHost, p->stream);
+        e = hipMemcpyAsync(val_s.data(), val_dev, size_t(n) * size_t(k) * sizeof(float), hipMemcpyDeviceToHost, p->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
     else (void)hipStreamSynchronize(p->stream);
-    (void)pool_free(rowm); (void)pool_free(idx_dev); (void)pool_free(val_dev);
+    (void)pool_free(wide); (void)pool_free(idx_dev); (void)pool_free(val_dev);
     if (e != hipSuccess) {
         set_error("simrank_plan_topk: %s", hipGetErrorString(e));
         (void)hipGetLastError();
         return SIMRANK_ERR_HIP;
     }
-    return rc;
+    if (rc) return rc;
+    for (int64_t r = 0; r < n; ++r) {
+        const int64_t a = p->ord[(size_t)r];
+        std::memcpy(idx_host + a * k, idx_s.data() + r * k, size_t(k) * sizeof(int32_t));
+        std::memcpy(val_host + a * k, val_s.data() + r * k, size_t(k) * sizeof(float));
+    }
+    return SIMRANK_OK;
 }
 
 int simrank_plan_info(const simrank_plan* p, int64_t* n, int32_t* updates, const simrank_graph** graph) {

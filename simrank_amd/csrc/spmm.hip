@@ -1579,6 +1579,90 @@ __global__ __launch_bounds__(256) void topk_rows_onepass_kernel(const float* __r
     }
 }
 
+// One pass over a PANEL-BLOCKED matrix (32-column panels of rows_pad rows): a wave takes EIGHT consecutive rows, lane
+// group g = lane >> 3 owns row 8 w + g, lane q = lane & 7 the columns 4 q .. 4 q + 3 of every panel — one load
+// instruction reads the eight rows' segments of a panel, 1 KiB contiguous (a single row of this layout is 128-byte
+// pieces rows_pad x 128 bytes apart: what made the callers copy the matrix to row-major first, 2 x N^2 x 4 bytes of
+// traffic the selection itself does not need).  Each lane keeps the K best of its columns, the eight lanes of a
+// group merge k times.  Same total order as the kernels above.
+template <int K>
+__global__ __launch_bounds__(256) void topk_rows_blocked_onepass_kernel(const float* __restrict__ S, int64_t rows_pad,
+                                                                        int64_t n_rows, int64_t n_cols, int64_t col0,
+                                                                        int k, int exclude_diag,
+                                                                        const int32_t* __restrict__ col_ids,
+                                                                        int32_t* idx_out, float* val_out) {
+    const int lane = threadIdx.x & 63, g = lane >> 3, q = lane & 7;
+    const int64_t wave = (blockIdx.x * int64_t(blockDim.x) + threadIdx.x) >> 6;
+    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    const int64_t n_panels = (n_cols + 31) / 32;
+    typedef float v4f32 __attribute__((ext_vector_type(4)));
+    for (int64_t a8 = wave * 8; a8 < n_rows; a8 += nwaves * 8) {
+        const int64_t a = a8 + g;
+        const bool live = a < n_rows;
+        const int64_t skip = exclude_diag ? a - col0 : -1;
+        float tv[K];
+        int ti[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) { tv[i] = -__builtin_inff(); ti[i] = 0x7fffffff; }
+        auto offer = [&](float v, int id, int64_t c) __attribute__((always_inline)) {
+            if (c < n_cols && c != skip && ((v > tv[K - 1]) || (v == tv[K - 1] && id < ti[K - 1]))) {
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    const bool better = (v > tv[i]) || (v == tv[i] && id < ti[i]);
+                    const float nv = better ? tv[i] : v;
+                    const int ni = better ? ti[i] : id;
+                    tv[i] = better ? v : tv[i];
+                    ti[i] = better ? id : ti[i];
+                    v = nv;
+                    id = ni;
+                }
+            }
+        };
+        if (live) {
+            const float* base = S + (a * 32 + 4 * q);
+            // two panels in flight
+            for (int64_t pn = 0; pn < n_panels; pn += 2) {
+                const bool two = pn + 1 < n_panels;
+                const v4f32 x0 = __builtin_nontemporal_load(reinterpret_cast<const v4f32*>(base + pn * rows_pad * 32));
+                const v4f32 x1 = two ? __builtin_nontemporal_load(reinterpret_cast<const v4f32*>(base + (pn + 1) * rows_pad * 32))
+                                     : v4f32{0, 0, 0, 0};
+                const int64_t c = pn * 32 + 4 * q, c2 = c + 32;
+                int i0[4], i1[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    i0[i] = col_ids ? (c + i < n_cols ? col_ids[c + i] : 0) : int(col0 + c + i);
+                    i1[i] = col_ids ? (two && c2 + i < n_cols ? col_ids[c2 + i] : 0) : int(col0 + c2 + i);
+                }
+                offer(x0.x, i0[0], c); offer(x0.y, i0[1], c + 1); offer(x0.z, i0[2], c + 2); offer(x0.w, i0[3], c + 3);
+                if (two) {
+                    offer(x1.x, i1[0], c2); offer(x1.y, i1[1], c2 + 1); offer(x1.z, i1[2], c2 + 2); offer(x1.w, i1[3], c2 + 3);
+                }
+            }
+        }
+        for (int j = 0; j < k; ++j) {
+            float bv = tv[0];
+            int bi = ti[0];
+#pragma unroll
+            for (int off = 4; off > 0; off >>= 1) {          // the eight lanes of the row's group
+                const float ov = __shfl_xor(bv, off);
+                const int oi = __shfl_xor(bi, off);
+                if ((ov > bv) || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            const bool found = bi != 0x7fffffff;
+            if (live && q == 0) {
+                idx_out[a * k + j] = found ? bi : -1;
+                val_out[a * k + j] = found ? bv : 0.f;
+            }
+            if (found && ti[0] == bi) {          // ids are distinct: exactly one lane of the group owns the pick
+#pragma unroll
+                for (int i = 0; i + 1 < K; ++i) { tv[i] = tv[i + 1]; ti[i] = ti[i + 1]; }
+                tv[K - 1] = -__builtin_inff();
+                ti[K - 1] = 0x7fffffff;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // dst[i][j] = src[row_idx[i]][col_idx[j]] (a NULL index list = identity): moves a matrix
 // between the solver's node order (rows sorted by length) and the caller's.  One workgroup
@@ -2198,6 +2282,18 @@ static int topk_impl(const float* S, int64_t ld, int64_t rows_pad, int64_t n_row
         else
             hipLaunchKernelGGL(topk_rows_onepass_kernel<32>, dim3(grid), dim3(256), 0, as_stream(stream), S, ld, n_rows,
                                n_cols, col0, k, exclude_diag, col_ids, idx_out, val_out);
+        SR_HIP(hipGetLastError());
+        return SIMRANK_OK;
+    }
+    // panel-blocked, any width: one pass, eight rows per wave (aligned panels: every panel starts 16-byte aligned)
+    if (rows_pad && k <= 32 && (reinterpret_cast<uintptr_t>(S) & 15) == 0) {
+        const int grid8 = (int)std::min<int64_t>((n_rows + 31) / 32, 256 * 8);
+        if (k <= 16)
+            hipLaunchKernelGGL(topk_rows_blocked_onepass_kernel<16>, dim3(grid8), dim3(256), 0, as_stream(stream), S, rows_pad,
+                               n_rows, n_cols, col0, k, exclude_diag, col_ids, idx_out, val_out);
+        else
+            hipLaunchKernelGGL(topk_rows_blocked_onepass_kernel<32>, dim3(grid8), dim3(256), 0, as_stream(stream), S, rows_pad,
+                               n_rows, n_cols, col0, k, exclude_diag, col_ids, idx_out, val_out);
         SR_HIP(hipGetLastError());
         return SIMRANK_OK;
     }

@@ -1191,9 +1191,10 @@ class Solver:
                 src, tmp, wide = self.cur[j][r], None, None
                 if src.dtype == np.float16:
                     src = wide = self.ops[r].widen(src)
-                if getattr(src, "blocked", False):
-                    # a row of a panel-blocked matrix is 128-byte pieces 4 MiB apart: the k selection
-                    # rounds re-read it, so they run on a row-major copy (one pass)
+                if getattr(src, "blocked", False) and not (k <= 32 and self.ops[r].name == "hip"):
+                    # a row of a panel-blocked matrix is 128-byte pieces 4 MiB apart: the k selection rounds of
+                    # the many-pass kernel (k > 32) re-read it, so they run on a row-major copy; up to k = 32 the
+                    # one-pass kernel reads the panel-blocked matrix itself, eight rows per wave
                     tmp = self.ops[r].matrix(src.rows, src.cols)
                     self.ops[r].permute(src, tmp)
                     src = tmp

@@ -470,6 +470,35 @@ def test_topk_rows_of_long_rows(ops, cols, k, with_ids):
         np.testing.assert_array_equal(val[r], h[r, order])
 
 
+@pytest.mark.parametrize("rows,cols,k,with_ids", [(37, 8192, 10, False), (70, 9001, 10, True), (5, 33, 3, False), (64, 100, 16, True),
+                                                  (129, 700, 20, True), (33, 2050, 32, False), (40, 300, 40, True), (1, 1, 1, False)])
+def test_topk_rows_of_a_panel_blocked_matrix(ops, rows, cols, k, with_ids):
+    """The one-pass selection on the panel-blocked layout itself (eight rows per wave, a lane group per row; k <= 32; k = 40
+    takes the many-pass kernel): same total order as on a row-major copy — rows full of ties, rows with fewer than k
+    candidates, row counts off the 8-row grid, widths off the 32-column grid, the diagonal at an offset."""
+    c0 = 3
+    rng = np.random.default_rng(rows * cols + k)
+    h = (rng.integers(0, 6, size=(rows, cols)) * (rng.random((rows, cols)) < 0.05)).astype(np.float32) / 8
+    h[0] = 0.0
+    if rows > 3:
+        h[3] = rng.random(cols).astype(np.float32)
+    ids = rng.permutation(3 * cols + 5)[:cols].astype(np.int32) if with_ids else None
+    key = ids if with_ids else c0 + np.arange(cols)
+    m = ops.matrix(rows, cols, blocked=True)
+    ops.upload(m, h)
+    kk = min(k, cols)
+    idx, val = ops.topk_rows(m, kk, col0=c0, exclude_diag=True, col_ids=ops.index_vector(ids) if with_ids else None)
+    for r in range(rows):
+        keep = np.ones(cols, bool)
+        if 0 <= r - c0 < cols:
+            keep[r - c0] = False
+        cand = np.flatnonzero(keep)
+        order = cand[np.lexsort((key[cand], -h[r, cand]))][:kk]
+        assert list(idx[r, :len(order)]) == [int(key[c]) for c in order], r
+        assert (idx[r, len(order):] == -1).all()
+        np.testing.assert_array_equal(val[r, :len(order)], h[r, order])
+
+
 @pytest.mark.parametrize("form", ["plain", "symmetric", "blocked"])
 def test_count_any_short_circuits_the_comparison(ops, form):
     """epilogue.count_any: the kernel may stop comparing with the previous iterate once a difference

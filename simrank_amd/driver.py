@@ -1206,12 +1206,15 @@ class Solver:
             else:
                 per_rank[r] = (np.full((n, 1), -1, np.int32), np.zeros((n, 1), np.float32))
         parts = self.world.gather_list(per_rank)
-        idx = np.concatenate([p[0] for p in parts], axis=1)
-        val = np.concatenate([p[1] for p in parts], axis=1).astype(np.float64)
-        key = np.where(idx >= 0, val, -np.inf)
-        order = np.lexsort((idx, -key), axis=1)[:, :k]
-        rows = np.arange(n)[:, None]
-        idx, val = idx[rows, order], np.where(idx[rows, order] >= 0, val[rows, order], 0.0)
+        if len(parts) == 1 and parts[0][0].shape[1] == k:
+            idx, val = parts[0][0], parts[0][1].astype(np.float64)        # one rank: the kernel's order is the answer
+        else:
+            idx = np.concatenate([p[0] for p in parts], axis=1)
+            val = np.concatenate([p[1] for p in parts], axis=1).astype(np.float64)
+            key = np.where(idx >= 0, val, -np.inf)
+            order = np.lexsort((idx, -key), axis=1)[:, :k]
+            rows = np.arange(n)[:, None]
+            idx, val = idx[rows, order], np.where(idx[rows, order] >= 0, val[rows, order], 0.0)
         if self.inv[j] is not None:                # rows back into the caller's order
             idx, val = idx[self.inv[j]], val[self.inv[j]]
         return idx, val

@@ -802,6 +802,7 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
     blk_gmeta.resize(blk_gmeta.size() + size_t(kSub) * 32 * 4 * 2, int32_t(0xFFFFFFFFu));   // (a unit's loads may run past its blocks)
     sids.reserve(size_t(r_nnz) + ulist.size() * 512);
     int32_t n_pslots = 0, n_cslots = 0;
+    std::vector<int32_t> blk_pslot(size_t(nblk), -1), blk_cslot(size_t(nblk), -1);
     for (size_t i = 0; i < ulist.size(); ++i) {
         const Unit& u = ulist[i];
         int32_t* rec = &units[i * 32];
@@ -812,10 +813,16 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
         rec[29] = u.gslot;                          // where the unit's row records live (an unsplit block: its own slot)
         rec[30] = u.split;
         if (u.nb > 1) {
-            // the units of a block are neighbours in the list (same cost, ordered by k): consecutive slots
-            if (u.k == 0) { rec[5] = n_pslots; rec[6] = n_cslots; }
-            else { rec[5] = units[(i - 1) * 32 + 5] + 1; rec[6] = units[(i - 1) * 32 + 6]; }
-            if (u.k == u.nb - 1) { n_pslots += u.nb; ++n_cslots; }
+            // the units of a block own consecutive slots, handed out when its first unit comes by — wherever the launch
+            // order (fuse_order) puts the others
+            if (blk_pslot[size_t(u.b0)] < 0) {
+                blk_pslot[size_t(u.b0)] = n_pslots;
+                blk_cslot[size_t(u.b0)] = n_cslots;
+                n_pslots += u.nb;
+                ++n_cslots;
+            }
+            rec[5] = blk_pslot[size_t(u.b0)] + u.k;
+            rec[6] = blk_cslot[size_t(u.b0)];
         }
         for (int w = 0; w < 4; ++w) {
             int32_t* wm = rec + 9 + w * 5;

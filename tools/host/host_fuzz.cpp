@@ -109,13 +109,23 @@ static void check_fused(const simrank_graph* g, const Csr& c) {
     std::vector<int> seen_block((size_t)nblk, 0), owners((size_t)c.M, 0);
     const uint32_t* ab = reinterpret_cast<const uint32_t*>(pl->abits);
     const int32_t* gm = reinterpret_cast<const int32_t*>(pl->gmeta);
-    std::map<int, int> units_of, quads_of;
+    std::map<int, int> units_of, quads_of, cslot_of, pbase_of;
+    std::set<int> pslots_seen;
     for (int u = 0; u < pl->n_units; ++u) {
         const int32_t* un = pl->units + size_t(u) * 32;
         const int b0 = un[0], q0 = un[1], nq = un[2], k = un[3], nb = un[4], nsub = un[8];
         CHECK(b0 >= 0 && b0 + nsub <= nblk && nsub >= 1 && nsub <= 4 && k >= 0 && k < nb, "bad unit record");
         CHECK((nq > 0) == (un[7] != 0) && (nsub == 1 || nq == 0) && (nsub == 1 || nb == 1), "unit kinds mixed up");
         CHECK((nb > 1) == (un[5] >= 0) && (nb > 1) == (un[6] >= 0), "partial slots");
+        if (nb > 1) {
+            // every unit of a split block has a partial-sum slot of its own inside the plan's range, all of them share
+            // the block's ticket — whatever the launch order put between them
+            CHECK(un[5] < pl->n_pslots && un[6] < pl->n_cslots, "partial slot out of range");
+            CHECK(pslots_seen.insert(un[5]).second, "two units share a partial slot");
+            auto it = cslot_of.find(b0);
+            if (it == cslot_of.end()) { cslot_of[b0] = un[6]; pbase_of[b0] = un[5] - k; }
+            else CHECK(it->second == un[6] && pbase_of[b0] == un[5] - k, "units of a block disagree about their slots");
+        }
         units_of[b0] += 1;
         // dense part: pattern bits -> entries
         for (int qd = q0; qd < q0 + nq; ++qd)
@@ -419,7 +429,7 @@ int main(int argc, char** argv) {
         simrank_set_tuning("fuse_unit", it % 3 == 0 ? 4 : (it % 3 == 1 ? 64 : 1 << 20));
         simrank_set_tuning("fuse_rows", it % 4 == 0 ? 64 : (it % 4 == 1 ? 700 : 8192));
         simrank_set_tuning("fuse_group", 1 + it % 4);
-        simrank_set_tuning("fuse_order", it % 5 == 1 ? 2 : 0);
+        simrank_set_tuning("fuse_order", it % 5 == 1 ? 2 : (it % 5 == 3 ? 1 : 0));
         simrank_set_tuning("fuse", it % 2 ? 2 : 1);
         simrank_set_tuning("fuse_cap", it % 3 == 0 ? 1000 : (it % 3 == 1 ? 3000 : 1 << 30));
         // (every 17th graph has no entries at all: plans of nothing but empty rows)
@@ -452,6 +462,23 @@ int main(int argc, char** argv) {
             CHECK(simrank_graph_create(c.M, c.K, (int64_t)bad.size(), c.rowptr.data(), bad.data(), c.scale.data(), &g)
                       == SIMRANK_ERR_INVALID && !g, "out-of-range column accepted");
         }
+    }
+    // launch orders that put other units between the units of a split block (fuse_order > 0): graphs with many blocks, some
+    // split into matrix-core and gather units, many not
+    for (int order : {1, 2, 3}) {
+        simrank_set_tuning("fuse", 1);
+        simrank_set_tuning("fuse_min", 3);
+        simrank_set_tuning("fuse_steps", 2);
+        simrank_set_tuning("fuse_unit", 4);
+        simrank_set_tuning("fuse_rows", 400);
+        simrank_set_tuning("fuse_group", 3);
+        simrank_set_tuning("fuse_order", order);
+        Csr c = random_graph(rng, 4000 + 700 * order, 5000, 6.0, 300, 0.08, true);
+        simrank_graph* g = nullptr;
+        CHECK(simrank_graph_create(c.M, c.K, (int64_t)c.col.size(), c.rowptr.data(), c.col.data(), c.scale.data(), &g) == SIMRANK_OK && g,
+              "simrank_graph_create: %s", simrank_last_error());
+        check_fused(g, c);
+        simrank_graph_destroy(g);
     }
     printf("host_fuzz: %d graphs passed\n", n_graphs);
     return 0;

@@ -40,7 +40,7 @@ for case in range(cases):
               csr.rowscale / np.maximum(1, np.diff(csr.rowptr)))
     knobs = dict(fuse_min=int(rng.choice([2, 3, 4, 8])), fuse_steps=int(rng.choice([1, 2, 8])),
                  fuse_group=int(rng.choice([1, 2, 4])), fuse_unit=int(rng.choice([4, 8, 48, 1 << 20])),
-                 fuse_rows=int(rng.choice([64, 500, 8192])))
+                 fuse_rows=int(rng.choice([64, 500, 8192])), fuse_order=int(rng.choice([0, 0, 1, 2, 3])))
     g = ops.graph(csr, knobs=knobs)
     # (fp16-held matrices take whole blocks only: the graph a fit on them creates, driver.Side)
     gh = ops.graph(csr, knobs=dict(knobs, fuse_unit=1 << 20))

@@ -187,12 +187,9 @@ int simrank_biplan_create(int64_t n1, int64_t n2, int64_t nnz, const int32_t* ro
     }
     for (int w = 0; w < 2; ++w) {
         side_t& a = p->s[w];
-        for (float** b : {&a.S[0], &a.S[1]}) {
-            BIPLAN_HIP(pool_hip_alloc((void**)b, a.mat_bytes));
-            BIPLAN_HIP(hipMemsetAsync(*b, 0, a.mat_bytes, p->stream));
-        }
+        // (no memset: as in plan.hip — reset fills S[0], every update writes all of Tt and of the other iterate first)
+        for (float** b : {&a.S[0], &a.S[1]}) BIPLAN_HIP(pool_hip_alloc((void**)b, a.mat_bytes));
         BIPLAN_HIP(pool_hip_alloc((void**)&a.Tt, a.t_bytes));
-        BIPLAN_HIP(hipMemsetAsync(a.Tt, 0, a.t_bytes, p->stream));
         BIPLAN_HIP(pool_hip_alloc((void**)&a.inv, size_t(a.n) * sizeof(int32_t)));
         BIPLAN_HIP(hipMemcpyAsync(a.inv, inv[w].data(), size_t(a.n) * sizeof(int32_t), hipMemcpyHostToDevice, p->stream));
         BIPLAN_HIP(hipStreamSynchronize(p->stream));

@@ -149,10 +149,11 @@ int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int
             return fail(e_ == hipErrorOutOfMemory ? SIMRANK_ERR_ALLOC : SIMRANK_ERR_HIP);         \
         }                                                                                         \
     } while (0)
-    for (float** b : {&p->S[0], &p->S[1], &p->Tt}) {
-        PLAN_HIP(pool_hip_alloc((void**)b, p->mat_bytes));
-        PLAN_HIP(hipMemsetAsync(*b, 0, p->mat_bytes, p->stream));
-    }
+    // (no memset: simrank_plan_reset fills S[0] — zeros and the diagonal —, every update writes all of Tt and of the other
+    // iterate before anything reads them, and the padding rows and columns of a panel are read by nobody: lanes that
+    // hold columns past the edge compute on whatever is there and never store.  Three 17 GiB memsets were 10 ms of a
+    // config-5 set-up.)
+    for (float** b : {&p->S[0], &p->S[1], &p->Tt}) PLAN_HIP(pool_hip_alloc((void**)b, p->mat_bytes));
     PLAN_HIP(pool_hip_alloc((void**)&p->counters, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS));
     for (int i = 0; i < 2; ++i) {
         PLAN_HIP(hipHostMalloc((void**)&p->host_counters[i], sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS, hipHostMallocPortable));

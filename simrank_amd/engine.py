@@ -50,7 +50,10 @@ class Matrix:
             self.nbytes = max(1, self.rows) * self.ld * self.dtype.itemsize
         self.external = external
         self.ptr = external.data_ptr() if external is not None else ops._malloc(self.nbytes)
-        if self.blocked:                   # padding rows / columns are read by nobody but stay defined
+        if self.blocked and self.dtype.itemsize == 1:
+            # evidence counts: rows without in-edges are not visited by the counting kernel and must read as zero.  The f32 /
+            # fp16 matrices of an update are written whole before they are read (identity fill, leg 1, leg 2) and the
+            # padding rows / columns of a panel are read by nobody: no memset (three of them were 10 ms of a config-5 fit)
             check(ops.lib.simrank_memset(C.c_void_p(self.ptr), 0, self.nbytes, ops.stream), "simrank_memset")
 
     def free(self):

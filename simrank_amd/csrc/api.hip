@@ -568,7 +568,8 @@ namespace simrank {
 // (the plans of the set-up — dense sets, one-launch plan(s) — are independent of each other and of the uploads:
 // they are built on threads of their own, simrank_graph_create of config 5 0.05 -> 0.03 s)
 int graph_create_with(const Tuning& tun, int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr,
-                      const int32_t* col, const float* rowscale, simrank_graph** out) {
+                      const int32_t* col, const float* rowscale, simrank_graph** out,
+                      const std::function<int(simrank_graph*)>* after_base) {
     SR_REQUIRE(out, "out is NULL");
     *out = nullptr;
     SR_REQUIRE(n_rows > 0 && n_cols > 0 && nnz >= 0, "bad graph shape %lld x %lld, nnz %lld",
@@ -663,6 +664,7 @@ int graph_create_with(const Tuning& tun, int64_t n_rows, int64_t n_cols, int64_t
     if (!rc) rc = up((void**)&g->t_pos, t_pos.data(), size_t(nnz) * 4);
     if (!rc && g->n_tiles) rc = up((void**)&g->tile_row0, tile_row0.data(), tile_row0.size() * 4);
     if (!rc && g->sym_blocks) rc = up((void**)&g->sym_map, sym_map.data(), sym_map.size() * 4);
+    if (!rc && after_base && *after_base) rc = (*after_base)(g);     // (the builders are still at work on their threads)
     for (int i = 0; i < n_jobs; ++i) {
         jobs[i].th.join();
         if (!rc && jobs[i].rc) {

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "simrank_hip.h"
@@ -109,8 +110,11 @@ inline void plan_free(void* p) { (void)hipFree(p); }
 #endif
 
 // simrank_graph_create with the knobs given (the plans set some per graph: fp16-held fits take no split blocks)
+// after_base (optional): called once the CSR / CSC arrays are on the device, while the host plan builders still run on their
+// threads — what a plan queues there (the evidence counts, which read those arrays only) runs beside them
 int graph_create_with(const Tuning& tun, int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr,
-                      const int32_t* col, const float* rowscale, simrank_graph** out);
+                      const int32_t* col, const float* rowscale, simrank_graph** out,
+                      const std::function<int(simrank_graph*)>* after_base = nullptr);
 
 // device block pool (api.hip): what simrank_malloc / simrank_free and the plans allocate through
 int pool_alloc(void** dptr, size_t bytes);

@@ -111,6 +111,13 @@ typedef struct simrank_graph simrank_graph;
  * rowscale[n_rows]: host arrays, copied.  Builds the transposed pattern (CSC) too. */
 SIMRANK_API int simrank_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr,
                          const int32_t* col, const float* rowscale, simrank_graph** out);
+/* The same, with the common-in-neighbour counts of the pattern (simrank_evidence_counts / _blocked below: columns
+ * [col0, col0 + n_cols_ev) into `counts`, zeroed by the caller; rows_pad > 0: panel-blocked, ld ignored) queued on `stream` as
+ * soon as the pattern is on the device: the counting kernel runs beside the host threads that build the graph's plans. */
+SIMRANK_API int simrank_graph_create_counting(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr,
+                                              const int32_t* col, const float* rowscale, int64_t col0, int64_t n_cols_ev,
+                                              uint8_t* counts, int64_t ld, int64_t rows_pad, void* stream,
+                                              simrank_graph** out);
 SIMRANK_API int simrank_graph_destroy(simrank_graph* g);
 SIMRANK_API int simrank_graph_shape(const simrank_graph* g, int64_t* n_rows, int64_t* n_cols, int64_t* nnz);
 /* Operand terms of the matrix-core part for THIS graph (3 = exact f32 products from three bf16 terms, the

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "simrank_event_synchronize": [_vp],
     "simrank_event_elapsed_ms": [_vp, _vp, C.POINTER(C.c_float)],
     "simrank_graph_create": [_i64, _i64, _i64, _vp, _vp, _vp, _pvp],
+    "simrank_graph_create_counting": [_i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, C.POINTER(_vp)],
     "simrank_graph_destroy": [_vp],
     "simrank_graph_shape": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
     "simrank_fill_identity": [_vp, _i64, _i64, _i64, _i64, _vp],

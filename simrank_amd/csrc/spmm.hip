@@ -1863,6 +1863,20 @@ using namespace simrank;
 
 extern "C" {
 
+// simrank_graph_create + simrank_evidence_counts(_blocked) of the same pattern, the counting kernel queued as soon as the CSR /
+// CSC arrays are on the device — it runs beside the host threads that build the graph's plans (SimRank.py:311-320 while
+// :24-52 is still being digested).  rows_pad > 0: panel-blocked counts (ld ignored).
+int simrank_graph_create_counting(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                                  const float* rowscale, int64_t col0, int64_t n_cols_ev, uint8_t* counts, int64_t ld,
+                                  int64_t rows_pad, void* stream, simrank_graph** out) {
+    SR_REQUIRE(counts && n_rows == n_cols, "evidence counts need a square pattern and a counts block");
+    std::function<int(simrank_graph*)> hook = [&](simrank_graph* g) -> int {
+        return rows_pad > 0 ? simrank_evidence_counts_blocked(g, col0, n_cols_ev, counts, rows_pad, stream)
+                            : simrank_evidence_counts(g, col0, n_cols_ev, counts, ld, stream);
+    };
+    return graph_create_with(tuning_snapshot(), n_rows, n_cols, nnz, rowptr, col, rowscale, out, &hook);
+}
+
 int simrank_evidence_live_segments(const uint8_t* counts, int64_t ld, int64_t rows_pad, int64_t n_rows,
                                    int64_t n_cols, int64_t* live, int64_t* total, void* stream) {
     SR_REQUIRE(counts && live && total && n_rows > 0 && n_cols > 0 &&

@@ -531,8 +531,18 @@ class Side:
             knobs["fuse_min"] = 4
             if ops.get_tuning("fuse_group") == 3:      # (and groups of four: 7 % faster than three at config 5 here,
                 knobs["fuse_group"] = 4                #  where three is 5 % faster than four in f32)
-        self.graph = (ops.graph(csr, spec.rowscale, dense_terms=spec.dense_terms, knobs=knobs) if knobs
-                      else ops.graph(csr, spec.rowscale, dense_terms=spec.dense_terms))
+        # SimRank++ on the graph's own pattern (the directed classes): the evidence counts are queued while the graph's
+        # plans are still being built on the host (engine.Graph(counting=)); counted below otherwise
+        self.ev = None
+        counted = False
+        gkw = dict(knobs=knobs) if knobs else {}
+        if (spec.evidence_from is csr and self.M == self.K and self.m_hi > self.m_lo and
+                getattr(ops, "supports_counting_graph", False)):
+            self.ev = (ops.matrix(self.M, self.m_hi - self.m_lo, np.uint8, blocked=True) if blocked
+                       else ops.matrix(self.M, self.m_hi - self.m_lo, np.uint8))
+            gkw["counting"] = (self.ev, self.m_lo)
+            counted = True
+        self.graph = ops.graph(csr, spec.rowscale, dense_terms=spec.dense_terms, **gkw)
         self.symmetric = spec.symmetric
         self.x1 = self.x2 = None
         self.broadcast_error = None
@@ -592,8 +602,11 @@ class Side:
                                                chunk=(s_hi - s_lo) * 1024))
                     lo = hi
                 self.sh_stages.reverse()
-        self.ev = None
-        if spec.evidence_from is not None:
+        if counted:
+            # support density of E decides between the two instantiations of leg 2
+            self.ev_live = ops.evidence_live_fraction(self.ev)
+            self.restrict = self.ev_live < RESTRICT_BELOW
+        elif spec.evidence_from is not None:
             ev = spec.evidence_from
             self.ev = (ops.matrix(self.M, self.Lm, np.uint8, blocked=True) if self.blocked
                        else ops.matrix(self.M, self.Lm, np.uint8))

@@ -70,16 +70,25 @@ class Matrix:
 
 
 class Graph:
-    def __init__(self, ops, csr: CSR, rowscale: np.ndarray | None = None):
+    def __init__(self, ops, csr: CSR, rowscale: np.ndarray | None = None, counting=None):
+        """``counting`` = (counts Matrix, col0): the evidence counts of the pattern (columns col0 ... of it) are queued as
+        soon as the pattern is on the device and run beside the host plan builders (simrank_graph_create_counting)."""
         lib = ops.lib
         rs = np.ascontiguousarray(csr.rowscale if rowscale is None else rowscale,
                                   dtype=np.float32)
         rowptr = np.ascontiguousarray(csr.rowptr, dtype=np.int32)
         col = np.ascontiguousarray(csr.col, dtype=np.int32)
         h = C.c_void_p()
-        check(lib.simrank_graph_create(csr.n_rows, csr.n_cols, col.size, rowptr.ctypes.data,
-                                       col.ctypes.data if col.size else None, rs.ctypes.data,
-                                       C.byref(h)), "simrank_graph_create")
+        if counting is not None:
+            cnt, col0 = counting
+            check(lib.simrank_graph_create_counting(csr.n_rows, csr.n_cols, col.size, rowptr.ctypes.data,
+                                                    col.ctypes.data if col.size else None, rs.ctypes.data, int(col0),
+                                                    cnt.cols, cnt.ptr, cnt.ld, cnt.rows_pad if cnt.blocked else 0,
+                                                    ops.stream, C.byref(h)), "simrank_graph_create_counting")
+        else:
+            check(lib.simrank_graph_create(csr.n_rows, csr.n_cols, col.size, rowptr.ctypes.data,
+                                           col.ctypes.data if col.size else None, rs.ctypes.data,
+                                           C.byref(h)), "simrank_graph_create")
         self.ops, self.handle = ops, h
         self.n_rows, self.n_cols, self.nnz = csr.n_rows, csr.n_cols, int(col.size)
 
@@ -370,6 +379,7 @@ class HipOps:
     supports_half_storage = True      # fp16-held matrices on 64-column panels (half.hip)
     HALF_SCALE = 16384.0              # what the solver's fp16 matrices are scaled by (include/simrank_hip.h, SCALE)
     supports_shard_symmetric = True   # sharded leg 2 in its half form (spmm_shard / shard_unpack)
+    supports_counting_graph = True    # graph(..., counting=): evidence counts queued during graph creation
 
     def __init__(self, device: int | None = None, stream: int | None = None):
         self.lib = _lib.load()
@@ -625,7 +635,7 @@ class HipOps:
     # ---- graph + kernels ----
     _knob_lock = threading.RLock()    # graph creation with per-graph knobs: set, create, restore as one step
 
-    def graph(self, csr: CSR, rowscale=None, dense_terms: int = 3, knobs: dict | None = None) -> Graph:
+    def graph(self, csr: CSR, rowscale=None, dense_terms: int = 3, knobs: dict | None = None, counting=None) -> Graph:
         """``dense_terms``: operand terms of the matrix-core part for this graph (3 exact, 1 = one fp16 term).
         ``knobs``: tuning values for THIS graph only (a graph keeps the knobs it was created with): set, create
         and restore under a lock that every graph creation of this module takes."""
@@ -634,7 +644,7 @@ class HipOps:
             try:
                 if knobs:
                     self.set_tuning(**knobs)
-                g = Graph(self, csr, rowscale)
+                g = Graph(self, csr, rowscale, counting)
             finally:
                 if saved:
                     self.set_tuning(**saved)

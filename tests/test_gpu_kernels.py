@@ -197,6 +197,28 @@ def test_evidence_counts_upper_triangle_and_mirror(ops, M, K, blocked):
     np.testing.assert_array_equal(got[0], want)
 
 
+@pytest.mark.parametrize("n,blocked,col0,L", [(700, True, 0, 700), (700, False, 0, 700), (1030, False, 256, 300), (25000, True, 0, 25000)])
+def test_graph_creation_that_counts_on_the_side(ops, n, blocked, col0, L):
+    """simrank_graph_create_counting: the evidence counts of the graph's own pattern are queued once the pattern is on the
+    device and run beside the host threads that build the graph's plans (the last case is large enough for those
+    threads) — the same bytes as counting afterwards; the graph is the ordinary one."""
+    csr = random_csr(n, n, 7 if n < 5000 else 3, seed=n + L, heavy={0: min(n, 400), n // 2: min(n, 300)})
+    cnt = ops.matrix(n, L, np.uint8, blocked=True) if blocked else ops.matrix(n, L, np.uint8)
+    g = ops.graph(csr, counting=(cnt, col0))
+    ref = ops.matrix(n, L, np.uint8, blocked=True) if blocked else ops.matrix(n, L, np.uint8)
+    g2 = ops.graph(csr)
+    ops.evidence_counts(g2, col0, ref)
+    got, want = ops.download(cnt), ops.download(ref)
+    assert np.array_equal(got, want) and want.any()
+    assert ops.fused_stats(g) == ops.fused_stats(g2)
+    x = ops.matrix(n, 64)
+    ops.upload(x, np.random.default_rng(1).random((n, 64)).astype(np.float32))
+    y, y2 = ops.matrix(n, 64), ops.matrix(n, 64)
+    ops.spmm(g, x, y)
+    ops.spmm(g2, x, y2)
+    assert np.array_equal(ops.download(y), ops.download(y2))
+
+
 def test_densify(ops):
     csr = random_csr(150, 90, 10, seed=3)
     g = ops.graph(csr)

@@ -77,18 +77,36 @@ def _reciprocal(x) -> np.ndarray:
 
 def _csr(rows: np.ndarray, cols: np.ndarray, n_rows: int, n_cols: int,
          row_value: np.ndarray) -> CSR:
-    key = rows.astype(np.int64) * n_cols + cols.astype(np.int64)
+    # one sort of (row, column) keys; the column sits in the low bits (shifts and masks instead of divisions)
+    bits = max(1, int(n_cols - 1).bit_length())
+    key = (rows.astype(np.int64) << bits) | cols.astype(np.int64)
     key.sort()
     if key.size > 1 and (key[1:] == key[:-1]).any():
         # what DataFrame.pivot raises on a repeated (index, column) pair (SimRank.py:50)
         raise ValueError("Index contains duplicate entries, cannot reshape")
-    r = key // n_cols
     rowptr = np.zeros(n_rows + 1, dtype=np.int64)
-    np.cumsum(np.bincount(r, minlength=n_rows), out=rowptr[1:])
+    np.cumsum(np.bincount(key >> bits, minlength=n_rows), out=rowptr[1:])
     if rowptr[-1] >= 2**31:
         raise ValueError("more than 2^31 edges")
-    return CSR(n_rows, n_cols, rowptr.astype(np.int32), (key % n_cols).astype(np.int32),
+    return CSR(n_rows, n_cols, rowptr.astype(np.int32), (key & ((1 << bits) - 1)).astype(np.int32),
                row_value)
+
+
+def _int_codes(nodes, src, dst):
+    """Positions of the edge endpoints in ``nodes`` through a lookup table, when both columns hold integers without
+    gaps worth mentioning; None otherwise (any other labels go through a pandas Index)."""
+    a, b = src.to_numpy(), dst.to_numpy()
+    if not (a.dtype.kind in "iu" and b.dtype.kind in "iu" and len(nodes)):
+        return None
+    arr = np.asarray(nodes)
+    if arr.dtype.kind not in "iu":
+        return None
+    lo, hi = int(arr.min()), int(arr.max())
+    if hi - lo > 16 * len(nodes) + 4096:
+        return None
+    lut = np.full(hi - lo + 1, -1, dtype=np.int64)
+    lut[arr.astype(np.int64) - lo] = np.arange(len(nodes), dtype=np.int64)
+    return lut[a.astype(np.int64) - lo], lut[b.astype(np.int64) - lo]
 
 
 def directed(data: pd.DataFrame, weighted: bool, from_node_column: str, to_node_column: str,
@@ -99,15 +117,28 @@ def directed(data: pd.DataFrame, weighted: bool, from_node_column: str, to_node_
     src = data[from_node_column]
     dst = data[to_node_column]
     nodes = list(set(src.unique()) | set(dst.unique()))
-    index = pd.Index(nodes)
     n = len(nodes)
-    if weighted:
-        per_target = data.groupby(to_node_column)[weight_column].sum()
+    codes = _int_codes(nodes, src, dst)
+    if codes is not None:
+        # integer labels in a compact range (the usual edge list): positions through a lookup table instead of two hash
+        # joins, in-degrees by counting — the same numbers (1/count is exact either way)
+        src_c, dst_c = codes
+        index = None
     else:
-        per_target = data.groupby(to_node_column)[from_node_column].count()
-    rowscale = np.zeros(n)
-    rowscale[index.get_indexer(per_target.index)] = _reciprocal(per_target.to_numpy())
-    return nodes, _csr(index.get_indexer(dst), index.get_indexer(src), n, n, rowscale)
+        index = pd.Index(nodes)
+        src_c, dst_c = index.get_indexer(src), index.get_indexer(dst)
+    if weighted or index is not None:
+        if index is None:
+            index = pd.Index(nodes)
+        if weighted:
+            per_target = data.groupby(to_node_column)[weight_column].sum()
+        else:
+            per_target = data.groupby(to_node_column)[from_node_column].count()
+        rowscale = np.zeros(n)
+        rowscale[index.get_indexer(per_target.index)] = _reciprocal(per_target.to_numpy())
+    else:
+        rowscale = _reciprocal(np.bincount(dst_c, minlength=n)) if n else np.zeros(0)
+    return nodes, _csr(dst_c, src_c, n, n, rowscale)
 
 
 def bipartite(data: pd.DataFrame, weighted: bool, node_group1_column: str,

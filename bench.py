@@ -642,11 +642,19 @@ def main():
             rows5 = [0, 11, csr5.n_rows // 2, csr5.n_rows - 300, csr5.n_rows - 2, csr5.n_rows - 1]
             res5, sample = {}, {}
             for prec, terms, storage in (("f32", 3, "f32"), ("fp16", 1, "f32"), ("fp16_storage", 3, "fp16")):
-                t0 = time.perf_counter()
-                s5 = Solver(lambda r: ops, world, [make_spec(csr5, True, terms, storage)], args.mode)
+                first_s = None
+                for attempt in range(2 if prec == "f32" else 1):
+                    # (the first creation of matrices of this size in the process pays the allocator — hipMalloc maps a
+                    # 17 GiB block in 0.0 .. 0.5 s depending on the box —; the second takes them from the block pool)
+                    t0 = time.perf_counter()
+                    s5 = Solver(lambda r: ops, world, [make_spec(csr5, True, terms, storage)], args.mode)
+                    ops.synchronize()
+                    setup_s = time.perf_counter() - t0
+                    if prec == "f32" and attempt == 0:
+                        first_s = setup_s
+                        s5.release()
+                        del s5
                 s5.exact_count = True
-                ops.synchronize()
-                setup_s = time.perf_counter() - t0
                 s5.reset()
                 for _ in range(2):
                     s5.step(0.0)
@@ -663,6 +671,8 @@ def main():
                 res5[prec] = {"value": 1.0 / dt, "unit": "iterations/s", "ms_per_step": dt * 1e3,
                               "leg1_ms": lt["leg1.0"][0], "leg2_ms": lt["leg2.0"][0],
                               "setup_s_graph_and_evidence": setup_s}
+                if first_s is not None:
+                    res5[prec]["setup_s_first_call_in_process"] = first_s
                 s5.release()
                 del s5
 

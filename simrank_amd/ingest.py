@@ -106,7 +106,8 @@ def _int_codes(nodes, src, dst):
         return None
     lut = np.full(hi - lo + 1, -1, dtype=np.int64)
     lut[arr.astype(np.int64) - lo] = np.arange(len(nodes), dtype=np.int64)
-    return lut[a.astype(np.int64) - lo], lut[b.astype(np.int64) - lo]
+    ca = lut[a.astype(np.int64) - lo]
+    return ca, (ca if dst is src else lut[b.astype(np.int64) - lo])
 
 
 def directed(data: pd.DataFrame, weighted: bool, from_node_column: str, to_node_column: str,
@@ -149,23 +150,38 @@ def bipartite(data: pd.DataFrame, weighted: bool, node_group1_column: str,
     label order, while the labels it later attaches are in Python-set order (quirk Q1)."""
     g1 = data[node_group1_column]
     g2 = data[node_group2_column]
-    set1 = list(set(g1.unique()))
-    set2 = list(set(g2.unique()))
-    sorted1 = pd.Index(np.sort(g1.unique()), name=node_group1_column)
-    sorted2 = pd.Index(np.sort(g2.unique()), name=node_group2_column)
-    if weighted:
-        d1 = data.groupby(node_group1_column)[weight_column].sum()
-        d2 = data.groupby(node_group2_column)[weight_column].sum()
-    else:
-        d1 = data.groupby(node_group1_column)[node_group2_column].count()
-        d2 = data.groupby(node_group2_column)[node_group1_column].count()
+    u1, u2 = g1.unique(), g2.unique()
+    set1 = list(set(u1))
+    set2 = list(set(u2))
+    sorted1 = pd.Index(np.sort(u1), name=node_group1_column)
+    sorted2 = pd.Index(np.sort(u2), name=node_group2_column)
     n1, n2 = len(sorted1), len(sorted2)
-    rs1 = np.zeros(n1)
-    rs1[sorted1.get_indexer(d1.index)] = _reciprocal(d1.to_numpy())
-    rs2 = np.zeros(n2)
-    rs2[sorted2.get_indexer(d2.index)] = _reciprocal(d2.to_numpy())
-    i1 = sorted1.get_indexer(g1)
-    i2 = sorted2.get_indexer(g2)
+    c1 = _int_codes(sorted1.to_numpy(), g1, g1)
+    c2 = _int_codes(sorted2.to_numpy(), g2, g2)
+    w = data[weight_column].to_numpy() if weighted else None
+    if c1 is not None and c2 is not None and (w is None or w.dtype.kind in "iu"):
+        # integer labels in compact ranges and counts / integer weights: lookup tables and exact integer sums instead of
+        # hash joins and group-bys (the same numbers: every sum is exact)
+        i1, i2 = c1[0], c2[0]
+        if w is None:
+            rs1 = _reciprocal(np.bincount(i1, minlength=n1))
+            rs2 = _reciprocal(np.bincount(i2, minlength=n2))
+        else:
+            rs1 = _reciprocal(np.bincount(i1, weights=w, minlength=n1))
+            rs2 = _reciprocal(np.bincount(i2, weights=w, minlength=n2))
+    else:
+        if weighted:
+            d1 = data.groupby(node_group1_column)[weight_column].sum()
+            d2 = data.groupby(node_group2_column)[weight_column].sum()
+        else:
+            d1 = data.groupby(node_group1_column)[node_group2_column].count()
+            d2 = data.groupby(node_group2_column)[node_group1_column].count()
+        rs1 = np.zeros(n1)
+        rs1[sorted1.get_indexer(d1.index)] = _reciprocal(d1.to_numpy())
+        rs2 = np.zeros(n2)
+        rs2[sorted2.get_indexer(d2.index)] = _reciprocal(d2.to_numpy())
+        i1 = sorted1.get_indexer(g1)
+        i2 = sorted2.get_indexer(g2)
     return (set1, set2, sorted1, sorted2,
             _csr(i1, i2, n1, n2, rs1), _csr(i2, i1, n2, n1, rs2))
 

@@ -2,6 +2,7 @@
 // tuning knobs.  Kernels live in spmm.hip (sparse legs, evidence, identity) and dense.hip
 // (densify + f32 MFMA GEMM).
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -633,14 +634,19 @@ int graph_create_with(const Tuning& tun, int64_t n_rows, int64_t n_cols, int64_t
 #ifndef SIMRANK_HOST_ONLY
     (void)hipGetDevice(&dev);
 #endif
-    struct Job { int rc = SIMRANK_OK; std::string err; std::thread th; };
+    struct Job { int rc = SIMRANK_OK; std::string err; std::thread th; double ms = 0; };
     Job jobs[3];
+    const bool timed = std::getenv("SIMRANK_TIME_BUILD") != nullptr;     // diagnostic: builder durations on stderr
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
     auto spawn = [&](Job& j, int (*fn)(simrank_graph*, const int32_t*, const int32_t*, const float*)) {
-        j.th = std::thread([&j, fn, g, rowptr, col, rowscale, dev]() {
+        j.th = std::thread([&j, fn, g, rowptr, col, rowscale, dev, &since]() {
 #ifndef SIMRANK_HOST_ONLY
             (void)hipSetDevice(dev);
 #endif
+            const double t0 = since();
             j.rc = fn(g, rowptr, col, rowscale);
+            j.ms = since() - t0;
             if (j.rc) j.err = simrank_last_error();
         });
     };
@@ -665,8 +671,10 @@ int graph_create_with(const Tuning& tun, int64_t n_rows, int64_t n_cols, int64_t
     if (!rc && g->n_tiles) rc = up((void**)&g->tile_row0, tile_row0.data(), tile_row0.size() * 4);
     if (!rc && g->sym_blocks) rc = up((void**)&g->sym_map, sym_map.data(), sym_map.size() * 4);
     if (!rc && after_base && *after_base) rc = (*after_base)(g);     // (the builders are still at work on their threads)
+    const double t_base = since();
     for (int i = 0; i < n_jobs; ++i) {
         jobs[i].th.join();
+        if (timed) std::fprintf(stderr, "simrank_graph_create: builder %d took %.1f ms\n", i, jobs[i].ms);
         if (!rc && jobs[i].rc) {
             rc = jobs[i].rc;
             set_error("%s", jobs[i].err.c_str());
@@ -677,6 +685,9 @@ int graph_create_with(const Tuning& tun, int64_t n_rows, int64_t n_cols, int64_t
         if (!rc && g->tun.fuse == 2 && g->nnz > 0) rc = build_fused2_plan(g, rowptr, col, rowscale);
         if (!rc && g->tun.fuse) rc = build_fused_plan(g, rowptr, col, rowscale);    // (also without entries: fp16-held updates have no other path)
     }
+    if (timed)
+        std::fprintf(stderr, "simrank_graph_create: n %lld nnz %lld: transposed pattern + tiles + base uploads %.1f ms, all %.1f ms\n",
+                     (long long)n_rows, (long long)nnz, t_base, since());
     if (rc) {
         simrank_graph_destroy(g);
         return rc;

@@ -14,6 +14,8 @@
 // Python's driver.Solver does the same choreography for every world size; this is the single-rank case
 // for callers that bind the library directly (examples/reference_hip_stub.py).
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -112,9 +114,17 @@ int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int
                         const simrank_plan_options* opt, void* stream, simrank_plan** out) {
     SR_REQUIRE(out, "out is NULL");
     *out = nullptr;
+    const bool timed = std::getenv("SIMRANK_TIME_BUILD") != nullptr;     // diagnostic: phase durations on stderr
+    const auto t_start = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (timed)
+            std::fprintf(stderr, "simrank_plan_create: %6.1f ms  %s\n",
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), what);
+    };
     PlanPrep pp;
     int rc = plan_prepare(n, nnz, rowptr, col, rowscale, opt, &pp);     // validation, node order, renamed pattern (planprep.hip)
     if (rc) return rc;
+    lap("validated, ordered, renamed");
     const std::vector<int32_t>& ord = pp.ord;
     const std::vector<int32_t>& inv = pp.inv;
     simrank_plan* p = new simrank_plan;
@@ -151,6 +161,7 @@ int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int
         rc = graph_create_with(t, n, n, nnz, pp.rp.data(), pp.cl.data(), pp.rs.data(), &p->g, &counts);
     }
     if (rc) return fail(rc);
+    lap("graph object (evidence counts queued)");
     if (p->half && !p->g->fused) {
         set_error("storage_fp16 needs the one-launch plan (tuning fuse = 1) and a graph that has one");
         return fail(SIMRANK_ERR_INVALID);
@@ -180,6 +191,7 @@ int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int
     PLAN_HIP(pool_hip_alloc((void**)&p->ord_dev, size_t(n) * sizeof(int32_t)));
     PLAN_HIP(hipMemcpyAsync(p->ord_dev, p->ord.data(), size_t(n) * sizeof(int32_t), hipMemcpyHostToDevice, p->stream));
     PLAN_HIP(hipStreamSynchronize(p->stream));          // (inv is a host vector about to go away)
+    lap("matrices allocated, orders uploaded, stream drained");
     if (opt->evidence) {
         int64_t live = 0, total = 1;
         rc = simrank_evidence_live_segments(p->ev, 32, p->rows_pad, n, n, &live, &total, p->stream);
@@ -211,8 +223,10 @@ int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int
         if (rc) return fail(rc);
     }
 #undef PLAN_HIP
+    lap("live segments, prior");
     rc = simrank_plan_reset(p);
     if (rc) return fail(rc);
+    lap("reset queued");
     *out = p;
     return SIMRANK_OK;
 }

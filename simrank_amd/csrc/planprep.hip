@@ -6,8 +6,10 @@
 // Replaces nothing of the reference by itself: it is what `_create_graph` (SimRank.py:24-52, :168-200) does to
 // an edge list, restated for callers that hand over CSR arrays.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <numeric>
+#include <thread>
 
 #include "common.h"
 
@@ -47,14 +49,45 @@ static int renamed(int64_t n_rows, const int32_t* rowptr, const int32_t* col, co
     rs.assign((size_t)n_rows, 0.f);
     for (int64_t r = 0; r < n_rows; ++r) {
         const int32_t a = ord[(size_t)r];
-        const int32_t s = rowptr[a], e = rowptr[a + 1];
-        int32_t* dst = cl.data() + rp[(size_t)r];
-        for (int32_t j = s; j < e; ++j) dst[j - s] = inv_cols[(size_t)col[j]];
-        std::sort(dst, dst + (e - s));
-        for (int32_t j = 1; j < e - s; ++j) SR_REQUIRE(dst[j] != dst[j - 1], "duplicate entry in row %d%s", a, what);
-        rp[(size_t)r + 1] = rp[(size_t)r] + (e - s);
+        rp[(size_t)r + 1] = rp[(size_t)r] + (rowptr[a + 1] - rowptr[a]);
         rs[(size_t)r] = scale[a];
     }
+    // the rows are independent once their places are known: renamed and sorted on a few threads (config 5: 1.6 M
+    // entries, 25 of the 35 ms this file took; the first duplicate of the lowest row is the one reported)
+    std::atomic<int64_t> dup_row{-1};
+    auto work = [&](int64_t r0, int64_t r1) {
+        for (int64_t r = r0; r < r1; ++r) {
+            const int32_t a = ord[(size_t)r];
+            const int32_t s = rowptr[a], e = rowptr[a + 1];
+            int32_t* dst = cl.data() + rp[(size_t)r];
+            for (int32_t j = s; j < e; ++j) dst[j - s] = inv_cols[(size_t)col[j]];
+            std::sort(dst, dst + (e - s));
+            for (int32_t j = 1; j < e - s; ++j)
+                if (dst[j] == dst[j - 1]) {
+                    int64_t seen = dup_row.load();
+                    while ((seen < 0 || r < seen) && !dup_row.compare_exchange_weak(seen, r)) {}
+                    break;
+                }
+        }
+    };
+    const int n_thr = nnz >= 100000 ? 8 : 1;
+    if (n_thr == 1) {
+        work(0, n_rows);
+    } else {
+        // equal shares of the ENTRIES (the order is ascending in row length: equal shares of the rows would not balance)
+        std::vector<std::thread> th;
+        int64_t r0 = 0;
+        for (int t = 0; t < n_thr; ++t) {
+            const int64_t target = nnz * (t + 1) / n_thr;
+            int64_t r1 = t + 1 == n_thr ? n_rows
+                                        : int64_t(std::upper_bound(rp.begin() + r0, rp.end(), (int32_t)target) - rp.begin()) - 1;
+            r1 = std::max(r0, std::min(n_rows, r1));
+            th.emplace_back(work, r0, r1);
+            r0 = r1;
+        }
+        for (std::thread& x : th) x.join();
+    }
+    SR_REQUIRE(dup_row.load() < 0, "duplicate entry in row %d%s", ord[(size_t)dup_row.load()], what);
     return SIMRANK_OK;
 }
 

@@ -479,6 +479,14 @@ int main(int argc, char** argv) {
               "simrank_graph_create: %s", simrank_last_error());
         check_fused(g, c);
         simrank_graph_destroy(g);
+        if (order == 1) {
+            // a square graph large enough for the threaded half of plan_prepare (renamed rows on eight threads): the same
+            // checks as the small ones, and a duplicate in a late row is found and named
+            Csr sq = random_graph(rng, 5000, 5000, 20.0, 300, 0.08, true);
+            Csr rect = random_graph(rng, 50, 40, 3.0, 5, 0.1, false);
+            CHECK((int64_t)sq.col.size() >= 100000, "the large plan graph has only %lld entries", (long long)sq.col.size());
+            fuzz_plan_inputs(rng, sq, rect);
+        }
     }
     printf("host_fuzz: %d graphs passed\n", n_graphs);
     return 0;

@@ -61,9 +61,10 @@ def relabel(csr: CSR, row_order: np.ndarray | None, col_order: np.ndarray | None
         new_id = np.empty(csr.n_cols, dtype=np.int64)
         new_id[np.asarray(col_order, dtype=np.int64)] = np.arange(csr.n_cols)
         col = new_id[col]
-        key = np.repeat(np.arange(M, dtype=np.int64), lens) * csr.n_cols + col
+        bits = max(1, int(csr.n_cols - 1).bit_length())          # (row, column) keys, the column in the low bits
+        key = (np.repeat(np.arange(M, dtype=np.int64), lens) << bits) | col
         key.sort()
-        col = key % csr.n_cols
+        col = key & ((1 << bits) - 1)
     return CSR(M, csr.n_cols, rowptr.astype(np.int32), col.astype(np.int32), csr.rowscale[rows])
 
 

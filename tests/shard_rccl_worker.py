@@ -77,6 +77,30 @@ def main():
         assert np.abs(got - want).max() < 1e-4 * 0.8 / 0.2 + 6e-4
     sp.free()
     ops.lib.simrank_comm_destroy(comm)
+    if world == 1:
+        # simrank_comm_adopt: a communicator the host program made itself (here through ctypes on the same RCCL build)
+        import ctypes as C
+        rccl = C.CDLL(os.environ.get("SIMRANK_RCCL_LIB", "librccl.so.1"))
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        uid2 = UniqueId()
+        rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+        rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        assert rccl.ncclGetUniqueId(C.byref(uid2)) == 0
+        theirs = C.c_void_p()
+        assert rccl.ncclCommInitRank(C.byref(theirs), 1, uid2, 0) == 0
+        adopted = C.c_void_p()
+        from simrank_amd._lib import check
+        check(ops.lib.simrank_comm_adopt(theirs, 0, 1, C.byref(adopted)), "simrank_comm_adopt")
+        sp = ShardPlans(ops, csr, rowscale=scale, world=1, comm=adopted, evidence=True, stages=2)
+        done, conv = sp.run(30, 1e-4)
+        assert (done, conv) == (want_done, want_conv)
+        np.testing.assert_allclose(sp.result(), want, rtol=1e-5, atol=1e-30)
+        sp.free()
+        ops.lib.simrank_comm_destroy(adopted)            # (does not destroy what it adopted)
+        assert rccl.ncclCommDestroy(theirs) == 0
     print("SHARDPLAN RCCL ok", flush=True)
 
 

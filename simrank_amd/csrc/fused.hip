@@ -39,6 +39,8 @@
 #include <numeric>
 #include <vector>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "fused_dev.h"
 
@@ -581,7 +583,11 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
     const int64_t thr = std::max<int64_t>(2, g->tun.fuse_min);
     const int64_t min_steps = fuse_min_steps(g->tun, g->n_cols);
     const int64_t nblk = (M + kFB - 1) / kFB;
-    const bool ids16 = K < 65535;
+    // 16-bit ids while 0xFFFF, the marker of an empty slot of a gather stream, is no column's id.  (Exactly 65536 operand rows
+    // — BASELINE config 5 — would need that one column kept out of the streams: forcing it into the dense set of every
+    // block that references it was tried and made config 5 slower, the column being a hub that nearly every block
+    // references; what 16-bit ids are worth was measured at config 4: 1.3-2.7 % of leg 1.)
+    const bool ids16 = K <= 65535;
     std::vector<int32_t> blk_quad0(size_t(nblk) + 1, 0);
     std::vector<int32_t> dcols;                       // padded to 64 per block
     std::vector<uint32_t> abits;                      // [quad][lane][4 steps]

@@ -150,6 +150,35 @@ def test_fused_ids_beyond_16_bits(ops):
     np.testing.assert_allclose(leg1(ops, g, X, M), (dense64(csr) @ X.astype(np.float64)).T, rtol=RTOL, atol=1e-30)
 
 
+@pytest.mark.parametrize("K", [65535, 65536, 65537])
+def test_fused_ids_at_the_16_bit_edge(ops, K):
+    """65535 operand rows stream 16-bit ids (0xFFFF marks an empty slot and is no column's id), 65536 and 65537 take 32-bit
+    ids (the last column's id would be the marker); the last columns are referenced by rows of several blocks, with and
+    without other shared columns."""
+    M, L = 420, 64
+    rng = np.random.default_rng(K)
+    hubs = rng.choice(K - 8, size=60, replace=False)
+    rows = []
+    for a in range(M):
+        c = set(rng.choice(K - 8, size=5, replace=False).tolist())
+        if a < 300:
+            c |= set(hubs[rng.random(60) < 0.3].tolist())
+        if a % 7 == 3:
+            c |= {K - 1}
+        if a % 11 == 2:
+            c |= {K - 2, K - 1}
+        rows.append(np.array(sorted(c), dtype=np.int32))
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    csr = CSR(M, K, rowptr, np.concatenate(rows), rng.random(M) + 0.1)
+    X = rng.random((K, L)).astype(np.float32)
+    X[K - 1] = 7.0 + rng.random(L).astype(np.float32)          # (a marker misread as this row would show)
+    want = (dense64(csr) @ X.astype(np.float64)).T
+    for fuse_min in (2, 100):                                   # with shared columns on the matrix cores, and without any
+        with knobs(ops, fuse_min=fuse_min):
+            g = ops.graph(csr)
+            np.testing.assert_allclose(leg1(ops, g, X, M), want, rtol=RTOL, atol=1e-30)
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_fused_randomized(ops, seed):
     rng = np.random.default_rng(3000 + seed)

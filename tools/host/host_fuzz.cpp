@@ -488,6 +488,29 @@ int main(int argc, char** argv) {
             fuzz_plan_inputs(rng, sq, rect);
         }
     }
+    {
+        // exactly 65536 operand rows, the last column referenced: the id 0xFFFF must not be mistaken for the empty-slot marker
+        // of 16-bit streams (such a graph takes 32-bit ids)
+        simrank_set_tuning("fuse", 1);
+        simrank_set_tuning("fuse_min", 3);
+        simrank_set_tuning("fuse_steps", 8);
+        simrank_set_tuning("fuse_unit", 48);
+        simrank_set_tuning("fuse_rows", 8192);
+        simrank_set_tuning("fuse_order", 0);
+        Csr c = random_graph(rng, 700, 65536, 5.0, 40, 0.2, true);
+        // (rows are ascending: the last column can simply be appended)
+        Csr d{c.M, c.K, {0}, {}, c.scale};
+        for (int64_t a = 0; a < c.M; ++a) {
+            d.col.insert(d.col.end(), c.col.begin() + c.rowptr[a], c.col.begin() + c.rowptr[a + 1]);
+            if (a % 37 == 5 && (d.col.size() == (size_t)d.rowptr.back() || d.col.back() != 65535)) d.col.push_back(65535);
+            d.rowptr.push_back((int32_t)d.col.size());
+        }
+        simrank_graph* g = nullptr;
+        CHECK(simrank_graph_create(d.M, d.K, (int64_t)d.col.size(), d.rowptr.data(), d.col.data(), d.scale.data(), &g) == SIMRANK_OK && g,
+              "simrank_graph_create: %s", simrank_last_error());
+        check_fused(g, d);
+        simrank_graph_destroy(g);
+    }
     printf("host_fuzz: %d graphs passed\n", n_graphs);
     return 0;
 }

@@ -478,6 +478,33 @@ int main(int argc, char** argv) {
         CHECK(simrank_graph_create(c.M, c.K, (int64_t)c.col.size(), c.rowptr.data(), c.col.data(), c.scale.data(), &g) == SIMRANK_OK && g,
               "simrank_graph_create: %s", simrank_last_error());
         check_fused(g, c);
+        {
+            // the same plan from ONE builder thread and from several: the arrays must be the same, entry for entry
+            simrank_graph* g1 = nullptr;
+            setenv("SIMRANK_BUILD_THREADS", order == 2 ? "5" : "1", 1);
+            CHECK(simrank_graph_create(c.M, c.K, (int64_t)c.col.size(), c.rowptr.data(), c.col.data(), c.scale.data(), &g1) == SIMRANK_OK && g1,
+                  "simrank_graph_create: %s", simrank_last_error());
+            unsetenv("SIMRANK_BUILD_THREADS");
+            const simrank_fused_plan* a = g->fused;
+            const simrank_fused_plan* b = g1->fused;
+            CHECK(a && b && a->n_units == b->n_units && a->n_quads == b->n_quads && a->n_steps == b->n_steps &&
+                      a->nnz_covered == b->nnz_covered && a->r_nnz == b->r_nnz && a->n_pslots == b->n_pslots &&
+                      a->n_cslots == b->n_cslots && a->ids16 == b->ids16, "threaded builder: other totals");
+            CHECK(!memcmp(a->units, b->units, size_t(a->n_units) * 32 * 4), "threaded builder: other unit records");
+            CHECK(!memcmp(a->abits, b->abits, size_t(a->n_quads) * 64 * 16), "threaded builder: other pattern bits");
+            CHECK(a->ids16 ? !memcmp(a->dcols16, b->dcols16, size_t(a->n_quads) * 64 * 2)
+                           : !memcmp(a->dcols32, b->dcols32, size_t(a->n_quads) * 64 * 4), "threaded builder: other set columns");
+            // the streams: as many rounds as the last unit record says
+            int64_t rounds = 0;
+            for (int u = 0; u < a->n_units; ++u)
+                for (int w = 0; w < 4; ++w) {
+                    const int32_t* wm = a->units + size_t(u) * 32 + 9 + w * 5;
+                    rounds = std::max<int64_t>(rounds, int64_t(wm[0]) + std::max({wm[1], wm[2], wm[3], wm[4]}));
+                }
+            CHECK(a->ids16 ? !memcmp(a->sids16, b->sids16, size_t(rounds) * 64 * 2)
+                           : !memcmp(a->sids32, b->sids32, size_t(rounds) * 64 * 4), "threaded builder: other id streams");
+            simrank_graph_destroy(g1);
+        }
         simrank_graph_destroy(g);
         if (order == 1) {
             // a square graph large enough for the threaded half of plan_prepare (renamed rows on eight threads): the same

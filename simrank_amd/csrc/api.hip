@@ -655,7 +655,9 @@ int graph_create_with(const Tuning& tun, int64_t n_rows, int64_t n_cols, int64_t
     int n_jobs = 0;
     if (big) {
         if (g->tun.dense_min > 0 && nnz > 0) spawn(jobs[n_jobs++], dense_job);
+#ifdef SIMRANK_EXPERIMENT_FUSED2
         if (g->tun.fuse == 2 && nnz > 0) spawn(jobs[n_jobs++], build_fused2_plan);
+#endif
         if (g->tun.fuse) spawn(jobs[n_jobs++], build_fused_plan);
     }
     int rc = up((void**)&g->rowptr, rowptr, size_t(n_rows + 1) * 4);
@@ -682,7 +684,9 @@ int graph_create_with(const Tuning& tun, int64_t n_rows, int64_t n_cols, int64_t
     }
     if (!big) {
         if (!rc && g->tun.dense_min > 0 && nnz > 0) rc = build_dense_plan(g, rowptr, col);
+#ifdef SIMRANK_EXPERIMENT_FUSED2
         if (!rc && g->tun.fuse == 2 && g->nnz > 0) rc = build_fused2_plan(g, rowptr, col, rowscale);
+#endif
         if (!rc && g->tun.fuse) rc = build_fused_plan(g, rowptr, col, rowscale);    // (also without entries: fp16-held updates have no other path)
     }
     if (timed)
@@ -712,7 +716,9 @@ int simrank_graph_destroy(simrank_graph* g) {
     plan_free(g->sym_map);
     free_dense_plan(g->dense);
     free_fused_plan(g->fused);
+#ifdef SIMRANK_EXPERIMENT_FUSED2
     free_fused2_plan(g->fused2);
+#endif
     delete g;
     return SIMRANK_OK;
 }
@@ -785,7 +791,11 @@ int simrank_set_tuning(const char* key, int64_t value) {
     } else if (!strcmp(key, "dense_sym")) {
         t.dense_sym = value < 0 ? -1 : (value ? 1 : 0);
     } else if (!strcmp(key, "fuse")) {
+#ifdef SIMRANK_EXPERIMENT_FUSED2
         SR_REQUIRE(value >= 0 && value <= 2, "fuse must be 0 (two launches), 1 (one launch) or 2 (one persistent launch)");
+#else
+        SR_REQUIRE(value == 0 || value == 1, "fuse must be 0 (two launches) or 1 (one launch)");
+#endif
         t.fuse = value;
     } else if (!strcmp(key, "fuse_min")) {
         SR_REQUIRE(value >= 2 && value <= 128, "fuse_min must be 2 .. 128");

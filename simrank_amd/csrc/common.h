@@ -78,9 +78,8 @@ struct Tuning {
                              // phase spread over the first 1/k of the order
     int64_t fuse_max_rows = 1 << 20;  // ... operands with more rows than this keep the two-launch leg (N = 65536: 20.4
                              // against 21.8 ms, so practically never)
-    int64_t fuse_cap = 40000;  // fuse = 2: a block whose estimated duration (cycles of one workgroup) exceeds this is cut into
-                             // pieces whose raw sums meet in memory
-    int64_t fuse_wgs = 4;    // fuse = 2: resident workgroups per CU
+    int64_t fuse_cap = 40000;  // (experiment build only, tools/experiments/fused2.hip) piece size of the persistent leg
+    int64_t fuse_wgs = 4;    // (experiment build only) its resident workgroups per CU
     int64_t fuse_shards = 1; // ... also for the row-major column block of a sharded rank (result in the all-to-all's chunks)
     int64_t fuse_group = 3;  // ... and up to this many consecutive blocks without a set share a workgroup (1..4)
     int64_t dense_sym = -1;  // dense part in the upper-triangle form of leg 2: 1 yes, 0 no, -1 = when the
@@ -234,8 +233,10 @@ struct simrank_fused_plan {
     int32_t* sids32 = nullptr;      //              32-bit ids (-1: no neighbour)
 };
 
-// fused2.hip: leg 1 as one PERSISTENT launch: the same dense sets and id streams, per PIECE of a block (a share of
-// the set's columns + a share of the rows), pulled from per-XCD queues by resident workgroups.
+#ifdef SIMRANK_EXPERIMENT_FUSED2
+// tools/experiments/fused2.hip (NOT in the product library; tools/build_variant.sh ... -DSIMRANK_EXPERIMENT_FUSED2): leg 1 as
+// one PERSISTENT launch: the same dense sets and id streams, per PIECE of a block (a share of the set's columns + a share of
+// the rows), pulled from per-XCD queues by resident workgroups.  Round 4: correct, slower than fused.hip (HISTORY.md).
 struct simrank_fused2_plan {
     int32_t n_items = 0;            // pieces per panel, launch order
     int32_t n_blocks = 0;
@@ -254,6 +255,7 @@ struct simrank_fused2_plan {
     uint16_t* sids16 = nullptr;
     int32_t* sids32 = nullptr;
 };
+#endif
 
 namespace simrank {
 constexpr int kFB = 128;          // rows per block of the one-launch plan
@@ -266,10 +268,12 @@ bool fused_rowmajor_fits(const simrank_graph* g, const float* X, int64_t ldx, in
                          int64_t t_pad);
 int launch_fused_trans_rowmajor(const simrank_graph* g, const float* X, int64_t ldx, int64_t L, float* Y, int64_t t_block,
                                 int64_t t_pad, hipStream_t st);
+#ifdef SIMRANK_EXPERIMENT_FUSED2
 void free_fused2_plan(simrank_fused2_plan* p);
 int build_fused2_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col, const float* rowscale);
 int launch_fused2_trans(const simrank_graph* g, const float* X, int64_t x_rows_pad, int64_t L, float* Y,
                         int64_t y_rows_pad, hipStream_t st);
+#endif
 struct DenseUse {                   // what the gather kernel needs from a dense launch
     const float* part = nullptr;
     int64_t ldp = 0;
@@ -309,7 +313,9 @@ struct simrank_graph {
     int32_t sym_blocks = 0;
     simrank_dense_plan* dense = nullptr;   // NULL: no block of the pattern is dense enough
     simrank_fused_plan* fused = nullptr;   // leg 1 as one launch (fused.hip); NULL: tuning "fuse" = 0
-    simrank_fused2_plan* fused2 = nullptr; // leg 1 as one persistent launch (fused2.hip); tuning "fuse" = 2
+#ifdef SIMRANK_EXPERIMENT_FUSED2
+    simrank_fused2_plan* fused2 = nullptr; // leg 1 as one persistent launch (experiment build); tuning "fuse" = 2
+#endif
     simrank::Tuning tun;                   // knobs in force when the graph was created (every launch on
                                            // this graph uses these, whatever is set afterwards)
 };

@@ -1992,8 +1992,10 @@ static int spmm_impl(const simrank_graph* g, const float* X, int64_t ldx, int64_
     // (measured against the two-launch leg: -13 % at K = 32768 power-law, -10 % Erdos-Renyi, -6 % at K = 65536)
     if (blocked && transpose_out && g->fused && T.fuse && vec_ok && T.dense_terms == 3 && g->n_cols <= T.fuse_max_rows &&
         (x_rows_pad + 1) * 128 < (int64_t(1) << 31)) {
+#ifdef SIMRANK_EXPERIMENT_FUSED2
         if (T.fuse == 2 && g->fused2 && (g->fused2->n_pslots == 0 || (n_cols_x + 31) / 32 <= g->fused2->cap_panels))
             return launch_fused2_trans(g, X, x_rows_pad, n_cols_x, Y, y_rows_pad, st);
+#endif
         return launch_fused_trans(g, X, x_rows_pad, n_cols_x, Y, y_rows_pad, st);
     }
     // ... and of a rank of a sharded update: the same launch on its row-major column block, the result in the

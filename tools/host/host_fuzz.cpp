@@ -1,5 +1,5 @@
 // Sanitizer run of the HOST side of libsimrank_hip (make -C simrank_amd/csrc asan): the library's
-// api.hip / blockdense.hip / fused.hip / fused2.hip / planprep.hip compiled for the host only with -DSIMRANK_HOST_ONLY
+// api.hip / blockdense.hip / fused.hip / planprep.hip compiled for the host only with -DSIMRANK_HOST_ONLY
 // -fsanitize=address,undefined, so that simrank_graph_create — argument validation, transposed pattern,
 // balanced tiles and launch lists, dense sets (blockdense.hip), the one-launch plan (fused.hip) — runs on
 // random graphs without a GPU, and the plans it builds are checked entry by entry against the CSR:
@@ -7,7 +7,7 @@
 //   * dense plan: covered + remainder = nnz, remainder rows ascending and a subset of the row;
 //   * fused plan: every entry of every block is EITHER a pattern bit of the block's dense set OR an id in
 //     exactly one lane group's stream (in ascending order inside its row), row ends and scales as recorded;
-//   * persistent plan (fused2.hip): the same per PIECE of a block, every row owned once, slots consecutive;
+//   * (experiment build, -DSIMRANK_EXPERIMENT_FUSED2) the persistent plan of tools/experiments/fused2.hip likewise;
 //   * plan inputs (planprep.hip): the node order is a permutation, the renamed patterns are the pattern, the
 //     transpose is the transpose; malformed CSR arrays and priors are refused.
 // Exit code 0 = all graphs passed.  No kernel is launched.
@@ -200,6 +200,7 @@ static void check_fused(const simrank_graph* g, const Csr& c) {
     }
 }
 
+#ifdef SIMRANK_EXPERIMENT_FUSED2
 // the persistent one-launch plan (fused2.hip): every entry of every block is EITHER a pattern bit of exactly one
 // piece's share of the block's dense set OR an id in exactly one lane group's stream of exactly one piece
 static void check_fused2(const simrank_graph* g, const Csr& c) {
@@ -290,6 +291,7 @@ static void check_fused2(const simrank_graph* g, const Csr& c) {
               got[(size_t)a].size(), want.size());
     }
 }
+#endif
 
 // the host half of the plans (planprep.hip): well-formed input gives a permutation and the same pattern under new
 // names; malformed input — rowptr not monotone or not spanning, columns out of range or repeated, a prior that is
@@ -430,7 +432,9 @@ int main(int argc, char** argv) {
         simrank_set_tuning("fuse_rows", it % 4 == 0 ? 64 : (it % 4 == 1 ? 700 : 8192));
         simrank_set_tuning("fuse_group", 1 + it % 4);
         simrank_set_tuning("fuse_order", it % 5 == 1 ? 2 : (it % 5 == 3 ? 1 : 0));
+#ifdef SIMRANK_EXPERIMENT_FUSED2
         simrank_set_tuning("fuse", it % 2 ? 2 : 1);
+#endif
         simrank_set_tuning("fuse_cap", it % 3 == 0 ? 1000 : (it % 3 == 1 ? 3000 : 1 << 30));
         // (every 17th graph has no entries at all: plans of nothing but empty rows)
         Csr c = random_graph(rng, M, K, it % 17 == 16 ? 0.0 : 1 + u(rng) * 12, it % 17 == 16 ? 0 : int(u(rng) * 200),
@@ -446,7 +450,9 @@ int main(int argc, char** argv) {
         check_tiles(g, c);
         check_dense(g, c);
         check_fused(g, c);
+#ifdef SIMRANK_EXPERIMENT_FUSED2
         check_fused2(g, c);
+#endif
         if (c.M == c.K && it % 4 == 1) {
             Csr rect = random_graph(rng, 1 + int64_t(u(rng) * 300), 1 + int64_t(u(rng) * 300), 1 + u(rng) * 6, 20, u(rng), false);
             fuzz_plan_inputs(rng, c, rect);

@@ -16,7 +16,7 @@ i64, vp = C.c_int64, C.c_void_p
 class PlanOptions(C.Structure):                # struct simrank_plan_options
     _fields_ = [("coef", C.c_float), ("lbd", C.c_float), ("apriori", vp), ("ld_apriori", i64),
                 ("evidence", C.c_int32), ("reorder", C.c_int32),
-                ("storage_fp16", C.c_int32), ("reserved", C.c_int32)]   # storage_fp16 = 1: config 5's reduced precision
+                ("storage_fp16", C.c_int32), ("dense_terms", C.c_int32)]   # storage_fp16 = 1: config 5's reduced precision
 
 
 def _ok(rc):

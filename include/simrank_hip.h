@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define SIMRANK_ABI_VERSION 5
+#define SIMRANK_ABI_VERSION 6
 #define SIMRANK_CHANGED_SLOTS 1024
 
 #if defined(__GNUC__)
@@ -86,13 +86,25 @@ SIMRANK_API int simrank_memcpy_d2d(void* dst_device, const void* src_device, siz
  * side (replaces the DataFrame hand-back of SimRank.py:141, :303). */
 SIMRANK_API int simrank_download_f64(double* dst_host, int64_t ld_dst, const float* src_device,
                          int64_t ld_src, int64_t n_rows, int64_t n_cols, void* stream);
+/* 2-D device->host hand-back of a BITWISE SYMMETRIC n x n float32 matrix as float64 in another node order:
+ * dst[i][j] = src[idx[i]][idx[j]] (idx: DEVICE int32[n], NULL = identity; src row-major with ld_src, or panel-blocked
+ * when src_rows_pad > 0).  Only the elements on or above the diagonal of the RESULT cross PCIe — packed band by band
+ * on the device — and a crew of host threads writes each of them twice while widening (replaces `pd.DataFrame(new_S)`
+ * of SimRank.py:141, :303 for the symmetric updates: every class except a fit with an asymmetric prior). */
+SIMRANK_API int simrank_download_f64_sym(double* dst_host, int64_t ld_dst, const float* src_device, int64_t ld_src,
+                                         int64_t src_rows_pad, int64_t n, const int32_t* idx_device, void* stream);
 /* The convergence count of an update without stopping the stream (`_converged`, SimRank.py:54-77, as a caller
- * that drives the legs itself reads it): _fetch queues the copy of n counters (the simrank_epilogue.n_changed
- * array) into pinned slot `slot` (0..3) of the current device and records an event behind it; _wait returns their
- * sum once that copy has landed, while whatever was queued behind the fetch — update k + 1 of the loop at
- * :129-140, issued before the count of update k is known — keeps running.  One stream per device uses them. */
-SIMRANK_API int simrank_counters_fetch(const unsigned long long* counters, int32_t n, int32_t slot, void* stream);
-SIMRANK_API int simrank_counters_wait(int32_t slot, unsigned long long* sum);
+ * that drives the legs itself reads it): a COUNTER SET owns four pinned slots and their events; _fetch queues the copy
+ * of n counters (the simrank_epilogue.n_changed array) into slot `slot` (0..3) and records an event behind it; _wait
+ * returns their sum once that copy has landed, while whatever was queued behind the fetch — update k + 1 of the loop
+ * at :129-140, issued before the count of update k is known — keeps running.  One set per engine (stream): two fits
+ * running side by side on one device never see each other's counts. */
+typedef struct simrank_counter_set simrank_counter_set;
+SIMRANK_API int simrank_counters_create(simrank_counter_set** out);
+SIMRANK_API int simrank_counters_destroy(simrank_counter_set* set);
+SIMRANK_API int simrank_counters_fetch(simrank_counter_set* set, const unsigned long long* counters, int32_t n, int32_t slot,
+                                       void* stream);
+SIMRANK_API int simrank_counters_wait(simrank_counter_set* set, int32_t slot, unsigned long long* sum);
 SIMRANK_API int simrank_stream_create(void** stream);
 SIMRANK_API int simrank_stream_destroy(void* stream);
 SIMRANK_API int simrank_stream_synchronize(void* stream);
@@ -408,7 +420,8 @@ typedef struct simrank_plan_options {
     int32_t storage_fp16;       /* 1: the matrices are HELD in fp16 ("FP16 STORAGE" above: value x 2^14 on 64-column
                                    panels, f32 sums, one rounding per stored value) — BASELINE config 5's
                                    reduced-precision mode, outside the parity bar; 0 (default): f32 */
-    int32_t reserved;           /* 0 */
+    int32_t dense_terms;        /* operand terms of the matrix-core part: 0 or 3 = exact f32 products (three bf16 terms);
+                                   1 = one fp16 term (BASELINE config 5 read literally; outside the parity bar) */
 } simrank_plan_options;
 SIMRANK_API int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col,
                                     const float* rowscale, const simrank_plan_options* options, void* stream,
@@ -417,8 +430,23 @@ SIMRANK_API int simrank_plan_reset(simrank_plan* p);
 SIMRANK_API int simrank_plan_step(simrank_plan* p, double eps, int32_t exact_count, int64_t* n_changed);
 SIMRANK_API int simrank_plan_run(simrank_plan* p, int32_t iterations, double eps, int32_t* updates_done,
                                  int32_t* converged_at);
+/* The same loop with the reference's console hooks: progress(user, k, 0) is called when loop index k goes on to an
+ * update (SimRank.py:135 `update_progress(k / iterations)`), progress(user, k, 1) when the test passes at loop index k
+ * (:131-133 "Converged at iteration k").  A nonzero return value of the first form ends the loop after k updates
+ * (how a binding propagates an exception raised in its callback).  This is what the Python classes' fit() runs. */
+typedef int32_t (*simrank_progress_fn)(void* user, int32_t k, int32_t converged);
+SIMRANK_API int simrank_plan_run_cb(simrank_plan* p, int32_t iterations, double eps, simrank_progress_fn progress,
+                                    void* user, int32_t* updates_done, int32_t* converged_at);
 SIMRANK_API int simrank_plan_result(simrank_plan* p, float* dst, int64_t ld);
+/* HOST float64 n x n in the caller's order (SimRank.py:141).  The iterates of a plan are bitwise symmetric, so only the
+ * elements on or above the diagonal cross PCIe; the host mirrors them while widening (simrank_download_f64_sym). */
 SIMRANK_API int simrank_plan_result_f64(simrank_plan* p, double* dst, int64_t ld);
+/* HOST u8 n x n in the caller's order: common in-neighbour counts, saturated at 255 (`Evidence` = 1 - 0.5 ** count,
+ * SimRank.py:311-320); plans created with options.evidence only */
+SIMRANK_API int simrank_plan_evidence_u8(simrank_plan* p, uint8_t* dst, int64_t ld);
+/* releases the iterates, the transposed product and the prior (a finished fit keeps its plan only for
+ * simrank_plan_evidence_u8); every entry point that needs them fails with SIMRANK_ERR_INVALID afterwards */
+SIMRANK_API int simrank_plan_trim(simrank_plan* p);
 /* the k most similar nodes of every node (HOST int32 / float [n][k], caller's ids, largest first, ties by the
  * lower id, -1 / 0 where a row has fewer; exclude_diag = 1 leaves the node itself out): 2 n k values cross
  * PCIe instead of n^2 */
@@ -461,7 +489,16 @@ SIMRANK_API int simrank_biplan_step(simrank_biplan* p, double eps, int32_t exact
                                     int64_t* changed2);
 SIMRANK_API int simrank_biplan_run(simrank_biplan* p, int32_t iterations, double eps, int32_t* updates_done,
                                    int32_t* converged_at);
+/* with the reference's console hooks, as simrank_plan_run_cb (SimRank.py:289-296) */
+SIMRANK_API int simrank_biplan_run_cb(simrank_biplan* p, int32_t iterations, double eps, simrank_progress_fn progress,
+                                      void* user, int32_t* updates_done, int32_t* converged_at);
 SIMRANK_API int simrank_biplan_result_f64(simrank_biplan* p, int32_t group, double* dst, int64_t ld);
+/* as simrank_plan_topk / simrank_plan_evidence_u8 / simrank_plan_trim, per group (1 | 2).  The counts are those that
+ * GATE the group's update: with strict_reference the group-2 counts are Evidence_N1's, position by position */
+SIMRANK_API int simrank_biplan_topk(simrank_biplan* p, int32_t group, int32_t k, int32_t exclude_diag, int32_t* idx_host,
+                                    float* val_host);
+SIMRANK_API int simrank_biplan_evidence_u8(simrank_biplan* p, int32_t group, uint8_t* dst, int64_t ld);
+SIMRANK_API int simrank_biplan_trim(simrank_biplan* p);
 SIMRANK_API int simrank_biplan_destroy(simrank_biplan* p);
 
 /* ---- SHARDED PLAN: the same loop with S split by COLUMN BLOCK over `world` GPUs, one process per GPU

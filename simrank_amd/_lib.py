@@ -39,6 +39,10 @@ class Epilogue(C.Structure):
     ]
 
 
+ABI_VERSION = 6          # SIMRANK_ABI_VERSION of include/simrank_hip.h
+# the console hooks of the C-level loops (simrank_progress_fn)
+PROGRESS_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_int32)
+
 _vp, _i64, _i32, _int = C.c_void_p, C.c_int64, C.c_int32, C.c_int
 _pvp = C.POINTER(C.c_void_p)
 
@@ -60,8 +64,11 @@ PROTOTYPES = {
     "simrank_memcpy_d2d": [_vp, _vp, C.c_size_t, _vp],
     "simrank_download_f64": [_vp, _i64, _vp, _i64, _i64, _i64, _vp],
     "simrank_read_counters": [_vp, _i32, C.POINTER(C.c_ulonglong), _vp],
-    "simrank_counters_fetch": [_vp, _i32, _i32, _vp],
-    "simrank_counters_wait": [_i32, C.POINTER(C.c_ulonglong)],
+    "simrank_download_f64_sym": [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp],
+    "simrank_counters_create": [_pvp],
+    "simrank_counters_destroy": [_vp],
+    "simrank_counters_fetch": [_vp, _vp, _i32, _i32, _vp],
+    "simrank_counters_wait": [_vp, _i32, C.POINTER(C.c_ulonglong)],
     "simrank_stream_create": [_pvp],
     "simrank_stream_destroy": [_vp],
     "simrank_stream_synchronize": [_vp],
@@ -89,6 +96,13 @@ PROTOTYPES = {
     "simrank_fill_identity_blocked": [_vp, _i64, _i64, _i64, _i64, _vp],
     "simrank_spmm_blocked": [_vp, _vp, _i64, _i64, _vp, _i64, _i32, C.POINTER(Epilogue), _vp],
     "simrank_plan_topk": [_vp, _i32, _i32, _vp, _vp],
+    "simrank_plan_run_cb": [_vp, C.c_int32, C.c_double, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    "simrank_plan_evidence_u8": [_vp, _vp, _i64],
+    "simrank_plan_trim": [_vp],
+    "simrank_biplan_run_cb": [_vp, C.c_int32, C.c_double, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    "simrank_biplan_topk": [_vp, _i32, _i32, _i32, _vp, _vp],
+    "simrank_biplan_evidence_u8": [_vp, _i32, _vp, _i64],
+    "simrank_biplan_trim": [_vp],
     "simrank_biplan_create": [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "simrank_biplan_reset": [_vp],
     "simrank_biplan_step": [_vp, C.c_double, _i32, _vp, _vp],
@@ -159,7 +173,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError = symbol missing from the .so
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
-    if lib.simrank_abi_version() != 5:
+    if lib.simrank_abi_version() != ABI_VERSION:
         raise ImportError("libsimrank_hip.so ABI version mismatch")
     _lib = lib
     return lib

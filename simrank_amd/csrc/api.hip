@@ -159,7 +159,7 @@ void pool_trim_locked(PoolState& P, int device) {
 }
 }  // namespace
 
-int pool_alloc(void** dptr, size_t bytes) {
+static int pool_alloc_raw(void** dptr, size_t bytes) {
     *dptr = nullptr;
     PoolState& P = pool();
     int dev = 0;
@@ -202,6 +202,23 @@ int pool_alloc(void** dptr, size_t bytes) {
         P.live.push_back({*dptr, {bytes, dev}});
     }
     return SIMRANK_OK;
+}
+
+// SIMRANK_POOL_POISON=1 (tests): every block handed out is filled with 0xFF bytes first — NaN as f32 and as fp16, 255 as
+// a count — so that a kernel which lets padding rows / columns of an un-zeroed matrix reach a sum, a count, a top-k
+// or a store shows (fresh hipMalloc memory is usually zero and hides it; advisor, round 4)
+static bool pool_poison() {
+    static const bool on = [] { const char* e = getenv("SIMRANK_POOL_POISON"); return e && *e && *e != '0'; }();
+    return on;
+}
+
+int pool_alloc(void** dptr, size_t bytes) {
+    const int rc = pool_alloc_raw(dptr, bytes);
+    if (rc == SIMRANK_OK && pool_poison() && *dptr) {
+        SR_HIP(hipMemset(*dptr, 0xFF, bytes));
+        SR_HIP(hipDeviceSynchronize());
+    }
+    return rc;
 }
 
 int pool_free(void* ptr) {
@@ -466,20 +483,34 @@ int simrank_read_counters(const unsigned long long* counters, int32_t n, unsigne
 
 // The count of an update WITHOUT stopping the stream (the loop of SimRank.py:129-140 as plan.hip runs it, for
 // callers that drive the legs themselves): _fetch queues the copy of the counters into pinned slot `slot` of the
-// current device and records an event behind it, _wait returns their sum once that copy has landed — whatever
-// was queued behind the fetch (update k + 1) keeps running.
-namespace {
-struct CountSlot { unsigned long long* host = nullptr; int32_t cap = 0, n = 0; hipEvent_t ev = nullptr; };
-std::mutex g_count_mutex;
-CountSlot g_count_slots[16][4];
-}  // namespace
+// caller's COUNTER SET and records an event behind it, _wait returns their sum once that copy has landed — whatever
+// was queued behind the fetch (update k + 1) keeps running.  The set belongs to one engine: round 4 kept the slots in a
+// per-device table, and two fits on one device read each other's counts (advisor, round 4).
+}  // extern "C"
+struct simrank_counter_set {
+    struct Slot { unsigned long long* host = nullptr; int32_t cap = 0, n = 0; hipEvent_t ev = nullptr; } slot[4];
+};
+extern "C" {
 
-int simrank_counters_fetch(const unsigned long long* counters, int32_t n, int32_t slot, void* stream) {
-    SR_REQUIRE(counters && n > 0 && n <= 65536 && slot >= 0 && slot < 4, "bad counter fetch");
-    int dev = 0;
-    SR_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(g_count_mutex);
-    CountSlot& sl = g_count_slots[dev & 15][slot];
+int simrank_counters_create(simrank_counter_set** out) {
+    SR_REQUIRE(out, "out is NULL");
+    *out = new simrank_counter_set;
+    return SIMRANK_OK;
+}
+
+int simrank_counters_destroy(simrank_counter_set* set) {
+    if (!set) return SIMRANK_OK;
+    for (auto& sl : set->slot) {
+        if (sl.ev) { (void)hipEventSynchronize(sl.ev); (void)hipEventDestroy(sl.ev); }
+        if (sl.host) (void)hipHostFree(sl.host);
+    }
+    delete set;
+    return SIMRANK_OK;
+}
+
+int simrank_counters_fetch(simrank_counter_set* set, const unsigned long long* counters, int32_t n, int32_t slot, void* stream) {
+    SR_REQUIRE(set && counters && n > 0 && n <= 65536 && slot >= 0 && slot < 4, "bad counter fetch");
+    auto& sl = set->slot[slot];
     if (!sl.ev) SR_HIP(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
     if (n > sl.cap) {
         if (sl.host) (void)hipHostFree(sl.host);
@@ -494,22 +525,13 @@ int simrank_counters_fetch(const unsigned long long* counters, int32_t n, int32_
     return SIMRANK_OK;
 }
 
-int simrank_counters_wait(int32_t slot, unsigned long long* sum) {
-    SR_REQUIRE(sum && slot >= 0 && slot < 4, "bad counter wait");
-    int dev = 0;
-    SR_HIP(hipGetDevice(&dev));
-    hipEvent_t ev;
-    const unsigned long long* host;
-    int32_t n;
-    {
-        std::lock_guard<std::mutex> lock(g_count_mutex);
-        const CountSlot& sl = g_count_slots[dev & 15][slot];
-        SR_REQUIRE(sl.ev && sl.host && sl.n > 0, "counter slot %d was never fetched into", slot);
-        ev = sl.ev; host = sl.host; n = sl.n;
-    }
-    SR_HIP(hipEventSynchronize(ev));
+int simrank_counters_wait(simrank_counter_set* set, int32_t slot, unsigned long long* sum) {
+    SR_REQUIRE(set && sum && slot >= 0 && slot < 4, "bad counter wait");
+    const auto& sl = set->slot[slot];
+    SR_REQUIRE(sl.ev && sl.host && sl.n > 0, "counter slot %d was never fetched into", slot);
+    SR_HIP(hipEventSynchronize(sl.ev));
     unsigned long long total = 0;
-    for (int32_t i = 0; i < n; ++i) total += host[i];
+    for (int32_t i = 0; i < sl.n; ++i) total += sl.host[i];
     *sum = total;
     return SIMRANK_OK;
 }

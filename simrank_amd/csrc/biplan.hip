@@ -16,6 +16,7 @@
 // one count gates every element; otherwise NumPy raises "operands could not be broadcast together" when the
 // first group-2 update RUNS (iterations = 0 or eps >= 1 still return the identities): so do step / run here.
 #include <algorithm>
+#include <cstring>
 #include <numeric>
 #include <vector>
 
@@ -129,6 +130,7 @@ int simrank_biplan_destroy(simrank_biplan* p) {
 
 int simrank_biplan_reset(simrank_biplan* p) {
     SR_REQUIRE(p, "plan is NULL");
+    SR_REQUIRE(p->s[0].S[0], "the plan's matrices were released (simrank_biplan_trim)");
     p->updates = 0;
     for (side_t& a : p->s) {
         a.cur = 0;
@@ -268,6 +270,7 @@ int simrank_biplan_create(int64_t n1, int64_t n2, int64_t nnz, const int32_t* ro
 
 int simrank_biplan_step(simrank_biplan* p, double eps, int32_t exact_count, int64_t* changed1, int64_t* changed2) {
     SR_REQUIRE(p, "plan is NULL");
+    SR_REQUIRE(p->s[0].S[0], "the plan's matrices were released (simrank_biplan_trim)");
     const int rc = iteration(p, eps, exact_count, 0);
     if (rc) return rc;
     ++p->updates;
@@ -281,15 +284,20 @@ int simrank_biplan_step(simrank_biplan* p, double eps, int32_t exact_count, int6
     return SIMRANK_OK;
 }
 
-int simrank_biplan_run(simrank_biplan* p, int32_t iterations, double eps, int32_t* updates_done, int32_t* converged_at) {
+int simrank_biplan_run_cb(simrank_biplan* p, int32_t iterations, double eps, simrank_progress_fn progress, void* user,
+                          int32_t* updates_done, int32_t* converged_at) {
     SR_REQUIRE(p, "plan is NULL");
     SR_REQUIRE(iterations >= 0, "iterations < 0");
+    SR_REQUIRE(p->s[0].S[0], "the plan's matrices were released (simrank_biplan_trim)");
     int rc = simrank_biplan_reset(p);
     if (rc) return rc;
     int32_t conv = -1, done = 0;
+    // progress(user, k, converged) as in simrank_plan_run_cb (SimRank.py:289-296): a nonzero return value ends the loop
+    auto tell = [&](int32_t k, int32_t converged) { return progress ? progress(user, k, converged) : 0; };
     if (iterations > 0 && !(1.0 > eps)) {
         conv = 0;           // loop index 0 compares the identities with zero matrices: "converged" unless 1 > eps
-    } else if (iterations > 0) {
+        (void)tell(0, 1);
+    } else if (iterations > 0 && tell(0, 0) == 0) {
         rc = iteration(p, eps, 0, 1);                    // iteration 1
         if (rc) return rc;
         for (int32_t k = 1;; ++k) {
@@ -307,8 +315,13 @@ int simrank_biplan_run(simrank_biplan* p, int32_t iterations, double eps, int32_
             unsigned long long c1 = 0, c2 = 0;
             rc = read_counts(p, k & 1, &c1, &c2);
             if (rc) return rc;
-            if (c1 == 0 && c2 == 0) {                    // SimRank.py:289: both groups
-                conv = k;
+            const bool conv_now = c1 == 0 && c2 == 0;    // SimRank.py:289: both groups
+            const bool stop = !conv_now && tell(k, 0) != 0;
+            if (conv_now || stop) {
+                if (conv_now) {
+                    conv = k;
+                    (void)tell(k, 1);
+                }
                 SR_HIP(hipStreamSynchronize(p->stream));  // (the speculative iteration must not outlive its inputs)
                 p->s[0].cur = c1_cur;
                 p->s[1].cur = c2_cur;
@@ -327,19 +340,95 @@ int simrank_biplan_run(simrank_biplan* p, int32_t iterations, double eps, int32_
     return SIMRANK_OK;
 }
 
+int simrank_biplan_run(simrank_biplan* p, int32_t iterations, double eps, int32_t* updates_done, int32_t* converged_at) {
+    return simrank_biplan_run_cb(p, iterations, eps, nullptr, nullptr, updates_done, converged_at);
+}
+
 int simrank_biplan_result_f64(simrank_biplan* p, int32_t group, double* dst, int64_t ld) {
     SR_REQUIRE(p && dst && (group == 1 || group == 2), "bad result arguments");
     side_t& a = p->s[group - 1];
     SR_REQUIRE(ld >= a.n, "ld %lld < n", (long long)ld);
-    float* tmp = nullptr;
-    const int64_t ldt = (a.n + 3) / 4 * 4;
-    SR_HIP(pool_hip_alloc((void**)&tmp, size_t(a.n) * size_t(ldt) * sizeof(float)));
-    // dst[i][j] = S[inv[i]][inv[j]]: out of the panel-blocked layout and the solver's node order in one pass
-    int rc = simrank_permute_layout(a.S[a.cur], 32, a.rows_pad, tmp, ldt, 0, a.n, a.n, a.inv, a.inv, 4, p->stream);
-    if (!rc) rc = simrank_download_f64(dst, ld, tmp, ldt, a.n, a.n, p->stream);
+    SR_REQUIRE(a.S[0], "the plan's matrices were released (simrank_biplan_trim)");
+    // dst[i][j] = S[inv[i]][inv[j]]; the iterates are bitwise symmetric: upper triangle over PCIe, mirrored on the host
+    const int rc = simrank_download_f64_sym(dst, ld, a.S[a.cur], 32, a.rows_pad, a.n, a.inv, p->stream);
     (void)hipStreamSynchronize(p->stream);
-    (void)pool_free(tmp);
     return rc;
+}
+
+int simrank_biplan_topk(simrank_biplan* p, int32_t group, int32_t k, int32_t exclude_diag, int32_t* idx_host, float* val_host) {
+    SR_REQUIRE(p && idx_host && val_host && (group == 1 || group == 2) && k > 0 && k <= 1024, "bad top-k arguments");
+    side_t& a = p->s[group - 1];
+    SR_REQUIRE(a.S[0], "the plan's matrices were released (simrank_biplan_trim)");
+    const int64_t n = a.n;
+    // as simrank_plan_topk: selected on the panel-blocked matrix in the solver's order, caller's ids reported, the rows
+    // put back into the caller's order on the host
+    int32_t* idx_dev = nullptr;
+    int32_t* ord_dev = nullptr;
+    float* val_dev = nullptr;
+    std::vector<int32_t> ord((size_t)n), idx_s((size_t)n * (size_t)k);
+    std::vector<float> val_s((size_t)n * (size_t)k);
+    hipError_t e = pool_hip_alloc((void**)&idx_dev, size_t(n) * size_t(k) * sizeof(int32_t));
+    if (e == hipSuccess) e = pool_hip_alloc((void**)&val_dev, size_t(n) * size_t(k) * sizeof(float));
+    if (e == hipSuccess) e = pool_hip_alloc((void**)&ord_dev, size_t(n) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(ord.data(), a.inv, size_t(n) * 4, hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    int rc = SIMRANK_OK;
+    if (e == hipSuccess) {
+        std::vector<int32_t> o((size_t)n);
+        for (int64_t i = 0; i < n; ++i) o[(size_t)ord[(size_t)i]] = (int32_t)i;      // position r holds caller's node o[r]
+        ord.swap(o);
+        e = hipMemcpyAsync(ord_dev, ord.data(), size_t(n) * 4, hipMemcpyHostToDevice, p->stream);
+    }
+    if (e == hipSuccess)
+        rc = simrank_topk_rows_blocked(a.S[a.cur], a.rows_pad, n, n, 0, ord_dev, k, exclude_diag, idx_dev, val_dev, p->stream);
+    if (e == hipSuccess && !rc)
+        e = hipMemcpyAsync(idx_s.data(), idx_dev, size_t(n) * size_t(k) * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess && !rc)
+        e = hipMemcpyAsync(val_s.data(), val_dev, size_t(n) * size_t(k) * sizeof(float), hipMemcpyDeviceToHost, p->stream);
+    const hipError_t e2 = hipStreamSynchronize(p->stream);
+    (void)pool_free(idx_dev); (void)pool_free(val_dev); (void)pool_free(ord_dev);
+    if (e != hipSuccess || e2 != hipSuccess) {
+        set_error("simrank_biplan_topk: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+        (void)hipGetLastError();
+        return SIMRANK_ERR_HIP;
+    }
+    if (rc) return rc;
+    for (int64_t r = 0; r < n; ++r) {
+        const int64_t node = ord[(size_t)r];
+        std::memcpy(idx_host + node * k, idx_s.data() + r * k, size_t(k) * sizeof(int32_t));
+        std::memcpy(val_host + node * k, val_s.data() + r * k, size_t(k) * sizeof(float));
+    }
+    return SIMRANK_OK;
+}
+
+int simrank_biplan_evidence_u8(simrank_biplan* p, int32_t group, uint8_t* dst, int64_t ld) {
+    SR_REQUIRE(p && dst && (group == 1 || group == 2), "bad evidence arguments");
+    side_t& a = p->s[group - 1];
+    SR_REQUIRE(ld >= a.n, "ld %lld < n", (long long)ld);
+    SR_REQUIRE(a.ev, "no evidence counts for group %d (created without evidence, or strict_reference with n1 != n2)", group);
+    // the counts that GATE this group's update (strict_reference: Evidence_N1's, position by position, for group 2 as well)
+    uint8_t* tmp = nullptr;
+    SR_HIP(pool_hip_alloc((void**)&tmp, size_t(a.n) * size_t(a.n)));
+    const int rc = simrank_permute_layout(a.ev, 32, a.rows_pad, tmp, a.n, 0, a.n, a.n, a.inv, a.inv, 1, p->stream);
+    hipError_t e = hipSuccess;
+    if (!rc) e = hipMemcpy2DAsync(dst, size_t(ld), tmp, size_t(a.n), size_t(a.n), size_t(a.n), hipMemcpyDeviceToHost, p->stream);
+    const hipError_t e2 = hipStreamSynchronize(p->stream);
+    (void)pool_free(tmp);
+    if (e != hipSuccess || e2 != hipSuccess) {
+        set_error("simrank_biplan_evidence_u8: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+        return SIMRANK_ERR_HIP;
+    }
+    return rc;
+}
+
+int simrank_biplan_trim(simrank_biplan* p) {
+    SR_REQUIRE(p, "plan is NULL");
+    if (p->stream) SR_HIP(hipStreamSynchronize(p->stream));
+    for (side_t& a : p->s) {
+        (void)pool_free(a.S[0]); (void)pool_free(a.S[1]); (void)pool_free(a.Tt); (void)pool_free(a.prior);
+        a.S[0] = a.S[1] = a.Tt = a.prior = nullptr;
+    }
+    return SIMRANK_OK;
 }
 
 }  // extern "C"

@@ -143,7 +143,16 @@ int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int
     const size_t ev_bytes = size_t(panels) * size_t(p->rows_pad) * 32;
     {
         Tuning t = tuning_snapshot();
-        if (p->half) t.fuse_unit = int64_t(1) << 20;      // (half.hip runs whole blocks: no units whose sums meet in memory)
+        if (p->half) {
+            t.fuse_unit = int64_t(1) << 20;      // (half.hip runs whole blocks: no units whose sums meet in memory)
+            // one fp16 MFMA term instead of three bf16 ones, but an operand segment serves 64 columns, so the gathers got
+            // cheaper still: the break-even moves up by one (4 is 3 % faster than 3, 2 is 12 % slower), and groups of four
+            // blocks without a set beat three (7 % at config 5) — while the knobs are at their defaults (as driver.Side did)
+            if (t.fuse_min == 3) {
+                t.fuse_min = 4;
+                if (t.fuse_group == 3) t.fuse_group = 4;
+            }
+        }
         // The evidence counts (SimRank.py:311-320: common in-neighbours of the pattern; 1 - 2^-count in the epilogue) read the
         // CSR / CSC arrays only: they are queued as soon as those are on the device and run while the host threads still
         // build the tile, dense-block and one-launch plans (14 ms beside 30 at config 5).
@@ -162,6 +171,10 @@ int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int
     }
     if (rc) return fail(rc);
     lap("graph object (evidence counts queued)");
+    if (opt->dense_terms == 1) {                 // one fp16 operand term on the matrix cores (config 5's literal reading)
+        rc = simrank_graph_set_dense_terms(p->g, 1);
+        if (rc) return fail(rc);
+    }
     if (p->half && !p->g->fused) {
         set_error("storage_fp16 needs the one-launch plan (tuning fuse = 1) and a graph that has one");
         return fail(SIMRANK_ERR_INVALID);
@@ -233,6 +246,7 @@ int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int
 
 int simrank_plan_reset(simrank_plan* p) {
     SR_REQUIRE(p, "plan is NULL");
+    SR_REQUIRE(p->S[0], "the plan's matrices were released (simrank_plan_trim)");
     p->cur = 0;
     p->updates = 0;
     if (p->half) return simrank_fill_identity_blocked_h16(p->S[0], p->n, p->n, p->rows_pad, 0, kHalfScale, p->stream);
@@ -241,6 +255,7 @@ int simrank_plan_reset(simrank_plan* p) {
 
 int simrank_plan_step(simrank_plan* p, double eps, int32_t exact_count, int64_t* n_changed) {
     SR_REQUIRE(p, "plan is NULL");
+    SR_REQUIRE(p->S[0], "the plan's matrices were released (simrank_plan_trim)");
     const int rc = leg_pair(p, eps, exact_count, 0);
     if (rc) return rc;
     p->cur ^= 1;
@@ -254,15 +269,22 @@ int simrank_plan_step(simrank_plan* p, double eps, int32_t exact_count, int64_t*
     return SIMRANK_OK;
 }
 
-int simrank_plan_run(simrank_plan* p, int32_t iterations, double eps, int32_t* updates_done, int32_t* converged_at) {
+int simrank_plan_run_cb(simrank_plan* p, int32_t iterations, double eps, simrank_progress_fn progress, void* user,
+                        int32_t* updates_done, int32_t* converged_at) {
     SR_REQUIRE(p, "plan is NULL");
     SR_REQUIRE(iterations >= 0, "iterations < 0");
+    SR_REQUIRE(p->S[0], "the plan's matrices were released (simrank_plan_trim)");
     int rc = simrank_plan_reset(p);
     if (rc) return rc;
     int32_t conv = -1, done = 0;
+    // progress(user, k, 0): loop index k goes on to an update (SimRank.py:135 `update_progress(k / iterations)`);
+    // progress(user, k, 1): the test passed at loop index k (:131-133).  A nonzero return value ends the loop there.
+    auto tell = [&](int32_t k, int32_t converged) { return progress ? progress(user, k, converged) : 0; };
+    bool stop = false;
     if (iterations > 0 && !(1.0 > eps)) {
         conv = 0;           // loop index 0 compares S_0 = I with the zero matrix: "converged" unless 1 > eps
-    } else if (iterations > 0) {
+        (void)tell(0, 1);
+    } else if (iterations > 0 && !(stop = tell(0, 0) != 0)) {
         rc = leg_pair(p, eps, 0, 1);                 // update 1: reads S[cur], writes S[cur ^ 1]
         if (rc) return rc;
         for (int32_t k = 1;; ++k) {
@@ -283,6 +305,11 @@ int simrank_plan_run(simrank_plan* p, int32_t iterations, double eps, int32_t* u
             if (rc) return rc;
             if (c == 0) {                            // converged at loop index k: k updates applied; the
                 conv = k;                            // speculative one is not adopted
+                (void)tell(k, 1);
+                break;
+            }
+            if (tell(k, 0) != 0) {                   // the caller ends the loop: k updates applied
+                stop = true;
                 break;
             }
             if (!spec) {
@@ -295,11 +322,17 @@ int simrank_plan_run(simrank_plan* p, int32_t iterations, double eps, int32_t* u
     p->updates = done;
     if (updates_done) *updates_done = done;
     if (converged_at) *converged_at = conv;
+    (void)stop;
     return SIMRANK_OK;
+}
+
+int simrank_plan_run(simrank_plan* p, int32_t iterations, double eps, int32_t* updates_done, int32_t* converged_at) {
+    return simrank_plan_run_cb(p, iterations, eps, nullptr, nullptr, updates_done, converged_at);
 }
 
 int simrank_plan_result(simrank_plan* p, float* dst, int64_t ld) {
     SR_REQUIRE(p && dst && ld >= p->n, "bad result arguments");
+    SR_REQUIRE(p->S[0], "the plan's matrices were released (simrank_plan_trim)");
     // dst[i][j] = S[inv[i]][inv[j]]: out of the panel-blocked layout and the solver's node order in one pass
     if (p->half) {
         // through an f32 panel-blocked scratch copy
@@ -317,18 +350,60 @@ int simrank_plan_result(simrank_plan* p, float* dst, int64_t ld) {
 
 int simrank_plan_result_f64(simrank_plan* p, double* dst, int64_t ld) {
     SR_REQUIRE(p && dst && ld >= p->n, "bad result arguments");
-    float* tmp = nullptr;
-    const int64_t ldt = (p->n + 3) / 4 * 4;
-    SR_HIP(pool_hip_alloc((void**)&tmp, size_t(p->n) * size_t(ldt) * sizeof(float)));
-    int rc = simrank_plan_result(p, tmp, ldt);
-    if (!rc) rc = simrank_download_f64(dst, ld, tmp, ldt, p->n, p->n, p->stream);
+    SR_REQUIRE(p->S[0], "the plan's matrices were released (simrank_plan_trim)");
+    // A plan's iterates are bitwise symmetric (symmetric priors only; leg 2 stores the mirror image of every tile it
+    // computes): only the elements on or above the diagonal of the result cross PCIe, the host mirrors them while it
+    // widens to float64 (handback.hip).  Out of the panel-blocked layout and the solver's node order band by band.
+    const float* src = p->S[p->cur];
+    float* wide = nullptr;
+    if (p->half) {
+        const size_t bytes = size_t((p->n + 31) / 32) * size_t(p->rows_pad) * 32 * sizeof(float);
+        SR_HIP(pool_hip_alloc((void**)&wide, bytes));
+        const int rc = simrank_widen_blocked_h16(p->S[p->cur], p->rows_pad, wide, p->rows_pad, p->n, p->n, kHalfScale, p->stream);
+        if (rc) {
+            (void)hipStreamSynchronize(p->stream);
+            (void)pool_free(wide);
+            return rc;
+        }
+        src = wide;
+    }
+    const int rc = simrank_download_f64_sym(dst, ld, src, 32, p->rows_pad, p->n, p->inv, p->stream);
     (void)hipStreamSynchronize(p->stream);
-    (void)pool_free(tmp);
+    (void)pool_free(wide);
     return rc;
+}
+
+int simrank_plan_evidence_u8(simrank_plan* p, uint8_t* dst, int64_t ld) {
+    SR_REQUIRE(p && dst && ld >= p->n, "bad evidence arguments");
+    SR_REQUIRE(p->ev, "the plan was created without evidence");
+    // dst[i][j] = counts[inv[i]][inv[j]] (saturated at 255; Evidence = 1 - 0.5 ** count, SimRank.py:316)
+    uint8_t* tmp = nullptr;
+    SR_HIP(pool_hip_alloc((void**)&tmp, size_t(p->n) * size_t(p->n)));
+    int rc = simrank_permute_layout(p->ev, 32, p->rows_pad, tmp, p->n, 0, p->n, p->n, p->inv, p->inv, 1, p->stream);
+    hipError_t e = hipSuccess;
+    if (!rc) e = hipMemcpy2DAsync(dst, size_t(ld), tmp, size_t(p->n), size_t(p->n), size_t(p->n), hipMemcpyDeviceToHost, p->stream);
+    const hipError_t e2 = hipStreamSynchronize(p->stream);
+    (void)pool_free(tmp);
+    if (e != hipSuccess || e2 != hipSuccess) {
+        set_error("simrank_plan_evidence_u8: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+        return SIMRANK_ERR_HIP;
+    }
+    return rc;
+}
+
+int simrank_plan_trim(simrank_plan* p) {
+    SR_REQUIRE(p, "plan is NULL");
+    // what a finished fit no longer needs: the iterates, the transposed product, the prior (the evidence counts and the
+    // node orders stay: simrank_plan_evidence_u8 reads them later — the estimators' lazy `Evidence` attribute)
+    if (p->stream) SR_HIP(hipStreamSynchronize(p->stream));
+    (void)pool_free(p->S[0]); (void)pool_free(p->S[1]); (void)pool_free(p->Tt); (void)pool_free(p->prior);
+    p->S[0] = p->S[1] = p->Tt = p->prior = nullptr;
+    return SIMRANK_OK;
 }
 
 int simrank_plan_topk(simrank_plan* p, int32_t k, int32_t exclude_diag, int32_t* idx_host, float* val_host) {
     SR_REQUIRE(p && idx_host && val_host && k > 0 && k <= 1024, "bad top-k arguments");
+    SR_REQUIRE(p->S[0], "the plan's matrices were released (simrank_plan_trim)");
     // The selection runs on the plan's own panel-blocked matrix in the solver's order (one pass, eight rows per wave;
     // fp16-held: on its f32 copy), reporting the caller's ids; the rows go back into the caller's order on the host —
     // 2 x n x k values across PCIe instead of n^2, and no n^2 copy on the device either.

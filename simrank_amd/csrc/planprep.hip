@@ -105,6 +105,7 @@ int plan_prepare(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* c
                  const simrank_plan_options* opt, PlanPrep* out) {
     SR_REQUIRE(opt && rowptr && rowscale && (col || nnz == 0) && n > 0 && nnz >= 0 && out, "bad plan arguments");
     SR_REQUIRE(n < (int64_t(1) << 24) - 16, "a plan holds at most 2^24 nodes");
+    SR_REQUIRE(opt->dense_terms == 0 || opt->dense_terms == 1 || opt->dense_terms == 3, "dense_terms must be 0, 1 or 3");
     int rc = check_csr(n, n, nnz, rowptr, col);
     if (!rc) rc = check_prior(opt->apriori, opt->ld_apriori, n, 1, opt->storage_fp16 != 0);
     if (rc) return rc;

@@ -106,7 +106,24 @@ class Graph:
 
 class PlanOptions(C.Structure):                # struct simrank_plan_options
     _fields_ = [("coef", C.c_float), ("lbd", C.c_float), ("apriori", C.c_void_p), ("ld_apriori", C.c_int64),
-                ("evidence", C.c_int32), ("reorder", C.c_int32), ("storage_fp16", C.c_int32), ("reserved", C.c_int32)]
+                ("evidence", C.c_int32), ("reorder", C.c_int32), ("storage_fp16", C.c_int32), ("dense_terms", C.c_int32)]
+
+
+def _progress_callback(on_iteration, on_converged):
+    """The console hooks of a C-level loop as a simrank_progress_fn (+ the list a Python exception raised inside one is
+    kept in: the loop is told to stop and the caller re-raises)."""
+    raised = []
+
+    def hook(_user, k, converged):
+        try:
+            fn = on_converged if converged else on_iteration
+            if fn is not None:
+                fn(int(k))
+            return 0
+        except BaseException as e:            # (ctypes would print and swallow it)
+            raised.append(e)
+            return 1
+    return _lib.PROGRESS_FN(hook), raised
 
 
 class Plan:
@@ -114,8 +131,9 @@ class Plan:
     :440-455): CSR + per-row scale in the caller's node order in, S (float64, caller's order) out."""
 
     def __init__(self, ops, csr: CSR, rowscale=None, coef: float = 0.8, evidence: bool = False,
-                 apriori=None, lbd: float = 0.0, reorder: bool = True, storage: str = "f32"):
-        """``storage``: "f32", or "fp16" (matrices held in fp16: config 5's reduced-precision mode)."""
+                 apriori=None, lbd: float = 0.0, reorder: bool = True, storage: str = "f32", dense_terms: int = 3):
+        """``storage``: "f32", or "fp16" (matrices held in fp16: config 5's reduced-precision mode).
+        ``dense_terms``: 3 = exact products on the matrix cores, 1 = one fp16 operand term."""
         assert storage in ("f32", "fp16")
         self.ops = ops
         rs = np.ascontiguousarray(csr.rowscale if rowscale is None else rowscale, dtype=np.float32)
@@ -124,7 +142,7 @@ class Plan:
         ap = None if apriori is None else np.ascontiguousarray(apriori, dtype=np.float32)
         opt = PlanOptions(coef=coef, lbd=lbd, apriori=None if ap is None else ap.ctypes.data,
                           ld_apriori=0 if ap is None else ap.shape[1], evidence=int(evidence), reorder=int(reorder),
-                          storage_fp16=int(storage == "fp16"), reserved=0)
+                          storage_fp16=int(storage == "fp16"), dense_terms=int(dense_terms))
         h = C.c_void_p()
         with HipOps._knob_lock:          # (the graph inside snapshots the process-wide knobs: not while another
             check(ops.lib.simrank_plan_create(csr.n_rows, col.size, rowptr.ctypes.data,       # thread has per-graph ones set)
@@ -132,12 +150,31 @@ class Plan:
                                               ops.stream, C.byref(h)), "simrank_plan_create")
         self.handle, self.n = h, csr.n_rows
 
-    def run(self, iterations: int, eps: float):
-        """-> (updates applied, loop index at which the convergence test passed or None)."""
+    def run(self, iterations: int, eps: float, on_iteration=None, on_converged=None):
+        """-> (updates applied, loop index at which the convergence test passed or None).  ``on_iteration(k)`` /
+        ``on_converged(k)``: the reference's console hooks (SimRank.py:131-135), called from inside the C loop."""
         done, conv = C.c_int32(0), C.c_int32(-1)
-        check(self.ops.lib.simrank_plan_run(self.handle, int(iterations), float(eps), C.byref(done), C.byref(conv)),
-              "simrank_plan_run")
+        if on_iteration is None and on_converged is None:
+            check(self.ops.lib.simrank_plan_run(self.handle, int(iterations), float(eps), C.byref(done), C.byref(conv)),
+                  "simrank_plan_run")
+        else:
+            cb, raised = _progress_callback(on_iteration, on_converged)
+            check(self.ops.lib.simrank_plan_run_cb(self.handle, int(iterations), float(eps), cb, None, C.byref(done),
+                                                   C.byref(conv)), "simrank_plan_run_cb")
+            if raised:
+                raise raised[0]
         return done.value, (None if conv.value < 0 else conv.value)
+
+    def evidence_counts(self) -> np.ndarray:
+        """uint8 [n, n] common in-neighbour counts (saturated at 255) in the caller's order."""
+        out = np.empty((self.n, self.n), dtype=np.uint8)
+        check(self.ops.lib.simrank_plan_evidence_u8(self.handle, out.ctypes.data, self.n), "simrank_plan_evidence_u8")
+        return out
+
+    def trim(self):
+        """Release the matrices of the loop; the evidence counts stay readable."""
+        if self.handle:
+            check(self.ops.lib.simrank_plan_trim(self.handle), "simrank_plan_trim")
 
     def reset(self):
         check(self.ops.lib.simrank_plan_reset(self.handle), "simrank_plan_reset")
@@ -329,12 +366,46 @@ class BiPlan:
                                                 C.byref(opt), ops.stream, C.byref(h)), "simrank_biplan_create")
         self.handle, self.n1, self.n2 = h, csr12.n_rows, csr12.n_cols
 
-    def run(self, iterations: int, eps: float):
-        """-> (loop bodies applied, loop index at which the convergence test passed or None)."""
+    def run(self, iterations: int, eps: float, on_iteration=None, on_converged=None):
+        """-> (loop bodies applied, loop index at which the convergence test passed or None); hooks as ``Plan.run``."""
         done, conv = C.c_int32(0), C.c_int32(-1)
-        check(self.ops.lib.simrank_biplan_run(self.handle, int(iterations), float(eps), C.byref(done), C.byref(conv)),
-              "simrank_biplan_run")
+        if on_iteration is None and on_converged is None:
+            check(self.ops.lib.simrank_biplan_run(self.handle, int(iterations), float(eps), C.byref(done), C.byref(conv)),
+                  "simrank_biplan_run")
+        else:
+            cb, raised = _progress_callback(on_iteration, on_converged)
+            check(self.ops.lib.simrank_biplan_run_cb(self.handle, int(iterations), float(eps), cb, None, C.byref(done),
+                                                     C.byref(conv)), "simrank_biplan_run_cb")
+            if raised:
+                raise raised[0]
         return done.value, (None if conv.value < 0 else conv.value)
+
+    def result_group(self, group: int) -> np.ndarray:
+        n = self.n1 if group == 1 else self.n2
+        m = np.empty((n, n), dtype=np.float64)
+        check(self.ops.lib.simrank_biplan_result_f64(self.handle, group, m.ctypes.data, n), "simrank_biplan_result_f64")
+        return m
+
+    def topk(self, group: int, k: int, exclude_diag: bool = True):
+        """(ids int32 [n, k], values float32 [n, k]) of group 1 | 2, caller's ids."""
+        n = self.n1 if group == 1 else self.n2
+        idx = np.empty((n, k), dtype=np.int32)
+        val = np.empty((n, k), dtype=np.float32)
+        check(self.ops.lib.simrank_biplan_topk(self.handle, int(group), int(k), int(exclude_diag), idx.ctypes.data,
+                                               val.ctypes.data), "simrank_biplan_topk")
+        return idx, val
+
+    def evidence_counts(self, group: int) -> np.ndarray:
+        """uint8 [n, n] counts gating group 1 | 2's update, caller's order."""
+        n = self.n1 if group == 1 else self.n2
+        out = np.empty((n, n), dtype=np.uint8)
+        check(self.ops.lib.simrank_biplan_evidence_u8(self.handle, int(group), out.ctypes.data, n),
+              "simrank_biplan_evidence_u8")
+        return out
+
+    def trim(self):
+        if self.handle:
+            check(self.ops.lib.simrank_biplan_trim(self.handle), "simrank_biplan_trim")
 
     def reset(self):
         check(self.ops.lib.simrank_biplan_reset(self.handle), "simrank_biplan_reset")
@@ -346,12 +417,7 @@ class BiPlan:
         return c1.value, c2.value
 
     def result(self):
-        out = []
-        for group, n in ((1, self.n1), (2, self.n2)):
-            m = np.empty((n, n), dtype=np.float64)
-            check(self.ops.lib.simrank_biplan_result_f64(self.handle, group, m.ctypes.data, n), "simrank_biplan_result_f64")
-            out.append(m)
-        return tuple(out)
+        return self.result_group(1), self.result_group(2)
 
     def free(self):
         if self.handle:
@@ -398,6 +464,7 @@ class HipOps:
         else:
             self.stream = C.c_void_p(stream)
         self._counter = self._malloc(8 * CHANGED_SLOTS)
+        self._counter_set = None          # pinned slots for fetch_changed / wait_changed: this engine's own
         self.pitch_pad = int(os.environ.get("SIMRANK_PITCH_PAD", "96"))
 
     # ---- memory ----
@@ -596,6 +663,19 @@ class HipOps:
         assert out.dtype == np.float64 and out.flags.c_contiguous and not m.blocked
         check(self.lib.simrank_download_f64(out.ctypes.data, out.shape[1], m.ptr, m.ld, m.rows,
                                             m.cols, self.stream), "simrank_download_f64")
+        return out
+
+    def download_f64_sym(self, m: Matrix, idx: Matrix | None = None, out: np.ndarray | None = None) -> np.ndarray:
+        """BITWISE SYMMETRIC float32 device matrix (either layout) -> float64 host array with rows and columns taken
+        in the order ``idx`` (an ``index_vector``; None = as stored): out[i][j] = m[idx[i]][idx[j]].  Only the upper
+        triangle crosses PCIe; the host mirrors it while widening (csrc/handback.hip)."""
+        assert m.rows == m.cols and m.dtype == np.float32
+        if out is None:
+            out = np.empty((m.rows, m.cols), dtype=np.float64)
+        assert out.dtype == np.float64 and out.flags.c_contiguous and out.shape == (m.rows, m.cols)
+        check(self.lib.simrank_download_f64_sym(out.ctypes.data, out.shape[1], m.ptr, m.ld, m.rows_pad if m.blocked else 0,
+                                                m.rows, idx.ptr if idx is not None else None, self.stream),
+              "simrank_download_f64_sym")
         return out
 
     def copy(self, dst: Matrix, src: Matrix):
@@ -829,13 +909,17 @@ class HipOps:
 
     def fetch_changed(self, slot: int):
         """Queue the read-back of the convergence counter into pinned slot ``slot`` (0..3); the stream goes on."""
-        check(self.lib.simrank_counters_fetch(self._counter, CHANGED_SLOTS, int(slot), self.stream),
+        if self._counter_set is None:
+            h = C.c_void_p()
+            check(self.lib.simrank_counters_create(C.byref(h)), "simrank_counters_create")
+            self._counter_set = h
+        check(self.lib.simrank_counters_fetch(self._counter_set, self._counter, CHANGED_SLOTS, int(slot), self.stream),
               "simrank_counters_fetch")
 
     def wait_changed(self, slot: int) -> int:
         """The counter value a ``fetch_changed(slot)`` read: waits for that copy only."""
         total = C.c_ulonglong(0)
-        check(self.lib.simrank_counters_wait(int(slot), C.byref(total)), "simrank_counters_wait")
+        check(self.lib.simrank_counters_wait(self._counter_set, int(slot), C.byref(total)), "simrank_counters_wait")
         return int(total.value)
 
     # ---- timing (HIP events on the engine's own stream) ----
@@ -861,6 +945,9 @@ class HipOps:
 
     def close(self):
         """Release the stream and the counter (matrices and graphs free themselves)."""
+        if getattr(self, "_counter_set", None) is not None:
+            self.lib.simrank_counters_destroy(self._counter_set)
+            self._counter_set = None
         if getattr(self, "_counter", 0):
             if getattr(self, "_counter_t", None) is None:
                 self._free(self._counter)

@@ -72,13 +72,26 @@ def _precision(dense_precision, storage_precision="f32"):
 
 def _make_solver(ops_factory, device, world, specs, mode):
     """The solver with the graphs created at the precision asked for: it travels in the specs and is set
-    per graph object (simrank_graph_set_dense_terms), not through the process-wide tuning defaults."""
-    factory = ops_factory or _default_ops_factory(device)
+    per graph object (simrank_graph_set_dense_terms), not through the process-wide tuning defaults.
+
+    One rank, symmetric iterates, gather legs (every class the reference has, unless the prior is asymmetric): the loop
+    behind the C ABI (``cplan.PlanSolver`` over simrank_plan_* / simrank_biplan_*).  Everything else —
+    asymmetric priors, dense / hybrid modes, several ranks, the CPU tests' NumPy double — ``driver.Solver``;
+    fp16-held matrices on several ranks: ``cshard.CShardSolver``."""
+    from . import cplan
     dense, storage = _precision_now.__dict__.get("stack", [("f32", "f32")])[-1]
     terms = _DENSE_TERMS[dense]
     if terms != 3 or storage != "f32":
         specs = [dataclasses.replace(s, dense_terms=terms, storage=storage) for s in specs]
-    if storage == "fp16" and (world.size > 1 or not isinstance(world, LocalWorld)):
+    if world.size == 1 and not isinstance(world, LocalWorld) and storage == "fp16":
+        world = LocalWorld(1)            # (a one-rank process group: this process holds everything)
+    if cplan.applies(ops_factory, world, specs, mode):
+        ops = _default_ops_factory(device)(0)
+        if cplan.lean_knobs(ops):
+            return cplan.PlanSolver(ops, world, specs)
+        ops_factory = lambda rank: ops
+    factory = ops_factory or _default_ops_factory(device)
+    if storage == "fp16" and world.size > 1:
         # fp16-held matrices on SHARDS: the sharded loop behind the C ABI (csrc/shardplan.hip) — config 5 as stated
         from . import cshard
         why = cshard.applies(world, specs, mode)

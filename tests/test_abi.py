@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_string():
     lib = _lib.load()
-    assert lib.simrank_abi_version() == 5
+    assert lib.simrank_abi_version() == 6
     rc = lib.simrank_set_tuning(b"no_such_knob", 1)
     assert rc == -1 and b"no_such_knob" in lib.simrank_last_error()
     assert lib.simrank_set_tuning(b"panel", 48) == -1
@@ -103,6 +103,9 @@ int main(void) {
         if (simrank_shardplan_create(4, 0, NULL, NULL, NULL, &so, NULL, NULL, &sp) != SIMRANK_ERR_INVALID) return 6;
         if (simrank_shardplan_step(NULL, 0, 0.0, 1, NULL) != SIMRANK_ERR_INVALID) return 7;
         if (simrank_comm_local_group(0, NULL) != SIMRANK_ERR_INVALID) return 8;
+        if (simrank_plan_run_cb(NULL, 1, 0.0, NULL, NULL, NULL, NULL) != SIMRANK_ERR_INVALID) return 9;
+        if (simrank_download_f64_sym(NULL, 0, NULL, 0, 0, 4, NULL, NULL) != SIMRANK_ERR_INVALID) return 10;
+        if (simrank_counters_fetch(NULL, NULL, 0, 0, NULL) != SIMRANK_ERR_INVALID) return 11;
     }
     printf("abi %d ok\n", simrank_abi_version());
     return 0;
@@ -115,4 +118,4 @@ int main(void) {
                         capture_output=True, text=True)
     assert cc.returncode == 0, cc.stderr
     run = subprocess.run([str(exe)], capture_output=True, text=True)
-    assert run.returncode == 0 and "abi 5 ok" in run.stdout, (run.returncode, run.stdout, run.stderr)
+    assert run.returncode == 0 and "abi 6 ok" in run.stdout, (run.returncode, run.stdout, run.stderr)

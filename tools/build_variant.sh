@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_variants
 mkdir -p $OUT/obj_$TAG
 SRC=$ROOT/simrank_amd/csrc
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -I$SRC -fvisibility=hidden -DSIMRANK_BUILD"
-for f in api spmm dense blockdense fused half planprep plan biplan shardplan; do
+for f in api spmm dense blockdense fused half planprep plan biplan shardplan handback; do
   /opt/rocm/bin/hipcc $FLAGS "$@" -c $SRC/$f.hip -o $OUT/obj_$TAG/$f.o &
 done
 # experiments that lost their A/B live outside the product library (tools/experiments/): the persistent leg 1

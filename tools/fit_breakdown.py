@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Where the wall-clock of a whole fit goes (second call: allocator warm).
-    python3 tools/fit_breakdown.py [f32|fp16] [workload = pl65536] [pp|plain] [top10|full]"""
+    python3 tools/fit_breakdown.py [f32|fp16] [workload = pl65536] [pp|plain] [top10|full] [plan|python]
+(plan = cplan.PlanSolver, what fit() runs on one GPU since round 5; python = driver.Solver)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,6 +14,8 @@ ops = HipOps(0)
 wl = sys.argv[2] if len(sys.argv) > 2 else "pl65536"
 pp = (sys.argv[3] if len(sys.argv) > 3 else "pp") == "pp"
 full = (sys.argv[4] if len(sys.argv) > 4 else "top10") == "full"
+use_plan = (sys.argv[5] if len(sys.argv) > 5 else "plan") == "plan"
+from simrank_amd.cplan import PlanSolver
 df = synth.WORKLOADS[wl][0]()
 for rep in range(2):
     t = [time.perf_counter()]
@@ -22,7 +25,8 @@ for rep in range(2):
     _, csr = ingest.directed(df, False, "from", "to", "weight"); lap("ingest")
     spec = (SideSpec(csr, ingest.spread(csr) * csr.rowscale, 0.8, evidence_from=csr, storage=storage) if pp
             else SideSpec(csr, csr.rowscale, 0.8, storage=storage)); lap("spread weights")
-    s = Solver(lambda r: ops, LocalWorld(1), [spec], "auto"); lap("solver (graph, evidence, S)")
+    s = (PlanSolver(ops, LocalWorld(1), [spec]) if use_plan
+         else Solver(lambda r: ops, LocalWorld(1), [spec], "auto")); lap("solver (graph, evidence, S)")
     k = s.run(100, 1e-4); lap(f"run to eps (k={k})")
     if full:
         import pandas as pd

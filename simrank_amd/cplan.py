@@ -35,7 +35,8 @@ def applies(ops_factory, world, specs, mode) -> bool:
             return False             # (the two-matrix plan is f32 with exact products only)
         if (a.evidence_from is None) != (b.evidence_from is None):
             return False
-        if a.evidence_from is not None and (a.evidence_from is not a.csr or b.evidence_from not in (a.csr, b.csr)):
+        if a.evidence_from is not None and (a.evidence_from is not a.csr or
+                                            not (b.evidence_from is a.csr or b.evidence_from is b.csr)):
             return False
         if a.csr.n_rows != b.csr.n_cols or a.csr.n_cols != b.csr.n_rows or a.csr.nnz != b.csr.nnz:
             return False

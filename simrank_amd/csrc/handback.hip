@@ -1,16 +1,29 @@
 // Hand-back of a SYMMETRIC similarity matrix (SimRank.py:141, :303: `pd.DataFrame(new_S, ...)` — the float64 N x N
 // frame the reference returns): only the elements on or above the diagonal cross PCIe.
 //
-// A symmetric update leaves a BITWISE symmetric matrix behind (leg 2 computes the 32 x 32 tiles on or above the
-// diagonal and stores each strictly-upper tile a second time, transposed: spmm.hip kSym, half.hip SYM), and a renaming
-// of the nodes applied to rows and columns alike keeps it so.  The full hand-back moved both triangles: N^2 floats over
-// PCIe, a third of a config-4 fit (0.089 of 0.265 s).  Here the result is cut into row bands; band b
-// (rows r0 .. r1) is brought into the caller's order and packed on the device as the trapezoid [r0, r1) x [r0, N) —
-// one simrank_permute_layout per band —, copied into a pinned slab, and a crew of host threads widens it to float64
-// twice: dst[r][c] and, for c > r, dst[c][r].  Two device and two pinned slabs: band b + 1 travels while band b is
-// widened.  The threads split a band by COLUMN blocks, so the direct writes (rows of the band, their columns) and the
-// mirrored writes (their columns as rows) of two threads never meet; stores are non-temporal (the frame is written once
-// and is far larger than any cache).
+// A symmetric update in its upper-triangle form (spmm.hip kSym, half.hip SYM) computes the 32 x 32 tiles on or above the
+// diagonal and stores each strictly-upper tile a second time, transposed: outside the 32 x 32 blocks ON the diagonal of
+// the solver's node order the iterate is BITWISE symmetric (inside them both triangles are computed, each with its own
+// summation order: equal to rounding only), and a renaming of the nodes applied to rows and columns alike keeps it so.
+// The full hand-back moved both triangles: N^2 floats over PCIe, a third of a config-4 fit.  Here:
+//
+//   1. a kernel CHECKS the premise — every tile pair (I, J), I < J, of the source is compared with its mirror image
+//      (one pass over the matrix at memory rate: 1.5 ms of a 50 ms hand-back); a matrix that fails (the full-form leg 2
+//      of tuning triangle = 0 or of fewer than 64 nodes, any asymmetric iterate) takes the full hand-back instead: the
+//      result never depends on the premise, only the speed does;
+//   2. the result is cut into row bands; band b (rows r0 .. r1 of the CALLER's order) is packed on the device as the
+//      trapezoid [r0, r1) x [r0, N) — one simrank_permute_layout per band —, copied into a pinned slab, and a crew of host
+//      threads widens it to float64 twice: dst[r][c] and, for c > r, dst[c][r].  Two device and two pinned slabs: band
+//      b + 1 travels while band b is widened.  A thread owns GROUPS OF RESULT ROWS, the same ones in every band (widen_band):
+//      no two threads ever write the same row, a page of the frame is first touched by its owner; stores are
+//      non-temporal (the frame is written once and is far larger than any cache);
+//   3. the 32 x 32 diagonal blocks of the SOURCE order (N x 32 floats) come over by themselves and are written where the
+//      caller's order puts them, both triangles: what the bands mirrored there is replaced by the element itself.
+//
+// The outcome is, bit for bit, the full hand-back's (tests/test_gpu_product_path.py compares every element at N = 32768).
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -25,21 +38,68 @@ namespace simrank {
 namespace {
 
 constexpr int64_t kSlabBytes = int64_t(64) << 20;     // per pinned / device slab
-constexpr int64_t kTile = 64;                         // host threads work in 64 x 64 blocks
+constexpr int64_t kTile = 64;                         // the host transposes 64 x 64 blocks (16 KiB of floats: L1)
+constexpr int64_t kGroup = 8;                         // result rows a host thread owns together (2 MiB of a 32768-wide frame)
+constexpr int64_t kDiag = 32;                         // diagonal blocks of the source that are handed over whole
+
+__device__ __forceinline__ int64_t at(int64_t r, int64_t c, int64_t ld, int64_t rows_pad) {
+    return rows_pad ? ((c >> 5) * rows_pad + r) * 32 + (c & 31) : r * ld + c;
+}
+
+// flag |= 1 when some src[a][b] != src[b][a] (compared as bits) with a, b in different 32-blocks.  One workgroup per
+// tile pair I < J, through LDS so that both tiles are read along their rows.
+__global__ __launch_bounds__(256) void mirror_check_kernel(const uint32_t* __restrict__ src, int64_t ld, int64_t rows_pad,
+                                                           int64_t n, int64_t n_tiles, int32_t* __restrict__ flag) {
+    __shared__ uint32_t tile[32][33];
+    // pair index -> (I, J), I < J: row J of the strict lower triangle holds J entries
+    const int64_t p = blockIdx.x;
+    int64_t J = (int64_t)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5);
+    while (J * (J - 1) / 2 > p) --J;
+    while ((J + 1) * J / 2 <= p) ++J;
+    const int64_t I = p - J * (J - 1) / 2;
+    if (J >= n_tiles) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 8 rows per pass
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t a = I * 32 + r, b = J * 32 + tx;
+        tile[r][tx] = (a < n && b < n) ? src[at(a, b, ld, rows_pad)] : 0u;
+    }
+    __syncthreads();
+    bool bad = false;
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t b = J * 32 + r, a = I * 32 + tx;               // element (b, a) against (a, b) = tile[tx][r]
+        if (a < n && b < n) bad |= src[at(b, a, ld, rows_pad)] != tile[tx][r];
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
+// out[a][t] = src[a][32 (a / 32) + t]: the diagonal blocks, compact
+__global__ __launch_bounds__(256) void diag_blocks_kernel(const float* __restrict__ src, int64_t ld, int64_t rows_pad, int64_t n,
+                                                          float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t a = i >> 5, t = i & 31;
+    if (a >= n) return;
+    const int64_t b = (a >> 5) * 32 + t;
+    out[i] = b < n ? src[at(a, b, ld, rows_pad)] : 0.f;
+}
 
 struct Band {
     int64_t r0 = 0, nr = 0;          // rows [r0, r0 + nr) of the result; columns [r0, n): width n - r0
-};
+    int64_t pitch = 0;               // floats per packed row: the width rounded up to an ODD number of 64-byte lines — a
+};                                   // power-of-two pitch sends the 64 rows of a block to ONE set of the L1 and L2
 
-// rows of a band: as many as fit a slab, a multiple of kTile (the last band takes what is left)
+int64_t odd_lines(int64_t w) {
+    int64_t lines = (w + 15) / 16;
+    if (!(lines & 1)) ++lines;
+    return lines * 16;
+}
+
 std::vector<Band> cut_bands(int64_t n) {
     std::vector<Band> bands;
     for (int64_t r0 = 0; r0 < n;) {
-        const int64_t w = n - r0;
-        int64_t nr = std::max<int64_t>(kTile, (kSlabBytes / 4 / w) / kTile * kTile);
-        // (a band may not be wider than tall beyond the slab: with nr rows it holds nr * w floats)
+        const int64_t pitch = odd_lines(n - r0);
+        int64_t nr = std::max<int64_t>(kTile, (kSlabBytes / 4 / pitch) / kTile * kTile);
         nr = std::min(nr, n - r0);
-        bands.push_back({r0, nr});
+        bands.push_back({r0, nr, pitch});
         r0 += nr;
     }
     return bands;
@@ -55,29 +115,49 @@ Slabs g_slabs[16];
 
 inline void store_nt(double* p, double v) { __builtin_nontemporal_store(v, p); }
 
-// one thread's share of a band: column blocks jb = t, t + nt, ...
+// one thread's share of a band: the GROUPS of kGroup consecutive result rows g = t, t + nt, ... (the same rows in every
+// band: a thread always writes the same pages of the frame — its first touches do not queue behind 63 others on one
+// transparent huge page, which is what a split of the band by column blocks cost: 380 ms instead of 40 at N = 32768 —
+// and they stay on its NUMA node).  A row R at or below the band's first row receives from this band
+//   * mirrored: dst[R][r0 + i] = slab[i][R - r0] for the band rows i above it (i < R - r0): one run of up to nr doubles,
+//     read down a column of the slab, 64 band rows at a time (8 x 64 floats: the lines stay in the L1);
+//   * direct (R inside the band): dst[R][R .. n) = slab[R - r0][R - r0 .. w): one long run.
 void widen_band(const float* slab, const Band& b, int64_t n, double* dst, int64_t ld, int64_t t, int64_t nt) {
     const int64_t w = n - b.r0;
-    const int64_t col_blocks = (w + kTile - 1) / kTile, row_blocks = (b.nr + kTile - 1) / kTile;
-    for (int64_t jb = t; jb < col_blocks; jb += nt) {
-        const int64_t j0 = jb * kTile, j1 = std::min(w, j0 + kTile);
-        for (int64_t ib = 0; ib < row_blocks && ib <= jb; ++ib) {       // (blocks left of the diagonal: nothing to do)
-            const int64_t i0 = ib * kTile, i1 = std::min(b.nr, i0 + kTile);
-            const bool diag = ib == jb;
-            // direct: rows of the band, this thread's columns
-            for (int64_t i = i0; i < i1; ++i) {
-                const float* s = slab + i * w;
-                double* d = dst + (b.r0 + i) * ld + b.r0;
-                for (int64_t j = diag ? std::max(j0, i) : j0; j < j1; ++j) store_nt(d + j, (double)s[j]);
-            }
-            // mirrored: this thread's columns as rows (strictly below the diagonal of the result)
+    const int64_t g0 = b.r0 / kGroup, g_end = (n + kGroup - 1) / kGroup;       // (r0 is a multiple of kTile)
+    for (int64_t g = g0 + ((t - g0 % nt) % nt + nt) % nt; g < g_end; g += nt) {
+        const int64_t j0 = g * kGroup - b.r0, j1 = std::min(n, (g + 1) * kGroup) - b.r0;
+        const int64_t imax = std::min(b.nr, j1 - 1);                              // band rows above the group's last row
+        for (int64_t ic = 0; ic < imax; ic += kTile) {
+            const int64_t ie = std::min(imax, ic + kTile);
             for (int64_t j = j0; j < j1; ++j) {
                 double* d = dst + (b.r0 + j) * ld + b.r0;
                 const float* s = slab + j;
-                for (int64_t i = i0; i < (diag ? std::min(i1, j) : i1); ++i) store_nt(d + i, (double)s[i * w]);
+                const int64_t iend = std::min(ie, j);
+                for (int64_t i = ic; i < iend; ++i) store_nt(d + i, (double)s[i * b.pitch]);
             }
         }
+        for (int64_t j = j0; j < std::min(j1, b.nr); ++j) {
+            const float* s = slab + j * b.pitch;
+            double* d = dst + (b.r0 + j) * ld + b.r0;
+            for (int64_t c = j; c < w; ++c) store_nt(d + c, (double)s[c]);
+        }
     }
+}
+
+// the full hand-back: one permute into a row-major copy, every element over PCIe
+int full_handback(double* dst, int64_t ld_dst, const float* src, int64_t ld_src, int64_t src_rows_pad, int64_t n,
+                  const int32_t* idx, hipStream_t st) {
+    if (!idx && src_rows_pad == 0) return simrank_download_f64(dst, ld_dst, src, ld_src, n, n, st);
+    float* tmp = nullptr;
+    const int64_t ldt = (n + 3) / 4 * 4;
+    int rc = pool_alloc((void**)&tmp, size_t(n) * size_t(ldt) * sizeof(float));
+    if (rc) return rc;
+    rc = simrank_permute_layout(src, ld_src, src_rows_pad, tmp, ldt, 0, n, n, idx, idx, 4, st);
+    if (!rc) rc = simrank_download_f64(dst, ld_dst, tmp, ldt, n, n, st);
+    (void)hipStreamSynchronize(st);
+    (void)pool_free(tmp);
+    return rc;
 }
 
 }  // namespace
@@ -95,10 +175,69 @@ int simrank_download_f64_sym(double* dst, int64_t ld_dst, const float* src, int6
     const bool timed = std::getenv("SIMRANK_TIME_HANDBACK") != nullptr;
     const auto t_start = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    hipStream_t st = as_stream(stream);
+    if (n <= 2 * kDiag || n > (int64_t(1) << 20) || std::getenv("SIMRANK_FULL_HANDBACK"))    // (nothing to save; beyond any
+        return full_handback(dst, ld_dst, src, ld_src, src_rows_pad, n, idx, st);   // dense hand-back; the benches' A/B switch)
+
+    // ---- 1. the premise, checked: mirror-equal outside the diagonal blocks?
+    const int64_t n_tiles = (n + 31) / 32, n_pairs = n_tiles * (n_tiles - 1) / 2;
+    int32_t* flag = nullptr;
+    float* diag_dev = nullptr;
+    {
+        const int rc = pool_alloc((void**)&flag, 64);
+        if (rc) return rc;
+    }
+    auto cleanup_small = [&] { (void)pool_free(flag); (void)pool_free(diag_dev); };
+    {
+        hipError_t e = hipMemsetAsync(flag, 0, 4, st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(mirror_check_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, (const uint32_t*)src, ld_src,
+                               src_rows_pad, n, n_tiles, flag);
+            e = hipGetLastError();
+        }
+        int32_t bad = 1;
+        if (e == hipSuccess) e = hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            cleanup_small();
+            set_error("simrank_download_f64_sym (symmetry check): %s", hipGetErrorString(e));
+            return SIMRANK_ERR_HIP;
+        }
+        if (bad) {
+            cleanup_small();
+            if (timed) std::fprintf(stderr, "simrank_download_f64_sym: not mirror-equal: full hand-back\n");
+            return full_handback(dst, ld_dst, src, ld_src, src_rows_pad, n, idx, st);
+        }
+    }
+    const double t_checked = since();
+
+    // ---- 3 (queued first: small). the diagonal blocks of the source order and the order itself
+    std::vector<float> diag((size_t)n * kDiag);
+    std::vector<int32_t> pos;                     // pos[i] = source position of caller's node i
+    {
+        int rc = pool_alloc((void**)&diag_dev, size_t(n) * kDiag * sizeof(float));
+        if (rc) { cleanup_small(); return rc; }
+        hipLaunchKernelGGL(diag_blocks_kernel, dim3((unsigned)((n * kDiag + 255) / 256)), dim3(256), 0, st, src, ld_src,
+                           src_rows_pad, n, diag_dev);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(diag.data(), diag_dev, size_t(n) * kDiag * sizeof(float), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && idx) {
+            pos.resize((size_t)n);
+            e = hipMemcpyAsync(pos.data(), idx, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            cleanup_small();
+            set_error("simrank_download_f64_sym (diagonal blocks): %s", hipGetErrorString(e));
+            return SIMRANK_ERR_HIP;
+        }
+    }
+
+    // ---- 2. the bands
     const std::vector<Band> bands = cut_bands(n);
     const int64_t nb = (int64_t)bands.size();
     size_t need = 0;
-    for (const Band& b : bands) need = std::max(need, size_t(b.nr) * size_t(n - b.r0) * 4);
+    for (const Band& b : bands) need = std::max(need, size_t(b.nr) * size_t(b.pitch) * 4);
     int dev = 0;
     SR_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_slab_mutex);      // (one symmetric hand-back per process at a time: it uses every core)
@@ -119,28 +258,34 @@ int simrank_download_f64_sym(double* dst, int64_t ld_dst, const float* src, int6
         const int rc = pool_alloc((void**)&dev_slab[i], need);
         if (rc) {
             (void)pool_free(dev_slab[0]);
+            cleanup_small();
             return rc;
         }
     }
-    hipStream_t st = as_stream(stream);
+    // the frame is written once, front to back, by many threads: ask for huge pages where the system leaves it to the
+    // caller (transparent_hugepage = madvise): 4 k first-touch faults instead of 2 M at N = 32768.  A hint, nothing more.
+    if (ld_dst == n && n >= 4096) {
+        const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+        const uintptr_t lo = ((uintptr_t)dst + page - 1) / page * page, hi = ((uintptr_t)(dst + n * n)) / page * page;
+        if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_HUGEPAGE);
+    }
     // band b: packed trapezoid in the caller's order on the device, then into its pinned slab
     auto issue = [&](int64_t b) -> int {
         const Band& bd = bands[(size_t)b];
         const int64_t w = n - bd.r0;
         const float* s = src;
         const int32_t* ri = idx ? idx + bd.r0 : nullptr;
-        if (!idx) {
-            // identity order: the band starts at (r0, r0) of the source.  Panel-blocked: r0 is a multiple of 32 (kTile)
+        if (!idx)       // identity order: the band starts at (r0, r0) of the source (r0 is a multiple of 64)
             s = src_rows_pad > 0 ? src + ((bd.r0 >> 5) * src_rows_pad + bd.r0) * 32 : src + bd.r0 * ld_src + bd.r0;
-        }
-        int rc = simrank_permute_layout(s, ld_src, src_rows_pad, dev_slab[b & 1], w, 0, bd.nr, w, ri, ri, 4, st);
+        int rc = simrank_permute_layout(s, ld_src, src_rows_pad, dev_slab[b & 1], bd.pitch, 0, bd.nr, w, ri, ri, 4, st);
         if (rc) return rc;
-        SR_HIP(hipMemcpyAsync(sl.pin[b & 1], dev_slab[b & 1], size_t(bd.nr) * size_t(w) * 4, hipMemcpyDeviceToHost, st));
+        SR_HIP(hipMemcpyAsync(sl.pin[b & 1], dev_slab[b & 1], size_t(bd.nr) * size_t(bd.pitch) * 4, hipMemcpyDeviceToHost, st));
         SR_HIP(hipEventRecord(sl.done[b & 1], st));
         return SIMRANK_OK;
     };
     // the crew: every thread takes its column blocks of every band, in band order
-    const int64_t nt = std::max<int64_t>(1, std::min<int64_t>({32, (int64_t)std::thread::hardware_concurrency(), (n + kTile - 1) / kTile,
+    const int64_t hc = std::max<int64_t>(1, (int64_t)std::thread::hardware_concurrency());
+    const int64_t nt = std::max<int64_t>(1, std::min<int64_t>({64, hc > 8 ? hc / 2 : hc, (n + 4 * kGroup - 1) / (4 * kGroup),
                                                                std::max<int64_t>(1, (n * n) >> 18)}));
     std::mutex m;
     std::condition_variable cv;
@@ -204,9 +349,36 @@ int simrank_download_f64_sym(double* dst, int64_t ld_dst, const float* src, int6
     (void)hipStreamSynchronize(st);
     (void)pool_free(dev_slab[0]);
     (void)pool_free(dev_slab[1]);
+    cleanup_small();
+    const double t_bands = since();
+    // ---- 3. the diagonal blocks of the source order, both triangles, where the caller's order puts them
+    if (!rc) {
+        std::vector<int32_t> node;               // node[a] = caller's node at source position a
+        if (idx) {
+            node.resize((size_t)n);
+            for (int64_t i = 0; i < n; ++i) node[(size_t)pos[(size_t)i]] = (int32_t)i;
+        }
+        auto patch = [&](int64_t a0, int64_t a1) {
+            for (int64_t a = a0; a < a1; ++a) {
+                const int64_t base = (a / kDiag) * kDiag, i = idx ? node[(size_t)a] : a;
+                double* d = dst + i * ld_dst;
+                const float* s = diag.data() + a * kDiag;
+                for (int64_t t = 0; t < kDiag && base + t < n; ++t) d[idx ? node[(size_t)(base + t)] : base + t] = (double)s[t];
+            }
+        };
+        const int64_t pt = std::max<int64_t>(1, std::min<int64_t>(nt, n / 1024));
+        if (pt == 1) {
+            patch(0, n);
+        } else {
+            std::vector<std::thread> ts;
+            for (int64_t t = 0; t < pt; ++t) ts.emplace_back(patch, n * t / pt, n * (t + 1) / pt);
+            for (std::thread& th : ts) th.join();
+        }
+    }
     if (timed)
-        std::fprintf(stderr, "simrank_download_f64_sym: n %lld, %lld bands, %lld threads: %.1f ms (waiting for the device %.1f, "
-                             "for the host crew %.1f)\n", (long long)n, (long long)nb, (long long)nt, since(), t_wait_dev, t_wait_host);
+        std::fprintf(stderr, "simrank_download_f64_sym: n %lld, %lld bands, %lld threads: %.1f ms (symmetry check %.1f, bands %.1f — "
+                             "waiting for the device %.1f, for the host crew %.1f —, diagonal blocks %.1f)\n", (long long)n,
+                     (long long)nb, (long long)nt, since(), t_checked, t_bands - t_checked, t_wait_dev, t_wait_host, since() - t_bands);
     return rc;
 }
 

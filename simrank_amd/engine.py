@@ -12,7 +12,7 @@ import threading
 
 import numpy as np
 
-from . import _lib
+from . import _lib, hostpool
 from ._lib import Epilogue, SimRankHipError, check
 from .ingest import CSR
 
@@ -185,7 +185,7 @@ class Plan:
         return c.value
 
     def result(self) -> np.ndarray:
-        out = np.empty((self.n, self.n), dtype=np.float64)
+        out = hostpool.empty_f64(self.n, self.n)        # (a frame the caller dropped earlier, when there is one)
         check(self.ops.lib.simrank_plan_result_f64(self.handle, out.ctypes.data, self.n), "simrank_plan_result_f64")
         return out
 
@@ -301,7 +301,7 @@ class ShardPlans:
 
     def result(self, root: int = 0, i_am_root: bool = True):
         """The whole matrix (float64, caller's order) on rank ``root``; None elsewhere.  Collective."""
-        out = np.empty((self.n, self.n), dtype=np.float64) if i_am_root else None
+        out = hostpool.empty_f64(self.n, self.n) if i_am_root else None
         check(self.ops.lib.simrank_shardplan_result_f64(self._arr, len(self.plans), int(root),
                                                         out.ctypes.data if out is not None else None, self.n),
               "simrank_shardplan_result_f64")
@@ -382,7 +382,7 @@ class BiPlan:
 
     def result_group(self, group: int) -> np.ndarray:
         n = self.n1 if group == 1 else self.n2
-        m = np.empty((n, n), dtype=np.float64)
+        m = hostpool.empty_f64(n, n)
         check(self.ops.lib.simrank_biplan_result_f64(self.handle, group, m.ctypes.data, n), "simrank_biplan_result_f64")
         return m
 
@@ -484,8 +484,10 @@ class HipOps:
 
     @classmethod
     def trim_pool(cls, device: int | None = None):
-        """Give the library's cached device blocks back to the driver (all devices, or one)."""
+        """Give the library's cached device blocks back to the driver (all devices, or one), and the host frames at rest
+        (hostpool.py) back to the system."""
         _lib.load().simrank_pool_trim(-1 if device is None else int(device))
+        hostpool.trim()
 
     @classmethod
     def pool_stats(cls, device: int | None = None):
@@ -659,7 +661,7 @@ class HipOps:
     def download_f64(self, m: Matrix, out: np.ndarray | None = None) -> np.ndarray:
         """float32 device matrix -> float64 host array (pinned, pipelined staging)."""
         if out is None:
-            out = np.empty((m.rows, m.cols), dtype=np.float64)
+            out = hostpool.empty_f64(m.rows, m.cols)
         assert out.dtype == np.float64 and out.flags.c_contiguous and not m.blocked
         check(self.lib.simrank_download_f64(out.ctypes.data, out.shape[1], m.ptr, m.ld, m.rows,
                                             m.cols, self.stream), "simrank_download_f64")
@@ -671,7 +673,7 @@ class HipOps:
         triangle crosses PCIe; the host mirrors it while widening (csrc/handback.hip)."""
         assert m.rows == m.cols and m.dtype == np.float32
         if out is None:
-            out = np.empty((m.rows, m.cols), dtype=np.float64)
+            out = hostpool.empty_f64(m.rows, m.cols)
         assert out.dtype == np.float64 and out.flags.c_contiguous and out.shape == (m.rows, m.cols)
         check(self.lib.simrank_download_f64_sym(out.ctypes.data, out.shape[1], m.ptr, m.ld, m.rows_pad if m.blocked else 0,
                                                 m.rows, idx.ptr if idx is not None else None, self.stream),

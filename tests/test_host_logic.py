@@ -386,3 +386,43 @@ def test_storage_precision_is_validated_on_the_host():
                                    storage_precision="fp16", world=LocalWorld(2), _ops_factory=lambda r: NumpyOps())
     ok = SRA.SimRank().fit(df, verbose=False, storage_precision="f32", _ops_factory=lambda r: NumpyOps())
     assert ok.shape == (4, 4)
+
+
+def test_host_frames_come_back_when_the_last_view_is_gone(monkeypatch):
+    """hostpool: the float64 frame of a dense hand-back is a mapping of the library's own that returns to a pool when
+    the caller's last reference to the array AND to every view of it (a DataFrame holds one) is gone, and is handed out
+    again for the next result of that size; SIMRANK_HOST_POOL_GIB bounds what rests, 0 disables."""
+    import gc
+    from simrank_amd import hostpool as hp
+    monkeypatch.setattr(hp, "MIN_BYTES", 1 << 10)
+    hp.trim()
+    a = hp.empty_f64(300, 300)
+    assert a.shape == (300, 300) and a.dtype == np.float64 and a.flags.c_contiguous and a.flags.writeable
+    a[:] = 7.0
+    frame = pd.DataFrame(a, index=range(300), columns=range(300))
+    del a
+    gc.collect()
+    assert hp.stats() == (0, 0)                       # the frame still holds it
+    view = frame.values[5:9]
+    del frame
+    gc.collect()
+    assert hp.stats() == (0, 0) and view[0, 0] == 7.0   # ... and so does a slice the caller kept
+    del view
+    gc.collect()
+    assert hp.stats() == (300 * 300 * 8, 1)
+    b = hp.empty_f64(300, 300)
+    assert hp.stats() == (0, 0) and b[0, 0] == 7.0    # the same pages (np.empty semantics: contents are arbitrary)
+    c = hp.empty_f64(300, 300)                        # a second one while the first is out: a new mapping
+    c[:] = 1.0
+    assert b[0, 0] == 7.0
+    del b, c
+    gc.collect()
+    assert hp.stats()[1] == 2
+    hp.trim()
+    assert hp.stats() == (0, 0)
+    monkeypatch.setenv("SIMRANK_HOST_POOL_GIB", "0")
+    d = hp.empty_f64(300, 300)
+    assert d.flags.owndata                            # plain np.empty
+    monkeypatch.setenv("SIMRANK_HOST_POOL_GIB", "0.0001")     # ~107 kB: a 720 kB frame is not kept
+    e = hp.empty_f64(300, 300)
+    assert e.flags.owndata

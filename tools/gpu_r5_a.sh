@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
 O=gpurun_out/r5a.log
 : > $O
-free -g | head -2 >> $O; nproc >> $O
+free -g | head -2 >> $O; nproc >> $O; cat /sys/kernel/mm/transparent_hugepage/enabled >> $O 2>&1
 timeout -k 10 900 python -m pytest tests/test_gpu_product_path.py -x -q -m gpu 2>&1 | tail -30 >> $O || { tail -40 $O; exit 1; }
 echo "== breakdown plan ==" >> $O
 SIMRANK_TIME_HANDBACK=1 timeout -k 10 300 python tools/fit_breakdown.py f32 pl32768d32 plain full plan >> $O 2>&1 || { tail -40 $O; exit 1; }

@@ -236,35 +236,53 @@ def main():
     # The headline is timed with the EXACT count of moved elements in every step: every element of S' is
     # compared with the previous iterate, as `_converged` (SimRank.py:74-77) literally does.  What fit()
     # runs by default — the short-circuit form of the same test — is timed afterwards and reported beside it.
+    # One GPU, gather legs: the loop behind the C ABI (simrank_plan_step: what fit() runs since round 5, cplan.PlanSolver),
+    # its legs stamped with HIP events on the plan's own stream.  Several ranks / GEMM modes: driver.Solver.
+    plan = None
+    terms_now = 1 if args.dense_precision == "fp16" else 3
+    if gpu and not use_dist and solver.mode == "sparse" and getattr(solver, "blocked", False):
+        from simrank_amd.engine import Plan
+        spec0 = make_spec(csr, args.pp, terms_now)
+        plan = Plan(ops, csr, spec0.rowscale, coef=coef, evidence=args.pp, dense_terms=terms_now)
     solver.exact_count = True
-    for _ in range(args.warmup):
-        solver.step(0.0)
-    solver.enable_timing(args.steps)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        solver.step(0.0)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if gpu else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    legs = solver.leg_times()                 # mean ms per launch, measured by HIP events
-    solver.events = None
-    # the same steps with the short-circuit convergence test (the product default)
     short_ms = None
-    if gpu and solver.mode == "sparse" and world_size == 1 and not args.exact_only:
-        solver.exact_count = False
-        solver.step(0.0)
+    if plan is not None:
+        for _ in range(args.warmup):
+            plan.step(0.0, exact_count=True)
+        plan.set_timing(args.steps)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            plan.step(0.0, exact_count=True)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        l1p, l2p, n_stamped = plan.leg_times()
+        plan.set_timing(0)
+        legs = {"leg1.0": (l1p, n_stamped), "leg2.0": (l2p, n_stamped)}
+        if not args.exact_only:
+            plan.step(0.0, exact_count=False)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                plan.step(0.0, exact_count=False)
+            barrier()
+            short_ms = (time.perf_counter() - t0) / args.steps * 1e3
+    else:
+        for _ in range(args.warmup):
+            solver.step(0.0)
+        solver.enable_timing(args.steps)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             solver.step(0.0)
         barrier()
-        short_ms = (time.perf_counter() - t0) / args.steps * 1e3
-        solver.exact_count = True
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if gpu else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        legs = solver.leg_times()                 # mean ms per launch, measured by HIP events
+        solver.events = None
     side = solver.sides[0][rank if use_dist else 0]
     side_stages = side.n_stages
     out = {
@@ -279,6 +297,8 @@ def main():
                                f"{' with fp16 dense blocks' if args.dense_precision == 'fp16' else ''}, "
                                f"eps test every iteration (every element compared, exact count)",
                    "N": n, "nnz": nnz, "mode": solver.mode,
+                   "loop": ("simrank_plan_step behind the C ABI (csrc/plan.hip): what fit() runs on one GPU" if plan is not None
+                            else "driver.Solver.step (Python choreography over the C ABI's kernels)"),
                    "layout": "panel-blocked (32-column panels)" if getattr(solver, "blocked", False) else "row-major",
                    "sharding": f"S column-sharded over {world_size} rank(s), all-to-all per update"
                                + (f" in {side_stages} overlapped stage(s)" if use_dist else "")
@@ -471,7 +491,7 @@ def main():
         # wall-clock to converge with the reference's defaults (eps = 1e-4)
         barrier()
         t0 = time.perf_counter()
-        k = solver.run(100, 1e-4)
+        k = plan.run(100, 1e-4)[1] if plan is not None else solver.run(100, 1e-4)
         barrier()
         out["converge"] = {"eps": 1e-4, "iterations": k, "seconds": time.perf_counter() - t0}
 
@@ -536,7 +556,7 @@ def main():
                 "leg2_algorithmic_GBps": leg_bytes(n2, n2, n2, z2, True, triangle=True)
                                          / (lt["leg2.0"][0] * 1e-3) / 1e9}
             try:
-                # the loop fit() runs (Solver.run: update k + 1 queued before the count of update k is read)
+                # the Python driver's loop (Solver.run: update k + 1 queued before the count of update k is read)
                 s2.events = None
                 s2.run(5, 0.0)
                 ops.synchronize()
@@ -544,26 +564,44 @@ def main():
                 s2.run(100, 0.0)
                 ops.synchronize()
                 dtf = (time.perf_counter() - t0) / 100
-                out["secondary"]["fit_loop"] = {"value": 1.0 / dtf, "unit": "iterations/s", "ms_per_step": dtf * 1e3,
-                                                "note": "Solver.run, 100 updates, eps = 0: the loop of fit(), count of "
-                                                        "every update read one update late"}
+                out["secondary"]["python_driver_loop"] = {"value": 1.0 / dtf, "unit": "iterations/s", "ms_per_step": dtf * 1e3,
+                                                          "note": "driver.Solver.run, 100 updates, eps = 0 (what fit() ran until round 4)"}
             except Exception as e:
-                out["secondary"]["fit_loop"] = {"error": f"{type(e).__name__}: {e}"}
-            try:
-                # the same loop behind the C ABI (simrank_plan_run: update k + 1 queued before the count of
-                # update k is read, no Python between the launches)
-                from simrank_amd.engine import Plan
-                plan = Plan(ops, csr2, coef=coef)
-                plan.run(5, 0.0)
-                ops.synchronize()
-                t0 = time.perf_counter()
-                plan.run(100, 0.0)
-                dtp = (time.perf_counter() - t0) / 100
-                out["secondary"]["c_plan"] = {"value": 1.0 / dtp, "unit": "iterations/s", "ms_per_step": dtp * 1e3,
-                                              "note": "simrank_plan_run, 100 updates, eps = 0 (count read every update)"}
-                plan.free()
-            except Exception as e:
-                out["secondary"]["c_plan"] = {"error": f"{type(e).__name__}: {e}"}
+                out["secondary"]["python_driver_loop"] = {"error": f"{type(e).__name__}: {e}"}
+            if gpu:
+                try:
+                    # what fit() runs: the loop behind the C ABI with the reference's console hooks attached
+                    # (cplan.PlanSolver -> simrank_plan_run_cb: update k + 1 queued before the count of update k is read)
+                    from simrank_amd.cplan import PlanSolver
+                    ps = PlanSolver(ops, LocalWorld(1), [SideSpec(csr2, csr2.rowscale, coef)])
+                    ps.run(5, 0.0)
+                    ops.synchronize()
+                    ticks = []
+                    t0 = time.perf_counter()
+                    ps.run(100, 0.0, on_iteration=ticks.append)
+                    dtp = (time.perf_counter() - t0) / 100
+                    out["secondary"]["fit_loop"] = {"value": 1.0 / dtp, "unit": "iterations/s", "ms_per_step": dtp * 1e3,
+                                                    "note": "cplan.PlanSolver.run = simrank_plan_run_cb, 100 updates, eps = 0, a "
+                                                            "progress hook called every loop index: the loop of fit()"}
+                    # the same plan step by step with the exact count, legs stamped on its stream
+                    pl2 = ps.plan
+                    pl2.reset()
+                    for _ in range(3):
+                        pl2.step(0.0, exact_count=True)
+                    pl2.set_timing(50)
+                    ops.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(50):
+                        pl2.step(0.0, exact_count=True)
+                    ops.synchronize()
+                    dts = (time.perf_counter() - t0) / 50
+                    a1, a2, _n = pl2.leg_times()
+                    out["secondary"]["c_plan_steps"] = {"value": 1.0 / dts, "unit": "iterations/s", "ms_per_step": dts * 1e3,
+                                                        "leg1_ms": a1, "leg2_ms": a2,
+                                                        "note": "simrank_plan_step x 50, exact count read every update"}
+                    ps.plan.free()
+                except Exception as e:
+                    out["secondary"]["fit_loop"] = {"error": f"{type(e).__name__}: {e}"}
             if rank == 0 and not args.no_cpu_baseline:
                 # the oracle on the whole N=8192 workload (no sampling needed at this size)
                 from oracle import simrank_oracle as O
@@ -608,25 +646,43 @@ def main():
                             f"{g12.n_cols}, nnz={g12.nnz}, BipartiteSimRankPP C1=C2=0.8 fp32",
                 "value": 1.0 / dt, "unit": "iterations/s", "ms_per_step": dt * 1e3,
                 "legs_ms": {k: v[0] for k, v in s3.leg_times().items()},
+                "legs_ms_note": "HIP events of the Python driver's launches of the same kernels (the C loop queues them "
+                                "back to back)",
                 "entries_in_dense_sets": [c / max(1, g12.nnz) for _, _, c in st3]}
             s3.release()
             del s3
             if gpu:
-                # the same loop behind the C ABI (simrank_biplan_run: iteration k + 1 queued before the counts of
-                # iteration k are read); 50 loop bodies with eps = 0: the counts are read every iteration
-                from simrank_amd.engine import BiPlan
+                # what BipartiteSimRankPP.fit() runs: the loop behind the C ABI (cplan.PlanSolver -> simrank_biplan_run_cb:
+                # iteration k + 1 queued before the counts of iteration k are read); 50 loop bodies with eps = 0, a
+                # progress hook called every loop index; then 10 loop bodies step by step with the exact counts
+                from simrank_amd.cplan import PlanSolver
                 t0 = time.perf_counter()
-                bp = BiPlan(ops, g12, g12.rowscale, g21.rowscale, c1=coef, c2=coef, evidence=True)
+                ps3 = PlanSolver(ops, LocalWorld(1), [SideSpec(g12, g12.rowscale, coef, evidence_from=g12),
+                                                      SideSpec(g21, g21.rowscale, coef, evidence_from=g21)])
                 ops.synchronize()
                 setup_s = time.perf_counter() - t0
-                bp.run(5, 0.0)
+                ps3.run(5, 0.0)
+                ticks = []
                 t0 = time.perf_counter()
-                done, _ = bp.run(50, 0.0)
-                dt_p = (time.perf_counter() - t0) / max(1, done)
+                ps3.run(50, 0.0, on_iteration=ticks.append)
+                dt_p = (time.perf_counter() - t0) / 50
+                bp = ps3.plan
+                bp.reset()
+                bp.step(0.0, True)
+                ops.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    bp.step(0.0, True)
+                dt_s = (time.perf_counter() - t0) / 10
                 bp.free()
-                out["bipartite_pp"]["c_biplan"] = {"value": 1.0 / dt_p, "unit": "iterations/s", "ms_per_step": dt_p * 1e3,
+                out["bipartite_pp"]["python_driver"] = {k: out["bipartite_pp"][k] for k in ("value", "unit", "ms_per_step")}
+                out["bipartite_pp"]["python_driver"]["note"] = "driver.Solver.step x 10 (what fit() ran until round 4)"
+                out["bipartite_pp"].update({"value": 1.0 / dt_s, "ms_per_step": dt_s * 1e3,
+                                            "loop": "simrank_biplan_step x 10, exact counts read every loop body (the C loop fit() runs)"})
+                out["bipartite_pp"]["fit_loop"] = {"value": 1.0 / dt_p, "unit": "iterations/s", "ms_per_step": dt_p * 1e3,
                                                    "setup_s": setup_s,
-                                                   "note": "simrank_biplan_run, 50 loop bodies, eps = 0"}
+                                                   "note": "cplan.PlanSolver.run = simrank_biplan_run_cb, 50 loop bodies, eps = 0, "
+                                                           "progress hook every loop index: the loop of BipartiteSimRankPP.fit()"}
         except Exception as e:
             out["bipartite_pp"] = {"error": f"{type(e).__name__}: {e}"}
 
@@ -756,6 +812,12 @@ def main():
 
             df4 = synth.WORKLOADS["pl32768d32"][0]()
             timed_fit("cfg4_SimRank_pl32768d32_full_handback", SRA.SimRank, df4)
+            try:
+                # A/B of the hand-back: both triangles over PCIe (round 4's path, kept behind an environment switch)
+                os.environ["SIMRANK_FULL_HANDBACK"] = "1"
+                timed_fit("cfg4_SimRank_pl32768d32_both_triangles_over_pcie", SRA.SimRank, df4)
+            finally:
+                os.environ.pop("SIMRANK_FULL_HANDBACK", None)
             try:
                 # the same fit through the C-level plan: create (graph + plans + matrices), run to eps, f64 hand-back
                 from simrank_amd.engine import Plan
@@ -897,7 +959,12 @@ def main():
             out["cpu_baseline"] = None
             out["cpu_baseline_note"] = f"skipped: needs {need / 2**30:.0f} GiB host RAM"
         else:
-            S_host = solver.result(0)
+            if plan is not None:
+                plan.run(3, 0.0)
+                S_host = plan.result()
+                plan.free()
+            else:
+                S_host = solver.result(0)
             solver.release()
             out["cpu_baseline"] = cpu_baseline(csr, S_host, coef)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -452,6 +452,12 @@ SIMRANK_API int simrank_plan_trim(simrank_plan* p);
  * PCIe instead of n^2 */
 SIMRANK_API int simrank_plan_topk(simrank_plan* p, int32_t k, int32_t exclude_diag, int32_t* idx_host,
                                   float* val_host);
+/* measurement: HIP events on the plan's own stream around both legs of the next `updates` updates (created at this call,
+ * outside the timed region; 0 = off); simrank_plan_leg_times drains the stream and returns the mean duration of leg 1
+ * (first .dot of SimRank.py:139) and of leg 2 (second .dot + :140 + :74) over the updates stamped since — what bench.py's
+ * roofline.achieved is computed from */
+SIMRANK_API int simrank_plan_set_timing(simrank_plan* p, int32_t updates);
+SIMRANK_API int simrank_plan_leg_times(simrank_plan* p, double* leg1_ms, double* leg2_ms, int32_t* updates);
 SIMRANK_API int simrank_plan_info(const simrank_plan* p, int64_t* n, int32_t* updates, const simrank_graph** graph);
 SIMRANK_API int simrank_plan_destroy(simrank_plan* p);
 

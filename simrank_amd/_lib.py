@@ -98,6 +98,8 @@ PROTOTYPES = {
     "simrank_plan_topk": [_vp, _i32, _i32, _vp, _vp],
     "simrank_plan_run_cb": [_vp, C.c_int32, C.c_double, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "simrank_plan_evidence_u8": [_vp, _vp, _i64],
+    "simrank_plan_set_timing": [_vp, C.c_int32],
+    "simrank_plan_leg_times": [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)],
     "simrank_plan_trim": [_vp],
     "simrank_biplan_run_cb": [_vp, C.c_int32, C.c_double, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "simrank_biplan_topk": [_vp, _i32, _i32, _i32, _vp, _vp],

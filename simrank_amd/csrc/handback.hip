@@ -28,6 +28,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstring>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -39,7 +40,7 @@ namespace {
 
 constexpr int64_t kSlabBytes = int64_t(64) << 20;     // per pinned / device slab
 constexpr int64_t kTile = 64;                         // the host transposes 64 x 64 blocks (16 KiB of floats: L1)
-constexpr int64_t kGroup = 8;                         // result rows a host thread owns together (2 MiB of a 32768-wide frame)
+constexpr int64_t kGroup = 16;                        // result rows a host thread owns together (one 64-byte line of every slab row)
 constexpr int64_t kDiag = 32;                         // diagonal blocks of the source that are handed over whole
 
 __device__ __forceinline__ int64_t at(int64_t r, int64_t c, int64_t ld, int64_t rows_pad) {
@@ -115,21 +116,25 @@ Slabs g_slabs[16];
 
 inline void store_nt(double* p, double v) { __builtin_nontemporal_store(v, p); }
 
-// one thread's share of a band: the GROUPS of kGroup consecutive result rows g = t, t + nt, ... (the same rows in every
-// band: a thread always writes the same pages of the frame — its first touches do not queue behind 63 others on one
-// transparent huge page, which is what a split of the band by column blocks cost: 380 ms instead of 40 at N = 32768 —
-// and they stay on its NUMA node).  A row R at or below the band's first row receives from this band
-//   * mirrored: dst[R][r0 + i] = slab[i][R - r0] for the band rows i above it (i < R - r0): one run of up to nr doubles,
-//     read down a column of the slab, 64 band rows at a time (8 x 64 floats: the lines stay in the L1);
-//   * direct (R inside the band): dst[R][R .. n) = slab[R - r0][R - r0 .. w): one long run.
+// one thread's share of a band.  MIRRORED part: the GROUPS of kGroup consecutive result rows g = t, t + nt, ... (the same
+// rows in every band: a thread always writes the same pages of the frame); a row R below the band's first row receives
+// dst[R][r0 + i] = slab[i][R - r0] for the band rows i above it — read down a column of the slab, kTile band rows at a time
+// (16 x 64 floats: whole 64-byte lines, which stay in the L1), the tiles of different threads started at different columns
+// (all of them walking the same columns of rows 256 KiB apart would queue on the same memory channels).  DIRECT part: the
+// band's own rows, dealt one by one: dst[R][R .. n) = slab[R - r0][R - r0 .. w), one long run each.
+// (tools/micro/widen_bench.cpp on the bench box: 76 - 81 ms for N = 32768 on 16 threads in this form, 94 - 100 in the
+// first cut — groups of 8, direct rows with their group; the box gives a process 16 CPUs' worth of time: 64 threads take
+// 200 - 270 ms for the same work, which is what the first version of this file measured.)
 void widen_band(const float* slab, const Band& b, int64_t n, double* dst, int64_t ld, int64_t t, int64_t nt) {
     const int64_t w = n - b.r0;
     const int64_t g0 = b.r0 / kGroup, g_end = (n + kGroup - 1) / kGroup;       // (r0 is a multiple of kTile)
     for (int64_t g = g0 + ((t - g0 % nt) % nt + nt) % nt; g < g_end; g += nt) {
         const int64_t j0 = g * kGroup - b.r0, j1 = std::min(n, (g + 1) * kGroup) - b.r0;
         const int64_t imax = std::min(b.nr, j1 - 1);                              // band rows above the group's last row
-        for (int64_t ic = 0; ic < imax; ic += kTile) {
-            const int64_t ie = std::min(imax, ic + kTile);
+        const int64_t chunks = (imax + kTile - 1) / kTile;
+        const int64_t first = chunks > 0 ? (t * 3 + g) % chunks : 0;
+        for (int64_t k = 0; k < chunks; ++k) {
+            const int64_t ic = ((first + k) % chunks) * kTile, ie = std::min(imax, ic + kTile);
             for (int64_t j = j0; j < j1; ++j) {
                 double* d = dst + (b.r0 + j) * ld + b.r0;
                 const float* s = slab + j;
@@ -137,12 +142,38 @@ void widen_band(const float* slab, const Band& b, int64_t n, double* dst, int64_
                 for (int64_t i = ic; i < iend; ++i) store_nt(d + i, (double)s[i * b.pitch]);
             }
         }
-        for (int64_t j = j0; j < std::min(j1, b.nr); ++j) {
-            const float* s = slab + j * b.pitch;
-            double* d = dst + (b.r0 + j) * ld + b.r0;
-            for (int64_t c = j; c < w; ++c) store_nt(d + c, (double)s[c]);
-        }
     }
+    for (int64_t j = t; j < b.nr; j += nt) {
+        const float* s = slab + j * b.pitch;
+        double* d = dst + (b.r0 + j) * ld + b.r0;
+        for (int64_t c = j; c < w; ++c) store_nt(d + c, (double)s[c]);
+    }
+}
+
+// CPUs this process may actually use: the affinity mask, cut by the cgroup's CPU quota (a container with 16 CPUs' worth
+// of time on a 256-thread host is what the bench box is: threads beyond the quota are throttled, not run)
+int64_t cpu_share() {
+    int64_t n = std::max<int64_t>(1, (int64_t)std::thread::hardware_concurrency());
+    for (const char* path : {"/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"}) {
+        FILE* f = std::fopen(path, "r");
+        if (!f) continue;
+        char a[64] = "", bq[64] = "";
+        const int got = std::fscanf(f, "%63s %63s", a, bq);
+        std::fclose(f);
+        if (got < 1 || !std::strcmp(a, "max")) continue;
+        double quota = std::atof(a), period = got == 2 ? std::atof(bq) : 0;
+        if (period <= 0) {                                   // cgroup v1: the period is in its own file
+            period = 100000;
+            if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (std::fscanf(g, "%63s", bq) == 1) period = std::atof(bq);
+                std::fclose(g);
+            }
+        }
+        if (quota > 0 && period > 0) n = std::min<int64_t>(n, std::max<int64_t>(1, (int64_t)(quota / period + 0.5)));
+        break;
+    }
+    if (const char* e = std::getenv("SIMRANK_HOST_THREADS")) n = std::max<int64_t>(1, std::atoll(e));
+    return n;
 }
 
 // the full hand-back: one permute into a row-major copy, every element over PCIe
@@ -284,27 +315,29 @@ int simrank_download_f64_sym(double* dst, int64_t ld_dst, const float* src, int6
         return SIMRANK_OK;
     };
     // the crew: every thread takes its column blocks of every band, in band order
-    const int64_t hc = std::max<int64_t>(1, (int64_t)std::thread::hardware_concurrency());
-    const int64_t nt = std::max<int64_t>(1, std::min<int64_t>({64, hc > 8 ? hc / 2 : hc, (n + 4 * kGroup - 1) / (4 * kGroup),
+    // (no default for a host without a quota: on the 256-thread bench box without one, 32 threads were the best)
+    const int64_t nt = std::max<int64_t>(1, std::min<int64_t>({32, cpu_share(), (n + 4 * kGroup - 1) / (4 * kGroup),
                                                                std::max<int64_t>(1, (n * n) >> 18)}));
     std::mutex m;
     std::condition_variable cv;
-    int64_t ready = 0;                       // bands 0 .. ready - 1 are in their pinned slabs
-    std::vector<int64_t> finished((size_t)nb, 0);
-    bool abort = false;
+    std::atomic<int64_t> ready{0};           // bands 0 .. ready - 1 are in their pinned slabs
+    std::vector<std::atomic<int64_t>> finished((size_t)nb);
+    for (auto& f : finished) f.store(0);
+    std::atomic<bool> abort{false};
+    // (the host is the slower side: the next band is usually there when a thread asks for it — no system call then; only
+    // the last thread through a band wakes the publisher)
     auto crew = [&](int64_t t) {
         for (int64_t b = 0; b < nb; ++b) {
-            {
+            if (ready.load(std::memory_order_acquire) <= b && !abort.load()) {
                 std::unique_lock<std::mutex> lk(m);
-                cv.wait(lk, [&] { return ready > b || abort; });
-                if (abort) return;
+                cv.wait(lk, [&] { return ready.load(std::memory_order_acquire) > b || abort.load(); });
             }
+            if (abort.load()) return;
             widen_band(sl.pin[b & 1], bands[(size_t)b], n, dst, ld_dst, t, nt);
-            {
+            if (finished[(size_t)b].fetch_add(1, std::memory_order_acq_rel) + 1 == nt) {
                 std::lock_guard<std::mutex> lk(m);
-                ++finished[(size_t)b];
+                cv.notify_all();
             }
-            cv.notify_all();
         }
     };
     std::vector<std::thread> threads;
@@ -328,12 +361,12 @@ int simrank_download_f64_sym(double* dst, int64_t ld_dst, const float* src, int6
         } else {
             {
                 std::lock_guard<std::mutex> lk(m);
-                ready = b + 1;
+                ready.store(b + 1, std::memory_order_release);
             }
             cv.notify_all();
             // slab b & 1 is free for band b + 2 once every thread is through with band b
             std::unique_lock<std::mutex> lk(m);
-            cv.wait(lk, [&] { return finished[(size_t)b] == nt; });
+            cv.wait(lk, [&] { return finished[(size_t)b].load(std::memory_order_acquire) == nt; });
         }
         t_wait_host += since() - c;
         if (b + 2 < nb) rc = issue(b + 2);
@@ -341,7 +374,7 @@ int simrank_download_f64_sym(double* dst, int64_t ld_dst, const float* src, int6
     if (nt > 1) {
         {
             std::lock_guard<std::mutex> lk(m);
-            if (rc) abort = true;
+            if (rc) abort.store(true);
         }
         cv.notify_all();
         for (std::thread& th : threads) th.join();

@@ -42,19 +42,35 @@ struct simrank_plan {
     int32_t half = 0;                         // 1: S and Tt are fp16 on 64-column panels (half.hip), value x kHalfScale
     int cur = 0;                              // S[cur] is the current iterate
     int32_t updates = 0;                      // updates applied since the last reset
+    // simrank_plan_set_timing: three events per update (before leg 1, between the legs, after leg 2) on the plan's stream
+    std::vector<hipEvent_t> ev_pool;          // created ahead of the timed region
+    std::vector<hipEvent_t> ev_used;          // 3 per timed update, in order
+    bool timing = false;
 };
 
 namespace simrank {
 
 constexpr float kHalfScale = 16384.0f;        // what fp16-held matrices are scaled by (include/simrank_hip.h, SCALE)
 
+static int stamp(simrank_plan* p) {
+    if (!p->timing || p->ev_pool.empty()) return SIMRANK_OK;
+    hipEvent_t e = p->ev_pool.back();
+    p->ev_pool.pop_back();
+    p->ev_used.push_back(e);
+    SR_HIP(hipEventRecord(e, p->stream));
+    return SIMRANK_OK;
+}
+
 static int leg_pair(simrank_plan* p, double eps, int32_t exact_count, int slot) {
     const int nx = p->cur ^ 1;
+    const bool timed = p->timing && p->ev_pool.size() >= 3;
+    if (timed) { const int rs = stamp(p); if (rs) return rs; }
     int rc = p->half ? simrank_spmm_blocked_h16(p->g, p->S[p->cur], p->rows_pad, p->n, p->Tt, p->rows_pad, 1, nullptr,
                                                 0, kHalfScale, p->stream)
                      : simrank_spmm_blocked(p->g, p->S[p->cur], p->rows_pad, p->n, p->Tt, p->rows_pad, 1, nullptr,
                                             p->stream);
     if (rc) return rc;
+    if (timed) { const int rs = stamp(p); if (rs) return rs; }
     simrank_epilogue ep{};
     ep.coef = p->coef;
     ep.lbd = p->lbd;
@@ -75,6 +91,7 @@ static int leg_pair(simrank_plan* p, double eps, int32_t exact_count, int slot) 
                                             kHalfScale, p->stream)
                  : simrank_spmm_blocked(p->g, p->Tt, p->rows_pad, p->n, p->S[nx], p->rows_pad, 0, &ep, p->stream);
     if (rc) return rc;
+    if (timed) { const int rs = stamp(p); if (rs) return rs; }
     SR_HIP(hipMemcpyAsync(p->host_counters[slot], p->counters, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS,
                           hipMemcpyDeviceToHost, p->stream));
     SR_HIP(hipEventRecord(p->counted[slot], p->stream));
@@ -105,6 +122,8 @@ int simrank_plan_destroy(simrank_plan* p) {
         if (p->host_counters[i]) (void)hipHostFree(p->host_counters[i]);
         if (p->counted[i]) (void)hipEventDestroy(p->counted[i]);
     }
+    for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->ev_used) (void)hipEventDestroy(e);
     simrank_graph_destroy(p->g);
     delete p;
     return SIMRANK_OK;
@@ -448,6 +467,40 @@ int simrank_plan_topk(simrank_plan* p, int32_t k, int32_t exclude_diag, int32_t*
         std::memcpy(idx_host + a * k, idx_s.data() + r * k, size_t(k) * sizeof(int32_t));
         std::memcpy(val_host + a * k, val_s.data() + r * k, size_t(k) * sizeof(float));
     }
+    return SIMRANK_OK;
+}
+
+int simrank_plan_set_timing(simrank_plan* p, int32_t updates) {
+    SR_REQUIRE(p && updates >= 0 && updates <= (1 << 20), "bad timing arguments");
+    // events for `updates` updates are created NOW (outside whatever the caller times); 0 switches the stamps off
+    for (hipEvent_t e : p->ev_used) p->ev_pool.push_back(e);
+    p->ev_used.clear();
+    while ((int64_t)p->ev_pool.size() < 3 * (int64_t)updates) {
+        hipEvent_t e;
+        SR_HIP(hipEventCreate(&e));
+        p->ev_pool.push_back(e);
+    }
+    p->timing = updates > 0;
+    return SIMRANK_OK;
+}
+
+int simrank_plan_leg_times(simrank_plan* p, double* leg1_ms, double* leg2_ms, int32_t* updates) {
+    SR_REQUIRE(p, "plan is NULL");
+    SR_HIP(hipStreamSynchronize(p->stream));
+    double a = 0, b = 0;
+    const size_t n = p->ev_used.size() / 3;
+    for (size_t u = 0; u < n; ++u) {
+        float t1 = 0, t2 = 0;
+        SR_HIP(hipEventElapsedTime(&t1, p->ev_used[3 * u], p->ev_used[3 * u + 1]));
+        SR_HIP(hipEventElapsedTime(&t2, p->ev_used[3 * u + 1], p->ev_used[3 * u + 2]));
+        a += t1;
+        b += t2;
+    }
+    if (leg1_ms) *leg1_ms = n ? a / (double)n : 0.0;
+    if (leg2_ms) *leg2_ms = n ? b / (double)n : 0.0;
+    if (updates) *updates = (int32_t)n;
+    for (hipEvent_t e : p->ev_used) p->ev_pool.push_back(e);
+    p->ev_used.clear();
     return SIMRANK_OK;
 }
 

@@ -165,6 +165,22 @@ class Plan:
                 raise raised[0]
         return done.value, (None if conv.value < 0 else conv.value)
 
+    def set_timing(self, updates: int):
+        """HIP events around both legs of the next ``updates`` updates, on the plan's stream (0 = off)."""
+        check(self.ops.lib.simrank_plan_set_timing(self.handle, int(updates)), "simrank_plan_set_timing")
+
+    def leg_times(self):
+        """(mean ms of leg 1, mean ms of leg 2, updates stamped) since ``set_timing`` / the last call."""
+        a, b, n = C.c_double(0), C.c_double(0), C.c_int32(0)
+        check(self.ops.lib.simrank_plan_leg_times(self.handle, C.byref(a), C.byref(b), C.byref(n)), "simrank_plan_leg_times")
+        return a.value, b.value, n.value
+
+    def graph_handle(self):
+        """The plan's graph object (for simrank_graph_fused_stats / _dense_stats); owned by the plan."""
+        g = C.c_void_p()
+        check(self.ops.lib.simrank_plan_info(self.handle, None, None, C.byref(g)), "simrank_plan_info")
+        return g
+
     def evidence_counts(self) -> np.ndarray:
         """uint8 [n, n] common in-neighbour counts (saturated at 255) in the caller's order."""
         out = np.empty((self.n, self.n), dtype=np.uint8)

@@ -13,3 +13,4 @@ for k in ("continuity_pl32768", "secondary", "bipartite_pp", "converge", "cpu_ba
     print(f"  {k}:", json.dumps(d.get(k))[:420])
 c5 = d.get("config5", {})
 print("  config5:", json.dumps({k: c5.get(k) for k in ("f32_exact_dense_blocks", "fp16_dense_blocks", "fp16_vs_f32_error", "error")})[:700])
+print("  fit_wall:", json.dumps(d.get("fit_wall"))[:1800])

@@ -238,33 +238,33 @@ def main():
     # runs by default — the short-circuit form of the same test — is timed afterwards and reported beside it.
     # One GPU, gather legs: the loop behind the C ABI (simrank_plan_step: what fit() runs since round 5, cplan.PlanSolver),
     # its legs stamped with HIP events on the plan's own stream.  Several ranks / GEMM modes: driver.Solver.
-    plan = None
+    hplan = None
     terms_now = 1 if args.dense_precision == "fp16" else 3
     if gpu and not use_dist and solver.mode == "sparse" and getattr(solver, "blocked", False):
         from simrank_amd.engine import Plan
         spec0 = make_spec(csr, args.pp, terms_now)
-        plan = Plan(ops, csr, spec0.rowscale, coef=coef, evidence=args.pp, dense_terms=terms_now)
+        hplan = Plan(ops, csr, spec0.rowscale, coef=coef, evidence=args.pp, dense_terms=terms_now)
     solver.exact_count = True
     short_ms = None
-    if plan is not None:
+    if hplan is not None:
         for _ in range(args.warmup):
-            plan.step(0.0, exact_count=True)
-        plan.set_timing(args.steps)
+            hplan.step(0.0, exact_count=True)
+        hplan.set_timing(args.steps)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            plan.step(0.0, exact_count=True)
+            hplan.step(0.0, exact_count=True)
         barrier()
         elapsed = time.perf_counter() - t0
-        l1p, l2p, n_stamped = plan.leg_times()
-        plan.set_timing(0)
+        l1p, l2p, n_stamped = hplan.leg_times()
+        hplan.set_timing(0)
         legs = {"leg1.0": (l1p, n_stamped), "leg2.0": (l2p, n_stamped)}
         if not args.exact_only:
-            plan.step(0.0, exact_count=False)
+            hplan.step(0.0, exact_count=False)
             barrier()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                plan.step(0.0, exact_count=False)
+                hplan.step(0.0, exact_count=False)
             barrier()
             short_ms = (time.perf_counter() - t0) / args.steps * 1e3
     else:
@@ -297,7 +297,7 @@ def main():
                                f"{' with fp16 dense blocks' if args.dense_precision == 'fp16' else ''}, "
                                f"eps test every iteration (every element compared, exact count)",
                    "N": n, "nnz": nnz, "mode": solver.mode,
-                   "loop": ("simrank_plan_step behind the C ABI (csrc/plan.hip): what fit() runs on one GPU" if plan is not None
+                   "loop": ("simrank_plan_step behind the C ABI (csrc/plan.hip): what fit() runs on one GPU" if hplan is not None
                             else "driver.Solver.step (Python choreography over the C ABI's kernels)"),
                    "layout": "panel-blocked (32-column panels)" if getattr(solver, "blocked", False) else "row-major",
                    "sharding": f"S column-sharded over {world_size} rank(s), all-to-all per update"
@@ -491,7 +491,7 @@ def main():
         # wall-clock to converge with the reference's defaults (eps = 1e-4)
         barrier()
         t0 = time.perf_counter()
-        k = plan.run(100, 1e-4)[1] if plan is not None else solver.run(100, 1e-4)
+        k = hplan.run(100, 1e-4)[1] if hplan is not None else solver.run(100, 1e-4)
         barrier()
         out["converge"] = {"eps": 1e-4, "iterations": k, "seconds": time.perf_counter() - t0}
 
@@ -813,11 +813,11 @@ def main():
             df4 = synth.WORKLOADS["pl32768d32"][0]()
             timed_fit("cfg4_SimRank_pl32768d32_full_handback", SRA.SimRank, df4)
             try:
-                # A/B of the hand-back: both triangles over PCIe (round 4's path, kept behind an environment switch)
-                os.environ["SIMRANK_FULL_HANDBACK"] = "1"
-                timed_fit("cfg4_SimRank_pl32768d32_both_triangles_over_pcie", SRA.SimRank, df4)
+                # A/B of the hand-back: the symmetric form (upper triangle over PCIe, mirrored by the host threads; same bits)
+                os.environ["SIMRANK_SYM_HANDBACK"] = "1"
+                timed_fit("cfg4_SimRank_pl32768d32_upper_triangle_over_pcie", SRA.SimRank, df4)
             finally:
-                os.environ.pop("SIMRANK_FULL_HANDBACK", None)
+                os.environ.pop("SIMRANK_SYM_HANDBACK", None)
             try:
                 # the same fit through the C-level plan: create (graph + plans + matrices), run to eps, f64 hand-back
                 from simrank_amd.engine import Plan
@@ -959,10 +959,10 @@ def main():
             out["cpu_baseline"] = None
             out["cpu_baseline_note"] = f"skipped: needs {need / 2**30:.0f} GiB host RAM"
         else:
-            if plan is not None:
-                plan.run(3, 0.0)
-                S_host = plan.result()
-                plan.free()
+            if hplan is not None:
+                hplan.run(3, 0.0)
+                S_host = hplan.result()
+                hplan.free()
             else:
                 S_host = solver.result(0)
             solver.release()

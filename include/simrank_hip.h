@@ -86,13 +86,16 @@ SIMRANK_API int simrank_memcpy_d2d(void* dst_device, const void* src_device, siz
  * side (replaces the DataFrame hand-back of SimRank.py:141, :303). */
 SIMRANK_API int simrank_download_f64(double* dst_host, int64_t ld_dst, const float* src_device,
                          int64_t ld_src, int64_t n_rows, int64_t n_cols, void* stream);
-/* 2-D device->host hand-back of a BITWISE SYMMETRIC n x n float32 matrix as float64 in another node order:
- * dst[i][j] = src[idx[i]][idx[j]] (idx: DEVICE int32[n], NULL = identity; src row-major with ld_src, or panel-blocked
- * when src_rows_pad > 0).  Only the elements on or above the diagonal of the RESULT cross PCIe — packed band by band
- * on the device — and a crew of host threads writes each of them twice while widening (replaces `pd.DataFrame(new_S)`
- * of SimRank.py:141, :303 for the symmetric updates: every class except a fit with an asymmetric prior). */
-SIMRANK_API int simrank_download_f64_sym(double* dst_host, int64_t ld_dst, const float* src_device, int64_t ld_src,
-                                         int64_t src_rows_pad, int64_t n, const int32_t* idx_device, void* stream);
+/* Device->host hand-back of an n x n float32 matrix as float64 in another node order (replaces `pd.DataFrame(new_S)` of
+ * SimRank.py:141, :303): dst[i][j] = src[idx[i]][idx[j]] (idx: DEVICE int32[n], NULL = identity; src row-major with
+ * ld_src, or panel-blocked when src_rows_pad > 0).  Pipelined band by band: re-ordering on the device, PCIe and the
+ * widening on the host overlap.  mode 0: every element crosses PCIe.  mode 1 (SYMMETRIC form): the matrix is checked on
+ * the device to be bitwise mirror-equal outside the 32 x 32 diagonal blocks of the source order (what the upper-triangle
+ * leg 2 leaves); if so only the elements on or above the diagonal of the result cross PCIe and the host writes each
+ * twice, the diagonal blocks come over whole; if not, mode 0 runs.  Same bits either way.  (On a host share of 16 CPUs
+ * mode 1 is the slower one — the mirrored writes cost more than the PCIe bytes they save; csrc/handback.hip.) */
+SIMRANK_API int simrank_handback_f64(double* dst_host, int64_t ld_dst, const float* src_device, int64_t ld_src,
+                                     int64_t src_rows_pad, int64_t n, const int32_t* idx_device, int32_t mode, void* stream);
 /* The convergence count of an update without stopping the stream (`_converged`, SimRank.py:54-77, as a caller
  * that drives the legs itself reads it): a COUNTER SET owns four pinned slots and their events; _fetch queues the copy
  * of n counters (the simrank_epilogue.n_changed array) into slot `slot` (0..3) and records an event behind it; _wait
@@ -438,8 +441,7 @@ typedef int32_t (*simrank_progress_fn)(void* user, int32_t k, int32_t converged)
 SIMRANK_API int simrank_plan_run_cb(simrank_plan* p, int32_t iterations, double eps, simrank_progress_fn progress,
                                     void* user, int32_t* updates_done, int32_t* converged_at);
 SIMRANK_API int simrank_plan_result(simrank_plan* p, float* dst, int64_t ld);
-/* HOST float64 n x n in the caller's order (SimRank.py:141).  The iterates of a plan are bitwise symmetric, so only the
- * elements on or above the diagonal cross PCIe; the host mirrors them while widening (simrank_download_f64_sym). */
+/* HOST float64 n x n in the caller's order (SimRank.py:141), through simrank_handback_f64 (pipelined band by band) */
 SIMRANK_API int simrank_plan_result_f64(simrank_plan* p, double* dst, int64_t ld);
 /* HOST u8 n x n in the caller's order: common in-neighbour counts, saturated at 255 (`Evidence` = 1 - 0.5 ** count,
  * SimRank.py:311-320); plans created with options.evidence only */

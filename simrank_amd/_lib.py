@@ -64,7 +64,7 @@ PROTOTYPES = {
     "simrank_memcpy_d2d": [_vp, _vp, C.c_size_t, _vp],
     "simrank_download_f64": [_vp, _i64, _vp, _i64, _i64, _i64, _vp],
     "simrank_read_counters": [_vp, _i32, C.POINTER(C.c_ulonglong), _vp],
-    "simrank_download_f64_sym": [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp],
+    "simrank_handback_f64": [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _i32, _vp],
     "simrank_counters_create": [_pvp],
     "simrank_counters_destroy": [_vp],
     "simrank_counters_fetch": [_vp, _vp, _i32, _i32, _vp],

@@ -1,26 +1,33 @@
-// Hand-back of a SYMMETRIC similarity matrix (SimRank.py:141, :303: `pd.DataFrame(new_S, ...)` — the float64 N x N
-// frame the reference returns): only the elements on or above the diagonal cross PCIe.
+// Hand-back of a similarity matrix (SimRank.py:141, :303: `pd.DataFrame(new_S, ...)` — the float64 N x N frame the
+// reference returns) out of the solver's layout and node order: dst[i][j] = (double)src[idx[i]][idx[j]].
 //
-// A symmetric update in its upper-triangle form (spmm.hip kSym, half.hip SYM) computes the 32 x 32 tiles on or above the
-// diagonal and stores each strictly-upper tile a second time, transposed: outside the 32 x 32 blocks ON the diagonal of
-// the solver's node order the iterate is BITWISE symmetric (inside them both triangles are computed, each with its own
-// summation order: equal to rounding only), and a renaming of the nodes applied to rows and columns alike keeps it so.
-// The full hand-back moved both triangles: N^2 floats over PCIe, a third of a config-4 fit.  Here:
+// PIPELINED (both forms): the result is cut into row bands; band b is brought into the caller's order and packed on the
+// device (one simrank_permute_layout per band), copied into a pinned slab, and widened to float64 by a crew of host
+// threads while band b + 1 travels — two device and two pinned slabs.  Round 4 permuted the WHOLE matrix before the
+// first byte moved.  The crew is sized by the CPUs the process may really use (cgroup quota: 16 on the bench box — 64
+// threads took 3 x as long as 16 for the same work); its threads meet on atomics, a condition variable only when one of
+// them really has to wait.
 //
-//   1. a kernel CHECKS the premise — every tile pair (I, J), I < J, of the source is compared with its mirror image
-//      (one pass over the matrix at memory rate: 1.5 ms of a 50 ms hand-back); a matrix that fails (the full-form leg 2
-//      of tuning triangle = 0 or of fewer than 64 nodes, any asymmetric iterate) takes the full hand-back instead: the
-//      result never depends on the premise, only the speed does;
-//   2. the result is cut into row bands; band b (rows r0 .. r1 of the CALLER's order) is packed on the device as the
-//      trapezoid [r0, r1) x [r0, N) — one simrank_permute_layout per band —, copied into a pinned slab, and a crew of host
-//      threads widens it to float64 twice: dst[r][c] and, for c > r, dst[c][r].  Two device and two pinned slabs: band
-//      b + 1 travels while band b is widened.  A thread owns GROUPS OF RESULT ROWS, the same ones in every band (widen_band):
-//      no two threads ever write the same row, a page of the frame is first touched by its owner; stores are
-//      non-temporal (the frame is written once and is far larger than any cache);
-//   3. the 32 x 32 diagonal blocks of the SOURCE order (N x 32 floats) come over by themselves and are written where the
-//      caller's order puts them, both triangles: what the bands mirrored there is replaced by the element itself.
+// FULL form (default): band = rows [r0, r1) x all columns; every thread widens whole rows.  PCIe-bound on the bench box:
+// 4.3 GB at 57 GB/s = 75 ms of a ~85 ms hand-back at N = 32768; the host side needs 59 ms on 16 threads.
 //
-// The outcome is, bit for bit, the full hand-back's (tests/test_gpu_product_path.py compares every element at N = 32768).
+// SYMMETRIC form (mode 1 / SIMRANK_SYM_HANDBACK=1): only the elements on or above the diagonal
+// cross PCIe.  A symmetric update in its upper-triangle form (spmm.hip kSym, half.hip SYM) computes the 32 x 32 tiles on
+// or above the diagonal and stores each strictly-upper tile a second time, transposed: outside the 32 x 32 blocks ON the
+// diagonal of the solver's order the iterate is BITWISE symmetric (inside them both triangles are computed, each with
+// its own summation order), and a renaming applied to rows and columns alike keeps it so.
+//   1. a kernel CHECKS the premise — every tile pair (I, J), I < J, against its mirror image (one pass at memory rate,
+//      1.5 ms); a matrix that fails (full-form leg 2, fewer than 64 nodes, asymmetric iterates) takes the full form: the
+//      result never depends on the premise;
+//   2. band b is the trapezoid [r0, r1) x [r0, N); the crew widens it twice: dst[r][c] and, for c > r, dst[c][r].  A
+//      thread owns GROUPS OF RESULT ROWS, the same ones in every band (widen_band);
+//   3. the diagonal blocks of the SOURCE order (N x 32 floats) come over by themselves and are written where the
+//      caller's order puts them, both triangles.
+// Bit for bit the full form's result (tests/test_gpu_product_path.py, every element at N = 32768) — and on the bench box
+// SLOWER: half the PCIe bytes (38 ms), but the mirrored writes (64-double runs into rows 256 KiB apart, read down the
+// columns of the slab) cost the 16 host threads 80 - 120 ms against 59 for whole rows (tools/micro/widen_bench.cpp,
+// profiles/r05_widen_bench*.log): 126 ms against 85.  It pays where the host side is not the bottleneck (a CPU share of
+// several times 16); hence opt-in.
 #include <sys/mman.h>
 #include <unistd.h>
 
@@ -42,6 +49,8 @@ constexpr int64_t kSlabBytes = int64_t(64) << 20;     // per pinned / device sla
 constexpr int64_t kTile = 64;                         // the host transposes 64 x 64 blocks (16 KiB of floats: L1)
 constexpr int64_t kGroup = 16;                        // result rows a host thread owns together (one 64-byte line of every slab row)
 constexpr int64_t kDiag = 32;                         // diagonal blocks of the source that are handed over whole
+
+inline void store_nt(double* p, double v) { __builtin_nontemporal_store(v, p); }
 
 __device__ __forceinline__ int64_t at(int64_t r, int64_t c, int64_t ld, int64_t rows_pad) {
     return rows_pad ? ((c >> 5) * rows_pad + r) * 32 + (c & 31) : r * ld + c;
@@ -84,9 +93,11 @@ __global__ __launch_bounds__(256) void diag_blocks_kernel(const float* __restric
 }
 
 struct Band {
-    int64_t r0 = 0, nr = 0;          // rows [r0, r0 + nr) of the result; columns [r0, n): width n - r0
+    int64_t r0 = 0, nr = 0;          // rows [r0, r0 + nr) of the result
     int64_t pitch = 0;               // floats per packed row: the width rounded up to an ODD number of 64-byte lines — a
-};                                   // power-of-two pitch sends the 64 rows of a block to ONE set of the L1 and L2
+                                     // power-of-two pitch sends the 64 rows of a block to ONE set of the L1 and L2
+    int64_t c0 = 0;                  // first column: r0 (symmetric form: the trapezoid) or 0 (full form)
+};
 
 int64_t odd_lines(int64_t w) {
     int64_t lines = (w + 15) / 16;
@@ -94,16 +105,26 @@ int64_t odd_lines(int64_t w) {
     return lines * 16;
 }
 
-std::vector<Band> cut_bands(int64_t n) {
+std::vector<Band> cut_bands(int64_t n, bool sym = true) {
     std::vector<Band> bands;
     for (int64_t r0 = 0; r0 < n;) {
-        const int64_t pitch = odd_lines(n - r0);
+        const int64_t c0 = sym ? r0 : 0;
+        const int64_t pitch = odd_lines(n - c0);
         int64_t nr = std::max<int64_t>(kTile, (kSlabBytes / 4 / pitch) / kTile * kTile);
         nr = std::min(nr, n - r0);
-        bands.push_back({r0, nr, pitch});
+        bands.push_back({r0, nr, pitch, c0});
         r0 += nr;
     }
     return bands;
+}
+
+// the full form: whole rows of the band, dealt one by one
+void widen_rows(const float* slab, const Band& b, int64_t n, double* dst, int64_t ld, int64_t t, int64_t nt) {
+    for (int64_t j = t; j < b.nr; j += nt) {
+        const float* s = slab + j * b.pitch;
+        double* d = dst + (b.r0 + j) * ld;
+        for (int64_t c = 0; c < n; ++c) store_nt(d + c, (double)s[c]);
+    }
 }
 
 struct Slabs {                       // kept per device for the life of the process (pinning memory is slow)
@@ -113,8 +134,6 @@ struct Slabs {                       // kept per device for the life of the proc
 };
 std::mutex g_slab_mutex;
 Slabs g_slabs[16];
-
-inline void store_nt(double* p, double v) { __builtin_nontemporal_store(v, p); }
 
 // one thread's share of a band.  MIRRORED part: the GROUPS of kGroup consecutive result rows g = t, t + nt, ... (the same
 // rows in every band: a thread always writes the same pages of the frame); a row R below the band's first row receives
@@ -176,21 +195,6 @@ int64_t cpu_share() {
     return n;
 }
 
-// the full hand-back: one permute into a row-major copy, every element over PCIe
-int full_handback(double* dst, int64_t ld_dst, const float* src, int64_t ld_src, int64_t src_rows_pad, int64_t n,
-                  const int32_t* idx, hipStream_t st) {
-    if (!idx && src_rows_pad == 0) return simrank_download_f64(dst, ld_dst, src, ld_src, n, n, st);
-    float* tmp = nullptr;
-    const int64_t ldt = (n + 3) / 4 * 4;
-    int rc = pool_alloc((void**)&tmp, size_t(n) * size_t(ldt) * sizeof(float));
-    if (rc) return rc;
-    rc = simrank_permute_layout(src, ld_src, src_rows_pad, tmp, ldt, 0, n, n, idx, idx, 4, st);
-    if (!rc) rc = simrank_download_f64(dst, ld_dst, tmp, ldt, n, n, st);
-    (void)hipStreamSynchronize(st);
-    (void)pool_free(tmp);
-    return rc;
-}
-
 }  // namespace
 }  // namespace simrank
 
@@ -198,28 +202,30 @@ using namespace simrank;
 
 extern "C" {
 
-int simrank_download_f64_sym(double* dst, int64_t ld_dst, const float* src, int64_t ld_src, int64_t src_rows_pad, int64_t n,
-                             const int32_t* idx, void* stream) {
+int simrank_handback_f64(double* dst, int64_t ld_dst, const float* src, int64_t ld_src, int64_t src_rows_pad, int64_t n,
+                         const int32_t* idx, int32_t mode, void* stream) {
     SR_REQUIRE(n >= 0 && ld_dst >= n && (src_rows_pad > 0 ? src_rows_pad >= n : ld_src >= n), "bad shape");
+    SR_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (full form) or 1 (symmetric form)");
     if (n == 0) return SIMRANK_OK;
     SR_REQUIRE(dst && src, "NULL pointer");
     const bool timed = std::getenv("SIMRANK_TIME_HANDBACK") != nullptr;
     const auto t_start = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
     hipStream_t st = as_stream(stream);
-    if (n <= 2 * kDiag || n > (int64_t(1) << 20) || std::getenv("SIMRANK_FULL_HANDBACK"))    // (nothing to save; beyond any
-        return full_handback(dst, ld_dst, src, ld_src, src_rows_pad, n, idx, st);   // dense hand-back; the benches' A/B switch)
+    if (const char* e = std::getenv("SIMRANK_SYM_HANDBACK")) mode = (*e && *e != '0') ? 1 : 0;     // (the benches' A/B switch)
+    bool sym = mode == 1 && n > 2 * kDiag && n <= (int64_t(1) << 20);
 
-    // ---- 1. the premise, checked: mirror-equal outside the diagonal blocks?
-    const int64_t n_tiles = (n + 31) / 32, n_pairs = n_tiles * (n_tiles - 1) / 2;
     int32_t* flag = nullptr;
     float* diag_dev = nullptr;
-    {
-        const int rc = pool_alloc((void**)&flag, 64);
-        if (rc) return rc;
-    }
-    auto cleanup_small = [&] { (void)pool_free(flag); (void)pool_free(diag_dev); };
-    {
+    auto cleanup_small = [&] { (void)pool_free(flag); (void)pool_free(diag_dev); flag = nullptr; diag_dev = nullptr; };
+    double t_checked = 0;
+    std::vector<float> diag;
+    std::vector<int32_t> pos;                     // pos[i] = source position of caller's node i
+    if (sym) {
+        // ---- 1. the premise, checked: mirror-equal outside the diagonal blocks?
+        const int64_t n_tiles = (n + 31) / 32, n_pairs = n_tiles * (n_tiles - 1) / 2;
+        const int rc0 = pool_alloc((void**)&flag, 64);
+        if (rc0) return rc0;
         hipError_t e = hipMemsetAsync(flag, 0, 4, st);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(mirror_check_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, (const uint32_t*)src, ld_src,
@@ -231,21 +237,18 @@ int simrank_download_f64_sym(double* dst, int64_t ld_dst, const float* src, int6
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) {
             cleanup_small();
-            set_error("simrank_download_f64_sym (symmetry check): %s", hipGetErrorString(e));
+            set_error("simrank_handback_f64 (symmetry check): %s", hipGetErrorString(e));
             return SIMRANK_ERR_HIP;
         }
         if (bad) {
-            cleanup_small();
-            if (timed) std::fprintf(stderr, "simrank_download_f64_sym: not mirror-equal: full hand-back\n");
-            return full_handback(dst, ld_dst, src, ld_src, src_rows_pad, n, idx, st);
+            sym = false;
+            if (timed) std::fprintf(stderr, "simrank_handback_f64: not mirror-equal: full form\n");
         }
+        t_checked = since();
     }
-    const double t_checked = since();
-
-    // ---- 3 (queued first: small). the diagonal blocks of the source order and the order itself
-    std::vector<float> diag((size_t)n * kDiag);
-    std::vector<int32_t> pos;                     // pos[i] = source position of caller's node i
-    {
+    if (sym) {
+        // ---- 3 (queued first: small). the diagonal blocks of the source order and the order itself
+        diag.resize((size_t)n * kDiag);
         int rc = pool_alloc((void**)&diag_dev, size_t(n) * kDiag * sizeof(float));
         if (rc) { cleanup_small(); return rc; }
         hipLaunchKernelGGL(diag_blocks_kernel, dim3((unsigned)((n * kDiag + 255) / 256)), dim3(256), 0, st, src, ld_src,
@@ -259,19 +262,20 @@ int simrank_download_f64_sym(double* dst, int64_t ld_dst, const float* src, int6
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) {
             cleanup_small();
-            set_error("simrank_download_f64_sym (diagonal blocks): %s", hipGetErrorString(e));
+            set_error("simrank_handback_f64 (diagonal blocks): %s", hipGetErrorString(e));
             return SIMRANK_ERR_HIP;
         }
     }
+    cleanup_small();
 
     // ---- 2. the bands
-    const std::vector<Band> bands = cut_bands(n);
+    const std::vector<Band> bands = cut_bands(n, sym);
     const int64_t nb = (int64_t)bands.size();
     size_t need = 0;
     for (const Band& b : bands) need = std::max(need, size_t(b.nr) * size_t(b.pitch) * 4);
     int dev = 0;
     SR_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(g_slab_mutex);      // (one symmetric hand-back per process at a time: it uses every core)
+    std::lock_guard<std::mutex> lock(g_slab_mutex);      // (one dense hand-back per process at a time: it uses every core)
     Slabs& sl = g_slabs[dev & 15];
     for (int i = 0; i < 2; ++i)
         if (!sl.done[i]) SR_HIP(hipEventCreateWithFlags(&sl.done[i], hipEventDisableTiming));
@@ -289,7 +293,6 @@ int simrank_download_f64_sym(double* dst, int64_t ld_dst, const float* src, int6
         const int rc = pool_alloc((void**)&dev_slab[i], need);
         if (rc) {
             (void)pool_free(dev_slab[0]);
-            cleanup_small();
             return rc;
         }
     }
@@ -300,21 +303,25 @@ int simrank_download_f64_sym(double* dst, int64_t ld_dst, const float* src, int6
         const uintptr_t lo = ((uintptr_t)dst + page - 1) / page * page, hi = ((uintptr_t)(dst + n * n)) / page * page;
         if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_HUGEPAGE);
     }
-    // band b: packed trapezoid in the caller's order on the device, then into its pinned slab
+    // band b: packed in the caller's order on the device (rows r0 .., columns c0 ..), then into its pinned slab
     auto issue = [&](int64_t b) -> int {
         const Band& bd = bands[(size_t)b];
-        const int64_t w = n - bd.r0;
+        const int64_t w = n - bd.c0;
         const float* s = src;
         const int32_t* ri = idx ? idx + bd.r0 : nullptr;
-        if (!idx)       // identity order: the band starts at (r0, r0) of the source (r0 is a multiple of 64)
-            s = src_rows_pad > 0 ? src + ((bd.r0 >> 5) * src_rows_pad + bd.r0) * 32 : src + bd.r0 * ld_src + bd.r0;
-        int rc = simrank_permute_layout(s, ld_src, src_rows_pad, dev_slab[b & 1], bd.pitch, 0, bd.nr, w, ri, ri, 4, st);
+        const int32_t* ci = idx ? idx + bd.c0 : nullptr;
+        if (!idx)       // identity order: the band starts at (r0, c0) of the source (both multiples of 64, or c0 = 0)
+            s = src_rows_pad > 0 ? src + ((bd.c0 >> 5) * src_rows_pad + bd.r0) * 32 : src + bd.r0 * ld_src + bd.c0;
+        int rc = simrank_permute_layout(s, ld_src, src_rows_pad, dev_slab[b & 1], bd.pitch, 0, bd.nr, w, ri, ci, 4, st);
         if (rc) return rc;
         SR_HIP(hipMemcpyAsync(sl.pin[b & 1], dev_slab[b & 1], size_t(bd.nr) * size_t(bd.pitch) * 4, hipMemcpyDeviceToHost, st));
         SR_HIP(hipEventRecord(sl.done[b & 1], st));
         return SIMRANK_OK;
     };
-    // the crew: every thread takes its column blocks of every band, in band order
+    auto widen = [&](int64_t b, int64_t t, int64_t nt) {
+        if (sym) widen_band(sl.pin[b & 1], bands[(size_t)b], n, dst, ld_dst, t, nt);
+        else widen_rows(sl.pin[b & 1], bands[(size_t)b], n, dst, ld_dst, t, nt);
+    };
     // (no default for a host without a quota: on the 256-thread bench box without one, 32 threads were the best)
     const int64_t nt = std::max<int64_t>(1, std::min<int64_t>({32, cpu_share(), (n + 4 * kGroup - 1) / (4 * kGroup),
                                                                std::max<int64_t>(1, (n * n) >> 18)}));
@@ -324,7 +331,7 @@ int simrank_download_f64_sym(double* dst, int64_t ld_dst, const float* src, int6
     std::vector<std::atomic<int64_t>> finished((size_t)nb);
     for (auto& f : finished) f.store(0);
     std::atomic<bool> abort{false};
-    // (the host is the slower side: the next band is usually there when a thread asks for it — no system call then; only
+    // (the host is often the slower side: the next band is then there when a thread asks for it — no system call; only
     // the last thread through a band wakes the publisher)
     auto crew = [&](int64_t t) {
         for (int64_t b = 0; b < nb; ++b) {
@@ -333,7 +340,7 @@ int simrank_download_f64_sym(double* dst, int64_t ld_dst, const float* src, int6
                 cv.wait(lk, [&] { return ready.load(std::memory_order_acquire) > b || abort.load(); });
             }
             if (abort.load()) return;
-            widen_band(sl.pin[b & 1], bands[(size_t)b], n, dst, ld_dst, t, nt);
+            widen(b, t, nt);
             if (finished[(size_t)b].fetch_add(1, std::memory_order_acq_rel) + 1 == nt) {
                 std::lock_guard<std::mutex> lk(m);
                 cv.notify_all();
@@ -351,13 +358,13 @@ int simrank_download_f64_sym(double* dst, int64_t ld_dst, const float* src, int6
         const hipError_t e = hipEventSynchronize(sl.done[b & 1]);
         t_wait_dev += since() - a;
         if (e != hipSuccess) {
-            set_error("simrank_download_f64_sym: %s", hipGetErrorString(e));
+            set_error("simrank_handback_f64: %s", hipGetErrorString(e));
             rc = SIMRANK_ERR_HIP;
             break;
         }
         const double c = since();
         if (nt == 1) {
-            widen_band(sl.pin[b & 1], bands[(size_t)b], n, dst, ld_dst, 0, 1);
+            widen(b, 0, 1);
         } else {
             {
                 std::lock_guard<std::mutex> lk(m);
@@ -382,10 +389,9 @@ int simrank_download_f64_sym(double* dst, int64_t ld_dst, const float* src, int6
     (void)hipStreamSynchronize(st);
     (void)pool_free(dev_slab[0]);
     (void)pool_free(dev_slab[1]);
-    cleanup_small();
     const double t_bands = since();
     // ---- 3. the diagonal blocks of the source order, both triangles, where the caller's order puts them
-    if (!rc) {
+    if (!rc && sym) {
         std::vector<int32_t> node;               // node[a] = caller's node at source position a
         if (idx) {
             node.resize((size_t)n);
@@ -409,9 +415,10 @@ int simrank_download_f64_sym(double* dst, int64_t ld_dst, const float* src, int6
         }
     }
     if (timed)
-        std::fprintf(stderr, "simrank_download_f64_sym: n %lld, %lld bands, %lld threads: %.1f ms (symmetry check %.1f, bands %.1f — "
+        std::fprintf(stderr, "simrank_handback_f64: n %lld, %s form, %lld bands, %lld threads: %.1f ms (symmetry check %.1f, bands %.1f — "
                              "waiting for the device %.1f, for the host crew %.1f —, diagonal blocks %.1f)\n", (long long)n,
-                     (long long)nb, (long long)nt, since(), t_checked, t_bands - t_checked, t_wait_dev, t_wait_host, since() - t_bands);
+                     sym ? "symmetric" : "full", (long long)nb, (long long)nt, since(), t_checked, t_bands - t_checked, t_wait_dev,
+                     t_wait_host, since() - t_bands);
     return rc;
 }
 

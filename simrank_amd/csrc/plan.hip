@@ -386,7 +386,7 @@ int simrank_plan_result_f64(simrank_plan* p, double* dst, int64_t ld) {
         }
         src = wide;
     }
-    const int rc = simrank_download_f64_sym(dst, ld, src, 32, p->rows_pad, p->n, p->inv, p->stream);
+    const int rc = simrank_handback_f64(dst, ld, src, 32, p->rows_pad, p->n, p->inv, 0, p->stream);
     (void)hipStreamSynchronize(p->stream);
     (void)pool_free(wide);
     return rc;

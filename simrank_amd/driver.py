@@ -1147,6 +1147,14 @@ class Solver:
             tmp = wide = None
             if src.dtype == np.float16:
                 src = wide = o.widen(src)
+            if self.blocked and hasattr(o, "handback_f64") and src.rows == src.cols:
+                # out of the panel-blocked layout and the solver's node order band by band, PCIe and the widening
+                # on the host overlapping (csrc/handback.hip)
+                rows = None if inv is None else self._index_vector(r, ("inv", j), inv)
+                blocks[r] = o.handback_f64(src, rows)
+                if wide is not None:
+                    wide.free()
+                continue
             if self.blocked:
                 # out of the panel-blocked layout and the solver's node order in one pass
                 rows = None if inv is None else self._index_vector(r, ("inv", j), inv)

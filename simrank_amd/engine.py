@@ -683,17 +683,19 @@ class HipOps:
                                             m.cols, self.stream), "simrank_download_f64")
         return out
 
-    def download_f64_sym(self, m: Matrix, idx: Matrix | None = None, out: np.ndarray | None = None) -> np.ndarray:
-        """BITWISE SYMMETRIC float32 device matrix (either layout) -> float64 host array with rows and columns taken
-        in the order ``idx`` (an ``index_vector``; None = as stored): out[i][j] = m[idx[i]][idx[j]].  Only the upper
-        triangle crosses PCIe; the host mirrors it while widening (csrc/handback.hip)."""
+    def handback_f64(self, m: Matrix, idx: Matrix | None = None, out: np.ndarray | None = None,
+                     symmetric: bool = False) -> np.ndarray:
+        """Square float32 device matrix (either layout) -> float64 host array with rows and columns taken in the order
+        ``idx`` (an ``index_vector``; None = as stored): out[i][j] = m[idx[i]][idx[j]], pipelined band by band
+        (csrc/handback.hip).  ``symmetric``: only the upper triangle crosses PCIe when the matrix proves mirror-equal
+        outside its 32 x 32 diagonal blocks (same bits; pays only where the host side has CPUs to spare)."""
         assert m.rows == m.cols and m.dtype == np.float32
         if out is None:
             out = hostpool.empty_f64(m.rows, m.cols)
         assert out.dtype == np.float64 and out.flags.c_contiguous and out.shape == (m.rows, m.cols)
-        check(self.lib.simrank_download_f64_sym(out.ctypes.data, out.shape[1], m.ptr, m.ld, m.rows_pad if m.blocked else 0,
-                                                m.rows, idx.ptr if idx is not None else None, self.stream),
-              "simrank_download_f64_sym")
+        check(self.lib.simrank_handback_f64(out.ctypes.data, out.shape[1], m.ptr, m.ld, m.rows_pad if m.blocked else 0,
+                                            m.rows, idx.ptr if idx is not None else None, int(bool(symmetric)), self.stream),
+              "simrank_handback_f64")
         return out
 
     def copy(self, dst: Matrix, src: Matrix):

@@ -104,7 +104,7 @@ int main(void) {
         if (simrank_shardplan_step(NULL, 0, 0.0, 1, NULL) != SIMRANK_ERR_INVALID) return 7;
         if (simrank_comm_local_group(0, NULL) != SIMRANK_ERR_INVALID) return 8;
         if (simrank_plan_run_cb(NULL, 1, 0.0, NULL, NULL, NULL, NULL) != SIMRANK_ERR_INVALID) return 9;
-        if (simrank_download_f64_sym(NULL, 0, NULL, 0, 0, 4, NULL, NULL) != SIMRANK_ERR_INVALID) return 10;
+        if (simrank_handback_f64(NULL, 0, NULL, 0, 0, 4, NULL, 0, NULL) != SIMRANK_ERR_INVALID) return 10;
         if (simrank_counters_fetch(NULL, NULL, 0, 0, NULL) != SIMRANK_ERR_INVALID) return 11;
     }
     printf("abi %d ok\n", simrank_abi_version());

@@ -33,21 +33,25 @@ def ops():
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("blocked", [False, True])
 @pytest.mark.parametrize("n", [1, 5, 64, 65, 300, 1000, 2049, 4096])
-def test_download_f64_sym_is_the_full_hand_back(ops, n, blocked):
-    """dst[i][j] = src[idx[i]][idx[j]] as float64 from a bitwise symmetric matrix in either layout, with and without a
-    node order: exactly the values the full hand-back (permute + simrank_download_f64) returns."""
+def test_handback_f64_in_both_forms(ops, n, blocked):
+    """dst[i][j] = src[idx[i]][idx[j]] as float64 from a matrix in either layout, with and without a node order, in the
+    full form and — on a matrix that is mirror-equal outside its diagonal blocks — the symmetric one: exactly the values
+    of round 4's hand-back (one permute of the whole matrix + simrank_download_f64)."""
     rng = np.random.default_rng(n)
     a = rng.random((n, n)).astype(np.float32)
     a = np.maximum(a, a.T)                                   # bitwise symmetric
     a[rng.random((n, n)) < 0.3] = 0.0
     a = np.maximum(a, a.T)
+    for k in range(0, n, 32):                                # ... except inside the 32 x 32 diagonal blocks
+        a[k:k + 32, k:k + 32] = rng.random(a[k:k + 32, k:k + 32].shape).astype(np.float32)
     m = ops.matrix(n, n, blocked=blocked)
     ops.upload(m, a)
     for order in (None, rng.permutation(n)):
         idx = None if order is None else ops.index_vector(order)
-        got = ops.download_f64_sym(m, idx)
         want = a.astype(np.float64) if order is None else a[order][:, order].astype(np.float64)
-        np.testing.assert_array_equal(got, want)
+        for symmetric in (False, True):
+            got = ops.handback_f64(m, idx, symmetric=symmetric)
+            np.testing.assert_array_equal(got, want)
         # the full path of round 4: one permute into a row-major copy, every element over PCIe
         tmp = ops.matrix(n, n)
         ops.permute(m, tmp, idx, idx)
@@ -58,31 +62,40 @@ def test_download_f64_sym_is_the_full_hand_back(ops, n, blocked):
     m.free()
 
 
-def test_download_f64_sym_into_a_wider_frame(ops):
+def test_handback_f64_into_a_wider_frame_and_of_an_asymmetric_matrix(ops):
     n, ld = 200, 333
     rng = np.random.default_rng(3)
     a = rng.random((n, n)).astype(np.float32)
-    a = np.minimum(a, a.T)
-    m = ops.matrix(n, n, blocked=True)
-    ops.upload(m, a)
-    out = np.full((n, ld), -1.0)
     from simrank_amd._lib import check
-    check(ops.lib.simrank_download_f64_sym(out.ctypes.data, ld, m.ptr, m.ld, m.rows_pad, n, None, ops.stream))
-    np.testing.assert_array_equal(out[:, :n], a.astype(np.float64))
-    assert (out[:, n:] == -1.0).all()                      # nothing beyond the n columns is touched
-    m.free()
+    for sym_input in (True, False):
+        b = np.minimum(a, a.T) if sym_input else a            # (asymmetric: the symmetric form must notice and fall back)
+        m = ops.matrix(n, n, blocked=True)
+        ops.upload(m, b)
+        for mode in (0, 1):
+            out = np.full((n, ld), -1.0)
+            check(ops.lib.simrank_handback_f64(out.ctypes.data, ld, m.ptr, m.ld, m.rows_pad, n, None, mode, ops.stream))
+            np.testing.assert_array_equal(out[:, :n], b.astype(np.float64))
+            assert (out[:, n:] == -1.0).all()                 # nothing beyond the n columns is touched
+        m.free()
 
 
-def test_half_and_full_hand_back_of_config_4_are_the_same_bits(ops):
-    """BASELINE config 4 (N = 32768, nnz 1 048 576): four updates through the C plan, then the symmetric hand-back
-    (what fit() returns) against the full one (simrank_plan_result + simrank_download_f64), every element."""
+def test_half_and_full_hand_back_of_config_4_are_the_same_bits(ops, monkeypatch):
+    """BASELINE config 4 (N = 32768, nnz 1 048 576): four updates through the C plan, then the hand-back fit() returns
+    (pipelined, full form), the symmetric form (upper triangle over PCIe) and round 4's path (simrank_plan_result +
+    simrank_download_f64), every element."""
     from simrank_amd.engine import Plan
     df = synth.WORKLOADS["pl32768d32"][0]()
     _, csr = ingest.directed(df, False, "from", "to", "weight")
     n = csr.n_rows
     plan = Plan(ops, csr, coef=0.8)
     plan.run(4, 0.0)
+    pipelined = plan.result()
+    monkeypatch.setenv("SIMRANK_SYM_HANDBACK", "1")
     half = plan.result()
+    monkeypatch.delenv("SIMRANK_SYM_HANDBACK")
+    for r0 in range(0, n, 4096):
+        assert np.array_equal(half[r0:r0 + 4096], pipelined[r0:r0 + 4096])
+    del pipelined
     tmp = ops.matrix(n, n)
     from simrank_amd._lib import check
     check(ops.lib.simrank_plan_result(plan.handle, tmp.ptr, tmp.ld), "simrank_plan_result")

@@ -45,7 +45,13 @@
 namespace simrank {
 namespace {
 
-constexpr int64_t kSlabBytes = int64_t(64) << 20;     // per pinned / device slab
+int64_t slab_bytes() {                                // per pinned / device slab
+    static const int64_t v = [] {
+        const char* e = std::getenv("SIMRANK_HANDBACK_SLAB_MB");
+        return (e && std::atoll(e) > 0 ? std::atoll(e) : 128) << 20;
+    }();
+    return v;
+}
 constexpr int64_t kTile = 64;                         // the host transposes 64 x 64 blocks (16 KiB of floats: L1)
 constexpr int64_t kGroup = 16;                        // result rows a host thread owns together (one 64-byte line of every slab row)
 constexpr int64_t kDiag = 32;                         // diagonal blocks of the source that are handed over whole
@@ -110,7 +116,7 @@ std::vector<Band> cut_bands(int64_t n, bool sym = true) {
     for (int64_t r0 = 0; r0 < n;) {
         const int64_t c0 = sym ? r0 : 0;
         const int64_t pitch = odd_lines(n - c0);
-        int64_t nr = std::max<int64_t>(kTile, (kSlabBytes / 4 / pitch) / kTile * kTile);
+        int64_t nr = std::max<int64_t>(kTile, (slab_bytes() / 4 / pitch) / kTile * kTile);
         nr = std::min(nr, n - r0);
         bands.push_back({r0, nr, pitch, c0});
         r0 += nr;
@@ -118,18 +124,25 @@ std::vector<Band> cut_bands(int64_t n, bool sym = true) {
     return bands;
 }
 
-// the full form: whole rows of the band, dealt one by one
+// the full form: whole rows of the band, a contiguous share per thread
+template <bool NT>
 void widen_rows(const float* slab, const Band& b, int64_t n, double* dst, int64_t ld, int64_t t, int64_t nt) {
-    for (int64_t j = t; j < b.nr; j += nt) {
+    for (int64_t j = b.nr * t / nt; j < b.nr * (t + 1) / nt; ++j) {
         const float* s = slab + j * b.pitch;
         double* d = dst + (b.r0 + j) * ld;
-        for (int64_t c = 0; c < n; ++c) store_nt(d + c, (double)s[c]);
+        if (NT)
+            for (int64_t c = 0; c < n; ++c) store_nt(d + c, (double)s[c]);
+        else
+            for (int64_t c = 0; c < n; ++c) d[c] = (double)s[c];
     }
 }
 
 struct Slabs {                       // kept per device for the life of the process (pinning memory is slow)
     float* pin[2] = {nullptr, nullptr};
-    hipEvent_t done[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};       // band in its pinned slab
+    hipEvent_t packed[2] = {nullptr, nullptr};     // band packed in its device slab
+    hipEvent_t begin = nullptr;                    // the caller's stream has produced the source
+    hipStream_t side = nullptr;                    // the packing kernels run here, beside the copies on the caller's stream
     size_t cap = 0;
 };
 std::mutex g_slab_mutex;
@@ -277,8 +290,14 @@ int simrank_handback_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
     SR_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_slab_mutex);      // (one dense hand-back per process at a time: it uses every core)
     Slabs& sl = g_slabs[dev & 15];
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
         if (!sl.done[i]) SR_HIP(hipEventCreateWithFlags(&sl.done[i], hipEventDisableTiming));
+        if (!sl.packed[i]) SR_HIP(hipEventCreateWithFlags(&sl.packed[i], hipEventDisableTiming));
+    }
+    if (!sl.begin) SR_HIP(hipEventCreateWithFlags(&sl.begin, hipEventDisableTiming));
+    if (!sl.side) SR_HIP(hipStreamCreateWithFlags(&sl.side, hipStreamNonBlocking));
+    SR_HIP(hipEventRecord(sl.begin, st));
+    SR_HIP(hipStreamWaitEvent(sl.side, sl.begin, 0));
     if (need > sl.cap) {
         for (int i = 0; i < 2; ++i) {
             if (sl.pin[i]) (void)hipHostFree(sl.pin[i]);
@@ -312,18 +331,25 @@ int simrank_handback_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
         const int32_t* ci = idx ? idx + bd.c0 : nullptr;
         if (!idx)       // identity order: the band starts at (r0, c0) of the source (both multiples of 64, or c0 = 0)
             s = src_rows_pad > 0 ? src + ((bd.c0 >> 5) * src_rows_pad + bd.r0) * 32 : src + bd.r0 * ld_src + bd.c0;
-        int rc = simrank_permute_layout(s, ld_src, src_rows_pad, dev_slab[b & 1], bd.pitch, 0, bd.nr, w, ri, ci, 4, st);
+        // (the packing kernel of band b + 2 runs on the side stream while band b + 1 is still on the wire: on one stream
+        // every band's copy waited for the next band's kernel — 35 x 0.2 ms at N = 32768)
+        int rc = simrank_permute_layout(s, ld_src, src_rows_pad, dev_slab[b & 1], bd.pitch, 0, bd.nr, w, ri, ci, 4, sl.side);
         if (rc) return rc;
+        SR_HIP(hipEventRecord(sl.packed[b & 1], sl.side));
+        SR_HIP(hipStreamWaitEvent(st, sl.packed[b & 1], 0));
         SR_HIP(hipMemcpyAsync(sl.pin[b & 1], dev_slab[b & 1], size_t(bd.nr) * size_t(bd.pitch) * 4, hipMemcpyDeviceToHost, st));
         SR_HIP(hipEventRecord(sl.done[b & 1], st));
         return SIMRANK_OK;
     };
+    const char* nt_env = std::getenv("SIMRANK_HANDBACK_NT");
+    const bool nt_stores = nt_env ? (*nt_env && *nt_env != '0') : true;
     auto widen = [&](int64_t b, int64_t t, int64_t nt) {
         if (sym) widen_band(sl.pin[b & 1], bands[(size_t)b], n, dst, ld_dst, t, nt);
-        else widen_rows(sl.pin[b & 1], bands[(size_t)b], n, dst, ld_dst, t, nt);
+        else if (nt_stores) widen_rows<true>(sl.pin[b & 1], bands[(size_t)b], n, dst, ld_dst, t, nt);
+        else widen_rows<false>(sl.pin[b & 1], bands[(size_t)b], n, dst, ld_dst, t, nt);
     };
-    // (no default for a host without a quota: on the 256-thread bench box without one, 32 threads were the best)
-    const int64_t nt = std::max<int64_t>(1, std::min<int64_t>({32, cpu_share(), (n + 4 * kGroup - 1) / (4 * kGroup),
+    // (16 threads: 93 ms for N = 32768 on the bench box, 32: 111 - 116 — its quota is 16 CPUs — 8: 104; profiles/r05_handback_knobs.log)
+    const int64_t nt = std::max<int64_t>(1, std::min<int64_t>({16, cpu_share(), (n + 4 * kGroup - 1) / (4 * kGroup),
                                                                std::max<int64_t>(1, (n * n) >> 18)}));
     std::mutex m;
     std::condition_variable cv;
@@ -386,6 +412,7 @@ int simrank_handback_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
         cv.notify_all();
         for (std::thread& th : threads) th.join();
     }
+    (void)hipStreamSynchronize(sl.side);
     (void)hipStreamSynchronize(st);
     (void)pool_free(dev_slab[0]);
     (void)pool_free(dev_slab[1]);

@@ -168,6 +168,23 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
     const int per = (nq + 3) >> 2;                          // quads per wave
     const int n_active = per ? (nq + per - 1) / per : 0;    // waves that have MFMA work
 
+    // ---- (round 5) the matrix-core phase's first loads depend on the unit record only: the operand-row ids and pattern
+    // bits of the wave's first two quads are requested before anything else, so that the chain unit record -> ids ->
+    // operand rows -> first MFMA (three dependent trips to memory, ~3 000 cycles each under the gather traffic, for a set
+    // of 1 - 3 quads per wave) runs beside the prologue instead of behind it.  Unconditional (the arrays carry one quad
+    // of padding): every load count stays static.
+    const int q_lo = wave * per, q_hi = min(nq, q_lo + per);
+    auto ld_ids = [&](int qd) -> int {
+        const size_t at = size_t(quad0 + qd) * 64 + lane;
+        if constexpr (IDS16) return int(p.dcols16[at]) & p.idx_mask;
+        else return p.dcols32[at] & p.idx_mask;
+    };
+    const int qa0 = max(0, min(q_lo, nq - 1)), qa1 = max(0, min(q_lo + 1, q_hi - 1));
+    int ids_a = ld_ids(qa0);
+    uint4 aw_a = p.abits[size_t(quad0 + qa0) * 64 + lane];
+    int ids_b = ld_ids(qa1);
+    uint4 aw_b = p.abits[size_t(quad0 + qa1) * 64 + lane];
+
     // ---- everything the gather phase needs that does not depend on another load is requested now: the
     // wave's stream geometry (scalar, part of the unit record), the rows of every lane group (into LDS),
     // the ids of the first two rounds
@@ -175,30 +192,52 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
     const int round0 = wm[0];
     const int e1 = wm[1], e2 = wm[2], e3 = wm[3], e4 = wm[4];      // rounds up to the end of each block of the unit
     const int n_rounds = (p.probe & 1) ? 0 : (n_sub == 1 ? e1 : n_sub == 2 ? e2 : n_sub == 3 ? e3 : e4);
-    auto ld_sid = [&](int r) -> int {                        // round r of the stream: this lane's id
-        const size_t at = (size_t(round0) + size_t(min(r, max(n_rounds - 1, 0)))) * 64 + lane;
-        if constexpr (IDS16) {
-            const int v = p.meta_nt ? int(__builtin_nontemporal_load(p.sids16 + at)) : int(p.sids16[at]);
-            return v == 0xFFFF ? sent : (v & p.idx_mask);
-        } else {
-            const int v = p.meta_nt ? __builtin_nontemporal_load(p.sids32 + at) : p.sids32[at];
-            return v < 0 ? sent : (v & p.idx_mask);
-        }
+    auto fix_sid = [&](int v) -> int {                       // a raw id of the stream -> operand row (empty slot: past the end)
+        if constexpr (IDS16) return v == 0xFFFF ? sent : (v & p.idx_mask);
+        else return v < 0 ? sent : (v & p.idx_mask);
     };
+    auto ld_sid_raw = [&](int r) -> int {                    // round r of the stream: this lane's id, as stored
+        const size_t at = (size_t(round0) + size_t(min(r, max(n_rounds - 1, 0)))) * 64 + lane;
+        if constexpr (IDS16) return p.meta_nt ? int(__builtin_nontemporal_load(p.sids16 + at)) : int(p.sids16[at]);
+        else return p.meta_nt ? __builtin_nontemporal_load(p.sids32 + at) : p.sids32[at];
+    };
+    auto ld_sid = [&](int r) -> int { return fix_sid(ld_sid_raw(r)); };
+    // (round 5) the row records and the ids of the first two rounds are REQUESTED together and only then used: the
+    // compiler had put the use of the first id load in front of the second load (two trips to memory one after the other
+    // in every workgroup's prologue) and read the row records through a flat load selected against a stack slot
+    int iv0 = sent, iv1 = sent;
     {   // lane (g, q): row q & 3 of lane group g, blocks q >> 2 and 2 + (q >> 2) of the unit
         const int sbA = q >> 2, sbB = 2 + (q >> 2);
         const int2* src = p.gmeta + ((size_t(un[29]) * 4 + wave) * 8 + g) * 4 + (q & 3);
         int2* dst = gm_lds + (wave * 8 + g) * 4 + (q & 3);
-        const int2 none = make_int2(int(0xFFFFFFFFu), 0);
-        const int2 a = sbA < n_sub ? src[size_t(sbA) * 4 * 8 * 4] : none;
-        const int2 c = sbB < n_sub ? src[size_t(sbB) * 4 * 8 * 4] : none;
+        int2 a = src[size_t(min(sbA, n_sub - 1)) * 4 * 8 * 4];
+        int2 c = src[size_t(min(sbB, n_sub - 1)) * 4 * 8 * 4];
+        int raw0 = 0, raw1 = 0;
+        if (n_rounds > 0) {
+            raw0 = ld_sid_raw(0);
+            raw1 = ld_sid_raw(1);
+        }
+        __builtin_amdgcn_sched_barrier(0);                   // (every load of the prologue is on its way before the first use)
+        if (sbA >= n_sub) a = make_int2(int(0xFFFFFFFFu), 0);
+        if (sbB >= n_sub) c = make_int2(int(0xFFFFFFFFu), 0);
         dst[sbA * 4 * 8 * 4] = a;
         dst[sbB * 4 * 8 * 4] = c;
+        if (n_rounds > 0) {
+            iv0 = fix_sid(raw0);
+            iv1 = fix_sid(raw1);
+        }
     }
-    int iv0 = sent, iv1 = sent;
-    if (n_rounds > 0) {
-        iv0 = ld_sid(0);
-        iv1 = ld_sid(1);
+
+    // ... and the operand rows of the wave's first two matrix-core steps follow as soon as their ids are there: they travel
+    // while the pattern table is built and the workgroup meets at its first barrier
+    float4 rA0 = make_float4(0.f, 0.f, 0.f, 0.f), rA1 = rA0, rB0 = rA0, rB1 = rA0;
+    auto issue = [&](int ids, int s4, float4& x0, float4& x1) {   // two wave instructions, 8 operand rows each
+        x0 = ld_seg_p(srd, __shfl(ids, s4 * 16 + g), pitch, qoff);
+        x1 = ld_seg_p(srd, __shfl(ids, s4 * 16 + 8 + g), pitch, qoff);
+    };
+    if (q_lo < q_hi) {
+        issue(ids_a, 0, rA0, rA1);
+        issue(ids_a, 1, rB0, rB1);
     }
 
     FST(1);
@@ -219,7 +258,6 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-        const int q_lo = wave * per, q_hi = min(nq, q_lo + per);
         if (q_lo < q_hi) {
             // Software pipeline over the wave's steps, one quad (4 steps) per loop iteration: while the 12
             // MFMAs of a step run, the next step goes registers -> LDS -> fragment -> three bf16 terms and
@@ -229,20 +267,7 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
             // steps that pad a set to whole quads multiply zero pattern bits.
             float* bbuf = bbuf_all + wave * (16 * 32);
             const int n = lane & 31, h = lane >> 5;
-            auto ld_ids = [&](int qd) -> int {
-                const size_t at = size_t(quad0 + qd) * 64 + lane;
-                if constexpr (IDS16) return int(p.dcols16[at]) & p.idx_mask;
-                else return p.dcols32[at] & p.idx_mask;
-            };
-            int ids_a = ld_ids(q_lo);
-            uint4 aw_a = p.abits[size_t(quad0 + q_lo) * 64 + lane];
-            int ids_b = ld_ids(min(q_lo + 1, q_hi - 1));
-            uint4 aw_b = p.abits[size_t(quad0 + min(q_lo + 1, q_hi - 1)) * 64 + lane];
             struct Terms { uint32_t lo[4], mid[4], hi[4]; };
-            auto issue = [&](int ids, int s4, float4& x0, float4& x1) {   // two wave instructions, 8 operand rows each
-                x0 = ld_seg_p(srd, __shfl(ids, s4 * 16 + g), pitch, qoff);
-                x1 = ld_seg_p(srd, __shfl(ids, s4 * 16 + 8 + g), pitch, qoff);
-            };
             // B fragment through the wave's LDS buffer: [k][n] -> lane (n, h) holds k = 8h .. 8h + 7
             auto stage = [&](const float4& x0, const float4& x1, float (&x)[8]) {
                 wave_lds_order();
@@ -269,11 +294,8 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
                     acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bh, acc[tt], 0, 0, 0);
                 }
             };
-            float4 rA0, rA1, rB0, rB1;
             Terms tA, tB;
             float x[8];
-            issue(ids_a, 0, rA0, rA1);
-            issue(ids_a, 1, rB0, rB1);
             stage(rA0, rA1, x);
             split(x, tA);
             issue(ids_a, 2, rA0, rA1);
@@ -428,25 +450,39 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
                     return;
                 }
                 const int first = pslot - unit_k;                // the block's units own consecutive slots
+                // (round 5) a thread's four pieces of a unit's tile are requested together: the loop used to wait for every
+                // single 16-byte load — 4 x units dependent trips to the L2 in the last arriver (two units per trip as well
+                // spilled 47 registers: the gather pipeline's two register sets are live across this code)
+                float4 acc4[4];
+                auto piece = [&](int k, int it) -> float4 {
+                    const int x = threadIdx.x + it * 256;
+                    const int c = x >> 5, r4 = (x & 31) * 4;
+                    const float* src = p.partials + (size_t(first + k) * p.n_panels + panel) * (32 * kFB);
+                    const __amdgpu_buffer_rsrc_t ssrd =
+                        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 32 * kFB * 4, 0x00020000);
+                    const v4u w = __builtin_amdgcn_raw_buffer_load_b128(ssrd, (c * kFB + r4) * 4, 0, 16);
+                    return make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+                };
+                for (int k = 0; k < unit_nb; ++k) {
+                    float4 va[4];
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) va[it] = piece(k, it);
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        if (k == 0) acc4[it] = va[it];
+                        else { acc4[it].x += va[it].x; acc4[it].y += va[it].y; acc4[it].z += va[it].z; acc4[it].w += va[it].w; }
+                    }
+                }
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int x = threadIdx.x + it * 256;
                     const int c = x >> 5, r4 = (x & 31) * 4;
-                    float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    for (int k = 0; k < unit_nb; ++k) {
-                        const float* src = p.partials + (size_t(first + k) * p.n_panels + panel) * (32 * kFB);
-                        const __amdgpu_buffer_rsrc_t ssrd =
-                            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 32 * kFB * 4, 0x00020000);
-                        const v4u w = __builtin_amdgcn_raw_buffer_load_b128(ssrd, (c * kFB + r4) * 4, 0, 16);
-                        const float4 v = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
-                        if (k == 0) acc4 = v;
-                        else { acc4.x += v.x; acc4.y += v.y; acc4.z += v.z; acc4.w += v.w; }
-                    }
                     float scv[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) scv[j] = row0 + r4 + j < p.M ? p.rowscale[row0 + r4 + j] : 0.f;
-                    acc4.x *= scv[0]; acc4.y *= scv[1]; acc4.z *= scv[2]; acc4.w *= scv[3];
-                    *reinterpret_cast<float4*>(tile + c * kTS + r4) = acc4;
+                    float4 a4 = acc4[it];
+                    a4.x *= scv[0]; a4.y *= scv[1]; a4.z *= scv[2]; a4.w *= scv[3];
+                    *reinterpret_cast<float4*>(tile + c * kTS + r4) = a4;
                 }
                 __syncthreads();
             }
@@ -680,6 +716,9 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
                     ++out.covered;
                 }
             }
+            // (round 5: ordering a row's gathered ids by how many rows of the block share the column — siblings at the head
+            // of both streams, the same few rounds of the workgroup — changed nothing: 4.84 against 4.82 ms at pl32768d32,
+            // 18.1 against 17.8 at N = 65536; a sibling's second access hits the L1 or the L2 either way.  Not kept.)
             out.rem += (int64_t)rem[rr].size();
         }
         int order[kFB];
@@ -924,6 +963,10 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
     pl->nnz_covered = covered;
     pl->r_nnz = r_nnz;
     pl->ids16 = ids16 ? 1 : 0;
+    // (one quad of padding behind the last set: the kernel requests the first ids and pattern bits of a unit's share of its
+    // set before it knows whether the unit has one — a unit of the last blocks without a set reads here)
+    dcols.resize(dcols.size() + 64, 0);
+    abits.resize(abits.size() + 64 * 4, 0u);
     int rc = upload_vec(&pl->units, units);
     if (!rc) {
         if (ids16) {

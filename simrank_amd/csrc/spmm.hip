@@ -813,7 +813,7 @@ template <int MODE>
 __device__ __forceinline__ void emit_row3(const SpmmArgs& p, float* tbuf_wave, int r_local, int64_t a,
                                           int q, int64_t mycol, int64_t colofs, float rowscale,
                                           const float (&acc)[4], const float (&dsum)[4], unsigned& changed,
-                                          bool mirror, bool check_prev) {
+                                          bool mirror, bool check_prev, const float* old_pre = nullptr) {
     // colofs: where this lane's 4 columns start inside a row of Y / prev / prior / evidence
     // (row-major: the column; panel-blocked: the panel's base + 4 q, rows then 32 apart)
     constexpr int RT = 32;
@@ -851,7 +851,12 @@ __device__ __forceinline__ void emit_row3(const SpmmArgs& p, float* tbuf_wave, i
             }
             if (check_prev) {       // (false: no previous iterate, or count_any and a difference is known)
                 float old[4];
-                vload_nt<4>(old, p.prev + a * p.ld_prev + colofs);
+                if (old_pre) {      // (phase B: requested before the pass's gathers, round 5)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) old[i] = old_pre[i];
+                } else {
+                    vload_nt<4>(old, p.prev + a * p.ld_prev + colofs);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     changed += (i < nvalid && fabs(double(o[i]) - double(old[i])) > p.eps)
@@ -1001,20 +1006,31 @@ void gather3_kernel(const SpmmArgs p) {
     unsigned long long seen = 0;
     const unsigned slot = ((blockIdx.x * 4u + unsigned(wave)) * 7u) % SIMRANK_CHANGED_SLOTS;
     if constexpr (!TRANS) {
-        if (p.has_ep && p.prev && p.count_any) {
-            // (the wave's own striped counter: one shared flag word would be a hot spot in one L2 channel)
-            const unsigned long long* flag = p.n_changed + slot;
-            asm volatile("" : "+v"(flag));
-            seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        {
+            // (the wave's own striped counter: one shared flag word would be a hot spot in one L2 channel.)  Round 5: an
+            // UNCONDITIONAL buffer load past the L1 (sc1; a descriptor of zero bytes when there is nothing to watch: no
+            // access, the value 0) — the generic-pointer atomic load inside a branch compiled to a FLAT load (which counts
+            // against lgkmcnt as well) with its wait right behind it: a trip to the L2 at the head of the prologue of
+            // every one of the launch's 275 k workgroups
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+            const bool watch = p.has_ep && p.prev && p.count_any;
+            const __amdgpu_buffer_rsrc_t csrd = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<unsigned long long*>(p.n_changed), 0, watch ? SIMRANK_CHANGED_SLOTS * 8 : 0, 0x00020000);
+            const v2u w = __builtin_amdgcn_raw_buffer_load_b64(csrd, int(slot * 8u), 0, 16);
+            seen = (unsigned long long)w.x | ((unsigned long long)w.y << 32);
         }
     }
 
     int row0 = (rt * kWaves + wave) * RT;
     int nrows = int(imin(RT, p.M - row0));
     if (p.tile_row0) {
+        // (wave-uniform: both ends of the tile through the scalar cache, requested together — they were two vector loads
+        // with a full wait between them)
         const int t = rt * kWaves + wave;
-        row0 = t < p.n_tiles ? p.tile_row0[t] : int(p.M);
-        nrows = t < p.n_tiles ? p.tile_row0[t + 1] - row0 : 0;
+        const int tc = __builtin_amdgcn_readfirstlane(max(0, min(t, p.n_tiles - 1)));
+        const int r0 = p.tile_row0[tc], r1 = p.tile_row0[tc + 1];
+        row0 = t < p.n_tiles ? r0 : int(p.M);
+        nrows = t < p.n_tiles ? r1 - r0 : 0;
     }
     bool mirror = false;
     if constexpr (MODE == kSym) {
@@ -1183,6 +1199,17 @@ void gather3_kernel(const SpmmArgs p) {
             return ((__ballot(w != 0u) >> gbase) & 0xFFull) != 0;
         };
         bool glive = group_live(r, src < nrows && col_active);
+        // (round 5) the previous iterate's values of the pass's rows — what the exact convergence count compares with — are
+        // requested BEFORE the pass's gathers (they depend on nothing the pass computes); they used to be loaded when a row
+        // was emitted: a trip to memory behind every pass of eight rows
+        float old[4] = {0.f, 0.f, 0.f, 0.f};
+        auto load_prev = [&](int row, bool on) {
+            // (32-bit operand addressing only: with 64-bit gather addresses the four registers no longer fit 6 waves per SIMD)
+            if constexpr (!TRANS && A32) {
+                if (check_prev && on) vload_nt<4>(old, p.prev + (int64_t(row0) + row) * p.ld_prev + colofs);
+            }
+        };
+        load_prev(r, src < nrows && col_active);
         while (true) {
             const bool same_pass = t0 + LPR < maxlen;
             const int npos = same_pass ? pos : pos + 8;
@@ -1208,12 +1235,14 @@ void gather3_kernel(const SpmmArgs p) {
 
             if (!same_pass) {
                 if (pos + g < nrows && col_active)
-                    emit_row3<MODE>(p, tbuf_wave, r, int64_t(row0) + r, q, mycol, colofs, sc, acc, dsum, changed, mirror, check_prev);
+                    emit_row3<MODE>(p, tbuf_wave, r, int64_t(row0) + r, q, mycol, colofs, sc, acc, dsum, changed, mirror, check_prev,
+                                    (!TRANS && A32) ? old : nullptr);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] = 0.f;
                 if (more) {
                     dense_partial<DENSE>(p, int64_t(row0) + nr, mycol, npos + g < nrows && col_active, tile_ns, tile_slab0, dsum);
                     glive = group_live(nr, npos + g < nrows && col_active);
+                    load_prev(nr, npos + g < nrows && col_active);
                 }
             }
             if (!more) break;

@@ -19,6 +19,7 @@ ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--set", default="")
 ap.add_argument("--storage", default="f32", choices=["f32", "fp16"])
 ap.add_argument("--pp", action="store_true", help="SimRank++ (evidence counts in the epilogue)")
+ap.add_argument("--exact", action="store_true", help="exact convergence count (every element compared): what bench.py's headline times")
 args = ap.parse_args()
 if "probe" in args.set:
     os.environ["SIMRANK_ENABLE_PROBES"] = "1"       # diagnostic knobs (wrong results, timing only)
@@ -31,6 +32,7 @@ spec = SideSpec(csr, csr.rowscale, 0.8, storage=args.storage)
 if args.pp:
     spec = SideSpec(csr, ingest.spread(csr) * csr.rowscale, 0.8, evidence_from=csr, storage=args.storage)
 s = Solver(lambda r: ops, LocalWorld(1), [spec], "sparse")
+s.exact_count = args.exact
 import time                                                        # noqa: E402
 s.reset()
 s.step(0.0)

@@ -637,6 +637,27 @@ int graph_create_with(const Tuning& tun, int64_t n_rows, int64_t n_cols, int64_t
     g->n_cols = n_cols;
     g->nnz = nnz;
     g->max_row_nnz = max_row;
+    // HUB columns of the evidence counts (round 5; spmm.hip evidence_hub_kernel): a column with d live rows costs the
+    // LDS-counter kernel d^2 / 2 paths (~1e11 paths/s) and one more column of the 0/1 image costs the matrix-core
+    // kernel n_rows^2 multiply-adds (~1e15/s): from d >= 0.014 n_rows on (tuning "ev_hub", in 1/1000 of n_rows; 0 = off)
+    // the column's pairs are counted as an i8 product P_H . P_H^T instead.  On a power-law pattern a few dozen columns
+    // carry nearly all of the paths; on a MovieLens-like one nearly every column qualifies.
+    std::vector<int32_t> hubidx(size_t(n_cols), -1);
+    if (g->tun.ev_hub > 0 && nnz > 0) {
+        const int64_t thr = std::max<int64_t>(48, (n_rows * g->tun.ev_hub + 999) / 1000);
+        std::vector<int32_t> cand;
+        for (int64_t i = 0; i < n_cols; ++i)
+            if (t_rowptr[size_t(i) + 1] - t_rowptr[size_t(i)] >= thr) cand.push_back((int32_t)i);
+        std::sort(cand.begin(), cand.end(), [&](int32_t x, int32_t y) {
+            const int32_t dx = t_rowptr[size_t(x) + 1] - t_rowptr[size_t(x)], dy = t_rowptr[size_t(y) + 1] - t_rowptr[size_t(y)];
+            return dx != dy ? dx > dy : x < y;
+        });
+        if (cand.size() > 4096) cand.resize(4096);
+        if (cand.size() >= 8) {
+            for (size_t h = 0; h < cand.size(); ++h) hubidx[size_t(cand[h])] = (int32_t)h;
+            g->ev_hubs = (int32_t)((cand.size() + 31) / 32 * 32);
+        }
+    }
     std::vector<int32_t> tile_row0, sym_map;
     g->n_tiles = (int32_t)build_tiles(rowptr, n_rows, nnz, g->tun.balance, tile_row0, sym_map, g->tun.sym_desc != 0);
     g->sym_blocks = (int32_t)(sym_map.size() / 2);
@@ -692,6 +713,7 @@ int graph_create_with(const Tuning& tun, int64_t n_rows, int64_t n_cols, int64_t
     if (!rc) rc = up((void**)&g->t_rowptr, t_rowptr.data(), size_t(n_cols + 1) * 4);
     if (!rc) rc = up((void**)&g->t_col, t_col.data(), size_t(nnz) * 4);
     if (!rc) rc = up((void**)&g->t_pos, t_pos.data(), size_t(nnz) * 4);
+    if (!rc && g->ev_hubs) rc = up((void**)&g->ev_hubidx, hubidx.data(), size_t(n_cols) * 4);
     if (!rc && g->n_tiles) rc = up((void**)&g->tile_row0, tile_row0.data(), tile_row0.size() * 4);
     if (!rc && g->sym_blocks) rc = up((void**)&g->sym_map, sym_map.data(), sym_map.size() * 4);
     if (!rc && after_base && *after_base) rc = (*after_base)(g);     // (the builders are still at work on their threads)
@@ -734,6 +756,8 @@ int simrank_graph_destroy(simrank_graph* g) {
     plan_free(g->t_rowptr);
     plan_free(g->t_col);
     plan_free(g->t_pos);
+    plan_free(g->ev_hubidx);
+    plan_free(g->ev_hub_image);
     plan_free(g->tile_row0);
     plan_free(g->sym_map);
     free_dense_plan(g->dense);
@@ -819,6 +843,9 @@ int simrank_set_tuning(const char* key, int64_t value) {
         SR_REQUIRE(value == 0 || value == 1, "fuse must be 0 (two launches) or 1 (one launch)");
 #endif
         t.fuse = value;
+    } else if (!strcmp(key, "ev_hub")) {
+        SR_REQUIRE(value >= 0 && value <= 1000, "ev_hub must be 0 (off) .. 1000 (thousandths of the row count)");
+        t.ev_hub = value;
     } else if (!strcmp(key, "fuse_min")) {
         SR_REQUIRE(value >= 2 && value <= 128, "fuse_min must be 2 .. 128");
         t.fuse_min = value;
@@ -881,6 +908,7 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     else if (!strcmp(key, "dense_cols")) *value = t.dense_cols;
     else if (!strcmp(key, "dense_sym")) *value = t.dense_sym;
     else if (!strcmp(key, "fuse")) *value = t.fuse;
+    else if (!strcmp(key, "ev_hub")) *value = t.ev_hub;
     else if (!strcmp(key, "fuse_min")) *value = t.fuse_min;
     else if (!strcmp(key, "fuse_steps")) *value = t.fuse_steps;
     else if (!strcmp(key, "fuse_dens")) *value = t.fuse_dens;

@@ -58,6 +58,8 @@ struct Tuning {
     int64_t sym_desc = 1;    // upper-triangle leg 2: an XCD takes its panels in descending order — the big ones (N/128
                              // workgroups: one panel at a time in its L2) first, the small ones as the tail: leg 2 -4.7 %
     int64_t ev_tri = 1;      // evidence counts of a whole square block: paths to b >= a only + a mirror pass (round 4)
+    int64_t ev_hub = 14;     // ... columns with at least this many thousandths of n_rows live rows (and >= 48) are counted on the
+                             // matrix cores (i8 product of their 0/1 image), the rest on the LDS counters (round 5); 0 = off
     int64_t fuse = 1;        // leg 1 of a panel-blocked update as ONE launch (fused.hip): the columns shared by
                              // >= fuse_min rows of a 128-row block on the matrix cores, the rest gathered, by the
                              // same workgroup on the same L2-resident panel slice; 0 = dense_tiles + gather3 launches
@@ -303,6 +305,9 @@ struct simrank_graph {
     int32_t* t_rowptr = nullptr;  // [n_cols+1]  transposed pattern
     int32_t* t_col = nullptr;     // [nnz]       row ids, ascending per column
     int32_t* t_pos = nullptr;     // [nnz]       slot of CSR entry j in its column's list (live rows only)
+    int32_t* ev_hubidx = nullptr; // [n_cols]    index of a HUB column in the 0/1 image of the evidence counts, -1: none
+    int32_t ev_hubs = 0;          // columns of that image (a multiple of 32; 0: no hub columns)
+    uint8_t* ev_hub_image = nullptr;  // [rows padded to 128][ev_hubs] the image itself, built at the first evidence call
     int32_t max_row_nnz = 0;
     // balanced tiling of the rows (api.hip: build_tiles): tile t = rows [tile_row0[t],
     // tile_row0[t+1]) — 32-row blocks, the heavy ones cut into aligned halves — and, for the

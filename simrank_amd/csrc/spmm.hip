@@ -1722,13 +1722,17 @@ __global__ __launch_bounds__(256) void permute_kernel(const T* __restrict__ src,
 // Round 2 walked every path once per 16384-column pass (4 x at N = 65536) with 4 waves per workgroup and a
 // rowscale load per path; the transposed pattern now lists live rows only (simrank_graph_create).
 constexpr int kEvChunk = 65536;  // columns per pass
-constexpr int kEvThreads = 1024;
+// (round 5, measured and dropped: with the hub columns on the matrix cores what is left per row is a short walk behind a chain
+// of dependent loads; four passes of 16384 columns with 512 threads — four workgroups per CU instead of one — paid that chain
+// four times: 4 x 3.5 ms against 6.3 ms in one pass at N = 65536)
 
+template <int kEvThreads>
 __global__ __launch_bounds__(kEvThreads) void evidence_counts_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ rowscale, const int32_t* __restrict__ t_rowptr,
     const int32_t* __restrict__ t_col, const int32_t* __restrict__ t_pos, int64_t M, int64_t col0, int n_cols,
-    uint8_t* out, int64_t ld, int64_t rows_pad, int64_t out_col0, int vec4, int tri) {
+    uint8_t* out, int64_t ld, int64_t rows_pad, int64_t out_col0, int vec4, int tri,
+    const int32_t* __restrict__ hubidx) {
     extern __shared__ unsigned cnt[];                 // counters of columns 2 w and 2 w + 1 in word w
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1740,13 +1744,40 @@ __global__ __launch_bounds__(kEvThreads) void evidence_counts_kernel(
     // Rows are taken LONGEST FIRST there (the long rows, late in the solver's order, have the short ranges).
     for (int64_t it = blockIdx.x; it < M; it += gridDim.x) {
         const int64_t a = tri ? M - 1 - it : it;
-        const int first = tri ? int(a & ~int64_t(31)) : 0;       // first column this row zeroes, counts from and writes
-        for (int w = (first >> 1) + tid; w < words; w += kEvThreads) cnt[w] = 0;
+        // first column (of this pass's n_cols) this row zeroes, counts from and writes; tri in several passes (out_col0 =
+        // where the pass starts in the square): a row below the pass's columns has nothing to do in it
+        const int64_t first64 = tri ? (a & ~int64_t(31)) - out_col0 : 0;
+        if (first64 >= n_cols) continue;
+        const int first = first64 > 0 ? int(first64) : 0;
+        if (hubidx) {
+            // (round 5) the pairs through the HUB columns were counted on the matrix cores (evidence_hub_kernel) and sit in
+            // `out` already: the counters start from them, and the walk below leaves those columns out
+            if (vec4) {
+                for (int c4 = first + tid * 4; c4 < n_cols; c4 += kEvThreads * 4) {
+                    const uint8_t* src = out + elem_at(a, out_col0 + c4, ld, rows_pad);
+                    unsigned v = 0;
+                    if (c4 + 4 <= n_cols) v = *reinterpret_cast<const unsigned*>(src);
+                    else for (int k = 0; c4 + k < n_cols; ++k) v |= unsigned(src[k]) << (8 * k);
+                    cnt[c4 >> 1] = (v & 0xFFu) | ((v >> 8) & 0xFFu) << 16;
+                    if (c4 + 2 < n_cols) cnt[(c4 >> 1) + 1] = ((v >> 16) & 0xFFu) | (v >> 24) << 16;
+                }
+            } else {
+                for (int w = (first >> 1) + tid; w < words; w += kEvThreads) {
+                    const int c = 2 * w;
+                    const unsigned lo = out[elem_at(a, out_col0 + c, ld, rows_pad)];
+                    const unsigned hi = c + 1 < n_cols ? out[elem_at(a, out_col0 + c + 1, ld, rows_pad)] : 0u;
+                    cnt[w] = lo | hi << 16;
+                }
+            }
+        } else {
+            for (int w = (first >> 1) + tid; w < words; w += kEvThreads) cnt[w] = 0;
+        }
         __syncthreads();
         if (rowscale[a] > 0.f) {
             const int s = rowptr[a], e = rowptr[a + 1];
             for (int j = s + wave; j < e; j += kEvThreads / 64) {
                 const int i = col[j];
+                if (hubidx && hubidx[i] >= 0) continue;
                 // (tri: column i's list is ascending and holds a itself at t_pos[j]: from there on it is b >= a)
                 const int ts = tri ? t_pos[j] : t_rowptr[i], te = t_rowptr[i + 1];
                 for (int t = ts + lane; t < te; t += 64) {
@@ -1787,41 +1818,132 @@ __global__ __launch_bounds__(kEvThreads) void evidence_counts_kernel(
     }
 }
 
-// The lower triangle of a square u8 count block from its upper one: 32 x 32 tiles, tile (I, J) with I > J is the
-// transpose of tile (J, I); a tile on the diagonal mirrors itself.  One workgroup of 256 threads per tile: the source
-// tile goes through LDS (coalesced 4-byte loads and stores on both sides, either layout).
-__global__ __launch_bounds__(256) void evidence_mirror_kernel(uint8_t* cnt, int64_t n, int64_t ld, int64_t rows_pad) {
-    __shared__ unsigned char t[32][36];
+// ---------------------------------------------------------------------------------------
+// K7h (round 5): the pairs through the HUB columns on the matrix cores.  counts(a, b) = sum over common in-neighbours i
+// (SimRank.py:315 `Graph.dot(Graph.T)` on the 0/1 pattern); for the H columns i that very many rows share, the 0/1
+// image P (live rows x H, one byte each) is built once and counts_hub = P . P^T is an integer GEMM:
+// v_mfma_i32_32x32x32_i8, exact.  A workgroup owns a 128 x 128 tile of the counts, a wave 64 x 64 of it (2 x 2 MFMA
+// tiles); A and B fragments come from the same matrix by the same rule (lane (m, h): 16 bytes of row m from byte
+// k0 + 16 h), so whatever order the instruction takes k in, both operands agree on it.  Saturated to u8 on the way out
+// through a 1 KiB LDS tile per wave (16-byte stores along the count rows, either layout).  tri: the tiles right of or on
+// the diagonal only (the LDS-counter kernel and the mirror pass do the rest, as without hubs).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hub_image_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                        const float* __restrict__ rowscale,
+                                                        const int32_t* __restrict__ hubidx, int64_t M, int Hp,
+                                                        uint8_t* __restrict__ P) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) >> 6, n_waves = (int64_t(gridDim.x) * 256) >> 6;
+    for (int64_t a = wave0; a < M; a += n_waves) {
+        if (!(rowscale[a] > 0.f)) continue;                     // (`G > 0`: rows without weight take no part)
+        for (int j = rowptr[a] + lane; j < rowptr[a + 1]; j += 64) {
+            const int h = hubidx[col[j]];
+            if (h >= 0) P[a * Hp + h] = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void evidence_hub_kernel(const uint8_t* __restrict__ P, int Hp, int64_t M, int64_t col0,
+                                                           int64_t n_cols, uint8_t* __restrict__ out, int64_t ld, int64_t rows_pad,
+                                                           int tiles_j, int tri, int vec16) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef int v16i __attribute__((ext_vector_type(16)));
+    __shared__ __attribute__((aligned(16))) unsigned char tbuf[4][32][48];
+    const int ti = int(blockIdx.x / unsigned(tiles_j)), tj = int(blockIdx.x % unsigned(tiles_j));
+    if (tri && tj < ti) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    const int64_t a0 = int64_t(ti) * 128 + (wave >> 1) * 64;          // rows of the counts
+    const int64_t c0 = int64_t(tj) * 128 + (wave & 1) * 64;           // columns of the block; node = col0 + column
+    const uint8_t* pa = P + (a0 + m) * Hp + 16 * h;
+    const uint8_t* pb = P + (col0 + c0 + m) * Hp + 16 * h;
+    v16i acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0;
+    for (int k0 = 0; k0 < Hp; k0 += 32) {
+        const v4i fa0 = *reinterpret_cast<const v4i*>(pa + k0), fa1 = *reinterpret_cast<const v4i*>(pa + 32 * Hp + k0);
+        const v4i fb0 = *reinterpret_cast<const v4i*>(pb + k0), fb1 = *reinterpret_cast<const v4i*>(pb + 32 * Hp + k0);
+        acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa0, fb0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa0, fb1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa1, fb0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa1, fb1, acc[1][1], 0, 0, 0);
+    }
+    // C/D layout of the 32 x 32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                tbuf[wave][(r & 3) + 8 * (r >> 2) + 4 * h][m] = (unsigned char)min(acc[x][y][r], 255);
+            __builtin_amdgcn_s_waitcnt(0xc07f);                   // (lgkmcnt(0): the wave's own bytes are in its tile)
+            __builtin_amdgcn_wave_barrier();
+            const int row = lane >> 1, half = lane & 1;
+            const int64_t a = a0 + 32 * x + row, c = c0 + 32 * y + 16 * half;
+            if (a < M && c < n_cols) {
+                const unsigned char* src = &tbuf[wave][row][16 * half];
+                uint8_t* dst = out + elem_at(a, c, ld, rows_pad);
+                if (vec16 && c + 16 <= n_cols) {
+                    *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+                } else {
+                    for (int k = 0; k < 16 && c + k < n_cols; ++k) dst[k] = src[k];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+}
+
+// The lower triangle of a square u8 count block from its upper one: 64 x 64 tiles, tile (I, J) with I > J is the
+// transpose of tile (J, I); a tile on the diagonal mirrors itself.  One workgroup of 256 threads per tile pair: thread
+// (row, piece) moves 16 bytes on both sides (a piece never straddles a 32-column panel of the blocked layout), the
+// transposition happens in LDS.  (Round 4: 32 x 32 tiles, 4 bytes per thread: 1.87 ms at N = 65536.)
+__global__ __launch_bounds__(256) void evidence_mirror_kernel(uint8_t* cnt, int64_t n, int64_t ld, int64_t rows_pad, int vec16) {
+    __shared__ __attribute__((aligned(16))) unsigned char t[64][80];
     const int64_t w = blockIdx.x;
     int64_t I = (int64_t)((sqrt(8.0 * double(w) + 1.0) - 1.0) * 0.5);
     while (I * (I + 1) / 2 > w) --I;
     while ((I + 1) * (I + 2) / 2 <= w) ++I;
     const int64_t J = w - I * (I + 1) / 2;                        // I >= J
-    const int tid = threadIdx.x, r = tid >> 3, q = tid & 7;       // row r of the tile, bytes 4 q .. 4 q + 3
-    // source tile (J, I): rows 32 J + r, columns 32 I + 4 q ..
+    const int tid = threadIdx.x, r = tid >> 2, p = tid & 3;       // row r of the tile, bytes 16 p .. 16 p + 15
+    // source tile (J, I): rows 64 J + r, columns 64 I + 16 p ..
     {
-        const int64_t row = 32 * J + r, c = 32 * I + 4 * q;
-        unsigned v = 0;
-        if (row < n) {
+        const int64_t row = 64 * J + r, c = 64 * I + 16 * p;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (row < n && c < n) {
             const uint8_t* src = cnt + elem_at(row, c, ld, rows_pad);
-            if (c + 4 <= n && ((reinterpret_cast<uintptr_t>(src) & 3) == 0)) v = *reinterpret_cast<const unsigned*>(src);
-            else for (int k = 0; k < 4; ++k) if (c + k < n) v |= unsigned(src[k]) << (8 * k);
+            if (vec16 && c + 16 <= n) {
+                v = *reinterpret_cast<const uint4*>(src);
+            } else {
+                unsigned char b[16];
+                for (int k = 0; k < 16; ++k) b[k] = c + k < n ? src[k] : 0;
+                memcpy(&v, b, 16);
+            }
         }
-        *reinterpret_cast<unsigned*>(&t[r][4 * q]) = v;
+        *reinterpret_cast<uint4*>(&t[r][16 * p]) = v;
     }
     __syncthreads();
-    // destination tile (I, J): row 32 I + r, columns 32 J + 4 q .. = source (column r, rows 4 q ..)
-    const int64_t row = 32 * I + r, c = 32 * J + 4 * q;
-    if (row >= n) return;
-    uint8_t* dst = cnt + elem_at(row, c, ld, rows_pad);
-    unsigned char b[4];
-    for (int k = 0; k < 4; ++k) b[k] = t[4 * q + k][r];
+    // destination tile (I, J): row 64 I + r, columns 64 J + 16 p .. = source (column r, rows 16 p ..)
+    const int64_t row = 64 * I + r, c = 64 * J + 16 * p;
+    if (row >= n || c >= n) return;
+    unsigned char b[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) b[k] = t[16 * p + k][r];
     if (I == J)                                                   // on the diagonal: only what lies left of it
-        for (int k = 0; k < 4; ++k) if (4 * q + k >= r) b[k] = t[r][4 * q + k];
-    if (c + 4 <= n && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0)) {
-        *reinterpret_cast<unsigned*>(dst) = unsigned(b[0]) | unsigned(b[1]) << 8 | unsigned(b[2]) << 16 | unsigned(b[3]) << 24;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (16 * p + k >= r) b[k] = t[r][16 * p + k];
+    uint8_t* dst = cnt + elem_at(row, c, ld, rows_pad);
+    if (vec16 && c + 16 <= n) {
+        uint4 v;
+        memcpy(&v, b, 16);
+        *reinterpret_cast<uint4*>(dst) = v;
     } else {
-        for (int k = 0; k < 4; ++k) if (c + k < n) dst[k] = b[k];
+        for (int k = 0; k < 16; ++k)
+            if (c + k < n) dst[k] = b[k];
     }
 }
 
@@ -2409,23 +2531,49 @@ static int evidence_counts_impl(const simrank_graph* g, int64_t col0, int64_t n_
     const int vec4 = (reinterpret_cast<uintptr_t>(counts) % 4 == 0) && (rows_pad ? true : ld % 4 == 0);
     // the whole square in one pass: upper triangle + mirror (tuning "ev_tri"; column blocks of sharded ranks and
     // blocks of more than 65536 columns take every path)
-    const int tri = (g->tun.ev_tri && col0 == 0 && n_cols == g->n_rows && n_cols <= kEvChunk) ? 1 : 0;
+    const bool hubs_on = g->ev_hubs > 0 && g->ev_hubidx;
+    const int tri = (g->tun.ev_tri && col0 == 0 && n_cols == g->n_rows && (hubs_on || n_cols <= kEvChunk)) ? 1 : 0;
+    // (round 5) the pairs through the hub columns first, on the matrix cores: the 0/1 image of the live rows over those
+    // columns (built once per graph, kept with it), then P . P^T in i8, saturated into `counts`; the LDS-counter kernel
+    // below starts from what is there and leaves the hub columns out of its walk
+    const int32_t* hubidx = nullptr;
+    if (hubs_on) {
+        simrank_graph* gm = const_cast<simrank_graph*>(g);
+        const int Hp = g->ev_hubs;
+        const int64_t Mp = (g->n_rows + 127) / 128 * 128;
+        hipStream_t st = as_stream(stream);
+        if (!gm->ev_hub_image) {
+            // (+ 128 rows: the last column tile of a block that does not start at a multiple of 128 reads past row Mp)
+            SR_HIP(plan_alloc((void**)&gm->ev_hub_image, size_t(Mp + 128) * size_t(Hp)));
+            SR_HIP(hipMemsetAsync(gm->ev_hub_image, 0, size_t(Mp + 128) * size_t(Hp), st));
+            hipLaunchKernelGGL(hub_image_kernel, dim3((unsigned)std::min<int64_t>((g->n_rows + 3) / 4, 4096)), dim3(256), 0, st,
+                               g->rowptr, g->col, g->rowscale, g->ev_hubidx, g->n_rows, Hp, gm->ev_hub_image);
+            SR_HIP(hipGetLastError());
+        }
+        const int tiles_i = int(Mp / 128), tiles_j = int((n_cols + 127) / 128);
+        const int vec16 = (reinterpret_cast<uintptr_t>(counts) % 16 == 0) && (rows_pad ? true : ld % 16 == 0);
+        hipLaunchKernelGGL(evidence_hub_kernel, dim3((unsigned)(tiles_i * tiles_j)), dim3(256), 0, st, gm->ev_hub_image, Hp,
+                           g->n_rows, col0, n_cols, counts, ld, rows_pad, tiles_j, tri, vec16);
+        SR_HIP(hipGetLastError());
+        hubidx = g->ev_hubidx;
+    }
     for (int64_t c = 0; c < n_cols; c += kEvChunk) {
         const int nc = (int)std::min<int64_t>(kEvChunk, n_cols - c);
         const size_t lds = size_t((nc + 1) / 2) * 4;
         if (lds > 64 * 1024)
-            SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(evidence_counts_kernel),
+            SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(evidence_counts_kernel<1024>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(evidence_counts_kernel, dim3(grid), dim3(kEvThreads), lds,
-                           as_stream(stream), g->rowptr, g->col, g->rowscale, g->t_rowptr,
-                           g->t_col, g->t_pos, g->n_rows, col0 + c, nc, counts, ld, rows_pad, c, vec4, tri);
+        hipLaunchKernelGGL(evidence_counts_kernel<1024>, dim3(grid), dim3(1024), lds, as_stream(stream), g->rowptr, g->col,
+                           g->rowscale, g->t_rowptr, g->t_col, g->t_pos, g->n_rows, col0 + c, nc, counts, ld, rows_pad, c,
+                           vec4, tri, hubidx);
         SR_HIP(hipGetLastError());
     }
     if (tri) {
-        const int64_t T = (g->n_rows + 31) / 32, tiles = T * (T + 1) / 2;
+        const int64_t T = (g->n_rows + 63) / 64, tiles = T * (T + 1) / 2;
         SR_REQUIRE(tiles < (int64_t(1) << 31), "evidence mirror: %lld tiles", (long long)tiles);
+        const int v16 = (reinterpret_cast<uintptr_t>(counts) % 16 == 0) && (rows_pad ? true : ld % 16 == 0);
         hipLaunchKernelGGL(evidence_mirror_kernel, dim3((unsigned)tiles), dim3(256), 0, as_stream(stream), counts,
-                           g->n_rows, ld, rows_pad);
+                           g->n_rows, ld, rows_pad, v16);
         SR_HIP(hipGetLastError());
     }
     return SIMRANK_OK;

@@ -197,6 +197,54 @@ def test_evidence_counts_upper_triangle_and_mirror(ops, M, K, blocked):
     np.testing.assert_array_equal(got[0], want)
 
 
+def hub_csr(M, K, n_hubs, p_hub, avg, seed):
+    """Random pattern whose first n_hubs columns are referenced by a share p_hub of the rows each (some rows without weight)."""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for a in range(M):
+        hubs = np.nonzero(rng.random(n_hubs) < p_hub)[0]
+        rest = n_hubs + rng.choice(K - n_hubs, size=min(K - n_hubs, rng.poisson(avg)), replace=False) if K > n_hubs else []
+        rows.append(np.unique(np.concatenate([hubs, rest]).astype(np.int64)))
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    col = np.concatenate(rows).astype(np.int32)
+    rs = rng.random(M) + 0.1
+    rs[rng.random(M) < 0.05] = 0.0
+    return CSR(M, K, rowptr, col, rs)
+
+
+@pytest.mark.parametrize("M,K,n_hubs,p_hub,blocked,block", [
+    (600, 900, 40, 0.5, True, None), (600, 900, 40, 0.5, False, None), (1000, 1000, 300, 0.95, True, None),
+    (257, 300, 33, 0.8, True, None), (2050, 2500, 70, 0.3, True, None), (1024, 1024, 64, 0.4, False, (200, 333)),
+    (900, 1200, 50, 0.6, False, (128, 512)), (130, 260, 130, 0.7, False, (1, 129))])
+def test_evidence_counts_with_hub_columns_on_the_matrix_cores(ops, M, K, n_hubs, p_hub, blocked, block):
+    """Round 5: the pairs through the columns that very many rows share are counted as an i8 product of their 0/1 image
+    (v_mfma_i32_32x32x32_i8, evidence_hub_kernel), everything else on the LDS counters starting from those counts —
+    the same bytes as the LDS counters alone (tuning ev_hub = 0) and as the exact product (`_cal_Evidence`,
+    SimRank.py:311-320): saturation beyond 255 common hubs, rows without weight, sizes off the 128-grid, both layouts,
+    a column block that starts off the grid (a sharded rank's), the upper-triangle form and the full one."""
+    csr = hub_csr(M, K, n_hubs, p_hub, 3, seed=M + n_hubs)
+    live = sp.diags((csr.rowscale.astype(np.float32) > 0).astype(np.float64)) @ sp.csr_matrix(
+        (np.ones(csr.col.size), csr.col, csr.rowptr), shape=(M, K))
+    want = np.minimum((live @ live.T).toarray(), 255).astype(np.uint8)
+    if p_hub > 0.9:
+        assert want.max() == 255
+    c0, L = block if block else (0, M)
+    got = {}
+    for hub, tri in ((1, 1), (1, 0), (0, 1)):
+        ops.set_tuning(ev_hub=hub, ev_tri=tri)            # (1/1000 of the rows, at least 48: every planted column qualifies)
+        try:
+            g = ops.graph(csr)
+            out = ops.matrix(M, L, np.uint8, blocked=True) if blocked else ops.matrix(M, L, np.uint8)
+            ops.evidence_counts(g, c0, out)
+            got[(hub, tri)] = ops.download(out)
+            ops.evidence_counts(g, c0, out)                # (the image is kept with the graph: a second call reuses it)
+            np.testing.assert_array_equal(ops.download(out), got[(hub, tri)])
+        finally:
+            ops.set_tuning(ev_hub=14, ev_tri=1)
+    for key, val in got.items():
+        np.testing.assert_array_equal(val, want[:, c0:c0 + L], err_msg=str(key))
+
+
 @pytest.mark.parametrize("n,blocked,col0,L", [(700, True, 0, 700), (700, False, 0, 700), (1030, False, 256, 300), (25000, True, 0, 25000)])
 def test_graph_creation_that_counts_on_the_side(ops, n, blocked, col0, L):
     """simrank_graph_create_counting: the evidence counts of the graph's own pattern are queued once the pattern is on the

@@ -583,6 +583,13 @@ SIMRANK_API int simrank_shardplan_result_f64(simrank_shardplan* const* plans, in
  * the links and PCIe instead of n^2 — the hand-back config 5 is meant for (its dense result is 34 GB of float64); collective */
 SIMRANK_API int simrank_shardplan_topk(simrank_shardplan* const* plans, int32_t n_local, int32_t root, int32_t k,
                                        int32_t exclude_diag, int32_t* idx_host, float* val_host);
+/* measurement: HIP events at the boundaries of the next `updates` updates of this rank's plan (0 = off), each on the stream its
+ * piece runs on; simrank_shardplan_timings drains both streams and returns mean milliseconds per update: ms[0] leg 1 (the
+ * stages' kernels), ms[1] exchange 1 (its stages, on the exchange stream: what RCCL took), ms[2] what the kernels' stream
+ * waited between the last stage's kernel and leg 2 (the part of exchange 1 leg 1 did not hide), ms[3] leg 2, ms[4] the
+ * all-reduce of the count + exchange 2, ms[5] the whole update on the kernels' stream */
+SIMRANK_API int simrank_shardplan_set_timing(simrank_shardplan* p, int32_t updates);
+SIMRANK_API int simrank_shardplan_timings(simrank_shardplan* p, double* ms, int32_t n_ms, int32_t* updates);
 SIMRANK_API int simrank_shardplan_info(const simrank_shardplan* p, int64_t* n, int64_t* col_lo, int64_t* col_hi,
                                        int32_t* half_form, int32_t* stages, int32_t* updates);
 SIMRANK_API int simrank_shardplan_destroy(simrank_shardplan* p);

@@ -152,6 +152,8 @@ PROTOTYPES = {
     "simrank_shardplan_info": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_int32),
                                C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "simrank_shardplan_destroy": [_vp],
+    "simrank_shardplan_set_timing": [_vp, C.c_int32],
+    "simrank_shardplan_timings": [_vp, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_int32)],
     "simrank_set_tuning": [C.c_char_p, _i64],
     "simrank_get_tuning": [C.c_char_p, C.POINTER(_i64)],
 }

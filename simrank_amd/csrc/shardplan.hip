@@ -170,9 +170,25 @@ struct simrank_shardplan {
     int32_t restrict_support = 0, half_form = 0, n_stages = 1, wire_fp16 = 0;
     int cur = 0;
     int32_t updates = 0;
+    // simrank_shardplan_set_timing: HIP events at the boundaries of an update (of the FIRST local plan), on the stream each
+    // piece runs on — the kernels' stream and the exchanges' stream
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<std::pair<int, hipEvent_t>> marks;       // (tag, event) in issue order
 };
 
 namespace simrank {
+
+enum { kMarkUpdate0 = 0, kMarkK0, kMarkK1, kMarkX0, kMarkX1, kMarkLeg2a, kMarkLeg2b, kMarkY0, kMarkY1, kMarkUpdate1 };
+static int mark(simrank_shardplan* p, hipStream_t st, int tag) {
+    if (!p->timing || p->ev_pool.empty()) return SIMRANK_OK;
+    hipEvent_t e = p->ev_pool.back();
+    p->ev_pool.pop_back();
+    p->marks.push_back({tag, e});
+    SR_HIP(hipEventRecord(e, st));
+    return SIMRANK_OK;
+}
+#define SR_MARK(p, st, tag) do { const int rm_ = mark(p, st, tag); if (rm_) return rm_; } while (0)
 
 // ---- one all-to-all: what every local plan sends to / receives from every rank, as lists of pieces (element counts;
 // rank s's i-th piece for rank d is rank d's i-th piece from rank s) ----
@@ -326,8 +342,10 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
     hipStream_t xs = local ? p0->stream : p0->xstream;
     // leg 1 + exchange 1, stage by stage
     const int32_t walign = p0->half ? 64 : 32;            // stage widths: whole panels of the operand
+    SR_MARK(p0, p0->stream, kMarkUpdate0);
     for (int32_t s = 0; s < S; ++s) {
         std::vector<Route> routes(n_local, Route(P));
+        SR_MARK(p0, p0->stream, kMarkK0);
         for (int32_t i = 0; i < n_local; ++i) {
             simrank_shardplan* p = plans[i];
             const int64_t w = stage_width(p->Lm, S, s, walign), c0 = stage_col0(p->Lm, S, s, walign);
@@ -369,13 +387,16 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
                     r.add_in(h, p->recv + (k_lo + ch) * p->recv_ld, p->Lm ? wh * p->recv_ld : 0);
                 }
             }
+            if (i == n_local - 1) SR_MARK(p0, p0->stream, kMarkK1);
             if (!local) {                                // RCCL's stream waits for this stage's kernel only
                 SR_HIP(hipEventRecord(p->staged[s], p->stream));
                 SR_HIP(hipStreamWaitEvent(xs, p->staged[s], 0));
             }
         }
+        SR_MARK(p0, xs, kMarkX0);
         const int rc = all_to_all(plans, n_local, routes, xs, p0->half ? 2 : 4);
         if (rc) return rc;
+        SR_MARK(p0, xs, kMarkX1);
     }
     // every RCCL call of this communicator is issued on ITS stream, in one order; `hop` makes one stream wait for the other
     auto hop = [&](hipStream_t from, hipStream_t to, hipEvent_t ev) -> int {
@@ -387,6 +408,7 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
     int rc = local ? SIMRANK_OK : hop(xs, p0->stream, p0->staged[S]);      // leg 2 reads what the last stage delivered
     if (rc) return rc;
     // leg 2 with the fused epilogue and count
+    SR_MARK(p0, p0->stream, kMarkLeg2a);
     for (int32_t i = 0; i < n_local; ++i) {
         simrank_shardplan* p = plans[i];
         simrank_epilogue ep;
@@ -404,9 +426,11 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
         }
         if (rc) return rc;
     }
+    SR_MARK(p0, p0->stream, kMarkLeg2b);
     if (!local) {
         rc = hop(p0->stream, xs, p0->staged[0]);
         if (rc) return rc;
+        SR_MARK(p0, xs, kMarkY0);
         if (P > 1)                                       // the count of the whole update, on every rank
             SR_RCCL(rccl()->AllReduce(p0->counters, p0->counters, SIMRANK_CHANGED_SLOTS, ncclUint64, ncclSum,
                                       p0->comm->nccl, xs));
@@ -425,10 +449,13 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
                 r.add_in(h, p->sh_recv + int64_t(h) * p->sh_chunk, p->sh_chunk);
             }
         }
+        if (local) SR_MARK(p0, xs, kMarkY0);
         rc = all_to_all(plans, n_local, routes, xs, 4);
         if (rc) return rc;
+        if (local) SR_MARK(p0, xs, kMarkY1);
     }
     if (!local) {
+        SR_MARK(p0, xs, kMarkY1);
         rc = hop(xs, p0->stream, p0->staged[S]);
         if (rc) return rc;
     }
@@ -442,6 +469,7 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
             if (rc) return rc;
         }
     }
+    SR_MARK(p0, p0->stream, kMarkUpdate1);
     return SIMRANK_OK;
 }
 
@@ -555,6 +583,8 @@ int simrank_shardplan_destroy(simrank_shardplan* p) {
         if (p->counted[i]) (void)hipEventDestroy(p->counted[i]);
     }
     for (hipEvent_t e : p->staged) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
+    for (auto& m : p->marks) (void)hipEventDestroy(m.second);
     if (p->xstream) (void)hipStreamDestroy(p->xstream);
     simrank_graph_destroy(p->g);
     delete p;
@@ -702,6 +732,57 @@ int simrank_shardplan_create(int64_t n, int64_t nnz, const int32_t* rowptr, cons
         if (rc) return fail(rc);
     }
     *out = p;
+    return SIMRANK_OK;
+}
+
+int simrank_shardplan_set_timing(simrank_shardplan* p, int32_t updates) {
+    SR_REQUIRE(p && updates >= 0 && updates <= 4096, "bad timing arguments");
+    for (auto& m : p->marks) p->ev_pool.push_back(m.second);
+    p->marks.clear();
+    const size_t per_update = size_t(4 * p->n_stages + 8);
+    while (p->ev_pool.size() < per_update * size_t(updates)) {
+        hipEvent_t e;
+        SR_HIP(hipEventCreate(&e));
+        p->ev_pool.push_back(e);
+    }
+    p->timing = updates > 0;
+    return SIMRANK_OK;
+}
+
+int simrank_shardplan_timings(simrank_shardplan* p, double* ms, int32_t n_ms, int32_t* updates) {
+    SR_REQUIRE(p && ms && n_ms >= 6, "bad timing arguments");
+    SR_HIP(hipStreamSynchronize(p->stream));
+    if (p->xstream) SR_HIP(hipStreamSynchronize(p->xstream));
+    // ms[0] leg 1 (the stages' kernels), [1] exchange 1 (its stages on the exchange stream), [2] what the kernels' stream
+    // waited between the last stage's kernel and leg 2, [3] leg 2, [4] all-reduce of the count + exchange 2, [5] the update
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    int32_t n_upd = 0;
+    hipEvent_t open[10] = {};
+    hipEvent_t last_k1 = nullptr;
+    auto el = [&](hipEvent_t a, hipEvent_t b) -> double {
+        float t = 0.f;
+        if (a && b && hipEventElapsedTime(&t, a, b) != hipSuccess) { (void)hipGetLastError(); t = 0.f; }
+        return (double)t;
+    };
+    for (auto& m : p->marks) {
+        switch (m.first) {
+            case kMarkUpdate0: open[kMarkUpdate0] = m.second; break;
+            case kMarkK0: open[kMarkK0] = m.second; break;
+            case kMarkK1: acc[0] += el(open[kMarkK0], m.second); last_k1 = m.second; break;
+            case kMarkX0: open[kMarkX0] = m.second; break;
+            case kMarkX1: acc[1] += el(open[kMarkX0], m.second); break;
+            case kMarkLeg2a: acc[2] += el(last_k1, m.second); open[kMarkLeg2a] = m.second; break;
+            case kMarkLeg2b: acc[3] += el(open[kMarkLeg2a], m.second); break;
+            case kMarkY0: open[kMarkY0] = m.second; break;
+            case kMarkY1: acc[4] += el(open[kMarkY0], m.second); break;
+            case kMarkUpdate1: acc[5] += el(open[kMarkUpdate0], m.second); ++n_upd; break;
+            default: break;
+        }
+    }
+    for (int i = 0; i < 6; ++i) ms[i] = n_upd ? acc[i] / n_upd : 0.0;
+    if (updates) *updates = n_upd;
+    for (auto& m : p->marks) p->ev_pool.push_back(m.second);
+    p->marks.clear();
     return SIMRANK_OK;
 }
 

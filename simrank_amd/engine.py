@@ -289,6 +289,21 @@ class ShardPlans:
         return dict(n=n.value, col_lo=lo.value, col_hi=hi.value, half_form=bool(half.value), stages=stages.value,
                     updates=updates.value)
 
+    TIMING_KEYS = ("leg1_ms", "exchange1_ms", "wait_before_leg2_ms", "leg2_ms", "count_and_exchange2_ms", "update_ms")
+
+    def set_timing(self, updates: int):
+        """HIP events at the boundaries of the next ``updates`` updates of the first local plan (0 = off)."""
+        check(self.ops.lib.simrank_shardplan_set_timing(self.plans[0], int(updates)), "simrank_shardplan_set_timing")
+
+    def timings(self) -> dict:
+        """Mean milliseconds per update since ``set_timing`` (keys: TIMING_KEYS; + "updates")."""
+        ms = (C.c_double * 6)()
+        n = C.c_int32(0)
+        check(self.ops.lib.simrank_shardplan_timings(self.plans[0], ms, 6, C.byref(n)), "simrank_shardplan_timings")
+        out = {k: float(ms[i]) for i, k in enumerate(self.TIMING_KEYS)}
+        out["updates"] = n.value
+        return out
+
     def reset(self):
         check(self.ops.lib.simrank_shardplan_reset(self._arr, len(self.plans)), "simrank_shardplan_reset")
 

@@ -594,6 +594,29 @@ SIMRANK_API int simrank_shardplan_info(const simrank_shardplan* p, int64_t* n, i
                                        int32_t* half_form, int32_t* stages, int32_t* updates);
 SIMRANK_API int simrank_shardplan_destroy(simrank_shardplan* p);
 
+/* ---- SHARDED BIPARTITE PLAN: the loops of BipartiteSimRank.fit / BipartiteSimRankPP.fit / BipartitleAprioriSimRank.fit
+ *      (SimRank.py:288-302, :410-424, :478-492) with S1 and S2 each split by column block over the ranks of a communicator:
+ *      a pair of sharded plans, one per group, each reading the other group's blocks in its leg 1 — two exchanges per loop
+ *      body in strict order (the group-2 update consumes the NEW S1, :300-302), the loop ends when neither matrix moved
+ *      (:289).  `options` as for simrank_biplan_create (evidence in its corrected form unless strict_reference: quirk Q2,
+ *      incl. NumPy's broadcast error at the first group-2 update); leg2_form / stages / wire_fp16 as in
+ *      simrank_shardplan_options, the half form taken group by group where that group's size allows it.  Symmetric
+ *      priors only.  simrank_shardbiplan_side hands out group 1 | 2's plan for the hand-back entry points of the
+ *      single-matrix plan (simrank_shardplan_result_f64 / _block_f64 / _columns / _topk / _info / _set_timing) — it
+ *      stays owned by the pair. */
+typedef struct simrank_shardbiplan simrank_shardbiplan;
+SIMRANK_API int simrank_shardbiplan_create(int64_t n1, int64_t n2, int64_t nnz, const int32_t* rowptr12, const int32_t* col12,
+                                           const float* rowscale1, const float* rowscale2,
+                                           const simrank_biplan_options* options, int32_t leg2_form, int32_t stages,
+                                           int32_t wire_fp16, simrank_comm* comm, void* stream, simrank_shardbiplan** out);
+SIMRANK_API int simrank_shardbiplan_side(simrank_shardbiplan* bp, int32_t group, simrank_shardplan** out);
+SIMRANK_API int simrank_shardbiplan_reset(simrank_shardbiplan* const* plans, int32_t n_local);
+SIMRANK_API int simrank_shardbiplan_step(simrank_shardbiplan* const* plans, int32_t n_local, double eps, int32_t exact_count,
+                                         int64_t* changed1, int64_t* changed2);
+SIMRANK_API int simrank_shardbiplan_run(simrank_shardbiplan* const* plans, int32_t n_local, int32_t iterations, double eps,
+                                        int32_t* updates_done, int32_t* converged_at);
+SIMRANK_API int simrank_shardbiplan_destroy(simrank_shardbiplan* bp);
+
 /* ---- tuning knobs (measurement harness; defaults are the tuned values).  simrank_set_tuning
  *      changes the process-wide DEFAULTS; simrank_graph_create copies them into the graph it
  *      builds (under a lock), and every launch on that graph uses its copy — a knob set later does

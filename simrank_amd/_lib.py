@@ -154,6 +154,13 @@ PROTOTYPES = {
     "simrank_shardplan_destroy": [_vp],
     "simrank_shardplan_set_timing": [_vp, C.c_int32],
     "simrank_shardplan_timings": [_vp, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_int32)],
+    "simrank_shardbiplan_create": [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp,
+                                   C.POINTER(_vp)],
+    "simrank_shardbiplan_side": [_vp, C.c_int32, C.POINTER(_vp)],
+    "simrank_shardbiplan_reset": [C.POINTER(_vp), C.c_int32],
+    "simrank_shardbiplan_step": [C.POINTER(_vp), C.c_int32, C.c_double, C.c_int32, C.POINTER(_i64), C.POINTER(_i64)],
+    "simrank_shardbiplan_run": [C.POINTER(_vp), C.c_int32, C.c_int32, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    "simrank_shardbiplan_destroy": [_vp],
     "simrank_set_tuning": [C.c_char_p, _i64],
     "simrank_get_tuning": [C.c_char_p, C.POINTER(_i64)],
 }

@@ -10,7 +10,10 @@ panels themselves on the links).  ``CShardSolver`` gives that loop the few metho
 * ``TorchWorld`` on RCCL ranks: the library's own RCCL communicator, made from an id rank 0 broadcasts through
   ``torch.distributed``; the library is pointed at the RCCL build torch itself loaded, so one process never runs two.
 
-Only what that entry point runs: one symmetric side (SimRank, SimRank++), no prior, n a multiple of 64 x ranks.
+Since round 5 the same solver runs the f32 (parity-grade) sharded fits of an RCCL world as well — every class with
+symmetric iterates, the two-matrix ones through ``simrank_shardbiplan_*`` — so that what a multi-GPU user's ``fit``
+runs is the C loop, not a second choreography in Python; ``driver.Solver`` keeps what the C loop does not run
+(asymmetric priors, the GEMM modes) and the CPU rehearsal over gloo with the NumPy test double.
 """
 from __future__ import annotations
 
@@ -22,18 +25,35 @@ from .driver import LocalWorld, TorchWorld
 
 
 def applies(world, specs, mode) -> str | None:
-    """None when the C sharded loop can run these specs on fp16-held matrices, else the reason it cannot."""
-    if len(specs) != 1:
-        return "the bipartite classes keep fp16-held matrices to one GPU"
-    s = specs[0]
-    if not s.symmetric or s.apriori is not None:
-        return "a prior keeps fp16-held matrices to one GPU"
+    """None when the C sharded loop can run these specs, else the reason it cannot."""
     if mode not in ("auto", "sparse"):
-        return "fp16-held matrices exist for the gather legs only (mode 'sparse' or 'auto')"
-    if s.csr.n_rows % (64 * world.size):
-        return f"fp16-held matrices on {world.size} ranks need the node count to be a multiple of {64 * world.size}"
+        return "the sharded C loop runs the gather legs only (mode 'sparse' or 'auto')"
+    if not all(s.symmetric for s in specs):
+        return "an asymmetric prior needs the un-fused epilogue (the Python driver has it)"
+    if len({s.storage for s in specs}) != 1 or any(s.dense_terms != 3 for s in specs):
+        return "one storage precision for every matrix, exact products on the matrix cores"
+    fp16 = specs[0].storage == "fp16"
     if isinstance(world, TorchWorld) and world.dist.get_backend(world.group) != "nccl":
-        return "fp16-held matrices on shards need RCCL ranks (one GPU per process)"
+        return "the sharded C loop exchanges over RCCL (one GPU per process)"
+    if len(specs) == 2:
+        a, b = specs
+        if fp16:
+            return "the bipartite classes keep fp16-held matrices to one GPU"
+        if (a.evidence_from is None) != (b.evidence_from is None):
+            return "evidence on one group only"
+        if a.evidence_from is not None and (a.evidence_from is not a.csr or
+                                            not (b.evidence_from is a.csr or b.evidence_from is b.csr)):
+            return "evidence of a foreign pattern"
+        if a.csr.n_rows != b.csr.n_cols or a.csr.n_cols != b.csr.n_rows or a.csr.nnz != b.csr.nnz:
+            return "the two patterns are not each other's transpose"
+        return None
+    s = specs[0]
+    if s.evidence_from is not None and s.evidence_from is not s.csr:
+        return "evidence of a foreign pattern"
+    if fp16 and s.apriori is not None:
+        return "a prior keeps fp16-held matrices to one GPU"
+    if fp16 and s.csr.n_rows % (64 * world.size):
+        return f"fp16-held matrices on {world.size} ranks need the node count to be a multiple of {64 * world.size}"
     return None
 
 
@@ -50,41 +70,91 @@ def _rccl_comm(world, ops):
             os.environ["SIMRANK_RCCL_LIB"] = bundled
     box = [ShardPlans.rccl_unique_id(ops.lib) if world.rank == 0 else None]
     world.dist.broadcast_object_list(box, src=0, group=world.group)
-    comm = ShardPlans.rccl_comm(ops.lib, box[0], world.rank, world.size)
+    # (RCCL prints a version banner on STDOUT when a communicator is made outside torch; a program that promised one JSON
+    # line there — bench.py — must not carry it: the banner goes to stderr)
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        comm = ShardPlans.rccl_comm(ops.lib, box[0], world.rank, world.size)
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
     world._c_comm = comm
     return comm
 
 
+def _prior32(spec):
+    if spec.apriori is None:
+        return None
+    a = np.asarray(spec.apriori)
+    n = spec.csr.n_rows
+    if a.shape != (n, n):
+        raise ValueError(f"operands could not be broadcast together with shapes ({n},{n}) {a.shape} ")
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
 class CShardSolver:
-    """The estimators' view of ``engine.ShardPlans`` (fp16-held matrices on every rank)."""
+    """The estimators' view of ``engine.ShardPlans`` / ``engine.ShardBiPlans``: the sharded loops behind the C ABI
+    (csrc/shardplan.hip) — every class with symmetric iterates, f32 (the parity path) or, for SimRank / SimRank++
+    without a prior, fp16-held matrices."""
 
     mode = "sparse"
-    storage = "fp16"
 
-    def __init__(self, make_ops, world, spec):
-        from .engine import ShardPlans
+    def __init__(self, make_ops, world, specs):
+        from .engine import ShardBiPlans, ShardPlans
+        if not isinstance(specs, (list, tuple)):
+            specs = [specs]
         self.world = world
-        self.n = [spec.csr.n_rows]
+        self.specs = specs
+        self.bipartite = len(specs) == 2
+        self.storage = specs[0].storage
+        self.n = [s.csr.n_rows for s in specs]
         self.ops = {r: make_ops(r) for r in world.local_ranks}
         ops = self.ops[world.local_ranks[0]]
-        if not getattr(ops, "supports_half_storage", False):
+        if self.storage == "fp16" and not getattr(ops, "supports_half_storage", False):
             raise ValueError("storage_precision='fp16' needs the HIP engine (matrices held in fp16: csrc/half.hip)")
-        evidence = spec.evidence_from is not None
-        if evidence and spec.evidence_from is not spec.csr:
-            raise ValueError("fp16-held matrices on shards take the evidence of the graph itself")
-        kw = dict(coef=spec.coef, evidence=evidence, storage="fp16", leg2_form=0, stages=getattr(world, "stages", 0))
-        if isinstance(world, LocalWorld):
-            self.plans = ShardPlans(ops, spec.csr, rowscale=spec.rowscale, world=world.size, **kw)
+        local = isinstance(world, LocalWorld)
+        sym = getattr(world, "symmetric_shards", True)
+        form = -1 if sym == "auto" else (1 if sym else 0)
+        if self.storage == "fp16":
+            form = 0
+        common = dict(world=world.size, comm=None if local else _rccl_comm(world, ops),
+                      stages=0 if local else getattr(world, "stages", 0),
+                      wire_fp16=getattr(world, "exchange_precision", "f32") == "fp16")
+        self.broadcast_error = None
+        if self.bipartite:
+            a, b = specs
+            evidence = a.evidence_from is not None
+            strict = evidence and b.evidence_from is a.csr              # quirk Q2: Evidence_N1 gates both updates
+            if strict and self.n[0] != self.n[1] and self.n[0] != 1:
+                self.broadcast_error = ValueError(
+                    f"operands could not be broadcast together with shapes "
+                    f"({self.n[0]},{self.n[0]}) ({self.n[1]},{self.n[1]}) ")
+            def fits(n):
+                return n % (32 * world.size) == 0
+            if form == 1 and not (fits(self.n[0]) or fits(self.n[1])):
+                form = 0
+            self.plans = ShardBiPlans(ops, a.csr, a.rowscale, b.rowscale, c1=a.coef, c2=b.coef, evidence=evidence,
+                                      apriori1=_prior32(a), apriori2=_prior32(b), lbd1=a.lbd, lbd2=b.lbd,
+                                      strict_reference=strict, leg2_form=form, **common)
         else:
-            self.plans = ShardPlans(ops, spec.csr, rowscale=spec.rowscale, world=world.size,
-                                    comm=_rccl_comm(world, ops), **kw)
-        self.root = isinstance(world, LocalWorld) or world.rank == 0
+            (s,) = specs
+            if form == 1 and s.csr.n_rows % (32 * world.size):
+                form = 0
+            self.plans = ShardPlans(ops, s.csr, rowscale=s.rowscale, coef=s.coef, evidence=s.evidence_from is not None,
+                                    apriori=_prior32(s), lbd=s.lbd, storage=self.storage, leg2_form=form, **common)
+        self.root = local or world.rank == 0
 
     def run(self, iterations, eps, on_iteration=None, on_converged=None):
-        """The loop of SimRank.py:129-140 (the count of every update is read before the next one is queued: a rank's
-        update on matrices this mode is for takes milliseconds)."""
+        """The loop of SimRank.py:129-140 / :288-302 (the count of every update is read before the next one is queued)."""
+        if self.broadcast_error is not None and iterations > 0 and 1.0 > eps:
+            if on_iteration:
+                on_iteration(0)
+            raise self.broadcast_error
         self.plans.reset()
-        changed = self.n[0] if 1.0 > eps else 0
+        changed = sum(self.n) if 1.0 > eps else 0
         for k in range(iterations):
             if changed == 0:
                 if on_converged:
@@ -92,7 +162,8 @@ class CShardSolver:
                 return k
             if on_iteration:
                 on_iteration(k)
-            changed = self.plans.step(eps, exact_count=False)
+            c = self.plans.step(eps, exact_count=False)
+            changed = sum(c) if self.bipartite else c
         return None
 
     def _share(self, value):
@@ -102,15 +173,22 @@ class CShardSolver:
         return box[0]
 
     def result(self, j=0):
-        full = self.plans.result(root=0, i_am_root=self.root)
+        full = (self.plans.result(j + 1, root=0, i_am_root=self.root) if self.bipartite
+                else self.plans.result(root=0, i_am_root=self.root))
         if isinstance(self.world, LocalWorld) or getattr(self.world, "handback", "root") == "root":
+            if not self.root:
+                import warnings
+                warnings.warn("TorchWorld(handback='root'): only rank 0 receives the similarity matrix, fit() returns "
+                              "None on this rank (pass handback='all', or fit(top_k=k), to get results on every rank)",
+                              RuntimeWarning, stacklevel=4)
             return full
         return self._share(full)
 
     def topk(self, j, k, exclude_diag=True):
-        n = self.n[0]
+        n = self.n[j]
         k = int(min(k, max(1, n - (1 if exclude_diag else 0))))
-        idx, val = self.plans.topk(k, exclude_diag, root=0, i_am_root=self.root)
+        idx, val = (self.plans.topk(j + 1, k, exclude_diag, root=0, i_am_root=self.root) if self.bipartite
+                    else self.plans.topk(k, exclude_diag, root=0, i_am_root=self.root))
         if not isinstance(self.world, LocalWorld):
             idx, val = self._share((idx, val))
         return idx, val.astype(np.float64)

@@ -145,6 +145,9 @@ int plan_prepare(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* c
 // nodes when n divides evenly (driver.dealt_order); deal <= 1: plain ascending order
 int shard_prepare(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* rowscale,
                   const float* apriori, int64_t ld_apriori, bool reorder, int32_t deal, PlanPrep* out);
+int shard_biplan_prepare(int64_t n1, int64_t n2, int64_t nnz, const int32_t* rowptr12, const int32_t* col12,
+                         const float* rowscale1, const float* rowscale2, const simrank_biplan_options* opt, int32_t deal1,
+                         int32_t deal2, BiPlanPrep* out);
 int biplan_prepare(int64_t n1, int64_t n2, int64_t nnz, const int32_t* rowptr12, const int32_t* col12,
                    const float* rowscale1, const float* rowscale2, const simrank_biplan_options* opt, BiPlanPrep* out);
 

@@ -101,6 +101,19 @@ static void length_order(int64_t n, const int32_t* rowptr, bool reorder, std::ve
     for (int64_t r = 0; r < n; ++r) inv[(size_t)ord[(size_t)r]] = (int32_t)r;
 }
 
+// the ascending order `ord` dealt to `deal` shards in runs of 128 (32) nodes when n divides evenly (driver.dealt_order)
+static void deal_order(int64_t n, int32_t deal, std::vector<int32_t>& ord, std::vector<int32_t>& inv) {
+    if (deal <= 1 || n % (32 * int64_t(deal))) return;
+    const int64_t unit = n % (128 * int64_t(deal)) == 0 ? 128 : 32, per = n / (unit * deal);
+    std::vector<int32_t> dealt((size_t)n);
+    for (int64_t b = 0; b < per; ++b)
+        for (int64_t w = 0; w < deal; ++w)
+            for (int64_t i = 0; i < unit; ++i)
+                dealt[(size_t)((w * per + b) * unit + i)] = ord[(size_t)((b * deal + w) * unit + i)];
+    ord.swap(dealt);
+    for (int64_t r = 0; r < n; ++r) inv[(size_t)ord[(size_t)r]] = (int32_t)r;
+}
+
 int plan_prepare(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* rowscale,
                  const simrank_plan_options* opt, PlanPrep* out) {
     SR_REQUIRE(opt && rowptr && rowscale && (col || nnz == 0) && n > 0 && nnz >= 0 && out, "bad plan arguments");
@@ -121,19 +134,50 @@ int shard_prepare(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* 
     if (!rc) rc = check_prior(apriori, ld_apriori, n, 1, false);
     if (rc) return rc;
     length_order(n, rowptr, reorder, out->ord, out->inv);
-    if (reorder && deal > 1 && n % (32 * int64_t(deal)) == 0) {
-        // tile t of the ascending order goes to shard t mod deal: every shard the same mix of short and long rows,
-        // ascending inside (what halves every rank's gathers in the half-form leg 2)
-        const int64_t unit = n % (128 * int64_t(deal)) == 0 ? 128 : 32, per = n / (unit * deal);
-        std::vector<int32_t> dealt((size_t)n);
-        for (int64_t b = 0; b < per; ++b)
-            for (int64_t w = 0; w < deal; ++w)
-                for (int64_t i = 0; i < unit; ++i)
-                    dealt[(size_t)((w * per + b) * unit + i)] = out->ord[(size_t)((b * deal + w) * unit + i)];
-        out->ord.swap(dealt);
-        for (int64_t r = 0; r < n; ++r) out->inv[(size_t)out->ord[(size_t)r]] = (int32_t)r;
-    }
+    // tile t of the ascending order goes to shard t mod deal: every shard the same mix of short and long rows,
+    // ascending inside (what halves every rank's gathers in the half-form leg 2)
+    if (reorder) deal_order(n, deal, out->ord, out->inv);
     return renamed(n, rowptr, col, rowscale, out->ord, out->inv, nnz, "", out->rp, out->cl, out->rs);
+}
+
+// the two-matrix plan's host half for SHARDS: as biplan_prepare, each group's ascending order dealt to deal1 / deal2 shards
+// (what the half-form leg 2 of that group wants; <= 1: plain ascending order)
+int shard_biplan_prepare(int64_t n1, int64_t n2, int64_t nnz, const int32_t* rowptr12, const int32_t* col12,
+                         const float* rowscale1, const float* rowscale2, const simrank_biplan_options* opt, int32_t deal1,
+                         int32_t deal2, BiPlanPrep* out) {
+    SR_REQUIRE(opt && rowptr12 && rowscale1 && rowscale2 && (col12 || nnz == 0) && n1 > 0 && n2 > 0 && nnz >= 0 && out,
+               "bad plan arguments");
+    SR_REQUIRE(n1 < (int64_t(1) << 24) - 16 && n2 < (int64_t(1) << 24) - 16, "a plan holds at most 2^24 nodes per group");
+    int rc = check_csr(n1, n2, nnz, rowptr12, col12);
+    if (!rc) rc = check_prior(opt->apriori1, opt->ld_apriori1, n1, 1, false);
+    if (!rc) rc = check_prior(opt->apriori2, opt->ld_apriori2, n2, 2, false);
+    if (rc) return rc;
+    std::vector<int32_t>& rowptr21 = out->rowptr21;
+    std::vector<int32_t>& col21 = out->col21;
+    rowptr21.assign((size_t)n2 + 1, 0);
+    col21.assign((size_t)std::max<int64_t>(1, nnz), 0);
+    for (int64_t j = 0; j < nnz; ++j) ++rowptr21[(size_t)col12[j] + 1];
+    for (int64_t i = 0; i < n2; ++i) rowptr21[(size_t)i + 1] += rowptr21[(size_t)i];
+    {
+        std::vector<int32_t> fill(rowptr21.begin(), rowptr21.end() - 1);
+        for (int64_t a = 0; a < n1; ++a)
+            for (int32_t j = rowptr12[a]; j < rowptr12[a + 1]; ++j) col21[(size_t)fill[(size_t)col12[j]]++] = (int32_t)a;
+    }
+    const int64_t ns[2] = {n1, n2};
+    const int32_t deals[2] = {deal1, deal2};
+    const int32_t* rps[2] = {rowptr12, rowptr21.data()};
+    const int32_t* cls[2] = {col12, col21.data()};
+    const float* scales[2] = {rowscale1, rowscale2};
+    for (int w = 0; w < 2; ++w) {
+        length_order(ns[w], rps[w], opt->reorder != 0, out->ord[w], out->inv[w]);
+        if (opt->reorder) deal_order(ns[w], deals[w], out->ord[w], out->inv[w]);
+    }
+    for (int w = 0; w < 2; ++w) {
+        rc = renamed(ns[w], rps[w], cls[w], scales[w], out->ord[w], out->inv[w ^ 1], nnz, w ? " of group 2" : " of group 1",
+                     out->rp[w], out->cl[w], out->rs[w]);
+        if (rc) return rc;
+    }
+    return SIMRANK_OK;
 }
 
 int biplan_prepare(int64_t n1, int64_t n2, int64_t nnz, const int32_t* rowptr12, const int32_t* col12,

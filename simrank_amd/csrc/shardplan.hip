@@ -89,6 +89,14 @@ struct LocalGroup {
     int32_t alive = 0;
 };
 
+struct PlanPrepView {                      // one group's share of a PlanPrep / BiPlanPrep
+    const std::vector<int32_t>* ord;
+    const std::vector<int32_t>* inv;
+    const std::vector<int32_t>* rp;
+    const std::vector<int32_t>* cl;
+    const std::vector<float>* rs;
+};
+
 constexpr float kHalfScale = 16384.0f;       // what fp16-held matrices are scaled by (include/simrank_hip.h, SCALE)
 constexpr float kWireScale = 16384.0f;       // what values on an fp16 wire are multiplied by (engine.HipOps.WIRE_SCALE)
 
@@ -142,6 +150,11 @@ struct simrank_shardplan {
     simrank_comm* comm = nullptr;
     int32_t rank = 0, world = 1;
     int64_t n = 0, mb = 0, m_lo = 0, m_hi = 0, Lm = 0;
+    // the OPERAND of leg 1: this rank's column block of S itself (the directed classes: k = n, Lk = Lm, src = NULL), or of the
+    // OTHER group's matrix (the two-matrix classes, simrank_shardbiplan_*: k = that group's size, Lk = this rank's block of
+    // it, src = that group's plan: S1 <- W12 . S2 . W12^T reads S2's blocks, SimRank.py:297-302)
+    int64_t k = 0, Lk = 0;
+    simrank_shardplan* src = nullptr;
     int64_t ld = 0, pad = 0, send_ld = 0, recv_ld = 0, ld_ev = 0;
     simrank_graph* g = nullptr;
     float* S[2] = {nullptr, nullptr};       // the rank's column block of the iterate, row-major n x Lm, ping-pong
@@ -348,7 +361,8 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
         SR_MARK(p0, p0->stream, kMarkK0);
         for (int32_t i = 0; i < n_local; ++i) {
             simrank_shardplan* p = plans[i];
-            const int64_t w = stage_width(p->Lm, S, s, walign), c0 = stage_col0(p->Lm, S, s, walign);
+            const int64_t w = stage_width(p->Lk, S, s, walign), c0 = stage_col0(p->Lk, S, s, walign);
+            const simrank_shardplan* sp = p->src ? p->src : p;      // whose block leg 1 reads
             Route& r = routes[i];
             if (p->half) {
                 // fp16-held: leg 1 stores rows [c0, c0 + w) of every 64-column panel of (W.S_block)^T (Lm rows x n
@@ -372,7 +386,7 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
             } else {
                 const int64_t send_off = c0 * p->send_ld;
                 if (w) {
-                    const int rc = simrank_spmm(p->g, p->S[p->cur] + c0, p->ld, w, p->send + send_off, 0, 1, p->mb, p->pad,
+                    const int rc = simrank_spmm(p->g, sp->S[sp->cur] + c0, sp->ld, w, p->send + send_off, 0, 1, p->mb, p->pad,
                                                 nullptr, p->stream);
                     if (rc) return rc;
                 }
@@ -381,7 +395,7 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
                 for (int32_t h = 0; h < P; ++h) {
                     r.add_out(h, p->send + send_off + int64_t(h) * w * (p->mb + p->pad), w * (span(p->n, P, h) + p->pad));
                     int64_t k_lo, k_hi;
-                    part(p->n, P, h, &k_lo, &k_hi);
+                    part(p->k, P, h, &k_lo, &k_hi);
                     const int64_t wh = stage_width(k_hi - k_lo, S, s, walign), ch = stage_col0(k_hi - k_lo, S, s, walign);
                     // (a rank without columns receives rows of zero length)
                     r.add_in(h, p->recv + (k_lo + ch) * p->recv_ld, p->Lm ? wh * p->recv_ld : 0);
@@ -591,52 +605,62 @@ int simrank_shardplan_destroy(simrank_shardplan* p) {
     return SIMRANK_OK;
 }
 
-int simrank_shardplan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* rowscale,
-                             const simrank_shardplan_options* opt, simrank_comm* comm, void* stream,
-                             simrank_shardplan** out) {
-    SR_REQUIRE(out, "out is NULL");
+}  // extern "C"
+
+namespace simrank {
+// One rank's share of ONE similarity matrix: everything simrank_shardplan_create and simrank_shardbiplan_create have in
+// common.  `pat` is the pattern in the solver's order, n rows x k columns (k = n: the directed classes).
+struct SideIn {
+    int64_t n = 0, k = 0, nnz = 0;
+    const PlanPrepView* pat = nullptr;
+    float coef = 0.8f, lbd = 0.f;
+    const float* apriori = nullptr;          // HOST n x n, the caller's order
+    int64_t ld_apriori = 0;
+    int32_t evidence = 0;                    // 1: counts of `pat` itself
+    bool half_form = false, fp16 = false;
+    int32_t stages = 0, wire_fp16 = 0;
+};
+
+static int create_side(const SideIn& in, simrank_comm* comm, void* stream, simrank_shardplan** out) {
     *out = nullptr;
-    SR_REQUIRE(opt && comm, "options / communicator missing");
     const int32_t P = comm->world;
-    SR_REQUIRE(opt->leg2_form >= -1 && opt->leg2_form <= 1 && opt->stages >= 0 && opt->stages <= 64, "bad options");
-    const bool fits_half = P > 1 && n % (32 * int64_t(P)) == 0;
-    SR_REQUIRE(opt->leg2_form != 1 || fits_half || (P == 1 && n % 32 == 0),
-               "the half form of leg 2 needs n to be a multiple of 32 x ranks");
-    const bool fp16 = opt->storage_fp16 != 0;
-    // fp16-held matrices (half.hip): every block whole 64-column panels, leg 2 in its full form, no prior, no fp16 wire
-    // (the exchange moves the fp16 values themselves)
-    SR_REQUIRE(!fp16 || (n % (64 * int64_t(P)) == 0 && opt->leg2_form != 1 && !opt->apriori && !opt->wire_fp16),
-               "storage_fp16 on shards needs n %% (64 x ranks) == 0, leg 2 in its full form, no prior and the f32 wire option off");
-    const bool half = !fp16 && (opt->leg2_form == 1 || (opt->leg2_form == -1 && fits_half && P >= 8));
-    PlanPrep pp;
-    int rc = shard_prepare(n, nnz, rowptr, col, rowscale, opt->apriori, opt->ld_apriori, opt->reorder != 0, half ? P : 1, &pp);
-    if (rc) return rc;
+    const int64_t n = in.n, k = in.k;
+    const bool fp16 = in.fp16;
+    const std::vector<int32_t>& ord = *in.pat->ord;
+    const std::vector<int32_t>& inv = *in.pat->inv;
     simrank_shardplan* p = new simrank_shardplan;
     p->comm = comm; p->rank = comm->rank; p->world = P;
     p->n = n;
+    p->k = k;
     p->stream = as_stream(stream);
-    p->coef = opt->coef; p->lbd = opt->lbd;
-    p->half_form = half ? 1 : 0;
-    p->wire_fp16 = opt->wire_fp16 ? 1 : 0;
+    p->coef = in.coef; p->lbd = in.lbd;
+    p->half_form = in.half_form ? 1 : 0;
+    p->wire_fp16 = in.wire_fp16 ? 1 : 0;
     p->mb = (n + P - 1) / P;
     part(n, P, p->rank, &p->m_lo, &p->m_hi);
     p->Lm = p->m_hi - p->m_lo;
+    {
+        int64_t k_lo, k_hi;
+        part(k, P, p->rank, &k_lo, &k_hi);
+        p->Lk = k_hi - k_lo;
+    }
     p->ld = pitch(p->Lm, 4);
     p->ld_ev = pitch(p->Lm, 1);
     p->pad = row_pad(p->mb);
     p->send_ld = int64_t(P) * (p->mb + p->pad);          // (>= n + P pad: only the last chunk can be short)
     p->recv_ld = std::max<int64_t>(1, p->Lm + p->pad);
-    // stages of exchange 1: by the width of the LARGEST block, so every rank takes the same number (driver.auto_stages)
-    p->n_stages = opt->stages > 0 ? opt->stages : int32_t(std::max<int64_t>(1, std::min<int64_t>(4, p->mb / 2048)));
-    p->ord = pp.ord;
+    // stages of exchange 1: by the width of the LARGEST block of the operand, so every rank takes the same number (driver.auto_stages)
+    p->n_stages = in.stages > 0 ? in.stages : int32_t(std::max<int64_t>(1, std::min<int64_t>(4, ((k + P - 1) / P) / 2048)));
+    p->ord = ord;
     auto fail = [&](int code) { simrank_shardplan_destroy(p); return code; };
     p->half = fp16 ? 1 : 0;
     p->rows_pad = (n + 7) / 8 * 8 + 8;
     p->rows_pad_t = (p->Lm + 7) / 8 * 8 + 8;
+    int rc;
     {
         Tuning t = tuning_snapshot();
         if (fp16) t.fuse_unit = int64_t(1) << 20;        // (half.hip runs whole blocks: no units whose sums meet in memory)
-        rc = graph_create_with(t, n, n, nnz, pp.rp.data(), pp.cl.data(), pp.rs.data(), &p->g);
+        rc = graph_create_with(t, n, k, in.nnz, in.pat->rp->data(), in.pat->cl->data(), in.pat->rs->data(), &p->g);
     }
     if (rc) return fail(rc);
     if (fp16 && !p->g->fused) {
@@ -660,8 +684,8 @@ int simrank_shardplan_create(int64_t n, int64_t nnz, const int32_t* rowptr, cons
     const size_t blk = fp16 ? size_t(p->Lm / 64) * size_t(p->rows_pad) * 128 : size_t(n) * size_t(p->ld) * 4;
     SP_HIP(dev((void**)&p->S[0], blk));
     SP_HIP(dev((void**)&p->S[1], blk));
-    const size_t send_floats = size_t(std::max<int64_t>(1, p->Lm)) * size_t(p->send_ld);
-    const size_t recv_floats = size_t(n) * size_t(p->recv_ld);
+    const size_t send_floats = size_t(std::max<int64_t>(1, p->Lk)) * size_t(p->send_ld);     // Lk columns of (W.S_block)^T
+    const size_t recv_floats = size_t(k) * size_t(p->recv_ld);                               // the leg-2 operand: k rows
     if (fp16) {
         SP_HIP(dev((void**)&p->send, size_t(n / 64) * size_t(p->rows_pad_t) * 128));      // (W.S_block)^T: Lm rows x n columns
         SP_HIP(dev((void**)&p->recv, blk));                                                // leg-2 operand: n rows x Lm columns
@@ -695,9 +719,9 @@ int simrank_shardplan_create(int64_t n, int64_t nnz, const int32_t* rowptr, cons
         for (hipEvent_t& e : p->staged) SP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     SP_HIP(dev((void**)&p->inv, size_t(n) * 4));
-    SP_HIP(hipMemcpyAsync(p->inv, pp.inv.data(), size_t(n) * 4, hipMemcpyHostToDevice, p->stream));
-    SP_HIP(hipStreamSynchronize(p->stream));             // (pp.inv is a host vector about to go away)
-    if (opt->evidence && p->Lm) {
+    SP_HIP(hipMemcpyAsync(p->inv, inv.data(), size_t(n) * 4, hipMemcpyHostToDevice, p->stream));
+    SP_HIP(hipStreamSynchronize(p->stream));             // (inv may be a host vector about to go away)
+    if (in.evidence && p->Lm) {
         // common in-neighbour counts of the rank's columns (SimRank.py:311-320), 1 - 2^-count in the epilogue
         if (fp16) {                                      // (32-column panels of n padded rows, as the single plan's)
             SP_HIP(dev((void**)&p->ev, size_t((p->Lm + 31) / 32) * size_t(p->rows_pad) * 32));
@@ -713,13 +737,13 @@ int simrank_shardplan_create(int64_t n, int64_t nnz, const int32_t* rowptr, cons
             p->restrict_support = 2 * live < total ? 1 : 0;
         }
     }
-    if (opt->apriori && p->Lm) {
+    if (in.apriori && p->Lm) {
         // the rank's columns of the prior in the solver's order: block[i][j] = A[ord[i]][ord[m_lo + j]]
         std::vector<float> host(size_t(n) * size_t(p->ld), 0.f);
         for (int64_t i = 0; i < n; ++i) {
-            const float* src = opt->apriori + int64_t(pp.ord[(size_t)i]) * opt->ld_apriori;
+            const float* src = in.apriori + int64_t(ord[(size_t)i]) * in.ld_apriori;
             float* dst = host.data() + i * p->ld;
-            for (int64_t j = 0; j < p->Lm; ++j) dst[j] = src[pp.ord[(size_t)(p->m_lo + j)]];
+            for (int64_t j = 0; j < p->Lm; ++j) dst[j] = src[ord[(size_t)(p->m_lo + j)]];
         }
         SP_HIP(dev((void**)&p->prior, blk));
         SP_HIP(hipMemcpyAsync(p->prior, host.data(), blk, hipMemcpyHostToDevice, p->stream));
@@ -733,6 +757,42 @@ int simrank_shardplan_create(int64_t n, int64_t nnz, const int32_t* rowptr, cons
     }
     *out = p;
     return SIMRANK_OK;
+}
+}  // namespace simrank
+
+extern "C" {
+
+int simrank_shardplan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* rowscale,
+                             const simrank_shardplan_options* opt, simrank_comm* comm, void* stream,
+                             simrank_shardplan** out) {
+    SR_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    SR_REQUIRE(opt && comm, "options / communicator missing");
+    const int32_t P = comm->world;
+    SR_REQUIRE(opt->leg2_form >= -1 && opt->leg2_form <= 1 && opt->stages >= 0 && opt->stages <= 64, "bad options");
+    const bool fits_half = P > 1 && n % (32 * int64_t(P)) == 0;
+    SR_REQUIRE(opt->leg2_form != 1 || fits_half || (P == 1 && n % 32 == 0),
+               "the half form of leg 2 needs n to be a multiple of 32 x ranks");
+    const bool fp16 = opt->storage_fp16 != 0;
+    // fp16-held matrices (half.hip): every block whole 64-column panels, leg 2 in its full form, no prior, no fp16 wire
+    // (the exchange moves the fp16 values themselves)
+    SR_REQUIRE(!fp16 || (n % (64 * int64_t(P)) == 0 && opt->leg2_form != 1 && !opt->apriori && !opt->wire_fp16),
+               "storage_fp16 on shards needs n %% (64 x ranks) == 0, leg 2 in its full form, no prior and the f32 wire option off");
+    const bool half = !fp16 && (opt->leg2_form == 1 || (opt->leg2_form == -1 && fits_half && P >= 8));
+    PlanPrep pp;
+    int rc = shard_prepare(n, nnz, rowptr, col, rowscale, opt->apriori, opt->ld_apriori, opt->reorder != 0, half ? P : 1, &pp);
+    if (rc) return rc;
+    PlanPrepView view{&pp.ord, &pp.inv, &pp.rp, &pp.cl, &pp.rs};
+    SideIn in;
+    in.n = in.k = n;
+    in.nnz = nnz;
+    in.pat = &view;
+    in.coef = opt->coef; in.lbd = opt->lbd;
+    in.apriori = opt->apriori; in.ld_apriori = opt->ld_apriori;
+    in.evidence = opt->evidence ? 1 : 0;
+    in.half_form = half; in.fp16 = fp16;
+    in.stages = opt->stages; in.wire_fp16 = opt->wire_fp16;
+    return create_side(in, comm, stream, out);
 }
 
 int simrank_shardplan_set_timing(simrank_shardplan* p, int32_t updates) {
@@ -1078,6 +1138,233 @@ int simrank_shardplan_info(const simrank_shardplan* p, int64_t* n, int64_t* col_
     if (half_form) *half_form = p->half_form;
     if (stages) *stages = p->n_stages;
     if (updates) *updates = p->updates;
+    return SIMRANK_OK;
+}
+
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The two-matrix classes on shards (round 5; SimRank.py:288-302, :410-424, :478-492 with S1 and S2 split by column block):
+// a pair of the plans above, one per group, each reading the OTHER group's blocks in its leg 1 —
+//     S1 <- E1 * C1 * W12.S2.W12^T (+ lbd1 A1), diag <- 1        exchange 1 (+ 2 in the half form) of group 1
+//     S2 <- E2 * C2 * W21.S1.W21^T (+ lbd2 A2), diag <- 1        from the NEW S1 (Gauss-Seidel, :300-302): exchanges of group 2
+// — two exchanges per loop body in strict order, the loop ends when NEITHER matrix moved (:289).  Same kernels, chunk
+// layouts, node orders (ascending row length per group, dealt to the shards where that group runs its half form) and
+// evidence rules (options.strict_reference: Evidence_N1 on both updates, quirk Q2) as the Python driver's Sides and as
+// simrank_biplan_* on one GPU.  Symmetric priors only (an asymmetric one needs the un-fused epilogue: the Python driver).
+// ---------------------------------------------------------------------------------------------------------------------
+struct simrank_shardbiplan {
+    simrank_shardplan* side[2] = {nullptr, nullptr};
+    int32_t broadcast_error = 0;
+    int64_t n1 = 0, n2 = 0;
+    int32_t updates = 0;
+};
+
+namespace simrank {
+static int bi_sides(simrank_shardbiplan* const* bps, int32_t n_local, int w, std::vector<simrank_shardplan*>& out) {
+    SR_REQUIRE(bps && n_local >= 1, "no plans");
+    out.resize((size_t)n_local);
+    for (int32_t i = 0; i < n_local; ++i) {
+        SR_REQUIRE(bps[i] && bps[i]->side[0] && bps[i]->side[1], "plans[%d] is NULL", i);
+        out[(size_t)i] = bps[i]->side[w];
+    }
+    return check_group(out.data(), n_local);
+}
+
+// one loop body on every local pair: both updates queued; group w's count lands in pinned slot `slot` of its plans
+static int bi_iteration(simrank_shardbiplan* const* bps, int32_t n_local, double eps, int32_t exact_count, int slot) {
+    SR_REQUIRE(!bps[0]->broadcast_error, "operands could not be broadcast together with shapes (%lld,%lld) (%lld,%lld) ",
+               (long long)bps[0]->n1, (long long)bps[0]->n1, (long long)bps[0]->n2, (long long)bps[0]->n2);
+    std::vector<simrank_shardplan*> s;
+    for (int w = 0; w < 2; ++w) {
+        int rc = bi_sides(bps, n_local, w, s);
+        if (!rc) rc = update(s.data(), n_local, eps, exact_count, slot);
+        if (rc) return rc;
+        flip(s.data(), n_local);             // (the group-2 update of the same loop body reads the new S1)
+    }
+    return SIMRANK_OK;
+}
+
+static int bi_counts(simrank_shardbiplan* const* bps, int32_t n_local, int slot, unsigned long long* c1, unsigned long long* c2) {
+    std::vector<simrank_shardplan*> s;
+    int rc = bi_sides(bps, n_local, 0, s);
+    if (!rc) rc = read_count(s.data(), n_local, slot, c1);
+    if (!rc) rc = bi_sides(bps, n_local, 1, s);
+    if (!rc) rc = read_count(s.data(), n_local, slot, c2);
+    return rc;
+}
+}  // namespace simrank
+
+extern "C" {
+
+int simrank_shardbiplan_destroy(simrank_shardbiplan* bp) {
+    if (!bp) return SIMRANK_OK;
+    simrank_shardplan_destroy(bp->side[0]);
+    simrank_shardplan_destroy(bp->side[1]);
+    delete bp;
+    return SIMRANK_OK;
+}
+
+int simrank_shardbiplan_create(int64_t n1, int64_t n2, int64_t nnz, const int32_t* rowptr12, const int32_t* col12,
+                               const float* rowscale1, const float* rowscale2, const simrank_biplan_options* opt,
+                               int32_t leg2_form, int32_t stages, int32_t wire_fp16, simrank_comm* comm, void* stream,
+                               simrank_shardbiplan** out) {
+    SR_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    SR_REQUIRE(opt && comm, "options / communicator missing");
+    SR_REQUIRE(leg2_form >= -1 && leg2_form <= 1 && stages >= 0 && stages <= 64, "bad options");
+    const int32_t P = comm->world;
+    const int64_t ns[2] = {n1, n2};
+    // the half form group by group: where a group's size is a multiple of 32 x ranks (and asked for, or 8 ranks on)
+    bool half[2];
+    for (int w = 0; w < 2; ++w) {
+        const bool fits = (P > 1 && ns[w] % (32 * int64_t(P)) == 0) || (P == 1 && ns[w] % 32 == 0);
+        half[w] = fits && (leg2_form == 1 || (leg2_form == -1 && P >= 8));
+    }
+    BiPlanPrep pp;
+    int rc = shard_biplan_prepare(n1, n2, nnz, rowptr12, col12, rowscale1, rowscale2, opt, half[0] ? P : 1, half[1] ? P : 1, &pp);
+    if (rc) return rc;
+    simrank_shardbiplan* bp = new simrank_shardbiplan;
+    bp->n1 = n1; bp->n2 = n2;
+    auto fail = [&](int code) { simrank_shardbiplan_destroy(bp); return code; };
+    const float* priors[2] = {opt->apriori1, opt->apriori2};
+    const int64_t lds[2] = {opt->ld_apriori1, opt->ld_apriori2};
+    for (int w = 0; w < 2; ++w) {
+        PlanPrepView view{&pp.ord[w], &pp.inv[w], &pp.rp[w], &pp.cl[w], &pp.rs[w]};
+        SideIn in;
+        in.n = ns[w];
+        in.k = ns[w ^ 1];
+        in.nnz = nnz;
+        in.pat = &view;
+        in.coef = w == 0 ? opt->c1 : opt->c2;
+        in.lbd = w == 0 ? opt->lbd1 : opt->lbd2;
+        in.apriori = priors[w];
+        in.ld_apriori = lds[w];
+        const bool q2 = opt->evidence && opt->strict_reference && w == 1;       // Evidence_N1 on the group-2 update
+        in.evidence = (opt->evidence && !q2) ? 1 : 0;
+        in.half_form = half[w];
+        in.stages = stages;
+        in.wire_fp16 = wire_fp16;
+        rc = create_side(in, comm, stream, &bp->side[w]);
+        if (rc) return fail(rc);
+        simrank_shardplan* p = bp->side[w];
+        if (q2 && n1 != n2 && n1 != 1) {
+            bp->broadcast_error = 1;             // NumPy raises when the first group-2 update runs (quirk Q2)
+        } else if (q2 && p->Lm) {
+            hipError_t e = pool_hip_alloc((void**)&p->ev, size_t(p->n) * size_t(p->ld_ev));
+            if (e != hipSuccess) { set_error("evidence counts: %s", hipGetErrorString(e)); return fail(SIMRANK_ERR_ALLOC); }
+            if (n1 == 1 && n2 != 1) {
+                // the 1 x 1 Evidence_N1 broadcasts: the one group-1 node's count (with itself) gates every element
+                const int cnt = rowscale1[0] != 0.f ? (int)std::min<int64_t>(255, nnz) : 0;
+                e = hipMemsetAsync(p->ev, cnt, size_t(p->n) * size_t(p->ld_ev), p->stream);
+                if (e != hipSuccess) { set_error("evidence counts: %s", hipGetErrorString(e)); return fail(SIMRANK_ERR_HIP); }
+            } else {
+                // n1 = n2: element (i, j) of the group-2 update is multiplied by Evidence_N1[i][j], positions in the caller's
+                // order: the counts of the group-1 pattern with its rows taken in THIS group's solver order
+                std::vector<int32_t> rp((size_t)n1 + 1, 0), cl((size_t)std::max<int64_t>(1, nnz));
+                std::vector<float> rs((size_t)n1);
+                for (int64_t r = 0; r < n1; ++r) {
+                    const int32_t src = pp.ord[1][(size_t)r];
+                    const int32_t b = rowptr12[src], e2 = rowptr12[src + 1];
+                    std::copy(col12 + b, col12 + e2, cl.data() + rp[(size_t)r]);
+                    std::sort(cl.data() + rp[(size_t)r], cl.data() + rp[(size_t)r] + (e2 - b));
+                    rp[(size_t)r + 1] = rp[(size_t)r] + (e2 - b);
+                    rs[(size_t)r] = rowscale1[src];
+                }
+                simrank_graph* g1 = nullptr;
+                rc = simrank_graph_create(n1, n2, nnz, rp.data(), cl.data(), rs.data(), &g1);
+                if (rc) return fail(rc);
+                e = hipMemsetAsync(p->ev, 0, size_t(p->n) * size_t(p->ld_ev), p->stream);
+                rc = e == hipSuccess ? simrank_evidence_counts(g1, p->m_lo, p->Lm, p->ev, p->ld_ev, p->stream) : SIMRANK_ERR_HIP;
+                (void)hipStreamSynchronize(p->stream);
+                simrank_graph_destroy(g1);
+                if (rc) return fail(rc);
+            }
+            int64_t live = 0, total = 1;
+            rc = simrank_evidence_live_segments(p->ev, p->ld_ev, 0, p->n, p->Lm, &live, &total, p->stream);
+            if (rc) return fail(rc);
+            p->restrict_support = 2 * live < total ? 1 : 0;
+        }
+    }
+    bp->side[0]->src = bp->side[1];
+    bp->side[1]->src = bp->side[0];
+    *out = bp;
+    return SIMRANK_OK;
+}
+
+int simrank_shardbiplan_side(simrank_shardbiplan* bp, int32_t group, simrank_shardplan** out) {
+    SR_REQUIRE(bp && out && (group == 1 || group == 2), "bad arguments");
+    *out = bp->side[group - 1];
+    return SIMRANK_OK;
+}
+
+int simrank_shardbiplan_reset(simrank_shardbiplan* const* bps, int32_t n_local) {
+    std::vector<simrank_shardplan*> s;
+    for (int w = 0; w < 2; ++w) {
+        int rc = bi_sides(bps, n_local, w, s);
+        if (!rc) rc = simrank_shardplan_reset(s.data(), n_local);
+        if (rc) return rc;
+    }
+    for (int32_t i = 0; i < n_local; ++i) bps[i]->updates = 0;
+    return SIMRANK_OK;
+}
+
+int simrank_shardbiplan_step(simrank_shardbiplan* const* bps, int32_t n_local, double eps, int32_t exact_count,
+                             int64_t* changed1, int64_t* changed2) {
+    SR_REQUIRE(bps && n_local >= 1 && bps[0], "no plans");
+    int rc = bi_iteration(bps, n_local, eps, exact_count, 0);
+    if (rc) return rc;
+    for (int32_t i = 0; i < n_local; ++i) ++bps[i]->updates;
+    if (changed1 || changed2) {
+        unsigned long long c1 = 0, c2 = 0;
+        rc = bi_counts(bps, n_local, 0, &c1, &c2);
+        if (rc) return rc;
+        if (changed1) *changed1 = (int64_t)c1;
+        if (changed2) *changed2 = (int64_t)c2;
+    }
+    return SIMRANK_OK;
+}
+
+int simrank_shardbiplan_run(simrank_shardbiplan* const* bps, int32_t n_local, int32_t iterations, double eps,
+                            int32_t* updates_done, int32_t* converged_at) {
+    SR_REQUIRE(bps && n_local >= 1 && bps[0], "no plans");
+    SR_REQUIRE(iterations >= 0, "iterations < 0");
+    int rc = simrank_shardbiplan_reset(bps, n_local);
+    if (rc) return rc;
+    int32_t conv = -1, done = 0;
+    if (iterations > 0 && !(1.0 > eps)) {
+        conv = 0;           // loop index 0 compares the identities with zero matrices: "converged" unless 1 > eps
+    } else {
+        // (the counts of a loop body are read before the next one is queued: two exchanges per body set the pace here,
+        // not the host's round trip)
+        for (int32_t k = 0; k < iterations; ++k) {
+            rc = bi_iteration(bps, n_local, eps, 0, k & 1);
+            if (rc) return rc;
+            done = k + 1;
+            if (done == iterations) break;               // the reference makes no test after its last iteration
+            unsigned long long c1 = 0, c2 = 0;
+            rc = bi_counts(bps, n_local, k & 1, &c1, &c2);
+            if (rc) return rc;
+            if (c1 == 0 && c2 == 0) {                    // SimRank.py:289: both groups
+                conv = done;
+                break;
+            }
+        }
+    }
+    std::vector<simrank_shardplan*> s;
+    for (int w = 0; w < 2; ++w) {
+        rc = bi_sides(bps, n_local, w, s);
+        if (rc) return rc;
+        for (simrank_shardplan* p : s) {
+            SR_HIP(hipStreamSynchronize(p->stream));
+            if (p->xstream) SR_HIP(hipStreamSynchronize(p->xstream));
+            p->updates = done;
+        }
+    }
+    for (int32_t i = 0; i < n_local; ++i) bps[i]->updates = done;
+    if (updates_done) *updates_done = done;
+    if (converged_at) *converged_at = conv;
     return SIMRANK_OK;
 }
 

@@ -162,7 +162,7 @@ class LocalWorld:
     """P virtual ranks inside this process (P = 1 is the ordinary single-GPU case)."""
 
     def __init__(self, size: int = 1, symmetric_shards: bool = True, leg2_stages: int = 1,
-                 exchange_precision: str = "f32"):
+                 exchange_precision: str = "f32", loop: str = "python"):
         """``symmetric_shards``: sharded symmetric updates run leg 2 in its half form when the node
         count allows it (``Side.shard_sym``); False keeps the full form, whose results are bit-equal
         to a single rank's full form.  ``leg2_stages``: the half-form leg 2 (and its exchange) cut into
@@ -171,6 +171,11 @@ class LocalWorld:
         wire format does (no bytes to save here: this is how that mode's arithmetic is tested on one GPU)."""
         if exchange_precision not in ("f32", "fp16"):
             raise ValueError("exchange_precision must be 'f32' or 'fp16'")
+        if loop not in ("python", "c"):
+            raise ValueError("loop must be 'python' or 'c'")
+        # "c": the virtual ranks run the sharded loop behind the C ABI (an in-process group of csrc/shardplan.hip — what
+        # the ranks of an RCCL world run, with device copies for links); "python": driver.Solver's own choreography
+        self.loop = loop
         self.exchange_precision = exchange_precision
         self.size = int(size)
         self.local_ranks = list(range(self.size))
@@ -230,7 +235,7 @@ class TorchWorld:
 
     def __init__(self, group=None, stages: int = 0, stage_single_rank: bool = False,
                  handback: str = "root", symmetric_shards="auto", measure_single_rank: bool = False,
-                 exchange_precision: str = "f32"):
+                 exchange_precision: str = "f32", loop: str = "auto"):
         """``stages``: leg 1 is cut into that many column slices, each exchanged by its own
         all_to_all_single as soon as its kernel has finished, so the transfers over xGMI overlap
         the remaining leg-1 kernels (1 = one exchange after the whole leg; 0 = by the width of a
@@ -249,6 +254,13 @@ class TorchWorld:
         import torch.distributed as dist
         if handback not in ("root", "all"):
             raise ValueError("handback must be 'root' or 'all'")
+        if loop not in ("auto", "c", "python"):
+            raise ValueError("loop must be 'auto', 'c' or 'python'")
+        # which choreography a fit on this world runs: "auto" = the sharded loop behind the C ABI (csrc/shardplan.hip over
+        # the library's own RCCL communicator) on several RCCL ranks wherever it applies, this module's Solver otherwise
+        # (gloo, asymmetric priors, GEMM modes); "c" asks for the C loop also in a one-rank RCCL world (how its RCCL path
+        # is exercised on one GPU); "python" keeps the Solver
+        self.loop = loop
         if exchange_precision not in ("f32", "fp16"):
             raise ValueError("exchange_precision must be 'f32' or 'fp16'")
         # "fp16": both all-to-alls move fp16 (value x 2^14) instead of f32 — HALF the bytes on the xGMI links, where

@@ -364,6 +364,112 @@ class ShardPlans:
             pass
 
 
+class ShardBiPlans:
+    """This process's share of a SHARDED two-matrix fit behind the C ABI (simrank_shardbiplan_*: the loops of
+    SimRank.py:288-302, :410-424, :478-492 with S1 and S2 split by column block over ``world`` ranks): one pair of plans
+    over an RCCL communicator, or all ``world`` pairs of an in-process group (``comm=None``).  Collective calls."""
+
+    def __init__(self, ops, csr12: CSR, rowscale1, rowscale2, world: int = 1, comm=None, c1: float = 0.8, c2: float = 0.8,
+                 evidence: bool = False, apriori1=None, apriori2=None, lbd1: float = 0.0, lbd2: float = 0.0,
+                 reorder: bool = True, strict_reference: bool = False, leg2_form: int = -1, stages: int = 0,
+                 wire_fp16: bool = False):
+        self.ops, self.n1, self.n2 = ops, csr12.n_rows, csr12.n_cols
+        lib = ops.lib
+        rowptr = np.ascontiguousarray(csr12.rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(csr12.col, dtype=np.int32)
+        rs1 = np.ascontiguousarray(rowscale1, dtype=np.float32)
+        rs2 = np.ascontiguousarray(rowscale2, dtype=np.float32)
+        a1 = None if apriori1 is None else np.ascontiguousarray(apriori1, dtype=np.float32)
+        a2 = None if apriori2 is None else np.ascontiguousarray(apriori2, dtype=np.float32)
+        opt = BiPlanOptions(c1=c1, c2=c2, lbd1=lbd1, lbd2=lbd2,
+                            apriori1=None if a1 is None else a1.ctypes.data, ld_apriori1=0 if a1 is None else a1.shape[1],
+                            apriori2=None if a2 is None else a2.ctypes.data, ld_apriori2=0 if a2 is None else a2.shape[1],
+                            evidence=int(evidence), reorder=int(reorder), strict_reference=int(strict_reference))
+        self.own_comms = comm is None
+        if comm is None:
+            arr = (C.c_void_p * world)()
+            check(lib.simrank_comm_local_group(int(world), arr), "simrank_comm_local_group")
+            self.comms = [C.c_void_p(arr[r]) for r in range(world)]
+        else:
+            self.comms = [comm]
+        self.pairs = []
+        with HipOps._knob_lock:
+            for c in self.comms:
+                h = C.c_void_p()
+                check(lib.simrank_shardbiplan_create(csr12.n_rows, csr12.n_cols, col.size, rowptr.ctypes.data,
+                                                     col.ctypes.data if col.size else None, rs1.ctypes.data, rs2.ctypes.data,
+                                                     C.byref(opt), int(leg2_form), int(stages), int(wire_fp16), c, ops.stream,
+                                                     C.byref(h)), "simrank_shardbiplan_create")
+                self.pairs.append(h)
+        self._arr = (C.c_void_p * len(self.pairs))(*[h.value for h in self.pairs])
+        self._sides = {}
+        for group in (1, 2):
+            hs = []
+            for h in self.pairs:
+                sp = C.c_void_p()
+                check(lib.simrank_shardbiplan_side(h, group, C.byref(sp)), "simrank_shardbiplan_side")
+                hs.append(sp)
+            self._sides[group] = (C.c_void_p * len(hs))(*[x.value for x in hs])
+
+    def reset(self):
+        check(self.ops.lib.simrank_shardbiplan_reset(self._arr, len(self.pairs)), "simrank_shardbiplan_reset")
+
+    def step(self, eps: float, exact_count: bool = True):
+        c1, c2 = C.c_int64(0), C.c_int64(0)
+        check(self.ops.lib.simrank_shardbiplan_step(self._arr, len(self.pairs), float(eps), int(exact_count), C.byref(c1),
+                                                    C.byref(c2)), "simrank_shardbiplan_step")
+        return c1.value, c2.value
+
+    def run(self, iterations: int, eps: float):
+        """-> (loop bodies applied, loop index at which the convergence test passed or None); the same on every rank."""
+        done, conv = C.c_int32(0), C.c_int32(-1)
+        check(self.ops.lib.simrank_shardbiplan_run(self._arr, len(self.pairs), int(iterations), float(eps), C.byref(done),
+                                                   C.byref(conv)), "simrank_shardbiplan_run")
+        return done.value, (None if conv.value < 0 else conv.value)
+
+    def side_info(self, group: int, i: int = 0) -> dict:
+        n, lo, hi = C.c_int64(), C.c_int64(), C.c_int64()
+        half, stages, updates = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.ops.lib.simrank_shardplan_info(C.c_void_p(self._sides[group][i]), C.byref(n), C.byref(lo), C.byref(hi),
+                                                  C.byref(half), C.byref(stages), C.byref(updates)), "simrank_shardplan_info")
+        return dict(n=n.value, col_lo=lo.value, col_hi=hi.value, half_form=bool(half.value), stages=stages.value,
+                    updates=updates.value)
+
+    def result(self, group: int, root: int = 0, i_am_root: bool = True):
+        """Group 1 | 2's whole matrix (float64, caller's order) on rank ``root``; None elsewhere.  Collective."""
+        n = self.n1 if group == 1 else self.n2
+        out = hostpool.empty_f64(n, n) if i_am_root else None
+        check(self.ops.lib.simrank_shardplan_result_f64(self._sides[group], len(self.pairs), int(root),
+                                                        out.ctypes.data if out is not None else None, n),
+              "simrank_shardplan_result_f64")
+        return out
+
+    def topk(self, group: int, k: int, exclude_diag: bool = True, root: int = 0, i_am_root: bool = True):
+        n = self.n1 if group == 1 else self.n2
+        idx = np.empty((n, k), dtype=np.int32) if i_am_root else None
+        val = np.empty((n, k), dtype=np.float32) if i_am_root else None
+        check(self.ops.lib.simrank_shardplan_topk(self._sides[group], len(self.pairs), int(root), int(k), int(exclude_diag),
+                                                  idx.ctypes.data if i_am_root else None,
+                                                  val.ctypes.data if i_am_root else None), "simrank_shardplan_topk")
+        return idx, val
+
+    def free(self):
+        lib = self.ops.lib
+        for h in self.pairs:
+            lib.simrank_shardbiplan_destroy(h)
+        self.pairs = []
+        if self.own_comms:
+            for c in self.comms:
+                lib.simrank_comm_destroy(c)
+        self.comms = []
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class BiPlanOptions(C.Structure):              # struct simrank_biplan_options
     _fields_ = [("c1", C.c_float), ("c2", C.c_float), ("lbd1", C.c_float), ("lbd2", C.c_float),
                 ("apriori1", C.c_void_p), ("ld_apriori1", C.c_int64), ("apriori2", C.c_void_p),

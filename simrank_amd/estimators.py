@@ -91,13 +91,21 @@ def _make_solver(ops_factory, device, world, specs, mode):
             return cplan.PlanSolver(ops, world, specs)
         ops_factory = lambda rank: ops
     factory = ops_factory or _default_ops_factory(device)
-    if storage == "fp16" and world.size > 1:
-        # fp16-held matrices on SHARDS: the sharded loop behind the C ABI (csrc/shardplan.hip) — config 5 as stated
+    if world.size > 1 or getattr(world, "loop", "auto") == "c":
+        # several ranks: the sharded loop behind the C ABI (csrc/shardplan.hip) wherever it applies — the ranks of an RCCL
+        # world, or virtual ranks that ask for it (LocalWorld(P, loop="c")); fp16-held matrices exist on shards only there
         from . import cshard
-        why = cshard.applies(world, specs, mode)
-        if why:
-            raise ValueError("storage_precision='fp16' on several ranks: " + why)
-        return cshard.CShardSolver(factory, world, specs[0])
+        from .driver import TorchWorld
+        wants_c = ops_factory is None and (
+            (isinstance(world, TorchWorld) and world.dist.get_backend(world.group) == "nccl" and
+             getattr(world, "loop", "auto") != "python") or
+            (isinstance(world, LocalWorld) and getattr(world, "loop", "python") == "c"))
+        if wants_c or storage == "fp16":
+            why = cshard.applies(world, specs, mode)
+            if why is None:
+                return cshard.CShardSolver(factory, world, specs)
+            if storage == "fp16":
+                raise ValueError("storage_precision='fp16' on several ranks: " + why)
     return Solver(factory, world, specs, mode)
 
 

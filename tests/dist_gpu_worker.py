@@ -35,6 +35,25 @@ def main():
             check_against_golden(g, est, res, text)
         else:                                   # root-only hand-back (TorchWorld default)
             assert res is None and text == ""
+    # the same vectors through the sharded loop behind the C ABI over the library's own RCCL communicator (what a fit on
+    # several RCCL ranks runs since round 5: cshard.CShardSolver -> simrank_shardplan_* / simrank_shardbiplan_*)
+    import simrank_amd.cshard as cshard
+    made_c = []
+    orig_c = cshard.CShardSolver.__init__
+
+    def spy_c(self, *a, **k):
+        orig_c(self, *a, **k)
+        made_c.append(self)
+    cshard.CShardSolver.__init__ = spy_c
+    for name in ("SimRank_er128", "SimRankPP_er128", "AprioriSimRank_er64", "BipartiteSimRank_b5030",
+                 "BipartiteSimRankPP_b40", "BipartitleAprioriSimRank_b40"):
+        g = Golden(name)
+        n_before = len(made_c)
+        est, res, text = run_estimator(g, world=TorchWorld(stages=2, loop="c"), mode="sparse")
+        assert len(made_c) == n_before + 1, name
+        if rank == 0:
+            check_against_golden(g, est, res, text)
+    cshard.CShardSolver.__init__ = orig_c
     # a graph with dense sets and several panels per stage, against the in-process world
     df = synth.powerlaw_directed(3000, 24, seed=5)
     want = SRA.SimRank().fit(df, iterations=5, eps=0, verbose=False, mode="sparse", world=LocalWorld(1))

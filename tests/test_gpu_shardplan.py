@@ -278,3 +278,102 @@ def test_shardplan_over_rccl_two_ranks(tmp_path):
         pytest.skip("needs two GPUs")
     outs = _run_workers(2, tmp_path)
     assert all(rc == 0 and "SHARDPLAN RCCL ok" in out for rc, out, err in outs), [o[1][-2000:] + o[2][-2000:] for o in outs]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the two-matrix classes on shards (simrank_shardbiplan_*), and fits through the C loop on virtual ranks
+# ---------------------------------------------------------------------------------------------------------------------
+from tests.conftest import golden_names          # noqa: E402
+from tests.helpers import check_against_golden, run_estimator          # noqa: E402
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4])
+@pytest.mark.parametrize("name", golden_names("BipartiteSimRank", "BipartiteSimRankPP", "BipartitleAprioriSimRank"))
+def test_bipartite_golden_vectors_through_the_sharded_c_loop(name, world):
+    """Every bipartite vector of the reference through `fit(world=LocalWorld(P, loop="c"))`: cshard.CShardSolver ->
+    simrank_shardbiplan_* on an in-process group of P virtual ranks (two exchanges per loop body, Gauss-Seidel order,
+    Evidence_N1 on both updates and NumPy's broadcast error in strict mode, uneven and empty blocks) — labels, values,
+    convergence index, console text.  An asymmetric prior keeps the Python driver."""
+    import simrank_amd.cshard as cshard
+    g = Golden(name)
+    made = []
+    orig = cshard.CShardSolver.__init__
+
+    def spy(self, *a, **k):
+        orig(self, *a, **k)
+        made.append(self)
+    cshard.CShardSolver.__init__ = spy
+    try:
+        if g.raises:
+            with pytest.raises(ValueError):
+                run_estimator(g, world=LocalWorld(world, loop="c"), mode="sparse")
+            return
+        est, res, text = run_estimator(g, world=LocalWorld(world, loop="c"), mode="sparse")
+    finally:
+        cshard.CShardSolver.__init__ = orig
+    if world > 1:
+        assert len(made) == (0 if name.endswith("_asym") else 1), (name, len(made))
+    check_against_golden(g, est, res, text)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name", ["SimRank_er128", "SimRankPP_quirky", "AprioriSimRank_er64", "SimRank_toy5", "SimRankPP_bts300"])
+def test_directed_golden_vectors_through_the_sharded_c_loop(name, world):
+    g = Golden(name)
+    est, res, text = run_estimator(g, world=LocalWorld(world, loop="c"), mode="sparse")
+    check_against_golden(g, est, res, text)
+
+
+@pytest.mark.parametrize("world,sym", [(2, False), (2, True), (4, True), (4, False), (8, True)])
+def test_sharded_bipartite_c_loop_is_the_python_drivers_bits(world, sym):
+    """The C loop of the two-matrix classes makes the launches of driver.Side on the same node orders: bit-equal to
+    `fit(world=LocalWorld(P))` in the full form and in the half form (group sizes multiples of 32 x ranks), plain and
+    SimRank++ (corrected evidence), with symmetric priors."""
+    from tests.graphs import bipartite_random
+    n1, n2 = 32 * world * 3, 32 * world * 2
+    df = bipartite_random(n1, n2, 0.06, seed=world)
+    rng = np.random.default_rng(world)
+    p1, p2 = rng.random((n1, n1)), rng.random((n2, n2))
+    p1, p2 = (p1 + p1.T) / 2, (p2 + p2.T) / 2
+    cases = [(SRA.BipartiteSimRank, (), {}), (SRA.BipartiteSimRankPP, (), dict(strict_reference=False)),
+             (SRA.BipartitleAprioriSimRank, (p1, p2), dict(strict_reference=False, lbd1=0.3, lbd2=0.2))]
+    for cls, args, kw in cases:
+        kw = dict(kw, iterations=5, eps=0, verbose=False, mode="sparse", C1=0.7, C2=0.85)
+        a1, a2 = cls().fit(df, *args, world=LocalWorld(world, symmetric_shards=sym), **kw)
+        b1, b2 = cls().fit(df, *args, world=LocalWorld(world, symmetric_shards=sym, loop="c"), **kw)
+        assert np.array_equal(a1.values, b1.values) and np.array_equal(a2.values, b2.values), cls.__name__
+        want = (O.fit_bipartite if cls is SRA.BipartiteSimRank else O.fit_bipartite_pp)(
+            df, **{k: v for k, v in kw.items() if k not in ("mode",)},
+            **(dict(apriori1=p1, apriori2=p2) if args else {}))
+        assert_close(b1.values, want["S1"])
+        assert_close(b2.values, want["S2"])
+
+
+def test_sharded_bipartite_plan_step_by_step_and_top_k(ops):
+    """simrank_shardbiplan_step / _run / hand-back entry points on 3 virtual ranks: counts of both groups, the convergence
+    index, top-k per group against a sort of the dense result, timing stamps of a group's plan."""
+    from simrank_amd.engine import ShardBiPlans
+    from tests.graphs import bipartite_random
+    df = bipartite_random(70, 45, 0.12, seed=2)
+    _, _, _, _, g12, g21 = ingest.bipartite(df, False, "user", "item", "weight")
+    want = O.fit_bipartite_pp(df, verbose=False, strict_reference=False)
+    bp = ShardBiPlans(ops, g12, g12.rowscale, g21.rowscale, world=3, evidence=True, leg2_form=0, stages=2)
+    done, conv = bp.run(100, 1e-4)
+    assert conv == want["k"] and done == conv
+    s1, s2 = bp.result(1), bp.result(2)
+    assert_close(s1, want["S1"])
+    assert_close(s2, want["S2"])
+    bp.reset()
+    counts = [bp.step(1e-4, exact_count=True) for _ in range(done)]
+    assert counts[-1] == (0, 0) and all(c1 + c2 > 0 for c1, c2 in counts[:-1])
+    for group, M in ((1, s1), (2, s2)):
+        idx, val = bp.topk(group, 4)
+        n = len(M)
+        for a in range(n):
+            cand = np.array([c for c in range(n) if c != a])
+            order = cand[np.lexsort((cand, -M[a, cand]))][:4]
+            assert list(idx[a]) == list(order)
+            np.testing.assert_array_equal(val[a].astype(np.float64), M[a, order])
+    assert bp.run(0, 1e-4) == (0, None) and bp.run(5, 1.0) == (0, 0)
+    np.testing.assert_array_equal(bp.result(2), np.eye(45))
+    bp.free()

@@ -110,6 +110,7 @@ def c_loop_section(args, ops, world, dist, torch, synth, ingest, csr, coef, gpu,
         for name, _, grade in variants:
             out["variants"][name] = {"skipped": why, "parity_grade": grade}
         out["config5"] = {"skipped": why}
+        out["config3"] = {"skipped": why}
         out["form_measured"] = {"skipped": why}
         return out
     from simrank_amd import cshard
@@ -180,6 +181,36 @@ def c_loop_section(args, ops, world, dist, torch, synth, ingest, csr, coef, gpu,
             out["config5"] = c5
         except Exception as e:
             out["config5"] = {"error": f"{type(e).__name__}: {e}"}
+        # BASELINE config 3 (MovieLens-1M-shaped BipartiteSimRankPP) through the two-matrix sharded loop (simrank_shardbiplan_*)
+        try:
+            from simrank_amd.engine import ShardBiPlans
+            df3 = synth.WORKLOADS["ml1m"][0]()
+            _, _, _, _, g12, g21 = ingest.bipartite(df3, False, "user", "item", "weight")
+            bp, err = None, None
+            try:
+                bp = ShardBiPlans(ops, g12, g12.rowscale, g21.rowscale, world=P, comm=comm, c1=coef, c2=coef, evidence=True,
+                                  leg2_form=0, stages=args.stages)
+            except Exception as e:
+                err = f"{type(e).__name__}: {e}"
+            if not all_ok(err is None):
+                if bp is not None:
+                    bp.free()
+                out["config3"] = {"error": err or "another rank failed to create its plans"}
+            else:
+                for _ in range(2):
+                    bp.step(0.0, True)
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    bp.step(0.0, True)
+                barrier()
+                dt = max_over_ranks(time.perf_counter() - t0) / 10
+                out["config3"] = {"workload": f"ml1m: {g12.n_rows} x {g12.n_cols}, nnz={g12.nnz}, BipartiteSimRankPP on {P} ranks, C loop "
+                                              "(two exchanges per loop body, full form)",
+                                  "value": 1.0 / dt, "unit": "iterations/s", "ms_per_step": dt * 1e3}
+                bp.free()
+        except Exception as e:
+            out["config3"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 

@@ -119,7 +119,7 @@ int64_t build_tiles(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int64_t 
 // set-up against 0.12 s for its four updates: profiles/r03_setup_before_pool.log), so blocks of at least
 // kPoolMin bytes are kept when their owner lets go of them and handed to the next request they fit (smallest
 // cached block of at least the size asked for and at most 1/8 larger).  Per device at most SIMRANK_POOL_GIB
-// (default 96) GiB at rest, least recently freed blocks leave first; a failed hipMalloc anywhere behind this
+// (default 56: one config-5 plan) GiB at rest, least recently freed blocks leave first; a failed hipMalloc anywhere behind this
 // interface empties the pool and tries once more, so cached blocks never cause an out-of-memory error the
 // process would not have had without them.  Cached memory is invisible to other allocators of the process
 // (torch's caching allocator, the caller's own hipMalloc): simrank_pool_trim() hands it back.
@@ -132,7 +132,7 @@ struct PoolState {
     std::vector<size_t> cached_bytes;
     std::vector<std::pair<void*, std::pair<size_t, int>>> live;   // blocks handed out: ptr -> (bytes, device)
     uint64_t clock = 0;
-    size_t limit = size_t(96) << 30;
+    size_t limit = size_t(56) << 30;      // what one config-5 plan holds: three 17 GiB matrices + its counts
     PoolState() {
         if (const char* e = getenv("SIMRANK_POOL_GIB")) limit = size_t(std::max(0ll, atoll(e))) << 30;
     }

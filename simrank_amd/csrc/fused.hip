@@ -41,6 +41,7 @@
 
 #include <cstdlib>
 
+#include <mutex>
 #include <thread>
 
 #include "common.h"
@@ -97,6 +98,12 @@ struct FusedArgs {
 };
 
 #ifndef SIMRANK_HOST_ONLY          // (the sanitizer build of the host logic has no device code: common.h)
+// The units of a split block hand their partial sums over with sc1 (write-through) stores, a drained vmcnt, a RELAXED
+// agent-scope ticket and sc1 loads past the L1 (step 4b below): that is the cache-policy behaviour of gfx942 / gfx950,
+// not a guarantee of the HIP memory model — refuse to build the device code for anything else.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "fused.hip: the sc1 hand-off between the units of a split block is written for gfx942 / gfx950"
+#endif
 #ifdef SIMRANK_FUSED_STAMPS
 // Diagnostic build only (bash tools/build_variant.sh fst -DSIMRANK_FUSED_STAMPS; tools/fused_stamps.py): the
 // timeline of the workgroups with blockIdx in [g_fst_base, g_fst_base + kFstCap): s_memtime at the phase
@@ -1014,6 +1021,11 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
 
 static int launch_fused(const simrank_graph* g, FusedArgs& a, hipStream_t st) {
     simrank_fused_plan* pl = g->fused;
+    // (the partial sums and tickets of the split blocks belong to the GRAPH: launches on one graph must be stream-ordered —
+    // one solver per graph object, include/simrank_hip.h — and two host threads must not launch on it at once: this lock
+    // covers the part that may re-allocate them; advisor, round 4)
+    static std::mutex launch_mutex;
+    std::lock_guard<std::mutex> launch_lock(launch_mutex);
     a.M = g->n_rows;
     a.n_panels = int32_t((a.L + 31) / 32);
     a.n_units = pl->n_units;

@@ -610,7 +610,7 @@ class HipOps:
     # library (csrc/api.hip: simrank_malloc / simrank_free; best fit within 1/8, least recently freed first out,
     # an allocation that fails empties the pool and is tried again; the C-level plans use the same pool).
     # Pooled memory is invisible to other allocators of the process (torch's among them): trim_pool() hands
-    # it back; SIMRANK_POOL_GIB bounds what may rest per device (default 96).
+    # it back; SIMRANK_POOL_GIB bounds what may rest per device (default 56: one config-5 plan).
     def _malloc(self, nbytes: int) -> int:
         p = C.c_void_p()
         check(self.lib.simrank_malloc(C.byref(p), max(16, int(nbytes))), "simrank_malloc")

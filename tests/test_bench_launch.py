@@ -35,7 +35,7 @@ def test_bench_launches_its_own_ranks_over_gloo():
                                                       "fp16_held_full_form"}
     assert all("skipped" in v and "value" not in v for v in c["variants"].values())
     assert [v["parity_grade"] for v in c["variants"].values()] == [True, True, False, False]
-    assert "skipped" in c["config5"] and "skipped" in c["form_measured"]
+    assert "skipped" in c["config5"] and "skipped" in c["config3"] and "skipped" in c["form_measured"]
     assert "exchange_ms" in out
 
 

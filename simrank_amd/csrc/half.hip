@@ -180,30 +180,37 @@ __global__ __launch_bounds__(256, SYM ? SIMRANK_HALF_LB2 : SIMRANK_HALF_LB1) voi
         if constexpr (IDS16) return (raw == 0xFFFF || !ok) ? sent : raw;
         else return (raw < 0 || !ok) ? sent : raw;
     };
+    // (round 5, as fused.hip / spmm.hip) everything the prologue reads is REQUESTED first and used afterwards: the row
+    // records through plain global loads of a clamped index (the select against a stack slot compiled to flat loads
+    // and scratch), the ids of the first two rounds side by side, the striped counter of the short-circuit test through an
+    // unconditional buffer load past the L1 (a zero-byte descriptor when there is nothing to watch) instead of a
+    // generic-pointer atomic load with its wait right behind it
+    int iv0 = 0, iv1 = 0;
+    unsigned long long seen = 0;
+    const unsigned slot = ((blockIdx.x * 4u + unsigned(wave)) * 7u) % SIMRANK_CHANGED_SLOTS;
     {
         const int sbA = q >> 2, sbB = 2 + (q >> 2);
         const int2* src = p.gmeta + ((size_t(b0) * 4 + wave) * 8 + g) * 4 + (q & 3);
         int2* dst = gm_lds + (wave * 8 + g) * 4 + (q & 3);
-        const int2 none = make_int2(int(0xFFFFFFFFu), 0);
-        const int2 a = sbA < n_sub ? src[size_t(sbA) * 4 * 8 * 4] : none;
-        const int2 c = sbB < n_sub ? src[size_t(sbB) * 4 * 8 * 4] : none;
+        int2 a = src[size_t(min(sbA, n_sub - 1)) * 4 * 8 * 4];
+        int2 c = src[size_t(min(sbB, n_sub - 1)) * 4 * 8 * 4];
+        if (n_rounds > 0) {
+            iv0 = ld_raw(0);
+            iv1 = ld_raw(1);
+        }
+        if constexpr (SYM) {
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+            const bool watch = p.prev && p.count_any;
+            const __amdgpu_buffer_rsrc_t csrd = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<unsigned long long*>(p.n_changed), 0, watch ? SIMRANK_CHANGED_SLOTS * 8 : 0, 0x00020000);
+            const v2u w = __builtin_amdgcn_raw_buffer_load_b64(csrd, int(slot * 8u), 0, 16);
+            seen = (unsigned long long)w.x | ((unsigned long long)w.y << 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (sbA >= n_sub) a = make_int2(int(0xFFFFFFFFu), 0);
+        if (sbB >= n_sub) c = make_int2(int(0xFFFFFFFFu), 0);
         dst[sbA * 4 * 8 * 4] = a;
         dst[sbB * 4 * 8 * 4] = c;
-    }
-    int iv0 = 0, iv1 = 0;
-    if (n_rounds > 0) {
-        iv0 = ld_raw(0);
-        iv1 = ld_raw(1);
-    }
-    // leg 2, count_any: has a wave that shares this wave's counter already found an element that moved?
-    unsigned long long seen = 0;
-    const unsigned slot = ((blockIdx.x * 4u + unsigned(wave)) * 7u) % SIMRANK_CHANGED_SLOTS;
-    if constexpr (SYM) {
-        if (p.prev && p.count_any) {
-            const unsigned long long* flag = p.n_changed + slot;
-            asm volatile("" : "+v"(flag));
-            seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
 
     // ---------------------------------------------------------------- 1. MFMA phase

@@ -288,6 +288,23 @@ class TorchWorld:
         self.stages = max(0, int(stages)) if (self.size > 1 or stage_single_rank) else 1
         self.leg2_stages = 0               # 0: the half-form leg 2 is cut like leg 1 (Side.n_stages)
 
+    def close(self):
+        """Destroy the library's own RCCL communicator of this world, if a fit over the C loop made one (cshard.py)."""
+        comm = getattr(self, "_c_comm", None)
+        if comm is not None:
+            self._c_comm = None
+            try:
+                from . import _lib
+                _lib.load().simrank_comm_destroy(comm)
+            except Exception:
+                pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     @property
     def stream_ordered(self):
         """RCCL collectives can be ordered on the engine's stream: no host synchronisation

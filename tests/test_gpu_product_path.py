@@ -88,8 +88,24 @@ def test_half_and_full_hand_back_of_config_4_are_the_same_bits(ops, monkeypatch)
     _, csr = ingest.directed(df, False, "from", "to", "weight")
     n = csr.n_rows
     plan = Plan(ops, csr, coef=0.8)
-    plan.run(4, 0.0)
+    plan.reset()
+    for _ in range(3):
+        plan.step(0.0)
+    before = plan.result()
+    plan.step(0.0)
     pipelined = plan.result()
+    # 24 sampled rows of the fourth update (the C loop fit() runs) within 1e-5 of a float64 recomputation from the third
+    import scipy.sparse as sp
+    rs = csr.rowscale.astype(np.float32).astype(np.float64)
+    W = sp.diags(rs) @ sp.csr_matrix((np.ones(csr.col.size), csr.col, csr.rowptr), shape=(n, n))
+    rows = sorted({0, n - 1, int(np.argmax(np.diff(csr.rowptr)))} |
+                  set(int(r) for r in np.random.default_rng(4).choice(n, size=21, replace=False)))
+    for a in rows:
+        t = rs[a] * before[csr.col[csr.rowptr[a]:csr.rowptr[a + 1]]].sum(axis=0)
+        want = 0.8 * (W @ t)
+        want[a] = 1.0
+        np.testing.assert_allclose(pipelined[a], want, rtol=1e-5, atol=1e-30)
+    del before
     monkeypatch.setenv("SIMRANK_SYM_HANDBACK", "1")
     half = plan.result()
     monkeypatch.delenv("SIMRANK_SYM_HANDBACK")

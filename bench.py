@@ -40,7 +40,7 @@ MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
 MFMA_BF16_PEAK_TF = 2500.0     # v_mfma_f32_32x32x16_bf16 dense peak
 
 
-def leg_bytes(n_rows, n_cols_in, n_cols_x, nnz, leg2, has_evidence=False, triangle=False, reads_previous=True):
+def leg_bytes(n_rows, n_cols_in, n_cols_x, nnz, leg2, has_evidence=False, triangle=False, reads_previous=True, elt=4):
     """Algorithmic HBM bytes of one gather-leg launch:
     read X once, write Y once, CSR (col + rowptr) once per launch; leg 2 also reads the
     previous iterate for the convergence count (and 1 B/elt of evidence counts).
@@ -48,15 +48,46 @@ def leg_bytes(n_rows, n_cols_in, n_cols_x, nnz, leg2, has_evidence=False, triang
     stores their mirror image — it still writes all of Y and gathers from all of X, but reads
     only half of the previous iterate and of the evidence counts.
     ``reads_previous=False``: the short-circuit convergence test (epilogue count_any) reads the
-    previous iterate only until a difference has been found (~1 % of it): not charged."""
-    b = 4 * n_cols_in * n_cols_x + 4 * n_rows * n_cols_x + 8 * nnz + 4 * (n_rows + 1)
+    previous iterate only until a difference has been found (~1 % of it): not charged.
+    ``elt``: bytes per stored value (2 for the fp16-held matrices of half.hip)."""
+    b = elt * n_cols_in * n_cols_x + elt * n_rows * n_cols_x + 8 * nnz + 4 * (n_rows + 1)
     if leg2:
         half = 2 if triangle else 1
         if reads_previous:
-            b += 4 * n_rows * n_cols_x // half
+            b += elt * n_rows * n_cols_x // half
         if has_evidence:
             b += n_rows * n_cols_x // half
     return b
+
+
+def config_roofline(key, legs, note=None):
+    """``roofline`` object of a secondary configuration: ``legs`` = [(kernel, "leg1" | "leg2", mean ms per launch,
+    algorithmic bytes per launch)]; the slower launch first, the other under ``other``.  ``traffic`` = HBM-side bytes
+    per launch of the per-config rocprofv3 --pmc passes (profiles/pmc_traffic.json[key], tools/gpu_profile_configs.sh),
+    not measured in this run."""
+    rec = {}
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key, {})
+    except Exception:
+        pass
+    objs = []
+    for kernel, leg, ms, b in legs:
+        gbs = b / (ms * 1e-3) / 1e9
+        o = {"kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": gbs / HBM_PEAK_GBS, "traffic": rec.get(leg), "ms": ms, "algorithmic_bytes": b}
+        if rec.get(leg):
+            o["traffic_over_algorithmic"] = rec[leg] / b
+            o["traffic_source"] = (f"profiles/pmc_traffic.json[{key!r}]: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc "
+                                   f"passes at commit {rec.get('commit', '?')}, NOT measured in this run")
+            if rec.get(leg + "_ms_rocprof"):
+                o["ms_rocprof"] = rec[leg + "_ms_rocprof"]
+        objs.append(o)
+    objs.sort(key=lambda o: -o["ms"])
+    top = objs[0]
+    top["other"] = objs[1:]
+    if note:
+        top["note"] = note
+    return top
 
 
 def cpu_baseline(csr, S_host, coef, budget_s=45.0):
@@ -736,6 +767,13 @@ def main():
                     out["secondary"]["c_plan_steps"] = {"value": 1.0 / dts, "unit": "iterations/s", "ms_per_step": dts * 1e3,
                                                         "leg1_ms": a1, "leg2_ms": a2,
                                                         "note": "simrank_plan_step x 50, exact count read every update"}
+                    out["secondary"]["roofline"] = config_roofline("er8192:1", [
+                        ("leg 1 (transposed store)", "leg1", a1, leg_bytes(n2, n2, n2, z2, False)),
+                        ("leg 2 = gather3_kernel (upper triangle, fused epilogue, exact count)", "leg2", a2,
+                         leg_bytes(n2, n2, n2, z2, True, triangle=True))],
+                        note="N = 8192: S, the transposed product and S' are 268 MB each - most of what the legs read is served "
+                             "by the 256 MB Infinity Cache and the L2s, so the HBM figure is not what binds here: the vector-"
+                             "memory path of the gathers is (the launches are 0.1 ms long; see `gather_path` of the headline)")
                     ps.plan.free()
                 except Exception as e:
                     out["secondary"]["fit_loop"] = {"error": f"{type(e).__name__}: {e}"}
@@ -786,6 +824,24 @@ def main():
                 "legs_ms_note": "HIP events of the Python driver's launches of the same kernels (the C loop queues them "
                                 "back to back)",
                 "entries_in_dense_sets": [c / max(1, g12.nnz) for _, _, c in st3]}
+            try:
+                # the mean launch of each leg over both groups (what the per-kernel rocprofv3 figures average too):
+                # group 1: S1' = C1 W12 S2 W12^T (leg 1 reads S2, n2 x n2, writes n1 x n2; leg 2 reads that, writes S1,
+                # n1 x n1, upper triangle + mirror); group 2 likewise with the sizes swapped
+                lm = out["bipartite_pp"]["legs_ms"]
+                m1, m2, z3 = g12.n_rows, g12.n_cols, g12.nnz
+                out["bipartite_pp"]["roofline"] = config_roofline("ml1m:1:pp", [
+                    ("leg 1 (fused_trans_kernel / gather3_kernel<1>), mean of both groups", "leg1",
+                     0.5 * (lm["leg1.0"] + lm["leg1.1"]),
+                     0.5 * (leg_bytes(m1, m2, m2, z3, False) + leg_bytes(m2, m1, m1, z3, False))),
+                    ("leg 2 = gather3_kernel (upper triangle, evidence epilogue, exact count), mean of both groups", "leg2",
+                     0.5 * (lm["leg2.0"] + lm["leg2.1"]),
+                     0.5 * (leg_bytes(m1, m2, m1, z3, True, has_evidence=True, triangle=True)
+                            + leg_bytes(m2, m1, m2, z3, True, has_evidence=True, triangle=True)))],
+                    note="6040 x 3706: the matrices are 146 MB, 55 MB and 90 MB - Infinity-Cache resident; the HBM figure is "
+                         "the contract's, the gathers' vector-memory path is what binds")
+            except Exception as e:
+                out["bipartite_pp"]["roofline"] = {"error": f"{type(e).__name__}: {e}"}
             s3.release()
             del s3
             if gpu:
@@ -876,6 +932,15 @@ def main():
                         "p99_rel": float(np.quantile(rel, 0.99)), "max_abs": float(np.abs(low - ref).max())}
 
             res5["fp16_storage"]["vs_f32_ms_per_step"] = res5["fp16_storage"]["ms_per_step"] / res5["f32"]["ms_per_step"]
+            n5, z5 = csr5.n_rows, csr5.nnz
+            for prec, key5, elt, k1, k2 in (("f32", "pl65536:1:pp", 4, "fused_trans_kernel", "gather3_kernel"),
+                                            ("fp16_storage", "pl65536:1:pp:fp16storage", 2, "half_leg_kernel (leg 1)",
+                                             "half_leg_kernel (leg 2)")):
+                res5[prec]["roofline"] = config_roofline(key5, [
+                    (f"leg 1 = {k1} (dense sets on MFMA + gathered remainder, transposed store)", "leg1",
+                     res5[prec]["leg1_ms"], leg_bytes(n5, n5, n5, z5, False, elt=elt)),
+                    (f"leg 2 = {k2} (upper triangle, evidence epilogue, exact count)", "leg2",
+                     res5[prec]["leg2_ms"], leg_bytes(n5, n5, n5, z5, True, has_evidence=True, triangle=True, elt=elt))])
             out["config5"] = {
                 "workload": f"pl65536: synthetic directed graph N={csr5.n_rows} nnz={csr5.nnz} SimRank++ "
                             f"(evidence counts in the epilogue, spread weights) C=0.8, one GPU, 8 iterations",

@@ -90,15 +90,45 @@ def config_roofline(key, legs, note=None):
     return top
 
 
+def cpu_share():
+    """CPUs this process may actually use: the affinity mask, cut by the cgroup's quota (the GPU boxes show 256 hardware
+    threads and grant 16 CPUs of time: cpu.max = "1600000 100000")."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(csr, S_host, coef, budget_s=45.0):
     """Oracle (dense float64 NumPy, the reference's arithmetic) on a row slab of one
     iteration; value = iterations/s of a full iteration extrapolated from the slab."""
     from oracle import simrank_oracle as O
+    share = cpu_share()
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        if threads > share:
+            # BLAS sized its pool by the hardware threads it sees; more runnable threads than granted CPUs only get
+            # throttled by the cgroup — the baseline runs on the CPUs it really has
+            threadpool_limits(limits=share)
+            threads = share
     except Exception:
-        threads = os.cpu_count()
+        threads = min(os.cpu_count() or 1, share)
     n = csr.n_rows
     G = csr.dense()                                        # what the reference keeps as `Graph`
     probe = slice(0, 128)
@@ -122,7 +152,8 @@ def cpu_baseline(csr, S_host, coef, budget_s=45.0):
             "sample": f"oracle dense f64 update (2 dgemm + copy + convergence test) of rows "
                       f"0..{rows - 1} of one N={n} iteration: {t_update + t_rest:.2f} s, "
                       f"scaled x{n / rows:.1f} to a full iteration ({per_iter:.1f} s); "
-                      f"host cpu_count={os.cpu_count()}"}
+                      f"host cpu_count={os.cpu_count()}, CPUs granted to this process (affinity + cgroup quota) "
+                      f"{share}, BLAS threads {threads}"}
 
 
 def c_loop_section(args, ops, world, dist, torch, synth, ingest, csr, coef, gpu, barrier, rank):

@@ -903,7 +903,7 @@ def reorder_specs(specs, deal: int = 1):
     the order it iterates in: every node set goes by ASCENDING ROW LENGTH of its graph.
     The rows a wave gathers together then have equal lengths (no masked gathers), and in the
     upper-triangle form of leg 2 the long rows own the short column ranges — on a power-law
-    graph a quarter of the gathers of the natural order.
+    graph a quarter of the gathers of the natural order (HISTORY.md §4.7).
     Returns (specs in the new order, [order of node set j]); results are handed back in the
     caller's order by ``Solver.result`` / ``topk`` / ``evidence``."""
     orders = [dealt_order(length_order(sp.csr), deal) for sp in specs]
@@ -953,7 +953,7 @@ class Solver:
         # One rank running the gather legs keeps S, the transposed product, evidence and prior
         # PANEL-BLOCKED (engine.Matrix): a panel's slice of the operand is then contiguous instead of
         # one 128-byte segment every 128 KiB, which is what the gathers need at N >= 16384 (TLB reach;
-        # DESIGN.md §4.9).  Sharded ranks hold N x N/P blocks whose rows are close together already.
+        # HISTORY.md §4.9).  Sharded ranks hold N x N/P blocks whose rows are close together already.
         self.blocked = (world.size == 1 and not torch_buffers and self.mode == "sparse" and
                         all(getattr(o, "supports_blocked", False) and lean_knobs(o) for o in self.ops.values()))
         # fp16 storage (SideSpec.storage): the panel-blocked single-rank gather solver only, symmetric iterates

@@ -156,7 +156,7 @@ def cpu_baseline(csr, S_host, coef, budget_s=45.0):
                       f"{share}, BLAS threads {threads}"}
 
 
-def c_loop_section(args, ops, world, dist, torch, synth, ingest, csr, coef, gpu, barrier, rank):
+def c_loop_section(args, ops, world, dist, torch, synth, ingest, csr, coef, gpu, barrier, rank, out=None):
     """The sharded loop behind the C ABI on this world's ranks: every variant `steps` updates with the exact count, the
     MAX over the ranks of the wall time, per-piece HIP-event times of rank 0.  Over gloo (the CPU rehearsal of the launch
     path) nothing can run — the loop moves data with RCCL or inside one process — and every key says so."""
@@ -166,7 +166,8 @@ def c_loop_section(args, ops, world, dist, torch, synth, ingest, csr, coef, gpu,
                 ("f32_half_form", dict(leg2_form=1), True),
                 ("f32_half_form_fp16_wire", dict(leg2_form=1, wire_fp16=True), False),
                 ("fp16_held_full_form", dict(storage="fp16", leg2_form=0), False)]
-    out = {"ranks": P, "variants": {}, "stages": args.stages}
+    out = {} if out is None else out             # (filled in place: the caller's watchdog prints what is there if a rank hangs)
+    out.update({"ranks": P, "variants": {}, "stages": args.stages})
     if not gpu:
         why = "not run: the C loop exchanges over RCCL (or inside one process); this is the gloo rehearsal of the launch path"
         for name, _, grade in variants:
@@ -498,7 +499,34 @@ def main():
         # (simrank_shardplan_*: ncclSend / ncclRecv groups on a stream of their own) in its forms — f32 full / half, the fp16
         # wire, fp16-held matrices — with HIP events on the kernels' and the exchanges' streams, and BASELINE config 5
         # (N = 65536 SimRank++) through the same loop.  The headline is the faster PARITY-GRADE (f32) loop, named.
-        out["sharded_c_loop"] = c_loop_section(args, ops, world, dist, torch, synth, ingest, csr, coef, gpu, barrier, rank)
+        # No P > 1 RCCL world has ever run this loop (one GPU per box until now), and a rank stuck in a collective would take the
+        # whole line with it: a watchdog prints what has been measured (the Python world's headline + the variants finished) and
+        # ends the rank if the section is not done after SIMRANK_BENCH_CLOOP_DEADLINE seconds (default 600).
+        import threading
+        section = {}
+        out["sharded_c_loop"] = section
+        deadline = float(os.environ.get("SIMRANK_BENCH_CLOOP_DEADLINE", "600"))
+
+        def give_up():
+            section["error"] = (f"watchdog: the C-loop section had not finished after {deadline:.0f} s (a rank stuck in a collective?); "
+                                "the variants above it are what had been measured; value = the Python world's loop")
+            if rank == 0:
+                try:
+                    line = json.dumps(out, default=str)
+                except Exception:
+                    line = json.dumps({k: v for k, v in out.items() if k != "sharded_c_loop"}, default=str)
+                sys.stdout.write(line + "\n")
+                sys.stdout.flush()
+            os._exit(0)
+        dog = threading.Timer(deadline, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            c_loop_section(args, ops, world, dist, torch, synth, ingest, csr, coef, gpu, barrier, rank, out=section)
+        except Exception as e:
+            section["error"] = f"{type(e).__name__}: {e}"
+        finally:
+            dog.cancel()
         best = None
         for name, rec in out["sharded_c_loop"].get("variants", {}).items():
             if rec.get("parity_grade") and "value" in rec and (best is None or rec["value"] > best[1]["value"]):

@@ -405,7 +405,9 @@ SIMRANK_API int simrank_dense_part(const simrank_graph* g, const float* X, int64
  *      order (row = target node, SimRank.py:45-52), re-orders the nodes for speed (ascending in-degree)
  *      when options.reorder is set, builds the graph object, the three panel-blocked matrices of an
  *      update, the evidence counts of SimRank++ (options.evidence) and the prior (options.apriori: HOST
- *      n x n row-major, must be symmetric).  simrank_plan_run is the reference loop: at most
+ *      n x n row-major; a prior that is not symmetric makes the iterates asymmetric (SimRank.py:453): the plan then runs
+ *      leg 2 as leg 1's launch again — its product stored transposed — and the epilogue as a pass of its own with the exact
+ *      count; f32 only, SIMRANK_ERR_INVALID with storage_fp16).  simrank_plan_run is the reference loop: at most
  *      `iterations` updates, stopping at loop index k when no element moved by more than eps
  *      (converged_at = k, exactly the "Converged at iteration k" of SimRank.py:132; -1 when the loop ran
  *      out); below 16384 nodes update k + 1 is queued before the count of update k is read.  simrank_plan_step is one
@@ -416,7 +418,7 @@ typedef struct simrank_plan simrank_plan;
 typedef struct simrank_plan_options {
     float coef;                 /* C */
     float lbd;                  /* prior blend (used when apriori != NULL) */
-    const float* apriori;       /* HOST n x n row-major symmetric prior, or NULL */
+    const float* apriori;       /* HOST n x n row-major prior (symmetric or not, see above), or NULL */
     int64_t ld_apriori;
     int32_t evidence;           /* 1: SimRank++ evidence factor 1 - 2^-|common in-neighbours| */
     int32_t reorder;            /* 1: iterate in ascending-row-length node order (recommended) */
@@ -474,14 +476,14 @@ SIMRANK_API int simrank_plan_destroy(simrank_plan* p);
  *      Evidence_N1, position by position; with n1 != n2 (and n1 != 1, where NumPy broadcasts the 1 x 1 array)
  *      simrank_biplan_step / _run fail with NumPy's "operands could not be broadcast together with shapes
  *      (n1,n1) (n2,n2) " at the first group-2 update, i.e. not for iterations = 0 or eps >= 1.
- *      Priors: HOST row-major, symmetric (an asymmetric prior is SIMRANK_ERR_INVALID: the Python classes run
- *      that case through their un-fused path).
+ *      Priors: HOST row-major.  When either is not symmetric both iterates are asymmetric (SimRank.py:488, :491): both
+ *      updates then store leg 2 transposed and run the epilogue as a pass of its own (exact counts).
  *      simrank_biplan_result_f64(group = 1 | 2) hands S1 / S2 back in the caller's node order. */
 typedef struct simrank_biplan simrank_biplan;
 typedef struct simrank_biplan_options {
     float c1, c2;               /* C1, C2 */
     float lbd1, lbd2;           /* prior blends (used when the prior is given) */
-    const float* apriori1;      /* HOST n1 x n1 row-major symmetric prior, or NULL */
+    const float* apriori1;      /* HOST n1 x n1 row-major prior, or NULL */
     int64_t ld_apriori1;
     const float* apriori2;      /* HOST n2 x n2, or NULL */
     int64_t ld_apriori2;

@@ -7,8 +7,9 @@ fastest loop the library has: both legs and the count of an update queued by one
 count of update k is read on small graphs, and a hand-back that moves only the upper triangle of the (bitwise
 symmetric) result over PCIe (csrc/handback.hip).
 
-``driver.Solver`` (the same choreography in Python) stays for what a plan does not run: asymmetric priors (un-fused
-epilogue), the dense / hybrid GEMM modes, virtual or real ranks (``LocalWorld(P > 1)``, ``TorchWorld``), non-default
+An asymmetric prior (``SimRank.py:453``: asymmetric iterates) runs in the same plans with leg 2 stored transposed and the
+epilogue as a pass of its own.  ``driver.Solver`` (the same choreography in Python) stays for what a plan does not run: the
+dense / hybrid GEMM modes, virtual or real ranks (``LocalWorld(P > 1)``, ``TorchWorld``), non-default
 kernel knobs, and the NumPy test double of the CPU tests.
 """
 from __future__ import annotations
@@ -25,8 +26,8 @@ def applies(ops_factory, world, specs, mode) -> bool:
         return False
     if mode not in ("auto", "sparse"):
         return False
-    if not all(s.symmetric for s in specs):
-        return False
+    if not all(s.symmetric for s in specs) and any(s.storage != "f32" for s in specs):
+        return False                 # (asymmetric priors: the f32 plans run them un-fused; fp16-held matrices do not)
     if len({s.storage for s in specs}) != 1 or len({s.dense_terms for s in specs}) != 1:
         return False
     if len(specs) == 2:

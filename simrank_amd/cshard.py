@@ -11,9 +11,9 @@ panels themselves on the links).  ``CShardSolver`` gives that loop the few metho
   ``torch.distributed``; the library is pointed at the RCCL build torch itself loaded, so one process never runs two.
 
 Since round 5 the same solver runs the f32 (parity-grade) sharded fits of an RCCL world as well — every class with
-symmetric iterates, the two-matrix ones through ``simrank_shardbiplan_*`` — so that what a multi-GPU user's ``fit``
-runs is the C loop, not a second choreography in Python; ``driver.Solver`` keeps what the C loop does not run
-(asymmetric priors, the GEMM modes) and the CPU rehearsal over gloo with the NumPy test double.
+class, the two-matrix ones through ``simrank_shardbiplan_*``, asymmetric priors with a second all-to-all and an un-fused
+epilogue — so that what a multi-GPU user's ``fit`` runs is the C loop, not a second choreography in Python;
+``driver.Solver`` keeps the GEMM modes and the CPU rehearsal over gloo with the NumPy test double.
 """
 from __future__ import annotations
 
@@ -29,7 +29,9 @@ def applies(world, specs, mode) -> str | None:
     if mode not in ("auto", "sparse"):
         return "the sharded C loop runs the gather legs only (mode 'sparse' or 'auto')"
     if not all(s.symmetric for s in specs):
-        return "an asymmetric prior needs the un-fused epilogue (the Python driver has it)"
+        # asymmetric iterates: leg 2's product goes round a second all-to-all, the epilogue is a pass of its own (f32 only)
+        if any(s.storage != "f32" for s in specs) or getattr(world, "exchange_precision", "f32") != "f32":
+            return "an asymmetric prior needs f32 matrices and the f32 wire in the sharded C loop"
     if len({s.storage for s in specs}) != 1 or any(s.dense_terms != 3 for s in specs):
         return "one storage precision for every matrix, exact products on the matrix cores"
     fp16 = specs[0].storage == "fp16"
@@ -97,8 +99,8 @@ def _prior32(spec):
 
 class CShardSolver:
     """The estimators' view of ``engine.ShardPlans`` / ``engine.ShardBiPlans``: the sharded loops behind the C ABI
-    (csrc/shardplan.hip) — every class with symmetric iterates, f32 (the parity path) or, for SimRank / SimRank++
-    without a prior, fp16-held matrices."""
+    (csrc/shardplan.hip) — every class, f32 (the parity path) or, for SimRank / SimRank++ without a prior, fp16-held
+    matrices."""
 
     mode = "sparse"
 
@@ -118,8 +120,8 @@ class CShardSolver:
         local = isinstance(world, LocalWorld)
         sym = getattr(world, "symmetric_shards", True)
         form = -1 if sym == "auto" else (1 if sym else 0)
-        if self.storage == "fp16":
-            form = 0
+        if self.storage == "fp16" or not all(s.symmetric for s in specs):
+            form = 0                 # (no mirror image to share: fp16-held blocks, asymmetric iterates)
         common = dict(world=world.size, comm=None if local else _rccl_comm(world, ops),
                       stages=0 if local else getattr(world, "stages", 0),
                       wire_fp16=getattr(world, "exchange_precision", "f32") == "fp16")

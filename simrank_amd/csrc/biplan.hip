@@ -48,6 +48,7 @@ struct simrank_biplan {
     hipStream_t stream = nullptr;
     int32_t updates = 0;
     int32_t broadcast_error = 0;     // strict_reference with evidence and n1 != n2, n1 != 1 (quirk Q2)
+    int32_t asym = 0;                // a prior of either group is not symmetric: both iterates are asymmetric (un-fused epilogue)
 };
 
 namespace simrank {
@@ -74,7 +75,16 @@ static int side_update(simrank_biplan* p, int w, double eps, int32_t exact_count
     ep.symmetric = 1;
     ep.restrict_support = a.restrict_support;
     ep.count_any = exact_count ? 0 : 1;
-    rc = simrank_spmm_blocked(a.g, a.Tt, a.k_rows_pad, a.n, a.S[a.cur ^ 1], a.rows_pad, 0, &ep, p->stream);
+    if (p->asym) {
+        // asymmetric iterates (SimRank.py:488, :491 with a prior that is not symmetric): W . Tt is the transpose of
+        // W S_other W^T — stored transposed, then the epilogue as a pass of its own (exact count)
+        ep.symmetric = 0;
+        ep.restrict_support = 0;
+        rc = simrank_spmm_blocked(a.g, a.Tt, a.k_rows_pad, a.n, a.S[a.cur ^ 1], a.rows_pad, 1, nullptr, p->stream);
+        if (!rc) rc = simrank_epilogue_apply_blocked(a.S[a.cur ^ 1], a.S[a.cur ^ 1], a.n, a.n, a.rows_pad, &ep, p->stream);
+    } else {
+        rc = simrank_spmm_blocked(a.g, a.Tt, a.k_rows_pad, a.n, a.S[a.cur ^ 1], a.rows_pad, 0, &ep, p->stream);
+    }
     if (rc) return rc;
     SR_HIP(hipMemcpyAsync(host_slot, p->counters, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS,
                           hipMemcpyDeviceToHost, p->stream));
@@ -157,6 +167,7 @@ int simrank_biplan_create(int64_t n1, int64_t n2, int64_t nnz, const int32_t* ro
     const std::vector<int32_t>* inv = pp.inv;
     simrank_biplan* p = new simrank_biplan;
     p->stream = as_stream(stream);
+    p->asym = pp.asym ? 1 : 0;
     auto fail = [&](int code) { simrank_biplan_destroy(p); return code; };
     for (int w = 0; w < 2; ++w) {
         side_t& a = p->s[w];

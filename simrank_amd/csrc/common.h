@@ -132,22 +132,27 @@ struct PlanPrep {
     std::vector<int32_t> ord, inv;          // ord[new] = old, inv[old] = new
     std::vector<int32_t> rp, cl;            // the pattern in the solver's order
     std::vector<float> rs;
+    bool asym = false;                      // the prior is not symmetric: un-fused epilogue (SimRank.py:453 on asymmetric iterates)
 };
 struct BiPlanPrep {
     std::vector<int32_t> rowptr21, col21;   // the group-2 pattern (transpose), caller's order
     std::vector<int32_t> ord[2], inv[2];
     std::vector<int32_t> rp[2], cl[2];      // group w's pattern with both sides renamed
     std::vector<float> rs[2];
+    bool asym = false;                      // a prior of either group is not symmetric: both iterates are asymmetric
 };
 int plan_prepare(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* rowscale,
                  const simrank_plan_options* opt, PlanPrep* out);
 // the sharded plan's host half: the single plan's, plus the ascending order DEALT to `deal` shards in runs of 128 (32)
 // nodes when n divides evenly (driver.dealt_order); deal <= 1: plain ascending order
+// (allow_asym: a prior that is not symmetric is reported in out->asym instead of refused)
 int shard_prepare(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* rowscale,
-                  const float* apriori, int64_t ld_apriori, bool reorder, int32_t deal, PlanPrep* out);
+                  const float* apriori, int64_t ld_apriori, bool reorder, int32_t deal, PlanPrep* out, bool allow_asym = false);
 int shard_biplan_prepare(int64_t n1, int64_t n2, int64_t nnz, const int32_t* rowptr12, const int32_t* col12,
                          const float* rowscale1, const float* rowscale2, const simrank_biplan_options* opt, int32_t deal1,
-                         int32_t deal2, BiPlanPrep* out);
+                         int32_t deal2, BiPlanPrep* out, bool allow_asym = false);
+// is a[i][j] == a[j][i] everywhere (NULL: yes)?  What decides between the fused and the un-fused epilogue before a plan is laid out.
+bool prior_symmetric(const float* a, int64_t ld, int64_t n);
 int biplan_prepare(int64_t n1, int64_t n2, int64_t nnz, const int32_t* rowptr12, const int32_t* col12,
                    const float* rowscale1, const float* rowscale2, const simrank_biplan_options* opt, BiPlanPrep* out);
 

@@ -40,6 +40,8 @@ struct simrank_plan {
     float coef = 0.8f, lbd = 0.f;
     int32_t restrict_support = 0;
     int32_t half = 0;                         // 1: S and Tt are fp16 on 64-column panels (half.hip), value x kHalfScale
+    int32_t asym = 0;                         // 1: the prior is not symmetric, so the iterates are not: leg 2 = leg 1's launch again
+                                              //    (its product stored transposed), then the epilogue as a pass of its own
     int cur = 0;                              // S[cur] is the current iterate
     int32_t updates = 0;                      // updates applied since the last reset
     // simrank_plan_set_timing: three events per update (before leg 1, between the legs, after leg 2) on the plan's stream
@@ -87,6 +89,15 @@ static int leg_pair(simrank_plan* p, double eps, int32_t exact_count, int slot) 
     ep.symmetric = 1;
     ep.restrict_support = p->restrict_support;
     ep.count_any = exact_count ? 0 : 1;
+    if (p->asym) {
+        // S is not symmetric (SimRank.py:453 with a prior that is not): W . Tt is the TRANSPOSE of W S W^T, so leg 2 is leg 1's
+        // launch on Tt — X -> (W X)^T, the one-launch kernel again — and the epilogue (coefficient, evidence, prior, diagonal,
+        // exact count) runs over the stored product in place
+        ep.symmetric = 0;
+        ep.restrict_support = 0;
+        rc = simrank_spmm_blocked(p->g, p->Tt, p->rows_pad, p->n, p->S[nx], p->rows_pad, 1, nullptr, p->stream);
+        if (!rc) rc = simrank_epilogue_apply_blocked(p->S[nx], p->S[nx], p->n, p->n, p->rows_pad, &ep, p->stream);
+    } else
     rc = p->half ? simrank_spmm_blocked_h16(p->g, p->Tt, p->rows_pad, p->n, p->S[nx], p->rows_pad, 0, &ep, p->rows_pad,
                                             kHalfScale, p->stream)
                  : simrank_spmm_blocked(p->g, p->Tt, p->rows_pad, p->n, p->S[nx], p->rows_pad, 0, &ep, p->stream);
@@ -153,6 +164,7 @@ int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int
     p->lbd = opt->lbd;
     p->rows_pad = (n + 7) / 8 * 8 + 8;
     p->half = opt->storage_fp16 ? 1 : 0;
+    p->asym = pp.asym ? 1 : 0;
     const int64_t panels = (n + 31) / 32;
     // (fp16: 64-column panels of 2-byte elements — a row segment is 128 bytes either way)
     p->mat_bytes = p->half ? size_t((n + 63) / 64) * size_t(p->rows_pad) * 128

@@ -23,14 +23,20 @@ static int check_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t*
     return SIMRANK_OK;
 }
 
-static int check_prior(const float* a, int64_t ld, int64_t n, int which, bool half) {
+// `asym` (may be NULL): where a prior that is not symmetric is reported instead of refused — the single-GPU f32 plans run
+// such a fit with leg 2 stored transposed and the epilogue as a pass of its own; the sharded plans and fp16-held matrices
+// refuse it (SIMRANK_ERR_INVALID)
+static int check_prior(const float* a, int64_t ld, int64_t n, int which, bool half, bool* asym = nullptr) {
     if (!a) return SIMRANK_OK;
     SR_REQUIRE(ld >= n, "prior %d: ld %lld < n", which, (long long)ld);
     for (int64_t i = 0; i < n; ++i)
         for (int64_t j = i; j < n; ++j) {
             const float v = a[i * ld + j];
-            SR_REQUIRE(v == a[j * ld + i], "a plan needs symmetric priors (prior %d, element %lld, %lld)", which, (long long)i,
-                       (long long)j);
+            if (!(v == a[j * ld + i])) {
+                SR_REQUIRE(asym && !half, "this plan needs symmetric priors (prior %d, element %lld, %lld)", which, (long long)i,
+                           (long long)j);
+                *asym = true;
+            }
             // (fp16-held matrices store value x 2^14: anything from 4 up, or not finite, leaves fp16's range and
             // turns into NaN behind the evidence factor)
             SR_REQUIRE(!half || (std::isfinite(v) && std::fabs(v) < 3.99f),
@@ -38,6 +44,14 @@ static int check_prior(const float* a, int64_t ld, int64_t n, int which, bool ha
                        (long long)j);
         }
     return SIMRANK_OK;
+}
+
+bool prior_symmetric(const float* a, int64_t ld, int64_t n) {
+    if (!a || ld < n) return true;                 // (a short ld is check_prior's to refuse)
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = i + 1; j < n; ++j)
+            if (!(a[i * ld + j] == a[j * ld + i])) return false;
+    return true;
 }
 
 // rows of (rowptr, col) taken in the order `ord`, columns renamed by `inv_cols`, sorted; duplicates refused
@@ -120,18 +134,20 @@ int plan_prepare(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* c
     SR_REQUIRE(n < (int64_t(1) << 24) - 16, "a plan holds at most 2^24 nodes");
     SR_REQUIRE(opt->dense_terms == 0 || opt->dense_terms == 1 || opt->dense_terms == 3, "dense_terms must be 0, 1 or 3");
     int rc = check_csr(n, n, nnz, rowptr, col);
-    if (!rc) rc = check_prior(opt->apriori, opt->ld_apriori, n, 1, opt->storage_fp16 != 0);
+    out->asym = false;
+    if (!rc) rc = check_prior(opt->apriori, opt->ld_apriori, n, 1, opt->storage_fp16 != 0, &out->asym);
     if (rc) return rc;
     length_order(n, rowptr, opt->reorder != 0, out->ord, out->inv);
     return renamed(n, rowptr, col, rowscale, out->ord, out->inv, nnz, "", out->rp, out->cl, out->rs);
 }
 
 int shard_prepare(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* rowscale,
-                  const float* apriori, int64_t ld_apriori, bool reorder, int32_t deal, PlanPrep* out) {
+                  const float* apriori, int64_t ld_apriori, bool reorder, int32_t deal, PlanPrep* out, bool allow_asym) {
     SR_REQUIRE(rowptr && rowscale && (col || nnz == 0) && n > 0 && nnz >= 0 && out, "bad plan arguments");
     SR_REQUIRE(n < (int64_t(1) << 24) - 16, "a plan holds at most 2^24 nodes");
     int rc = check_csr(n, n, nnz, rowptr, col);
-    if (!rc) rc = check_prior(apriori, ld_apriori, n, 1, false);
+    out->asym = false;
+    if (!rc) rc = check_prior(apriori, ld_apriori, n, 1, false, allow_asym ? &out->asym : nullptr);
     if (rc) return rc;
     length_order(n, rowptr, reorder, out->ord, out->inv);
     // tile t of the ascending order goes to shard t mod deal: every shard the same mix of short and long rows,
@@ -144,13 +160,14 @@ int shard_prepare(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* 
 // (what the half-form leg 2 of that group wants; <= 1: plain ascending order)
 int shard_biplan_prepare(int64_t n1, int64_t n2, int64_t nnz, const int32_t* rowptr12, const int32_t* col12,
                          const float* rowscale1, const float* rowscale2, const simrank_biplan_options* opt, int32_t deal1,
-                         int32_t deal2, BiPlanPrep* out) {
+                         int32_t deal2, BiPlanPrep* out, bool allow_asym) {
     SR_REQUIRE(opt && rowptr12 && rowscale1 && rowscale2 && (col12 || nnz == 0) && n1 > 0 && n2 > 0 && nnz >= 0 && out,
                "bad plan arguments");
     SR_REQUIRE(n1 < (int64_t(1) << 24) - 16 && n2 < (int64_t(1) << 24) - 16, "a plan holds at most 2^24 nodes per group");
     int rc = check_csr(n1, n2, nnz, rowptr12, col12);
-    if (!rc) rc = check_prior(opt->apriori1, opt->ld_apriori1, n1, 1, false);
-    if (!rc) rc = check_prior(opt->apriori2, opt->ld_apriori2, n2, 2, false);
+    out->asym = false;
+    if (!rc) rc = check_prior(opt->apriori1, opt->ld_apriori1, n1, 1, false, allow_asym ? &out->asym : nullptr);
+    if (!rc) rc = check_prior(opt->apriori2, opt->ld_apriori2, n2, 2, false, allow_asym ? &out->asym : nullptr);
     if (rc) return rc;
     std::vector<int32_t>& rowptr21 = out->rowptr21;
     std::vector<int32_t>& col21 = out->col21;
@@ -186,8 +203,9 @@ int biplan_prepare(int64_t n1, int64_t n2, int64_t nnz, const int32_t* rowptr12,
                "bad plan arguments");
     SR_REQUIRE(n1 < (int64_t(1) << 24) - 16 && n2 < (int64_t(1) << 24) - 16, "a plan holds at most 2^24 nodes per group");
     int rc = check_csr(n1, n2, nnz, rowptr12, col12);
-    if (!rc) rc = check_prior(opt->apriori1, opt->ld_apriori1, n1, 1, false);
-    if (!rc) rc = check_prior(opt->apriori2, opt->ld_apriori2, n2, 2, false);
+    out->asym = false;
+    if (!rc) rc = check_prior(opt->apriori1, opt->ld_apriori1, n1, 1, false, &out->asym);
+    if (!rc) rc = check_prior(opt->apriori2, opt->ld_apriori2, n2, 2, false, &out->asym);
     if (rc) return rc;
     // the group-2 pattern: the transpose
     std::vector<int32_t>& rowptr21 = out->rowptr21;

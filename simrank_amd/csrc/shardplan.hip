@@ -160,6 +160,11 @@ struct simrank_shardplan {
     float* S[2] = {nullptr, nullptr};       // the rank's column block of the iterate, row-major n x Lm, ping-pong
     float* send = nullptr;                  // exchange 1: Lm columns x (n + world pad) floats, chunked per stage
     float* recv = nullptr;                  //             the leg-2 operand, n rows x (Lm + pad)
+    // asymmetric iterates (a prior that is not symmetric, SimRank.py:453 / :488 / :491): leg 2 is leg 1's launch on `recv` — its
+    // product leaves transposed through `send2`, a second all-to-all lands it in `recv2`, the epilogue runs as a pass of its own
+    int32_t asym = 0;
+    float* send2 = nullptr;                 // Lm columns x (n + world pad) floats, chunked per stage
+    float* recv2 = nullptr;                 // n rows x (Lm + pad): W S W^T's columns of this rank, raw
     float* sh_send = nullptr;               // exchange 2 (half form): world chunks of packed mirrored tiles
     float* sh_recv = nullptr;
     int64_t sh_chunk = 0;
@@ -319,7 +324,7 @@ static int check_group(simrank_shardplan* const* plans, int32_t n_local) {
             SR_REQUIRE(plans[i] && plans[i]->comm->group == p0->comm->group && plans[i]->rank == i &&
                            plans[i]->stream == p0->stream && plans[i]->n == p0->n &&
                            plans[i]->half_form == p0->half_form && plans[i]->n_stages == p0->n_stages &&
-                           plans[i]->wire_fp16 == p0->wire_fp16 && plans[i]->half == p0->half,
+                           plans[i]->wire_fp16 == p0->wire_fp16 && plans[i]->half == p0->half && plans[i]->asym == p0->asym,
                        "plans[%d] is not rank %d of the same in-process group, stream and options", i, i);
     } else {
         SR_REQUIRE(n_local == 1, "a process of a multi-process world holds one plan");
@@ -353,64 +358,80 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
     const int32_t P = p0->world, S = p0->n_stages;
     const bool local = p0->comm->group != nullptr;
     hipStream_t xs = local ? p0->stream : p0->xstream;
-    // leg 1 + exchange 1, stage by stage
+    // X -> (W X)^T in column stages, the chunks of each stage leaving for their ranks behind its kernel.  second = false: leg 1
+    // (X = the rank's block of the operand matrix, Lk columns; what arrives is the leg-2 operand `recv`).  second = true
+    // (asymmetric iterates only): leg 2 as the same launch on `recv` (Lm columns) — W . Tt is the TRANSPOSE of the wanted
+    // block, so its product travels exactly like leg 1's and lands in `recv2`.
     const int32_t walign = p0->half ? 64 : 32;            // stage widths: whole panels of the operand
-    SR_MARK(p0, p0->stream, kMarkUpdate0);
-    for (int32_t s = 0; s < S; ++s) {
-        std::vector<Route> routes(n_local, Route(P));
-        SR_MARK(p0, p0->stream, kMarkK0);
-        for (int32_t i = 0; i < n_local; ++i) {
-            simrank_shardplan* p = plans[i];
-            const int64_t w = stage_width(p->Lk, S, s, walign), c0 = stage_col0(p->Lk, S, s, walign);
-            const simrank_shardplan* sp = p->src ? p->src : p;      // whose block leg 1 reads
-            Route& r = routes[i];
-            if (p->half) {
-                // fp16-held: leg 1 stores rows [c0, c0 + w) of every 64-column panel of (W.S_block)^T (Lm rows x n
-                // columns); the panels of rank h's columns go to rank h and land, panel by panel, at the rows of its
-                // leg-2 operand this rank's columns own
-                uint16_t* T = reinterpret_cast<uint16_t*>(p->send);
-                uint16_t* X2 = reinterpret_cast<uint16_t*>(p->recv);
-                if (w) {
-                    const int rc = simrank_spmm_blocked_h16(p->g, reinterpret_cast<uint16_t*>(p->S[p->cur]) + (c0 / 64) * p->rows_pad * 64,
-                                                            p->rows_pad, w, T + c0 * 64, p->rows_pad_t, 1, nullptr, 0,
-                                                            kHalfScale, p->stream);
-                    if (rc) return rc;
+    auto transposed_leg = [&](bool second) -> int {
+        for (int32_t s = 0; s < S; ++s) {
+            std::vector<Route> routes(n_local, Route(P));
+            if (!second) SR_MARK(p0, p0->stream, kMarkK0);
+            for (int32_t i = 0; i < n_local; ++i) {
+                simrank_shardplan* p = plans[i];
+                const int64_t L = second ? p->Lm : p->Lk;
+                const int64_t w = stage_width(L, S, s, walign), c0 = stage_col0(L, S, s, walign);
+                const simrank_shardplan* sp = p->src ? p->src : p;      // whose block leg 1 reads
+                Route& r = routes[i];
+                if (p->half) {
+                    // fp16-held: leg 1 stores rows [c0, c0 + w) of every 64-column panel of (W.S_block)^T (Lm rows x n
+                    // columns); the panels of rank h's columns go to rank h and land, panel by panel, at the rows of its
+                    // leg-2 operand this rank's columns own
+                    uint16_t* T = reinterpret_cast<uint16_t*>(p->send);
+                    uint16_t* X2 = reinterpret_cast<uint16_t*>(p->recv);
+                    if (w) {
+                        const int rc = simrank_spmm_blocked_h16(p->g, reinterpret_cast<uint16_t*>(p->S[p->cur]) + (c0 / 64) * p->rows_pad * 64,
+                                                                p->rows_pad, w, T + c0 * 64, p->rows_pad_t, 1, nullptr, 0,
+                                                                kHalfScale, p->stream);
+                        if (rc) return rc;
+                    }
+                    for (int32_t h = 0; h < P; ++h) {
+                        int64_t lo, hi;
+                        part(p->n, P, h, &lo, &hi);
+                        r.add_out(h, T + ((lo / 64) * p->rows_pad_t + c0) * 64, w * 64, (hi - lo) / 64, p->rows_pad_t * 64);
+                        const int64_t wh = stage_width(hi - lo, S, s, walign), ch = stage_col0(hi - lo, S, s, walign);
+                        r.add_in(h, X2 + (lo + ch) * 64, wh * 64, p->Lm / 64, p->rows_pad * 64);
+                    }
+                } else {
+                    const float* X = second ? p->recv + c0 : sp->S[sp->cur] + c0;
+                    const int64_t ldx = second ? p->recv_ld : sp->ld;
+                    float* outb = second ? p->send2 : p->send;
+                    float* inb = second ? p->recv2 : p->recv;
+                    const int64_t send_off = c0 * p->send_ld;
+                    if (w) {
+                        const int rc = simrank_spmm(p->g, X, ldx, w, outb + send_off, 0, 1, p->mb, p->pad, nullptr, p->stream);
+                        if (rc) return rc;
+                    }
+                    r.send_base = outb; r.recv_base = inb;
+                    r.send_h = second ? nullptr : p->wire[0]; r.recv_h = second ? nullptr : p->wire[1];
+                    for (int32_t h = 0; h < P; ++h) {
+                        r.add_out(h, outb + send_off + int64_t(h) * w * (p->mb + p->pad), w * (span(p->n, P, h) + p->pad));
+                        // what rank h computed: the columns of ITS block — of the operand matrix (leg 1: k nodes) or of the
+                        // result itself (second: n nodes) — which are rows here
+                        int64_t k_lo, k_hi;
+                        part(second ? p->n : p->k, P, h, &k_lo, &k_hi);
+                        const int64_t wh = stage_width(k_hi - k_lo, S, s, walign), ch = stage_col0(k_hi - k_lo, S, s, walign);
+                        // (a rank without columns receives rows of zero length)
+                        r.add_in(h, inb + (k_lo + ch) * p->recv_ld, p->Lm ? wh * p->recv_ld : 0);
+                    }
                 }
-                for (int32_t h = 0; h < P; ++h) {
-                    int64_t lo, hi;
-                    part(p->n, P, h, &lo, &hi);
-                    r.add_out(h, T + ((lo / 64) * p->rows_pad_t + c0) * 64, w * 64, (hi - lo) / 64, p->rows_pad_t * 64);
-                    const int64_t wh = stage_width(hi - lo, S, s, walign), ch = stage_col0(hi - lo, S, s, walign);
-                    r.add_in(h, X2 + (lo + ch) * 64, wh * 64, p->Lm / 64, p->rows_pad * 64);
-                }
-            } else {
-                const int64_t send_off = c0 * p->send_ld;
-                if (w) {
-                    const int rc = simrank_spmm(p->g, sp->S[sp->cur] + c0, sp->ld, w, p->send + send_off, 0, 1, p->mb, p->pad,
-                                                nullptr, p->stream);
-                    if (rc) return rc;
-                }
-                r.send_base = p->send; r.recv_base = p->recv;
-                r.send_h = p->wire[0]; r.recv_h = p->wire[1];
-                for (int32_t h = 0; h < P; ++h) {
-                    r.add_out(h, p->send + send_off + int64_t(h) * w * (p->mb + p->pad), w * (span(p->n, P, h) + p->pad));
-                    int64_t k_lo, k_hi;
-                    part(p->k, P, h, &k_lo, &k_hi);
-                    const int64_t wh = stage_width(k_hi - k_lo, S, s, walign), ch = stage_col0(k_hi - k_lo, S, s, walign);
-                    // (a rank without columns receives rows of zero length)
-                    r.add_in(h, p->recv + (k_lo + ch) * p->recv_ld, p->Lm ? wh * p->recv_ld : 0);
+                if (!second && i == n_local - 1) SR_MARK(p0, p0->stream, kMarkK1);
+                if (!local) {                                // RCCL's stream waits for this stage's kernel only
+                    SR_HIP(hipEventRecord(p->staged[s], p->stream));
+                    SR_HIP(hipStreamWaitEvent(xs, p->staged[s], 0));
                 }
             }
-            if (i == n_local - 1) SR_MARK(p0, p0->stream, kMarkK1);
-            if (!local) {                                // RCCL's stream waits for this stage's kernel only
-                SR_HIP(hipEventRecord(p->staged[s], p->stream));
-                SR_HIP(hipStreamWaitEvent(xs, p->staged[s], 0));
-            }
+            if (!second) SR_MARK(p0, xs, kMarkX0);
+            const int rc = all_to_all(plans, n_local, routes, xs, p0->half ? 2 : 4);
+            if (rc) return rc;
+            if (!second) SR_MARK(p0, xs, kMarkX1);
         }
-        SR_MARK(p0, xs, kMarkX0);
-        const int rc = all_to_all(plans, n_local, routes, xs, p0->half ? 2 : 4);
-        if (rc) return rc;
-        SR_MARK(p0, xs, kMarkX1);
+        return SIMRANK_OK;
+    };
+    SR_MARK(p0, p0->stream, kMarkUpdate0);
+    {
+        const int rc1 = transposed_leg(false);               // leg 1 + exchange 1, stage by stage
+        if (rc1) return rc1;
     }
     // every RCCL call of this communicator is issued on ITS stream, in one order; `hop` makes one stream wait for the other
     auto hop = [&](hipStream_t from, hipStream_t to, hipEvent_t ev) -> int {
@@ -423,11 +444,20 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
     if (rc) return rc;
     // leg 2 with the fused epilogue and count
     SR_MARK(p0, p0->stream, kMarkLeg2a);
+    if (p0->asym) {
+        // asymmetric iterates: leg 2's product goes round once more (transposed_leg), then the epilogue — coefficient, evidence,
+        // prior, diagonal, the exact count — over what arrived
+        rc = transposed_leg(true);
+        if (!rc && !local) rc = hop(xs, p0->stream, p0->staged[S]);
+        if (rc) return rc;
+    }
     for (int32_t i = 0; i < n_local; ++i) {
         simrank_shardplan* p = plans[i];
         simrank_epilogue ep;
         fill_epilogue(p, eps, exact_count, &ep);
-        if (!p->Lm) {
+        if (p->asym && p->Lm) {
+            rc = simrank_epilogue_apply(p->recv2, p->recv_ld, p->S[p->cur ^ 1], p->ld, p->n, p->Lm, &ep, p->stream);
+        } else if (!p->Lm) {
             SR_HIP(hipMemsetAsync(p->counters, 0, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS, p->stream));
         } else if (p->half) {
             rc = simrank_spmm_blocked_h16(p->g, p->recv, p->rows_pad, p->Lm, p->S[p->cur ^ 1], p->rows_pad, 0, &ep, p->rows_pad,
@@ -590,7 +620,8 @@ int simrank_shardplan_destroy(simrank_shardplan* p) {
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     for (void* b : {(void*)p->S[0], (void*)p->S[1], (void*)p->send, (void*)p->recv, (void*)p->sh_send, (void*)p->sh_recv,
                     (void*)p->wire[0], (void*)p->wire[1], (void*)p->wire[2], (void*)p->wire[3], (void*)p->ev,
-                    (void*)p->prior, (void*)p->inv, (void*)p->counters, (void*)p->hand[0], (void*)p->hand[1]})
+                    (void*)p->prior, (void*)p->inv, (void*)p->counters, (void*)p->hand[0], (void*)p->hand[1], (void*)p->send2,
+                    (void*)p->recv2})
         (void)pool_free(b);
     for (int i = 0; i < 2; ++i) {
         if (p->host_counters[i]) (void)hipHostFree(p->host_counters[i]);
@@ -617,7 +648,7 @@ struct SideIn {
     const float* apriori = nullptr;          // HOST n x n, the caller's order
     int64_t ld_apriori = 0;
     int32_t evidence = 0;                    // 1: counts of `pat` itself
-    bool half_form = false, fp16 = false;
+    bool half_form = false, fp16 = false, asym = false;
     int32_t stages = 0, wire_fp16 = 0;
 };
 
@@ -636,6 +667,7 @@ static int create_side(const SideIn& in, simrank_comm* comm, void* stream, simra
     p->coef = in.coef; p->lbd = in.lbd;
     p->half_form = in.half_form ? 1 : 0;
     p->wire_fp16 = in.wire_fp16 ? 1 : 0;
+    p->asym = in.asym ? 1 : 0;
     p->mb = (n + P - 1) / P;
     part(n, P, p->rank, &p->m_lo, &p->m_hi);
     p->Lm = p->m_hi - p->m_lo;
@@ -692,6 +724,10 @@ static int create_side(const SideIn& in, simrank_comm* comm, void* stream, simra
     } else {
         SP_HIP(dev((void**)&p->send, send_floats * 4));
         SP_HIP(dev((void**)&p->recv, recv_floats * 4));
+    }
+    if (p->asym) {
+        SP_HIP(dev((void**)&p->send2, size_t(std::max<int64_t>(1, p->Lm)) * size_t(p->send_ld) * 4));
+        SP_HIP(dev((void**)&p->recv2, size_t(n) * size_t(p->recv_ld) * 4));
     }
     if (p->wire_fp16) {
         SP_HIP(dev((void**)&p->wire[0], send_floats * 2));
@@ -778,9 +814,14 @@ int simrank_shardplan_create(int64_t n, int64_t nnz, const int32_t* rowptr, cons
     // (the exchange moves the fp16 values themselves)
     SR_REQUIRE(!fp16 || (n % (64 * int64_t(P)) == 0 && opt->leg2_form != 1 && !opt->apriori && !opt->wire_fp16),
                "storage_fp16 on shards needs n %% (64 x ranks) == 0, leg 2 in its full form, no prior and the f32 wire option off");
-    const bool half = !fp16 && (opt->leg2_form == 1 || (opt->leg2_form == -1 && fits_half && P >= 8));
+    // a prior that is not symmetric: asymmetric iterates — f32, leg 2 in its full form (there is no mirror image to share),
+    // the f32 wire; the second exchange carries leg 2's product back to the ranks that own its columns
+    const bool asym = opt->apriori && opt->ld_apriori >= n && !prior_symmetric(opt->apriori, opt->ld_apriori, n);
+    SR_REQUIRE(!asym || (!fp16 && opt->leg2_form != 1 && !opt->wire_fp16),
+               "a prior that is not symmetric needs f32 matrices, leg 2 in its full form and the f32 wire");
+    const bool half = !fp16 && !asym && (opt->leg2_form == 1 || (opt->leg2_form == -1 && fits_half && P >= 8));
     PlanPrep pp;
-    int rc = shard_prepare(n, nnz, rowptr, col, rowscale, opt->apriori, opt->ld_apriori, opt->reorder != 0, half ? P : 1, &pp);
+    int rc = shard_prepare(n, nnz, rowptr, col, rowscale, opt->apriori, opt->ld_apriori, opt->reorder != 0, half ? P : 1, &pp, true);
     if (rc) return rc;
     PlanPrepView view{&pp.ord, &pp.inv, &pp.rp, &pp.cl, &pp.rs};
     SideIn in;
@@ -790,7 +831,7 @@ int simrank_shardplan_create(int64_t n, int64_t nnz, const int32_t* rowptr, cons
     in.coef = opt->coef; in.lbd = opt->lbd;
     in.apriori = opt->apriori; in.ld_apriori = opt->ld_apriori;
     in.evidence = opt->evidence ? 1 : 0;
-    in.half_form = half; in.fp16 = fp16;
+    in.half_form = half; in.fp16 = fp16; in.asym = pp.asym;
     in.stages = opt->stages; in.wire_fp16 = opt->wire_fp16;
     return create_side(in, comm, stream, out);
 }
@@ -1217,13 +1258,19 @@ int simrank_shardbiplan_create(int64_t n1, int64_t n2, int64_t nnz, const int32_
     const int32_t P = comm->world;
     const int64_t ns[2] = {n1, n2};
     // the half form group by group: where a group's size is a multiple of 32 x ranks (and asked for, or 8 ranks on)
+    // (a prior of either group that is not symmetric makes BOTH iterates asymmetric: full form, f32 wire, second exchange)
+    const bool asym = (opt->apriori1 && opt->ld_apriori1 >= n1 && !prior_symmetric(opt->apriori1, opt->ld_apriori1, n1)) ||
+                      (opt->apriori2 && opt->ld_apriori2 >= n2 && !prior_symmetric(opt->apriori2, opt->ld_apriori2, n2));
+    SR_REQUIRE(!asym || (leg2_form != 1 && !wire_fp16),
+               "a prior that is not symmetric needs leg 2 in its full form and the f32 wire");
     bool half[2];
     for (int w = 0; w < 2; ++w) {
         const bool fits = (P > 1 && ns[w] % (32 * int64_t(P)) == 0) || (P == 1 && ns[w] % 32 == 0);
-        half[w] = fits && (leg2_form == 1 || (leg2_form == -1 && P >= 8));
+        half[w] = !asym && fits && (leg2_form == 1 || (leg2_form == -1 && P >= 8));
     }
     BiPlanPrep pp;
-    int rc = shard_biplan_prepare(n1, n2, nnz, rowptr12, col12, rowscale1, rowscale2, opt, half[0] ? P : 1, half[1] ? P : 1, &pp);
+    int rc = shard_biplan_prepare(n1, n2, nnz, rowptr12, col12, rowscale1, rowscale2, opt, half[0] ? P : 1, half[1] ? P : 1, &pp,
+                                  true);
     if (rc) return rc;
     simrank_shardbiplan* bp = new simrank_shardbiplan;
     bp->n1 = n1; bp->n2 = n2;
@@ -1244,6 +1291,7 @@ int simrank_shardbiplan_create(int64_t n1, int64_t n2, int64_t nnz, const int32_
         const bool q2 = opt->evidence && opt->strict_reference && w == 1;       // Evidence_N1 on the group-2 update
         in.evidence = (opt->evidence && !q2) ? 1 : 0;
         in.half_form = half[w];
+        in.asym = pp.asym;
         in.stages = stages;
         in.wire_fp16 = wire_fp16;
         rc = create_side(in, comm, stream, &bp->side[w]);

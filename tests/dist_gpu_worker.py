@@ -45,8 +45,8 @@ def main():
         orig_c(self, *a, **k)
         made_c.append(self)
     cshard.CShardSolver.__init__ = spy_c
-    for name in ("SimRank_er128", "SimRankPP_er128", "AprioriSimRank_er64", "BipartiteSimRank_b5030",
-                 "BipartiteSimRankPP_b40", "BipartitleAprioriSimRank_b40"):
+    for name in ("SimRank_er128", "SimRankPP_er128", "AprioriSimRank_er64", "AprioriSimRank_er64_asym", "BipartiteSimRank_b5030",
+                 "BipartiteSimRankPP_b40", "BipartitleAprioriSimRank_b40", "BipartitleAprioriSimRank_b40_asym"):
         g = Golden(name)
         n_before = len(made_c)
         est, res, text = run_estimator(g, world=TorchWorld(stages=2, loop="c"), mode="sparse")

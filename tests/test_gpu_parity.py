@@ -910,7 +910,9 @@ def test_plan_topk_in_the_callers_ids(ops):
 
 def test_plan_api_with_a_prior_and_in_the_callers_order(ops):
     """AprioriSimRank's loop (SimRank.py:443-454) through the plan: symmetric prior, nodes re-ordered inside
-    and handed back in the caller's order; an asymmetric prior is refused."""
+    and handed back in the caller's order; an asymmetric prior (asymmetric iterates: leg 2 stored transposed, the
+    epilogue as a pass of its own) against the oracle too, step by step with its exact counts; refused only for
+    fp16-held matrices."""
     from simrank_amd.engine import Plan
     from simrank_amd._lib import SimRankHipError
     df = synth.powerlaw_directed(700, 9, seed=5)
@@ -927,8 +929,31 @@ def test_plan_api_with_a_prior_and_in_the_callers_order(ops):
     assert_close(plan.result(), want_S)
     plan.free()
     A[3, 5] += 0.5
+    A[10:40, 200:260] *= 0.25
+    A32 = A.astype(np.float32).astype(np.float64)
+    want_S, want_k = O.iterate_directed(G, C=0.7, iterations=100, eps=1e-4, E=O.evidence(G), apriori=A32, lbd=0.3)
+    assert not np.array_equal(want_S, want_S.T)
+    plan = Plan(ops, csr, coef=0.7, evidence=True, apriori=A, lbd=0.3)
+    done, conv = plan.run(100, 1e-4)
+    assert conv == want_k
+    got = plan.result()
+    assert_close(got, want_S)
+    idx, val = plan.topk(5)
+    for a in (0, 3, 11, 699):
+        cand = np.array([c for c in range(csr.n_rows) if c != a])
+        np.testing.assert_array_equal(val[a].astype(np.float64), got[a, cand[np.lexsort((cand, -got[a, cand]))][:5]])
+    # step by step: the exact number of moved elements of every update (the epilogue pass counts every element)
+    plan.reset()
+    S = np.eye(csr.n_rows)
+    for _ in range(3):
+        new = O.update(G, S, 0.7, E=O.evidence(G), apriori=A32, lbd=0.3)
+        moved = int((np.abs(new - S) > 1e-4).sum())
+        got_moved = plan.step(1e-4, exact_count=True)
+        assert abs(got_moved - moved) <= max(3, moved // 2000)       # (f32 values at the threshold)
+        S = new
+    plan.free()
     with pytest.raises(SimRankHipError, match="symmetric"):
-        Plan(ops, csr, apriori=A, lbd=0.3)
+        Plan(ops, csr, apriori=A, lbd=0.3, storage="fp16")
 
 
 # ---------------------------------------------------------------------------------------
@@ -966,7 +991,8 @@ def test_biplan_reproduces_the_golden_vectors(ops, name):
     BipartiteSimRankPP and BipartitleAprioriSimRank with options.strict_reference = 1 (Evidence_N1 on both
     updates, SimRank.py:420-423, :488-491): S1 and S2 to 1e-5, the "Converged at iteration k" index exactly,
     iterations = 0 and eps >= 1 included; NumPy's broadcast error for n1 != n2 where the reference raises it
-    (first group-2 update), the 1 x 1 broadcast; step by step the same.  An asymmetric prior is refused."""
+    (first group-2 update), the 1 x 1 broadcast; step by step the same.  Asymmetric priors (`*_asym`: both iterates
+    asymmetric, un-fused epilogue inside the plan) included."""
     from simrank_amd._lib import SimRankHipError
     from simrank_amd.engine import BiPlan
     g = Golden(name)
@@ -975,10 +1001,6 @@ def test_biplan_reproduces_the_golden_vectors(ops, name):
     pri = dict(apriori1=g.args[0], apriori2=g.args[1], lbd1=kw.get("lbd1", 0.5), lbd2=kw.get("lbd2", 0.5)) if g.args else {}
     make = lambda: BiPlan(ops, csr, w1, w2, c1=kw.get("C1", 0.8), c2=kw.get("C2", 0.8), evidence=pp,
                           strict_reference=True, **pri)
-    if name.endswith("_asym"):
-        with pytest.raises(SimRankHipError, match="symmetric"):
-            make()
-        return
     plan = make()
     its, eps = kw.get("iterations", 100), kw.get("eps", 1e-4)
     if g.raises:
@@ -1007,7 +1029,7 @@ def test_biplan_reproduces_the_golden_vectors(ops, name):
 
 def test_biplan_with_evidence_and_priors_against_the_oracle(ops):
     """BipartiteSimRankPP in its corrected form (E2 from the group-2 pattern, strict_reference = False) and
-    BipartitleAprioriSimRank with symmetric priors, n1 != n2, through the C-level loop."""
+    BipartitleAprioriSimRank with symmetric priors and with one that is not, n1 != n2, through the C-level loop."""
     from simrank_amd.engine import BiPlan
     from simrank_amd._lib import SimRankHipError
     df = bipartite_random(700, 300, 0.03, seed=21)
@@ -1036,6 +1058,16 @@ def test_biplan_with_evidence_and_priors_against_the_oracle(ops):
     assert_close(s1, want["S1"])
     assert_close(s2, want["S2"])
     plan.free()
+    # ONE prior that is not symmetric makes both iterates asymmetric (S1 feeds S2 and back): both updates un-fused
     a2[1, 2] += 0.25
-    with pytest.raises(SimRankHipError, match="symmetric"):
-        BiPlan(ops, csr, w1, w2, apriori2=a2)
+    a2[40:90, 100:180] *= 0.5
+    want = O.fit_bipartite_pp(df, verbose=False, strict_reference=False, apriori1=f32(a1), apriori2=f32(a2),
+                              lbd1=0.2, lbd2=0.4)
+    assert not np.array_equal(want["S1"], want["S1"].T) and not np.array_equal(want["S2"], want["S2"].T)
+    plan = BiPlan(ops, csr, w1, w2, evidence=True, apriori1=a1, apriori2=a2, lbd1=0.2, lbd2=0.4)
+    done, conv = plan.run(100, 1e-4)
+    s1, s2 = plan.result()
+    assert conv == want["k"]
+    assert_close(s1, want["S1"])
+    assert_close(s2, want["S2"])
+    plan.free()

@@ -133,8 +133,9 @@ def test_half_and_full_hand_back_of_config_4_are_the_same_bits(ops, monkeypatch)
 # which loop fit() runs, and its console hooks
 # ---------------------------------------------------------------------------------------------------------------
 def test_fit_runs_the_c_level_loops(monkeypatch):
-    """Every class on one GPU with symmetric iterates goes through cplan.PlanSolver (simrank_plan_run_cb /
-    simrank_biplan_run_cb); an asymmetric prior, the GEMM modes and virtual ranks keep driver.Solver."""
+    """Every class on one GPU goes through cplan.PlanSolver (simrank_plan_run_cb / simrank_biplan_run_cb) — asymmetric
+    priors included (un-fused epilogue inside the plan) unless the matrices are fp16-held; the GEMM modes and virtual
+    ranks keep driver.Solver."""
     import simrank_amd.cplan as cplan
     import simrank_amd.driver as drv
     made = []
@@ -159,7 +160,8 @@ def test_fit_runs_the_c_level_loops(monkeypatch):
         (lambda: SRA.SimRankPP().fit(df, verbose=False, storage_precision="fp16"), "plan"),
         (lambda: SRA.SimRankPP().fit(df, verbose=False, dense_precision="fp16"), "plan"),
         (lambda: SRA.AprioriSimRank().fit(df, sym, verbose=False), "plan"),
-        (lambda: SRA.AprioriSimRank().fit(df, asym, verbose=False), "python"),
+        (lambda: SRA.AprioriSimRank().fit(df, asym, verbose=False), "plan"),
+        (lambda: SRA.BipartitleAprioriSimRank().fit(dfb, b1, rng.random((40, 40)), verbose=False), "plan"),
         (lambda: SRA.BipartiteSimRank().fit(dfb, verbose=False), "plan"),
         (lambda: SRA.BipartiteSimRankPP().fit(dfb, verbose=False), "plan"),
         (lambda: SRA.BipartiteSimRankPP().fit(dfb, verbose=False, strict_reference=False, top_k=3), "plan"),

@@ -351,8 +351,22 @@ static void fuzz_plan_inputs(std::mt19937& rng, const Csr& sq, const Csr& rect) 
         prior[0] = 0.5f;
         opt.storage_fp16 = 0;
         if (n > 1) {
-            prior[1] += 0.25f;
-            CHECK(simrank::plan_prepare(n, nnz, sq.rowptr.data(), sq.col.data(), sq.scale.data(), &opt, &pp) == SIMRANK_ERR_INVALID, "asymmetric prior accepted");
+            const float keep = prior[1];
+            prior[1] = keep + 0.25f;
+            // (an f32 plan takes it and says so: un-fused epilogue; fp16-held matrices and the sharded plans refuse it)
+            CHECK(simrank::plan_prepare(n, nnz, sq.rowptr.data(), sq.col.data(), sq.scale.data(), &opt, &pp) == SIMRANK_OK && pp.asym,
+                  "asymmetric prior not reported");
+            opt.storage_fp16 = 1;
+            CHECK(simrank::plan_prepare(n, nnz, sq.rowptr.data(), sq.col.data(), sq.scale.data(), &opt, &pp) == SIMRANK_ERR_INVALID,
+                  "asymmetric prior accepted for fp16");
+            opt.storage_fp16 = 0;
+            simrank::PlanPrep sp2;
+            CHECK(simrank::shard_prepare(n, nnz, sq.rowptr.data(), sq.col.data(), sq.scale.data(), prior.data(), n, true, 2, &sp2) == SIMRANK_ERR_INVALID,
+                  "asymmetric prior accepted by the sharded plan");
+            prior[1] = keep;
+            CHECK(simrank::plan_prepare(n, nnz, sq.rowptr.data(), sq.col.data(), sq.scale.data(), &opt, &pp) == SIMRANK_OK && !pp.asym,
+                  "symmetric prior reported as asymmetric");
+            prior[1] = keep + 0.25f;
         }
         opt.ld_apriori = n - 1;
         CHECK(simrank::plan_prepare(n, nnz, sq.rowptr.data(), sq.col.data(), sq.scale.data(), &opt, &pp) == SIMRANK_ERR_INVALID, "short ld accepted");

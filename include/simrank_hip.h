@@ -530,7 +530,9 @@ SIMRANK_API int simrank_biplan_destroy(simrank_biplan* p);
  *      Nodes: ascending row length, dealt to the shards in runs of 128 in the half form (as driver.dealt_order).
  *      Results: simrank_shardplan_block_f64 = the rank's columns (all n rows, caller's row order) + their node ids by
  *      simrank_shardplan_columns; simrank_shardplan_result_f64 assembles the whole matrix on rank `root`.
- *      Only symmetric iterates (SimRank, SimRank++, symmetric priors); f32, or fp16-held matrices (options.storage_fp16).
+ *      f32, or fp16-held matrices (options.storage_fp16).  A prior that is not symmetric makes the iterates asymmetric
+ *      (SimRank.py:453): leg 2's product then goes round a SECOND all-to-all (W . Tt is the transpose of the wanted block) and
+ *      the epilogue runs as a pass of its own with the exact count — f32, leg2_form 0 or -1, wire_fp16 0, else SIMRANK_ERR_INVALID.
  *      Lifetime: destroy the plans before their communicator.  Failure: these calls are collectives — a rank whose call
  *      fails (out of memory, a bad argument the others did not pass) leaves its peers waiting inside RCCL, as in any
  *      RCCL program; the host program owns that failure mode (validate on every rank before, tear the job down after). */
@@ -550,7 +552,7 @@ typedef struct simrank_shardplan simrank_shardplan;
 typedef struct simrank_shardplan_options {
     float coef;                 /* C */
     float lbd;                  /* prior blend (used when apriori != NULL) */
-    const float* apriori;       /* HOST n x n row-major symmetric prior (the same on every rank), or NULL */
+    const float* apriori;       /* HOST n x n row-major prior (the same on every rank; symmetric or not, see above), or NULL */
     int64_t ld_apriori;
     int32_t evidence;           /* 1: SimRank++ evidence factor */
     int32_t reorder;            /* 1: ascending-row-length node order (dealt to the shards in the half form) */

@@ -349,8 +349,8 @@ int simrank_handback_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
         else widen_rows<false>(sl.pin[b & 1], bands[(size_t)b], n, dst, ld_dst, t, nt);
     };
     // (16 threads: 93 ms for N = 32768 on the bench box, 32: 111 - 116 — its quota is 16 CPUs — 8: 104; profiles/r05_handback_knobs.log)
-    const int64_t nt = std::max<int64_t>(1, std::min<int64_t>({16, cpu_share(), (n + 4 * kGroup - 1) / (4 * kGroup),
-                                                               std::max<int64_t>(1, (n * n) >> 18)}));
+    int64_t nt = std::max<int64_t>(1, std::min<int64_t>({16, cpu_share(), (n + 4 * kGroup - 1) / (4 * kGroup),
+                                                         std::max<int64_t>(1, (n * n) >> 18)}));
     std::mutex m;
     std::condition_variable cv;
     std::atomic<int64_t> ready{0};           // bands 0 .. ready - 1 are in their pinned slabs
@@ -374,8 +374,22 @@ int simrank_handback_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
         }
     };
     std::vector<std::thread> threads;
-    if (nt > 1)
-        for (int64_t t = 0; t < nt; ++t) threads.emplace_back(crew, t);
+    if (nt > 1) {
+        try {
+            for (int64_t t = 0; t < nt; ++t) threads.emplace_back(crew, t);
+        } catch (const std::exception&) {
+            // (no more threads to be had: the ones that started are still waiting for band 0 — send them home, widen here)
+            {
+                std::lock_guard<std::mutex> lk(m);
+                abort.store(true);
+            }
+            cv.notify_all();
+            for (std::thread& th : threads) th.join();
+            threads.clear();
+            abort.store(false);
+            nt = 1;
+        }
+    }
     int rc = issue(0);
     if (!rc && nb > 1) rc = issue(1);
     double t_wait_dev = 0, t_wait_host = 0;

@@ -74,10 +74,11 @@ def _make_solver(ops_factory, device, world, specs, mode):
     """The solver with the graphs created at the precision asked for: it travels in the specs and is set
     per graph object (simrank_graph_set_dense_terms), not through the process-wide tuning defaults.
 
-    One rank, symmetric iterates, gather legs (every class the reference has, unless the prior is asymmetric): the loop
-    behind the C ABI (``cplan.PlanSolver`` over simrank_plan_* / simrank_biplan_*).  Everything else —
-    asymmetric priors, dense / hybrid modes, several ranks, the CPU tests' NumPy double — ``driver.Solver``;
-    fp16-held matrices on several ranks: ``cshard.CShardSolver``."""
+    One rank, gather legs (every class the reference has; a prior that is not symmetric in f32 only): the loop behind the
+    C ABI (``cplan.PlanSolver`` over simrank_plan_* / simrank_biplan_*).  Several RCCL ranks (or virtual ranks with
+    ``loop="c"``): the sharded loops behind the C ABI (``cshard.CShardSolver``), fp16-held matrices included.
+    Everything else — dense / hybrid modes, gloo worlds, ``LocalWorld(P)`` in its default form, the CPU tests' NumPy
+    double — ``driver.Solver``."""
     from . import cplan
     dense, storage = _precision_now.__dict__.get("stack", [("f32", "f32")])[-1]
     terms = _DENSE_TERMS[dense]

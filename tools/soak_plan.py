@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak of the C-level loop (simrank_plan_*: create / run / result) on a real GPU: random directed graphs,
-SimRank and SimRank++ (and a symmetric prior every third case), against the float64 oracle at 1e-5 with the
+SimRank and SimRank++ (a prior every third case, every sixth one NOT symmetric: asymmetric iterates), against the float64 oracle at 1e-5 with the
 reference's convergence iteration.  `python3 tools/soak_plan.py [first_seed] [count]`."""
 import os
 import sys
@@ -32,7 +32,8 @@ for seed in range(first, first + count):
     prior = None
     if seed % 3 == 0:
         prior = rng.random((csr.n_rows, csr.n_rows)).astype(np.float32)
-        prior = ((prior + prior.T) / 2).astype(np.float32)
+        if seed % 6:
+            prior = ((prior + prior.T) / 2).astype(np.float32)
         kw = dict(apriori=prior.astype(np.float64), lbd=0.3)
     want = (O.fit_simrank_pp if pp else O.fit_simrank)(df, C=coef, verbose=False, **kw)
     plan = Plan(ops, csr, rowscale=scale, coef=coef, evidence=pp, apriori=prior, lbd=0.3 if prior is not None else 0.0)
@@ -55,15 +56,25 @@ for seed in range(first, first + count // 2):
     df = bipartite_random(n1, n2, float(rng.uniform(0.005, 0.3)), seed=seed)
     pp = bool(rng.integers(0, 2))
     c1, c2 = float(rng.uniform(0.5, 0.9)), float(rng.uniform(0.5, 0.9))
+    pri = {}
+    if len(df) == 0:
+        continue
+    n1, n2 = df["user"].nunique(), df["item"].nunique()     # (nodes without an edge do not exist for the reference)
+    if pp and seed % 3 == 0:                     # BipartitleAprioriSimRank; every other one with a prior that is not symmetric
+        a1, a2 = rng.random((n1, n1)).astype(np.float32), rng.random((n2, n2)).astype(np.float32)
+        a1 = ((a1 + a1.T) / 2).astype(np.float32)
+        if seed % 2:
+            a2 = ((a2 + a2.T) / 2).astype(np.float32)
+        pri = dict(apriori1=a1.astype(np.float64), apriori2=a2.astype(np.float64), lbd1=0.25, lbd2=0.4)
     if pp:
-        want = O.fit_bipartite_pp(df, verbose=False, strict_reference=False, C1=c1, C2=c2)
+        want = O.fit_bipartite_pp(df, verbose=False, strict_reference=False, C1=c1, C2=c2, **pri)
         m1, m2 = want["W1"], want["W2"]
     else:
         want = O.fit_bipartite(df, verbose=False, C1=c1, C2=c2)
         m1, m2 = want["G12"], want["G21"]
     csr, _, _ = _csr_and_scales(want["G12"], want["G21"])
     rs1, rs2 = np.asarray(m1).max(axis=1), np.asarray(m2).max(axis=1)     # one value per row
-    plan = BiPlan(ops, csr, rs1, rs2, c1=c1, c2=c2, evidence=pp)
+    plan = BiPlan(ops, csr, rs1, rs2, c1=c1, c2=c2, evidence=pp, **pri)
     done, conv = plan.run(100, 1e-4)
     s1, s2 = plan.result()
     plan.free()

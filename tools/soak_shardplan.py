@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak of the sharded loop behind the C ABI (simrank_shardplan_*, in-process groups of 1..8 virtual ranks) on a real
-GPU: random directed graphs, SimRank / SimRank++ (a symmetric prior every third case), random rank counts (uneven and
+GPU: random directed graphs, SimRank / SimRank++ (a prior every third case, every sixth one NOT symmetric: a second all-to-all per update), random rank counts (uneven and
 empty blocks included), both forms of leg 2 where the size allows, exchange 1 in 1..4 stages — against the float64
 oracle at 1e-5 with the reference's convergence iteration; every fourth case on the fp16 wire (looser bound, no
 convergence index).  `python3 tools/soak_shardplan.py [first_seed] [count]`."""
@@ -38,11 +38,13 @@ for seed in range(first, first + count):
     kw, prior = {}, None
     if seed % 3 == 0:
         prior = rng.random((csr.n_rows, csr.n_rows)).astype(np.float32)
-        prior = ((prior + prior.T) / 2).astype(np.float32)
+        if seed % 6:
+            prior = ((prior + prior.T) / 2).astype(np.float32)
         kw = dict(apriori=prior.astype(np.float64), lbd=0.3)
     want = (O.fit_simrank_pp if pp else O.fit_simrank)(df, C=coef, verbose=False, **kw)
-    form = int(rng.integers(0, 2)) if csr.n_rows % (32 * world) == 0 else 0
-    wire = seed % 4 == 3
+    asym = prior is not None and seed % 6 == 0
+    form = int(rng.integers(0, 2)) if csr.n_rows % (32 * world) == 0 and not asym else 0
+    wire = seed % 4 == 3 and not asym
     if seed % 5 == 1 and csr.n_rows % (64 * world) == 0 and prior is None:
         # fp16-held matrices on every rank: the bars of tests/test_gpu_half.py (may end later than the reference, never
         # earlier by more than one update; within eps C / (1 - C) + the arithmetic error of the mode)

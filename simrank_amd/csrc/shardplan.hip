@@ -168,6 +168,13 @@ struct simrank_shardplan {
     float* sh_send = nullptr;               // exchange 2 (half form): world chunks of packed mirrored tiles
     float* sh_recv = nullptr;
     int64_t sh_chunk = 0;
+    // the half-form leg 2 (and exchange 2) in stages of column tiles, heaviest (last tiles) first: column tile j packs j mirrored
+    // tiles per source shard into slots j (j - 1) / 2 ..., so tiles [lo, hi) own a contiguous slot range of every chunk; the
+    // buffers hold those ranges stage-major (per stage one piece per rank) and a stage's tiles leave while the next computes
+    // (driver.Side.sh_stages).  Empty: the leg is one launch, its tiles leave after it.
+    struct Stage2 { int32_t tile_lo, tile_hi; int64_t off, chunk; };
+    std::vector<Stage2> sh_stages;
+    std::vector<hipEvent_t> staged2;        // RCCL worlds: "this stage's kernel is done"
     uint16_t* wire[4] = {nullptr, nullptr, nullptr, nullptr};   // fp16 shadows of send / recv / sh_send / sh_recv
     uint8_t* ev = nullptr;
     float* prior = nullptr;
@@ -324,6 +331,7 @@ static int check_group(simrank_shardplan* const* plans, int32_t n_local) {
             SR_REQUIRE(plans[i] && plans[i]->comm->group == p0->comm->group && plans[i]->rank == i &&
                            plans[i]->stream == p0->stream && plans[i]->n == p0->n &&
                            plans[i]->half_form == p0->half_form && plans[i]->n_stages == p0->n_stages &&
+                           plans[i]->sh_stages.size() == p0->sh_stages.size() &&
                            plans[i]->wire_fp16 == p0->wire_fp16 && plans[i]->half == p0->half && plans[i]->asym == p0->asym,
                        "plans[%d] is not rank %d of the same in-process group, stream and options", i, i);
     } else {
@@ -462,6 +470,8 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
         } else if (p->half) {
             rc = simrank_spmm_blocked_h16(p->g, p->recv, p->rows_pad, p->Lm, p->S[p->cur ^ 1], p->rows_pad, 0, &ep, p->rows_pad,
                                           kHalfScale, p->stream);
+        } else if (p->half_form && !p->sh_stages.empty()) {
+            continue;                                    // (stage by stage, below)
         } else if (p->half_form) {
             rc = simrank_spmm_shard(p->g, p->recv, p->recv_ld, p->S[p->cur ^ 1], p->ld, &ep, p->rank, P, p->sh_send,
                                     p->sh_chunk, p->stream);
@@ -469,6 +479,46 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
             rc = simrank_spmm(p->g, p->recv, p->recv_ld, p->Lm, p->S[p->cur ^ 1], p->ld, 0, 0, 0, &ep, p->stream);
         }
         if (rc) return rc;
+    }
+    // the mirrored tiles of one stage (or of the whole leg): equal chunks, the one a rank addresses to itself is empty
+    auto exchange_mirrors = [&](int64_t off, int64_t chunk) -> int {
+        std::vector<Route> routes(n_local, Route(P));
+        for (int32_t i = 0; i < n_local; ++i) {
+            simrank_shardplan* p = plans[i];
+            Route& r = routes[i];
+            r.send_base = p->sh_send; r.recv_base = p->sh_recv;
+            r.send_h = p->wire[2]; r.recv_h = p->wire[3];
+            for (int32_t h = 0; h < P; ++h) {
+                if (h == p->rank) continue;
+                r.add_out(h, p->sh_send + off + int64_t(h) * chunk, chunk);
+                r.add_in(h, p->sh_recv + off + int64_t(h) * chunk, chunk);
+            }
+        }
+        return all_to_all(plans, n_local, routes, xs, 4);
+    };
+    const bool staged2 = p0->half_form && !p0->sh_stages.empty();
+    if (staged2) {
+        // half-form leg 2 stage by stage, heaviest tiles first: a stage's mirrored tiles leave (on RCCL's stream, behind an
+        // event) while the next stage computes; the counters are zeroed by the first stage only
+        for (size_t k = 0; k < p0->sh_stages.size(); ++k) {
+            for (int32_t i = 0; i < n_local; ++i) {
+                simrank_shardplan* p = plans[i];
+                const simrank_shardplan::Stage2& sg = p->sh_stages[k];
+                simrank_epilogue ep;
+                fill_epilogue(p, eps, exact_count, &ep);
+                rc = simrank_spmm_shard_stage(p->g, p->recv, p->recv_ld, p->S[p->cur ^ 1], p->ld, &ep, p->rank, P,
+                                              p->sh_send + sg.off, sg.chunk, sg.tile_lo, sg.tile_hi, k == 0 ? 1 : 0, p->stream);
+                if (rc) return rc;
+                if (!local) {
+                    SR_HIP(hipEventRecord(p->staged2[k], p->stream));
+                    SR_HIP(hipStreamWaitEvent(xs, p->staged2[k], 0));
+                }
+            }
+            if (p0->sh_stages[k].chunk) {
+                rc = exchange_mirrors(p0->sh_stages[k].off, p0->sh_stages[k].chunk);
+                if (rc) return rc;
+            }
+        }
     }
     SR_MARK(p0, p0->stream, kMarkLeg2b);
     if (!local) {
@@ -479,22 +529,10 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
             SR_RCCL(rccl()->AllReduce(p0->counters, p0->counters, SIMRANK_CHANGED_SLOTS, ncclUint64, ncclSum,
                                       p0->comm->nccl, xs));
     }
-    if (p0->half_form) {
-        // exchange 2: the packed mirrored tiles (the chunk a rank addresses to itself is empty: stored in place)
-        std::vector<Route> routes(n_local, Route(P));
-        for (int32_t i = 0; i < n_local; ++i) {
-            simrank_shardplan* p = plans[i];
-            Route& r = routes[i];
-            r.send_base = p->sh_send; r.recv_base = p->sh_recv;
-            r.send_h = p->wire[2]; r.recv_h = p->wire[3];
-            for (int32_t h = 0; h < P; ++h) {
-                if (h == p->rank) continue;
-                r.add_out(h, p->sh_send + int64_t(h) * p->sh_chunk, p->sh_chunk);
-                r.add_in(h, p->sh_recv + int64_t(h) * p->sh_chunk, p->sh_chunk);
-            }
-        }
+    if (p0->half_form && !staged2) {
+        // exchange 2 after the whole leg: the packed mirrored tiles
         if (local) SR_MARK(p0, xs, kMarkY0);
-        rc = all_to_all(plans, n_local, routes, xs, 4);
+        rc = exchange_mirrors(0, p0->sh_chunk);
         if (rc) return rc;
         if (local) SR_MARK(p0, xs, kMarkY1);
     }
@@ -508,7 +546,14 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
         SR_HIP(hipMemcpyAsync(p->host_counters[slot], p->counters, sizeof(unsigned long long) * SIMRANK_CHANGED_SLOTS,
                               hipMemcpyDeviceToHost, p->stream));
         SR_HIP(hipEventRecord(p->counted[slot], p->stream));
-        if (p->half_form) {
+        if (p->half_form && !p->sh_stages.empty()) {
+            for (const simrank_shardplan::Stage2& sg : p->sh_stages) {
+                if (!sg.chunk) continue;
+                rc = simrank_shard_unpack_stage(p->S[p->cur ^ 1], p->ld, p->sh_recv + sg.off, sg.chunk, p->rank, P, p->n,
+                                                sg.tile_lo, sg.tile_hi, p->stream);
+                if (rc) return rc;
+            }
+        } else if (p->half_form) {
             rc = simrank_shard_unpack(p->S[p->cur ^ 1], p->ld, p->sh_recv, p->sh_chunk, p->rank, P, p->n, p->stream);
             if (rc) return rc;
         }
@@ -628,6 +673,7 @@ int simrank_shardplan_destroy(simrank_shardplan* p) {
         if (p->counted[i]) (void)hipEventDestroy(p->counted[i]);
     }
     for (hipEvent_t e : p->staged) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->staged2) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
     for (auto& m : p->marks) (void)hipEventDestroy(m.second);
     if (p->xstream) (void)hipStreamDestroy(p->xstream);
@@ -737,6 +783,23 @@ static int create_side(const SideIn& in, simrank_comm* comm, void* stream, simra
         const int64_t t = p->mb / 32;
         p->sh_chunk = std::max<int64_t>(1, t * (t - 1) / 2 * 1024);
         const size_t sh = size_t(P) * size_t(p->sh_chunk);
+        // leg 2 in as many stages as exchange 1 (at most one per two column tiles), cut at T sqrt(k / S) for equal slot counts
+        const int64_t want = std::min<int64_t>(p->n_stages, t / 2);
+        if (want > 1) {
+            std::vector<int64_t> cuts;
+            for (int64_t k = 1; k < want; ++k)
+                cuts.push_back(std::min<int64_t>(t, std::max<int64_t>(2, (int64_t)std::llround(double(t) * std::sqrt(double(k) / double(want))))));
+            cuts.push_back(t);
+            std::sort(cuts.begin(), cuts.end());
+            cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+            int64_t lo = 0;
+            for (int64_t hi : cuts) {
+                const int64_t s_lo = lo * (lo - 1) / 2, s_hi = hi * (hi - 1) / 2;
+                p->sh_stages.push_back({(int32_t)lo, (int32_t)hi, int64_t(P) * s_lo * 1024, (s_hi - s_lo) * 1024});
+                lo = hi;
+            }
+            std::reverse(p->sh_stages.begin(), p->sh_stages.end());
+        }
         SP_HIP(dev((void**)&p->sh_send, sh * 4));
         SP_HIP(dev((void**)&p->sh_recv, sh * 4));
         if (p->wire_fp16) {
@@ -753,6 +816,8 @@ static int create_side(const SideIn& in, simrank_comm* comm, void* stream, simra
         SP_HIP(hipStreamCreateWithFlags(&p->xstream, hipStreamNonBlocking));
         p->staged.resize(size_t(p->n_stages) + 1, nullptr);
         for (hipEvent_t& e : p->staged) SP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        p->staged2.resize(p->sh_stages.size(), nullptr);
+        for (hipEvent_t& e : p->staged2) SP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     SP_HIP(dev((void**)&p->inv, size_t(n) * 4));
     SP_HIP(hipMemcpyAsync(p->inv, inv.data(), size_t(n) * 4, hipMemcpyHostToDevice, p->stream));

@@ -38,7 +38,7 @@ def main():
     want_done, want_conv = one.run(30, 1e-4)
     want = one.result()
     one.free()
-    for form, stages, wire in ((0, 1, False), (0, 3, False), (1, 2, False), (0, 2, True)):
+    for form, stages, wire in ((0, 1, False), (0, 3, False), (1, 2, False), (1, 4, False), (0, 2, True), (1, 3, True)):
         sp = ShardPlans(ops, csr, rowscale=scale, world=world, comm=comm, evidence=True, leg2_form=form, stages=stages,
                         wire_fp16=wire)
         done, conv = sp.run(30, 1e-4)
@@ -56,6 +56,20 @@ def main():
             assert np.array_equal(got[:, ids], blk)
         c = sp.step(0.0, exact_count=True)
         assert c > 0
+        sp.free()
+    # a prior that is not symmetric: leg 2's product goes round a second exchange on RCCL's stream, epilogue as its own pass
+    prior = np.random.default_rng(4).random((n, n)).astype(np.float32)
+    one = Plan(ops, csr, rowscale=scale, evidence=True, apriori=prior, lbd=0.3)
+    want_a = one.run(30, 1e-4)
+    want_s = one.result()
+    one.free()
+    for stages in (1, 3):
+        sp = ShardPlans(ops, csr, rowscale=scale, world=world, comm=comm, evidence=True, apriori=prior, lbd=0.3, stages=stages)
+        assert sp.run(30, 1e-4) == want_a
+        got = sp.result(root=0, i_am_root=rank == 0)
+        if rank == 0:
+            assert not np.array_equal(got, got.T)
+            np.testing.assert_allclose(got, want_s, rtol=1e-5, atol=1e-30)
         sp.free()
     # top-k hand-back: every rank's candidates meet on rank 0
     sp = ShardPlans(ops, csr, rowscale=scale, world=world, comm=comm, evidence=True)

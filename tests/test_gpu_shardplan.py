@@ -112,6 +112,18 @@ def test_shardplan_full_form_is_the_python_drivers_bits(ops, pp):
         staged = sp.result()
         sp.free()
         np.testing.assert_allclose(staged, got, rtol=2e-6, atol=1e-30)
+        # the half form with leg 2 (and the exchange of the mirrored tiles) in stages of column tiles: the same tiles, the
+        # same sums — the unstaged half form's bits whatever exchange 1's stages did to the operand's order of arrival
+        for stages in (2, 4):
+            sp = ShardPlans(ops, csr, rowscale=scale, world=world, evidence=pp, leg2_form=1, stages=stages)
+            counts = [sp.step(0.0, exact_count=True) for _ in range(5)]
+            staged_half = sp.result()
+            sp.free()
+            assert all(c > 0 for c in counts)
+            if 2048 // (32 * world) >= 2 * 2:                       # (at least two column tiles per stage: really staged)
+                assert np.array_equal(staged_half, half), (world, stages)
+            else:
+                np.testing.assert_allclose(staged_half, half, rtol=2e-6, atol=1e-30)
 
 
 def test_shardplan_with_a_prior_against_the_oracle(ops):

@@ -40,9 +40,10 @@ if os.environ.get("STORAGE") == "fp16":
                   f"and update ({ms:.2f} ms for the {P} virtual ranks, device copies included); exchange payload per rank "
                   f"{per:.0f} MiB", flush=True)
     sys.exit(0)
+STAGES = int(os.environ.get("STAGES", "1"))       # exchange 1 (and, in the half form, leg 2 + exchange 2) in that many stages
 for P in [int(v) for v in os.environ.get("PS", "8,4").split(",")]:
     for form in (0, 1):
-        sp = ShardPlans(ops, csr, world=P, leg2_form=form, stages=1)
+        sp = ShardPlans(ops, csr, world=P, leg2_form=form, stages=STAGES)
         sp.step(0.0)
         ops.synchronize()
         t0 = time.perf_counter()
@@ -68,6 +69,6 @@ for P in [int(v) for v in os.environ.get("PS", "8,4").split(",")]:
         same = np.array_equal(got.astype(np.float64), blk[ids[:3]][:, :])
         s.release()
         del s
-        print(f"{w} P={P} leg 2 in its {'half' if form else 'full'} form: C loop {c_ms / P:.3f} ms per rank and update "
+        print(f"{w} P={P} stages={STAGES} leg 2 in its {'half' if form else 'full'} form: C loop {c_ms / P:.3f} ms per rank and update "
               f"({c_ms:.2f} ms for the {P} virtual ranks, device copies included), Python driver {py_ms / P:.3f}; "
               f"four updates, sampled rows of the last rank's block bit-equal: {same}", flush=True)

@@ -532,7 +532,7 @@ SIMRANK_API int simrank_biplan_destroy(simrank_biplan* p);
  *      simrank_shardplan_columns; simrank_shardplan_result_f64 assembles the whole matrix on rank `root`.
  *      f32, or fp16-held matrices (options.storage_fp16).  A prior that is not symmetric makes the iterates asymmetric
  *      (SimRank.py:453): leg 2's product then goes round a SECOND all-to-all (W . Tt is the transpose of the wanted block) and
- *      the epilogue runs as a pass of its own with the exact count — f32, leg2_form 0 or -1, wire_fp16 0, else SIMRANK_ERR_INVALID.
+ *      the epilogue runs as a pass of its own with the exact count — f32 matrices, leg2_form 0 or -1, else SIMRANK_ERR_INVALID.
  *      Lifetime: destroy the plans before their communicator.  Failure: these calls are collectives — a rank whose call
  *      fails (out of memory, a bad argument the others did not pass) leaves its peers waiting inside RCCL, as in any
  *      RCCL program; the host program owns that failure mode (validate on every rank before, tear the job down after). */

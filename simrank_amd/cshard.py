@@ -30,8 +30,8 @@ def applies(world, specs, mode) -> str | None:
         return "the sharded C loop runs the gather legs only (mode 'sparse' or 'auto')"
     if not all(s.symmetric for s in specs):
         # asymmetric iterates: leg 2's product goes round a second all-to-all, the epilogue is a pass of its own (f32 only)
-        if any(s.storage != "f32" for s in specs) or getattr(world, "exchange_precision", "f32") != "f32":
-            return "an asymmetric prior needs f32 matrices and the f32 wire in the sharded C loop"
+        if any(s.storage != "f32" for s in specs):
+            return "an asymmetric prior needs f32 matrices"
     if len({s.storage for s in specs}) != 1 or any(s.dense_terms != 3 for s in specs):
         return "one storage precision for every matrix, exact products on the matrix cores"
     fp16 = specs[0].storage == "fp16"

@@ -175,7 +175,7 @@ struct simrank_shardplan {
     struct Stage2 { int32_t tile_lo, tile_hi; int64_t off, chunk; };
     std::vector<Stage2> sh_stages;
     std::vector<hipEvent_t> staged2;        // RCCL worlds: "this stage's kernel is done"
-    uint16_t* wire[4] = {nullptr, nullptr, nullptr, nullptr};   // fp16 shadows of send / recv / sh_send / sh_recv
+    uint16_t* wire[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // fp16 shadows of send / recv / sh_send / sh_recv / send2 / recv2
     uint8_t* ev = nullptr;
     float* prior = nullptr;
     int32_t* inv = nullptr;                 // device: position of caller's node i in the solver's order
@@ -411,7 +411,7 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
                         if (rc) return rc;
                     }
                     r.send_base = outb; r.recv_base = inb;
-                    r.send_h = second ? nullptr : p->wire[0]; r.recv_h = second ? nullptr : p->wire[1];
+                    r.send_h = p->wire[second ? 4 : 0]; r.recv_h = p->wire[second ? 5 : 1];
                     for (int32_t h = 0; h < P; ++h) {
                         r.add_out(h, outb + send_off + int64_t(h) * w * (p->mb + p->pad), w * (span(p->n, P, h) + p->pad));
                         // what rank h computed: the columns of ITS block — of the operand matrix (leg 1: k nodes) or of the
@@ -664,7 +664,8 @@ int simrank_shardplan_destroy(simrank_shardplan* p) {
     if (p->xstream) (void)hipStreamSynchronize(p->xstream);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     for (void* b : {(void*)p->S[0], (void*)p->S[1], (void*)p->send, (void*)p->recv, (void*)p->sh_send, (void*)p->sh_recv,
-                    (void*)p->wire[0], (void*)p->wire[1], (void*)p->wire[2], (void*)p->wire[3], (void*)p->ev,
+                    (void*)p->wire[0], (void*)p->wire[1], (void*)p->wire[2], (void*)p->wire[3], (void*)p->wire[4],
+                    (void*)p->wire[5], (void*)p->ev,
                     (void*)p->prior, (void*)p->inv, (void*)p->counters, (void*)p->hand[0], (void*)p->hand[1], (void*)p->send2,
                     (void*)p->recv2})
         (void)pool_free(b);
@@ -772,8 +773,13 @@ static int create_side(const SideIn& in, simrank_comm* comm, void* stream, simra
         SP_HIP(dev((void**)&p->recv, recv_floats * 4));
     }
     if (p->asym) {
-        SP_HIP(dev((void**)&p->send2, size_t(std::max<int64_t>(1, p->Lm)) * size_t(p->send_ld) * 4));
-        SP_HIP(dev((void**)&p->recv2, size_t(n) * size_t(p->recv_ld) * 4));
+        const size_t s2 = size_t(std::max<int64_t>(1, p->Lm)) * size_t(p->send_ld), r2 = size_t(n) * size_t(p->recv_ld);
+        SP_HIP(dev((void**)&p->send2, s2 * 4));
+        SP_HIP(dev((void**)&p->recv2, r2 * 4));
+        if (p->wire_fp16) {
+            SP_HIP(dev((void**)&p->wire[4], s2 * 2));
+            SP_HIP(dev((void**)&p->wire[5], r2 * 2));
+        }
     }
     if (p->wire_fp16) {
         SP_HIP(dev((void**)&p->wire[0], send_floats * 2));
@@ -879,11 +885,11 @@ int simrank_shardplan_create(int64_t n, int64_t nnz, const int32_t* rowptr, cons
     // (the exchange moves the fp16 values themselves)
     SR_REQUIRE(!fp16 || (n % (64 * int64_t(P)) == 0 && opt->leg2_form != 1 && !opt->apriori && !opt->wire_fp16),
                "storage_fp16 on shards needs n %% (64 x ranks) == 0, leg 2 in its full form, no prior and the f32 wire option off");
-    // a prior that is not symmetric: asymmetric iterates — f32, leg 2 in its full form (there is no mirror image to share),
-    // the f32 wire; the second exchange carries leg 2's product back to the ranks that own its columns
+    // a prior that is not symmetric: asymmetric iterates — f32, leg 2 in its full form (there is no mirror image to share);
+    // the second exchange carries leg 2's product back to the ranks that own its columns
     const bool asym = opt->apriori && opt->ld_apriori >= n && !prior_symmetric(opt->apriori, opt->ld_apriori, n);
-    SR_REQUIRE(!asym || (!fp16 && opt->leg2_form != 1 && !opt->wire_fp16),
-               "a prior that is not symmetric needs f32 matrices, leg 2 in its full form and the f32 wire");
+    SR_REQUIRE(!asym || (!fp16 && opt->leg2_form != 1),
+               "a prior that is not symmetric needs f32 matrices and leg 2 in its full form");
     const bool half = !fp16 && !asym && (opt->leg2_form == 1 || (opt->leg2_form == -1 && fits_half && P >= 8));
     PlanPrep pp;
     int rc = shard_prepare(n, nnz, rowptr, col, rowscale, opt->apriori, opt->ld_apriori, opt->reorder != 0, half ? P : 1, &pp, true);
@@ -1323,11 +1329,10 @@ int simrank_shardbiplan_create(int64_t n1, int64_t n2, int64_t nnz, const int32_
     const int32_t P = comm->world;
     const int64_t ns[2] = {n1, n2};
     // the half form group by group: where a group's size is a multiple of 32 x ranks (and asked for, or 8 ranks on)
-    // (a prior of either group that is not symmetric makes BOTH iterates asymmetric: full form, f32 wire, second exchange)
+    // (a prior of either group that is not symmetric makes BOTH iterates asymmetric: full form, second exchange)
     const bool asym = (opt->apriori1 && opt->ld_apriori1 >= n1 && !prior_symmetric(opt->apriori1, opt->ld_apriori1, n1)) ||
                       (opt->apriori2 && opt->ld_apriori2 >= n2 && !prior_symmetric(opt->apriori2, opt->ld_apriori2, n2));
-    SR_REQUIRE(!asym || (leg2_form != 1 && !wire_fp16),
-               "a prior that is not symmetric needs leg 2 in its full form and the f32 wire");
+    SR_REQUIRE(!asym || leg2_form != 1, "a prior that is not symmetric needs leg 2 in its full form");
     bool half[2];
     for (int w = 0; w < 2; ++w) {
         const bool fits = (P > 1 && ns[w] % (32 * int64_t(P)) == 0) || (P == 1 && ns[w] % 32 == 0);

@@ -129,8 +129,8 @@ def test_shardplan_full_form_is_the_python_drivers_bits(ops, pp):
 def test_shardplan_with_a_prior_against_the_oracle(ops):
     """AprioriSimRank's loop (SimRank.py:443-454) on four virtual ranks: symmetric prior, evidence, nodes dealt inside,
     results in the caller's order.  A prior that is NOT symmetric (asymmetric iterates: leg 2's product goes round a second
-    all-to-all, the epilogue is a pass of its own) on 1 - 5 ranks, staged or not, uneven and empty blocks included; the half
-    form and the fp16 wire refuse it."""
+    all-to-all, the epilogue is a pass of its own) on 1 - 5 ranks, staged or not, uneven and empty blocks included, also on
+    the fp16 wire; the half form refuses it."""
     from simrank_amd._lib import SimRankHipError
     from simrank_amd.engine import ShardPlans
     df = synth.powerlaw_directed(640, 9, seed=5)
@@ -176,8 +176,18 @@ def test_shardplan_with_a_prior_against_the_oracle(ops):
     sp.free()
     with pytest.raises(SimRankHipError, match="not symmetric"):
         ShardPlans(ops, csr, world=4, apriori=A, lbd=0.3, leg2_form=1)
-    with pytest.raises(SimRankHipError, match="not symmetric"):
-        ShardPlans(ops, csr, world=2, apriori=A, lbd=0.3, wire_fp16=True)
+    # the fp16 wire under asymmetric iterates: both exchanges narrowed, one fp16 rounding of each product per update
+    sp = ShardPlans(ops, csr, world=3, coef=0.7, evidence=True, apriori=A, lbd=0.3, wire_fp16=True, stages=2)
+    sp.run(6, 0.0)
+    wired = sp.result()
+    sp.free()
+    sp = ShardPlans(ops, csr, world=3, coef=0.7, evidence=True, apriori=A, lbd=0.3, stages=2)
+    sp.run(6, 0.0)
+    exact = sp.result()
+    sp.free()
+    assert not np.array_equal(wired, exact)
+    big = exact > 1e-4
+    assert (np.abs(wired - exact)[big] / exact[big]).max() < 5e-3 and np.abs(wired - exact).max() < 1e-3
 
 
 def test_shardplan_fp16_wire(ops):

@@ -358,6 +358,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world_size
 
+    # Rank 0 owes its caller ONE JSON line on stdout.  Libraries print there too (RCCL: a five-line version banner whenever a
+    # communicator is made — torch's eager init below, the library's own in cshard._rccl_comm): from here on file descriptor 1
+    # is stderr's, and the line goes out through a duplicate of the real stdout at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(real_stdout, (line + "\n").encode())
+
     import torch
     import torch.distributed as dist
     from simrank_amd import ingest, synth
@@ -515,8 +525,7 @@ def main():
                     line = json.dumps(out, default=str)
                 except Exception:
                     line = json.dumps({k: v for k, v in out.items() if k != "sharded_c_loop"}, default=str)
-                sys.stdout.write(line + "\n")
-                sys.stdout.flush()
+                emit(line)
             os._exit(0)
         dog = threading.Timer(deadline, give_up)
         dog.daemon = True
@@ -702,8 +711,10 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc) and "roofline" in out:
         try:
+            # (the recorded passes are of the single-rank solver's kernels: a sharded run — also --force-dist's world of one — launches
+            # other instantiations on other layouts and carries no traffic figure)
             key = f"{args.workload}:{world_size}" + (":pp" if args.pp else "") + \
-                  (":fp16" if args.dense_precision == "fp16" else "")
+                  (":fp16" if args.dense_precision == "fp16" else "") + (":sharded" if use_dist else "")
             rec = json.load(open(pmc)).get(key, {})
             for r in (out["roofline"], out.get("roofline_other", {})):
                 key = "leg1" if "leg 1" in r.get("kernel", "") else "leg2"
@@ -1232,7 +1243,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(csr, S_host, coef)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
-        print(json.dumps(out))
+        emit(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
 

@@ -511,11 +511,11 @@ def main():
         # (N = 65536 SimRank++) through the same loop.  The headline is the faster PARITY-GRADE (f32) loop, named.
         # No P > 1 RCCL world has ever run this loop (one GPU per box until now), and a rank stuck in a collective would take the
         # whole line with it: a watchdog prints what has been measured (the Python world's headline + the variants finished) and
-        # ends the rank if the section is not done after SIMRANK_BENCH_CLOOP_DEADLINE seconds (default 600).
+        # ends the rank if the section is not done after SIMRANK_BENCH_CLOOP_DEADLINE seconds (default 300; the section takes well under a minute).
         import threading
         section = {}
         out["sharded_c_loop"] = section
-        deadline = float(os.environ.get("SIMRANK_BENCH_CLOOP_DEADLINE", "600"))
+        deadline = float(os.environ.get("SIMRANK_BENCH_CLOOP_DEADLINE", "300"))
 
         def give_up():
             section["error"] = (f"watchdog: the C-loop section had not finished after {deadline:.0f} s (a rank stuck in a collective?); "

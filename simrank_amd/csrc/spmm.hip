@@ -1732,7 +1732,7 @@ __global__ __launch_bounds__(kEvThreads) void evidence_counts_kernel(
     const float* __restrict__ rowscale, const int32_t* __restrict__ t_rowptr,
     const int32_t* __restrict__ t_col, const int32_t* __restrict__ t_pos, int64_t M, int64_t col0, int n_cols,
     uint8_t* out, int64_t ld, int64_t rows_pad, int64_t out_col0, int vec4, int tri,
-    const int32_t* __restrict__ hubidx) {
+    const int32_t* __restrict__ hubidx, int regroup_rows) {
     extern __shared__ unsigned cnt[];                 // counters of columns 2 w and 2 w + 1 in word w
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1742,7 +1742,18 @@ __global__ __launch_bounds__(kEvThreads) void evidence_counts_kernel(
     // = of (b, a) — so row a counts the paths to b >= a only (half the LDS atomics, which bound this kernel) and
     // writes its columns from the 32-column panel of the diagonal on; evidence_mirror_kernel fills the rest.
     // Rows are taken LONGEST FIRST there (the long rows, late in the solver's order, have the short ranges).
-    for (int64_t it = blockIdx.x; it < M; it += gridDim.x) {
+    // Blocked layout: a row's 32 bytes of a panel share a 128-byte line with its three neighbours' — rows 4 k .. 4 k + 3 are
+    // given to workgroups of ONE XCD that run at the same time (blocks b, b + 8, b + 16, b + 24), so that its L2 reads and
+    // writes the line once instead of four L2s a quarter each (round 5: 11.3 GB through the fabric for 4.3 GB of counts).
+    const bool regroup = regroup_rows && rows_pad > 0 && (gridDim.x & 7) == 0;
+    const int64_t M_it = regroup ? (M + 31) / 32 * 32 : M;
+    for (int64_t it0 = blockIdx.x; it0 < M_it; it0 += gridDim.x) {
+        int64_t it = it0;
+        if (regroup) {
+            const int64_t q = it0 >> 3, x = it0 & 7;
+            it = (((q >> 2) << 3) + x) * 4 + (q & 3);
+            if (it >= M) continue;
+        }
         const int64_t a = tri ? M - 1 - it : it;
         // first column (of this pass's n_cols) this row zeroes, counts from and writes; tri in several passes (out_col0 =
         // where the pass starts in the square): a row below the pass's columns has nothing to do in it
@@ -2526,6 +2537,7 @@ static int evidence_counts_impl(const simrank_graph* g, int64_t col0, int64_t n_
                "evidence block [%lld, %lld) of %lld, ld %lld", (long long)col0,
                (long long)(col0 + n_cols), (long long)g->n_rows, (long long)ld);
     const int grid = (int)std::min<int64_t>(g->n_rows, 256 * 4);
+    static const int regroup_rows = [] { const char* e = std::getenv("SIMRANK_EV_REGROUP"); return e && *e == '0' ? 0 : 1; }();
     // 4-byte stores need the block's first column, the pass boundaries (multiples of 65536) and the row
     // pitch to be multiples of 4 (the blocked layout: always, out_col0 being a multiple of 4)
     const int vec4 = (reinterpret_cast<uintptr_t>(counts) % 4 == 0) && (rows_pad ? true : ld % 4 == 0);
@@ -2565,7 +2577,7 @@ static int evidence_counts_impl(const simrank_graph* g, int64_t col0, int64_t n_
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(evidence_counts_kernel<1024>, dim3(grid), dim3(1024), lds, as_stream(stream), g->rowptr, g->col,
                            g->rowscale, g->t_rowptr, g->t_col, g->t_pos, g->n_rows, col0 + c, nc, counts, ld, rows_pad, c,
-                           vec4, tri, hubidx);
+                           vec4, tri, hubidx, regroup_rows);
         SR_HIP(hipGetLastError());
     }
     if (tri) {

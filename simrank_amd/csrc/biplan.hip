@@ -49,6 +49,8 @@ struct simrank_biplan {
     int32_t updates = 0;
     int32_t broadcast_error = 0;     // strict_reference with evidence and n1 != n2, n1 != 1 (quirk Q2)
     int32_t asym = 0;                // a prior of either group is not symmetric: both iterates are asymmetric (un-fused epilogue)
+    int32_t identity_leg1 = 1;       // group 1's first update reads S2 = I: its leg 1 is W12^T written directly (SIMRANK_IDENTITY_LEG1=0: off)
+    int32_t at_identity = 0;         // S2 is the identity (reset), no update queued since
 };
 
 namespace simrank {
@@ -56,8 +58,12 @@ namespace simrank {
 static int side_update(simrank_biplan* p, int w, double eps, int32_t exact_count, unsigned long long* host_slot) {
     side_t& a = p->s[w];
     const side_t& o = p->s[w ^ 1];
-    // leg 1: Tt (k x n) = (W . S_other)^T; S_other is k x k
-    int rc = simrank_spmm_blocked(a.g, o.S[o.cur], o.rows_pad, a.k, a.Tt, a.k_rows_pad, 1, nullptr, p->stream);
+    // leg 1: Tt (k x n) = (W . S_other)^T; S_other is k x k — the identity for the very first update of group 1 (SimRank.py:280-285:
+    // group 2's first update already reads the new S1), whose product is W^T written directly: the same bits, no gathers
+    const bool from_identity = w == 0 && p->at_identity && p->identity_leg1;
+    if (w == 0) p->at_identity = 0;
+    int rc = from_identity ? identity_leg1_blocked(a.g, a.Tt, a.k_rows_pad, p->stream)
+                           : simrank_spmm_blocked(a.g, o.S[o.cur], o.rows_pad, a.k, a.Tt, a.k_rows_pad, 1, nullptr, p->stream);
     if (rc) return rc;
     simrank_epilogue ep{};
     ep.coef = a.coef;
@@ -142,6 +148,7 @@ int simrank_biplan_reset(simrank_biplan* p) {
     SR_REQUIRE(p, "plan is NULL");
     SR_REQUIRE(p->s[0].S[0], "the plan's matrices were released (simrank_biplan_trim)");
     p->updates = 0;
+    p->at_identity = 1;
     for (side_t& a : p->s) {
         a.cur = 0;
         const int rc = simrank_fill_identity_blocked(a.S[0], a.n, a.n, a.rows_pad, 0, p->stream);
@@ -168,6 +175,7 @@ int simrank_biplan_create(int64_t n1, int64_t n2, int64_t nnz, const int32_t* ro
     simrank_biplan* p = new simrank_biplan;
     p->stream = as_stream(stream);
     p->asym = pp.asym ? 1 : 0;
+    if (const char* e = std::getenv("SIMRANK_IDENTITY_LEG1")) p->identity_leg1 = (*e == '0') ? 0 : 1;
     auto fail = [&](int code) { simrank_biplan_destroy(p); return code; };
     for (int w = 0; w < 2; ++w) {
         side_t& a = p->s[w];

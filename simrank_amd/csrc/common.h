@@ -127,6 +127,9 @@ inline hipError_t pool_hip_alloc(void** p, size_t bytes) {       // (for call si
     return rc == SIMRANK_OK ? hipSuccess : (rc == SIMRANK_ERR_ALLOC ? hipErrorOutOfMemory : hipErrorUnknown);
 }
 
+// spmm.hip: (W . I)^T = W^T into a panel-blocked matrix of n_cols(g) rows x n_rows(g) columns — leg 1 of a fit's first update
+int identity_leg1_blocked(const simrank_graph* g, float* Tt, int64_t t_rows_pad, void* stream);
+
 // planprep.hip: the host-only half of the plans (validation, solver node order, renamed patterns)
 struct PlanPrep {
     std::vector<int32_t> ord, inv;          // ord[new] = old, inv[old] = new

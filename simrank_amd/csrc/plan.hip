@@ -44,6 +44,8 @@ struct simrank_plan {
                                               //    (its product stored transposed), then the epilogue as a pass of its own
     int cur = 0;                              // S[cur] is the current iterate
     int32_t updates = 0;                      // updates applied since the last reset
+    int32_t identity_leg1 = 1;                // the first update's leg 1 without gathers (S_0 = I; SIMRANK_IDENTITY_LEG1=0: off)
+    int32_t at_identity = 0;                  // S[cur] is the identity (simrank_plan_reset), no update queued since
     // simrank_plan_set_timing: three events per update (before leg 1, between the legs, after leg 2) on the plan's stream
     std::vector<hipEvent_t> ev_pool;          // created ahead of the timed region
     std::vector<hipEvent_t> ev_used;          // 3 per timed update, in order
@@ -67,8 +69,12 @@ static int leg_pair(simrank_plan* p, double eps, int32_t exact_count, int slot) 
     const int nx = p->cur ^ 1;
     const bool timed = p->timing && p->ev_pool.size() >= 3;
     if (timed) { const int rs = stamp(p); if (rs) return rs; }
+    // (the first update of a fit multiplies by the identity: W^T is written directly — the same bits without a gather)
+    const bool from_identity = p->at_identity && p->identity_leg1 && !p->half;
+    p->at_identity = 0;
     int rc = p->half ? simrank_spmm_blocked_h16(p->g, p->S[p->cur], p->rows_pad, p->n, p->Tt, p->rows_pad, 1, nullptr,
                                                 0, kHalfScale, p->stream)
+             : from_identity ? identity_leg1_blocked(p->g, p->Tt, p->rows_pad, p->stream)
                      : simrank_spmm_blocked(p->g, p->S[p->cur], p->rows_pad, p->n, p->Tt, p->rows_pad, 1, nullptr,
                                             p->stream);
     if (rc) return rc;
@@ -165,6 +171,7 @@ int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int
     p->rows_pad = (n + 7) / 8 * 8 + 8;
     p->half = opt->storage_fp16 ? 1 : 0;
     p->asym = pp.asym ? 1 : 0;
+    if (const char* e = std::getenv("SIMRANK_IDENTITY_LEG1")) p->identity_leg1 = (*e == '0') ? 0 : 1;
     const int64_t panels = (n + 31) / 32;
     // (fp16: 64-column panels of 2-byte elements — a row segment is 128 bytes either way)
     p->mat_bytes = p->half ? size_t((n + 63) / 64) * size_t(p->rows_pad) * 128
@@ -280,6 +287,7 @@ int simrank_plan_reset(simrank_plan* p) {
     SR_REQUIRE(p->S[0], "the plan's matrices were released (simrank_plan_trim)");
     p->cur = 0;
     p->updates = 0;
+    p->at_identity = 1;
     if (p->half) return simrank_fill_identity_blocked_h16(p->S[0], p->n, p->n, p->rows_pad, 0, kHalfScale, p->stream);
     return simrank_fill_identity_blocked(p->S[0], p->n, p->n, p->rows_pad, 0, p->stream);
 }

@@ -371,3 +371,56 @@ def test_fits_on_poisoned_memory_at_ragged_sizes(tmp_path):
     env = dict(os.environ, SIMRANK_POOL_POISON="1")
     run = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=900)
     assert run.returncode == 0 and "poisoned pool ok" in run.stdout, (run.stdout[-2000:], run.stderr[-4000:])
+
+
+def test_first_update_from_the_identity_without_gathers(ops, monkeypatch):
+    """S_0 = I (SimRank.py:124-126): the first leg 1 of a plan writes W^T directly (a zero fill + one value per entry) instead
+    of gathering — the SAME BITS as the gather leg, update by update, for every class a plan runs (plain, evidence,
+    symmetric and asymmetric priors, the two-matrix plan whose group 1 reads S2 = I), also after a reset and in run()."""
+    from simrank_amd.engine import BiPlan, Plan
+    from simrank_amd import ingest
+    df = synth.powerlaw_directed(2500, 14, seed=3)
+    _, csr = ingest.directed(df, False, "from", "to", "weight")
+    rng = np.random.default_rng(5)
+    sym = rng.random((csr.n_rows, csr.n_rows))
+    sym = (sym + sym.T) / 2
+    asym = rng.random((csr.n_rows, csr.n_rows))
+
+    def directed(**kw):
+        p = Plan(ops, csr, coef=0.75, **kw)
+        outs = []
+        for _ in range(3):
+            p.step(0.0, exact_count=True)
+            outs.append(p.result())
+        p.reset()
+        p.step(0.0)
+        outs.append(p.result())                      # after a reset: from the identity again
+        outs.append(p.run(6, 1e-4))
+        outs.append(p.result())
+        p.free()
+        return outs
+    dfb = bipartite_random(900, 400, 0.03, seed=4)
+    _, _, _, _, g12, g21 = ingest.bipartite(dfb, False, "user", "item", "weight")
+
+    def two_matrix():
+        p = BiPlan(ops, g12, g12.rowscale, g21.rowscale, evidence=True)
+        outs = []
+        for _ in range(2):
+            p.step(0.0, True)
+            outs.extend(p.result())
+        outs.append(p.run(5, 1e-4))
+        outs.extend(p.result())
+        p.free()
+        return outs
+    cases = [lambda: directed(), lambda: directed(evidence=True), lambda: directed(evidence=True, apriori=sym, lbd=0.3),
+             lambda: directed(evidence=True, apriori=asym, lbd=0.3), two_matrix]
+    for case in cases:
+        monkeypatch.setenv("SIMRANK_IDENTITY_LEG1", "0")
+        want = case()
+        monkeypatch.delenv("SIMRANK_IDENTITY_LEG1")
+        got = case()
+        for a, b in zip(got, want):
+            if isinstance(a, tuple):
+                assert a == b
+            else:
+                assert np.array_equal(a, b)

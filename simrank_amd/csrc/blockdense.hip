@@ -257,6 +257,9 @@ int build_dense_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
         ++n_blocks_dense;
         set_cols += (int64_t)set.size();
     }
+    // (a single-GPU plan whose leg 1 is the one-launch kernel: the only taker would be the upper-triangle leg 2, and it takes
+    // the plan only under this rule — spmm.hip, `dp && want_sym`)
+    if (g->tun.dense_lazy && !(g->tun.dense_sym > 0 || (g->tun.dense_sym < 0 && 2 * covered >= g->nnz))) return SIMRANK_OK;
     // Units: a workgroup per (unit, 256 output columns); an XCD works through a column block with
     // 64 resident workgroups, so no unit should be longer than 1/64 of the column block's work —
     // and none shorter than kUnitCols, because every unit costs a slab of partial sums.

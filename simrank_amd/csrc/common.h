@@ -84,6 +84,9 @@ struct Tuning {
     int64_t fuse_wgs = 4;    // (experiment build only) its resident workgroups per CU
     int64_t fuse_shards = 1; // ... also for the row-major column block of a sharded rank (result in the all-to-all's chunks)
     int64_t fuse_group = 3;  // ... and up to this many consecutive blocks without a set share a workgroup (1..4)
+    int64_t dense_lazy = 0;  // (set by simrank_plan_create, not a knob) the graph's only launch that could use the dense-block
+                             // plan is the upper-triangle leg 2: build it only if that leg would take it (dense_sym), i.e. skip
+                             // the 256-byte-per-column fragment image and its upload on power-law graphs (8 ms at N = 65536)
     int64_t dense_sym = -1;  // dense part in the upper-triangle form of leg 2: 1 yes, 0 no, -1 = when the
                              // dense sets hold at least half of the pattern's entries
 };

@@ -191,6 +191,13 @@ int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int
                 if (t.fuse_group == 3) t.fuse_group = 4;
             }
         }
+        // leg 1 = the one-launch kernel (fp16-held: always; f32: whenever spmm.hip's conditions hold), so the dense-block plan
+        // could only serve the upper-triangle leg 2: built only if that leg would take it
+        // (and only where that leg IS the upper-triangle one — knob on, 64 nodes or more — or stores transposed: asymmetric priors)
+        if (t.fuse == 1 && ((t.triangle && n >= 64) || p->asym) &&
+            (p->half || ((opt->dense_terms == 0 || opt->dense_terms == 3) && n <= t.fuse_max_rows &&
+                         (p->rows_pad + 1) * 128 < (int64_t(1) << 31))))
+            t.dense_lazy = 1;
         // The evidence counts (SimRank.py:311-320: common in-neighbours of the pattern; 1 - 2^-count in the epilogue) read the
         // CSR / CSC arrays only: they are queued as soon as those are on the device and run while the host threads still
         // build the tile, dense-block and one-launch plans (14 ms beside 30 at config 5).

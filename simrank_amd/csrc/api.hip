@@ -603,7 +603,6 @@ int graph_create_with(const Tuning& tun, int64_t n_rows, int64_t n_cols, int64_t
     SR_REQUIRE(rowptr && rowscale && (col || nnz == 0), "NULL CSR array");
     SR_REQUIRE(rowptr[0] == 0 && rowptr[n_rows] == nnz, "rowptr does not span [0, nnz]");
     int32_t max_row = 0;
-    std::vector<int32_t> t_rowptr(size_t(n_cols) + 1, 0);
     for (int64_t a = 0; a < n_rows; ++a) {
         SR_REQUIRE(rowptr[a + 1] >= rowptr[a], "rowptr not monotone at row %lld", (long long)a);
         max_row = std::max(max_row, rowptr[a + 1] - rowptr[a]);
@@ -612,11 +611,53 @@ int graph_create_with(const Tuning& tun, int64_t n_rows, int64_t n_cols, int64_t
                        col[j], (long long)a);
             SR_REQUIRE(j == rowptr[a] || col[j] > col[j - 1],
                        "columns of row %lld not strictly ascending", (long long)a);
-            // (the transposed pattern serves the evidence counts, which ignore rows without weight:
-            // `G > 0` in SimRank.py:315 — it lists live rows only)
-            if (rowscale[a] > 0.f) t_rowptr[size_t(col[j]) + 1]++;
         }
     }
+    simrank_graph* g = new simrank_graph;
+    g->tun = tun;
+    g->n_rows = n_rows;
+    g->n_cols = n_cols;
+    g->nnz = nnz;
+    g->max_row_nnz = max_row;
+    // plan builders on their own threads (each sets the device, keeps its own error text)
+    int dev = 0;
+#ifndef SIMRANK_HOST_ONLY
+    (void)hipGetDevice(&dev);
+#endif
+    struct Job { int rc = SIMRANK_OK; std::string err; std::thread th; double ms = 0; };
+    Job jobs[3];
+    const bool timed = std::getenv("SIMRANK_TIME_BUILD") != nullptr;     // diagnostic: builder durations on stderr
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    auto spawn = [&](Job& j, int (*fn)(simrank_graph*, const int32_t*, const int32_t*, const float*)) {
+        j.th = std::thread([&j, fn, g, rowptr, col, rowscale, dev, &since]() {
+#ifndef SIMRANK_HOST_ONLY
+            (void)hipSetDevice(dev);
+#endif
+            const double t0 = since();
+            j.rc = fn(g, rowptr, col, rowscale);
+            j.ms = since() - t0;
+            if (j.rc) j.err = simrank_last_error();
+        });
+    };
+    const bool big = nnz >= 20000;         // (threads cost more than they save on small graphs)
+    auto dense_job = [](simrank_graph* gg, const int32_t* rp, const int32_t* cl, const float*) { return build_dense_plan(gg, rp, cl); };
+    int n_jobs = 0;
+    if (big) {
+        if (g->tun.dense_min > 0 && nnz > 0) spawn(jobs[n_jobs++], dense_job);
+#ifdef SIMRANK_EXPERIMENT_FUSED2
+        if (g->tun.fuse == 2 && nnz > 0) spawn(jobs[n_jobs++], build_fused2_plan);
+#endif
+        if (g->tun.fuse) spawn(jobs[n_jobs++], build_fused_plan);
+    }
+    // (the plan builders above read the validated CSR only: the transposed pattern, the hub list and the tiles are worked out
+    // here, beside them)
+    std::vector<int32_t> t_rowptr(size_t(n_cols) + 1, 0);
+    // (the transposed pattern serves the evidence counts, which ignore rows without weight: `G > 0` in SimRank.py:315 — it
+    // lists live rows only)
+    for (int64_t a = 0; a < n_rows; ++a)
+        if (rowscale[a] > 0.f)
+            for (int32_t j = rowptr[a]; j < rowptr[a + 1]; ++j) t_rowptr[size_t(col[j]) + 1]++;
     for (int64_t i = 0; i < n_cols; ++i) t_rowptr[i + 1] += t_rowptr[i];
     std::vector<int32_t> t_col(std::max<size_t>(1, size_t(nnz)));
     // t_pos[j]: where entry j = (a, i) of the CSR sits in column i's list of the transposed pattern — the list is
@@ -631,12 +672,6 @@ int graph_create_with(const Tuning& tun, int64_t n_rows, int64_t n_cols, int64_t
                     t_col[cur[col[j]]++] = (int32_t)a;
                 }
     }
-    simrank_graph* g = new simrank_graph;
-    g->tun = tun;
-    g->n_rows = n_rows;
-    g->n_cols = n_cols;
-    g->nnz = nnz;
-    g->max_row_nnz = max_row;
     // HUB columns of the evidence counts (round 5; spmm.hip evidence_hub_kernel): a column with d live rows costs the
     // LDS-counter kernel d^2 / 2 paths (~1e11 paths/s) and one more column of the 0/1 image costs the matrix-core
     // kernel n_rows^2 multiply-adds (~1e15/s): from d >= 0.014 n_rows on (tuning "ev_hub", in 1/1000 of n_rows; 0 = off)
@@ -672,37 +707,6 @@ int graph_create_with(const Tuning& tun, int64_t n_rows, int64_t n_cols, int64_t
         }
         return SIMRANK_OK;
     };
-    // plan builders on their own threads (each sets the device, keeps its own error text)
-    int dev = 0;
-#ifndef SIMRANK_HOST_ONLY
-    (void)hipGetDevice(&dev);
-#endif
-    struct Job { int rc = SIMRANK_OK; std::string err; std::thread th; double ms = 0; };
-    Job jobs[3];
-    const bool timed = std::getenv("SIMRANK_TIME_BUILD") != nullptr;     // diagnostic: builder durations on stderr
-    const auto t_start = std::chrono::steady_clock::now();
-    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
-    auto spawn = [&](Job& j, int (*fn)(simrank_graph*, const int32_t*, const int32_t*, const float*)) {
-        j.th = std::thread([&j, fn, g, rowptr, col, rowscale, dev, &since]() {
-#ifndef SIMRANK_HOST_ONLY
-            (void)hipSetDevice(dev);
-#endif
-            const double t0 = since();
-            j.rc = fn(g, rowptr, col, rowscale);
-            j.ms = since() - t0;
-            if (j.rc) j.err = simrank_last_error();
-        });
-    };
-    const bool big = nnz >= 20000;         // (threads cost more than they save on small graphs)
-    auto dense_job = [](simrank_graph* gg, const int32_t* rp, const int32_t* cl, const float*) { return build_dense_plan(gg, rp, cl); };
-    int n_jobs = 0;
-    if (big) {
-        if (g->tun.dense_min > 0 && nnz > 0) spawn(jobs[n_jobs++], dense_job);
-#ifdef SIMRANK_EXPERIMENT_FUSED2
-        if (g->tun.fuse == 2 && nnz > 0) spawn(jobs[n_jobs++], build_fused2_plan);
-#endif
-        if (g->tun.fuse) spawn(jobs[n_jobs++], build_fused_plan);
-    }
     int rc = up((void**)&g->rowptr, rowptr, size_t(n_rows + 1) * 4);
     if (!rc) rc = up((void**)&g->col, col, size_t(nnz) * 4);
     if (!rc && n_cols <= 65536 && nnz > 0) {

@@ -3,7 +3,7 @@
 //
 // PIPELINED (both forms): the result is cut into row bands; band b is brought into the caller's order and packed on the
 // device (one simrank_permute_layout per band), copied into a pinned slab, and widened to float64 by a crew of host
-// threads while band b + 1 travels — two device and two pinned slabs.  Round 4 permuted the WHOLE matrix before the
+// threads while band b + 1 travels — three device and three pinned slabs.  Round 4 permuted the WHOLE matrix before the
 // first byte moved.  The crew is sized by the CPUs the process may really use (cgroup quota: 16 on the bench box — 64
 // threads took 3 x as long as 16 for the same work); its threads meet on atomics, a condition variable only when one of
 // them really has to wait.
@@ -137,10 +137,13 @@ void widen_rows(const float* slab, const Band& b, int64_t n, double* dst, int64_
     }
 }
 
+constexpr int kSlabs = 3;            // bands in flight: one being widened, one on the wire, one queued behind it (with two the copy
+                                     // engine idled between a band's last host thread and the next band's packing kernel: ~0.4 ms
+                                     // x 35 bands at N = 32768)
 struct Slabs {                       // kept per device for the life of the process (pinning memory is slow)
-    float* pin[2] = {nullptr, nullptr};
-    hipEvent_t done[2] = {nullptr, nullptr};       // band in its pinned slab
-    hipEvent_t packed[2] = {nullptr, nullptr};     // band packed in its device slab
+    float* pin[kSlabs] = {};
+    hipEvent_t done[kSlabs] = {};                  // band in its pinned slab
+    hipEvent_t packed[kSlabs] = {};                // band packed in its device slab
     hipEvent_t begin = nullptr;                    // the caller's stream has produced the source
     hipStream_t side = nullptr;                    // the packing kernels run here, beside the copies on the caller's stream
     size_t cap = 0;
@@ -290,7 +293,7 @@ int simrank_handback_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
     SR_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_slab_mutex);      // (one dense hand-back per process at a time: it uses every core)
     Slabs& sl = g_slabs[dev & 15];
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kSlabs; ++i) {
         if (!sl.done[i]) SR_HIP(hipEventCreateWithFlags(&sl.done[i], hipEventDisableTiming));
         if (!sl.packed[i]) SR_HIP(hipEventCreateWithFlags(&sl.packed[i], hipEventDisableTiming));
     }
@@ -299,19 +302,19 @@ int simrank_handback_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
     SR_HIP(hipEventRecord(sl.begin, st));
     SR_HIP(hipStreamWaitEvent(sl.side, sl.begin, 0));
     if (need > sl.cap) {
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < kSlabs; ++i) {
             if (sl.pin[i]) (void)hipHostFree(sl.pin[i]);
             sl.pin[i] = nullptr;
         }
         sl.cap = 0;
-        for (int i = 0; i < 2; ++i) SR_HIP(hipHostMalloc((void**)&sl.pin[i], need, hipHostMallocPortable));
+        for (int i = 0; i < kSlabs; ++i) SR_HIP(hipHostMalloc((void**)&sl.pin[i], need, hipHostMallocPortable));
         sl.cap = need;
     }
-    float* dev_slab[2] = {nullptr, nullptr};
-    for (int i = 0; i < 2; ++i) {
+    float* dev_slab[kSlabs] = {};
+    for (int i = 0; i < kSlabs; ++i) {
         const int rc = pool_alloc((void**)&dev_slab[i], need);
         if (rc) {
-            (void)pool_free(dev_slab[0]);
+            for (int k = 0; k < i; ++k) (void)pool_free(dev_slab[k]);
             return rc;
         }
     }
@@ -333,20 +336,22 @@ int simrank_handback_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
             s = src_rows_pad > 0 ? src + ((bd.c0 >> 5) * src_rows_pad + bd.r0) * 32 : src + bd.r0 * ld_src + bd.c0;
         // (the packing kernel of band b + 2 runs on the side stream while band b + 1 is still on the wire: on one stream
         // every band's copy waited for the next band's kernel — 35 x 0.2 ms at N = 32768)
-        int rc = simrank_permute_layout(s, ld_src, src_rows_pad, dev_slab[b & 1], bd.pitch, 0, bd.nr, w, ri, ci, 4, sl.side);
+        const int k = int(b % kSlabs);
+        int rc = simrank_permute_layout(s, ld_src, src_rows_pad, dev_slab[k], bd.pitch, 0, bd.nr, w, ri, ci, 4, sl.side);
         if (rc) return rc;
-        SR_HIP(hipEventRecord(sl.packed[b & 1], sl.side));
-        SR_HIP(hipStreamWaitEvent(st, sl.packed[b & 1], 0));
-        SR_HIP(hipMemcpyAsync(sl.pin[b & 1], dev_slab[b & 1], size_t(bd.nr) * size_t(bd.pitch) * 4, hipMemcpyDeviceToHost, st));
-        SR_HIP(hipEventRecord(sl.done[b & 1], st));
+        SR_HIP(hipEventRecord(sl.packed[k], sl.side));
+        SR_HIP(hipStreamWaitEvent(st, sl.packed[k], 0));
+        SR_HIP(hipMemcpyAsync(sl.pin[k], dev_slab[k], size_t(bd.nr) * size_t(bd.pitch) * 4, hipMemcpyDeviceToHost, st));
+        SR_HIP(hipEventRecord(sl.done[k], st));
         return SIMRANK_OK;
     };
     const char* nt_env = std::getenv("SIMRANK_HANDBACK_NT");
     const bool nt_stores = nt_env ? (*nt_env && *nt_env != '0') : true;
     auto widen = [&](int64_t b, int64_t t, int64_t nt) {
-        if (sym) widen_band(sl.pin[b & 1], bands[(size_t)b], n, dst, ld_dst, t, nt);
-        else if (nt_stores) widen_rows<true>(sl.pin[b & 1], bands[(size_t)b], n, dst, ld_dst, t, nt);
-        else widen_rows<false>(sl.pin[b & 1], bands[(size_t)b], n, dst, ld_dst, t, nt);
+        const float* slab = sl.pin[b % kSlabs];
+        if (sym) widen_band(slab, bands[(size_t)b], n, dst, ld_dst, t, nt);
+        else if (nt_stores) widen_rows<true>(slab, bands[(size_t)b], n, dst, ld_dst, t, nt);
+        else widen_rows<false>(slab, bands[(size_t)b], n, dst, ld_dst, t, nt);
     };
     // (16 threads: 93 ms for N = 32768 on the bench box, 32: 111 - 116 — its quota is 16 CPUs — 8: 104; profiles/r05_handback_knobs.log)
     int64_t nt = std::max<int64_t>(1, std::min<int64_t>({16, cpu_share(), (n + 4 * kGroup - 1) / (4 * kGroup),
@@ -390,12 +395,12 @@ int simrank_handback_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
             nt = 1;
         }
     }
-    int rc = issue(0);
-    if (!rc && nb > 1) rc = issue(1);
+    int rc = SIMRANK_OK;
+    for (int64_t b = 0; b < std::min<int64_t>(nb, kSlabs) && !rc; ++b) rc = issue(b);
     double t_wait_dev = 0, t_wait_host = 0;
     for (int64_t b = 0; b < nb && !rc; ++b) {
         const double a = since();
-        const hipError_t e = hipEventSynchronize(sl.done[b & 1]);
+        const hipError_t e = hipEventSynchronize(sl.done[b % kSlabs]);
         t_wait_dev += since() - a;
         if (e != hipSuccess) {
             set_error("simrank_handback_f64: %s", hipGetErrorString(e));
@@ -411,12 +416,12 @@ int simrank_handback_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
                 ready.store(b + 1, std::memory_order_release);
             }
             cv.notify_all();
-            // slab b & 1 is free for band b + 2 once every thread is through with band b
+            // slab b % kSlabs is free for band b + kSlabs once every thread is through with band b
             std::unique_lock<std::mutex> lk(m);
             cv.wait(lk, [&] { return finished[(size_t)b].load(std::memory_order_acquire) == nt; });
         }
         t_wait_host += since() - c;
-        if (b + 2 < nb) rc = issue(b + 2);
+        if (b + kSlabs < nb) rc = issue(b + kSlabs);
     }
     if (nt > 1) {
         {
@@ -428,8 +433,7 @@ int simrank_handback_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
     }
     (void)hipStreamSynchronize(sl.side);
     (void)hipStreamSynchronize(st);
-    (void)pool_free(dev_slab[0]);
-    (void)pool_free(dev_slab[1]);
+    for (int i = 0; i < kSlabs; ++i) (void)pool_free(dev_slab[i]);
     const double t_bands = since();
     // ---- 3. the diagonal blocks of the source order, both triangles, where the caller's order puts them
     if (!rc && sym) {

@@ -310,8 +310,10 @@ int simrank_handback_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
         for (int i = 0; i < kSlabs; ++i) SR_HIP(hipHostMalloc((void**)&sl.pin[i], need, hipHostMallocPortable));
         sl.cap = need;
     }
+    // (SIMRANK_HANDBACK_SLABS=2: the two-slab pipeline of the first version, for A/B runs)
+    static const int n_slabs = [] { const char* e = std::getenv("SIMRANK_HANDBACK_SLABS"); return e && std::atoi(e) == 2 ? 2 : kSlabs; }();
     float* dev_slab[kSlabs] = {};
-    for (int i = 0; i < kSlabs; ++i) {
+    for (int i = 0; i < n_slabs; ++i) {
         const int rc = pool_alloc((void**)&dev_slab[i], need);
         if (rc) {
             for (int k = 0; k < i; ++k) (void)pool_free(dev_slab[k]);
@@ -336,7 +338,7 @@ int simrank_handback_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
             s = src_rows_pad > 0 ? src + ((bd.c0 >> 5) * src_rows_pad + bd.r0) * 32 : src + bd.r0 * ld_src + bd.c0;
         // (the packing kernel of band b + 2 runs on the side stream while band b + 1 is still on the wire: on one stream
         // every band's copy waited for the next band's kernel — 35 x 0.2 ms at N = 32768)
-        const int k = int(b % kSlabs);
+        const int k = int(b % n_slabs);
         int rc = simrank_permute_layout(s, ld_src, src_rows_pad, dev_slab[k], bd.pitch, 0, bd.nr, w, ri, ci, 4, sl.side);
         if (rc) return rc;
         SR_HIP(hipEventRecord(sl.packed[k], sl.side));
@@ -348,7 +350,7 @@ int simrank_handback_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
     const char* nt_env = std::getenv("SIMRANK_HANDBACK_NT");
     const bool nt_stores = nt_env ? (*nt_env && *nt_env != '0') : true;
     auto widen = [&](int64_t b, int64_t t, int64_t nt) {
-        const float* slab = sl.pin[b % kSlabs];
+        const float* slab = sl.pin[b % n_slabs];
         if (sym) widen_band(slab, bands[(size_t)b], n, dst, ld_dst, t, nt);
         else if (nt_stores) widen_rows<true>(slab, bands[(size_t)b], n, dst, ld_dst, t, nt);
         else widen_rows<false>(slab, bands[(size_t)b], n, dst, ld_dst, t, nt);
@@ -396,11 +398,11 @@ int simrank_handback_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
         }
     }
     int rc = SIMRANK_OK;
-    for (int64_t b = 0; b < std::min<int64_t>(nb, kSlabs) && !rc; ++b) rc = issue(b);
+    for (int64_t b = 0; b < std::min<int64_t>(nb, n_slabs) && !rc; ++b) rc = issue(b);
     double t_wait_dev = 0, t_wait_host = 0;
     for (int64_t b = 0; b < nb && !rc; ++b) {
         const double a = since();
-        const hipError_t e = hipEventSynchronize(sl.done[b % kSlabs]);
+        const hipError_t e = hipEventSynchronize(sl.done[b % n_slabs]);
         t_wait_dev += since() - a;
         if (e != hipSuccess) {
             set_error("simrank_handback_f64: %s", hipGetErrorString(e));
@@ -421,7 +423,7 @@ int simrank_handback_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
             cv.wait(lk, [&] { return finished[(size_t)b].load(std::memory_order_acquire) == nt; });
         }
         t_wait_host += since() - c;
-        if (b + kSlabs < nb) rc = issue(b + kSlabs);
+        if (b + n_slabs < nb) rc = issue(b + n_slabs);
     }
     if (nt > 1) {
         {

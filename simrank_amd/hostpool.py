@@ -19,7 +19,7 @@ import weakref
 
 import numpy as np
 
-_lock = threading.Lock()
+_lock = threading.RLock()         # (re-entrant: a frame's finalizer can run inside a collection that starts under the lock)
 _free: dict[int, list] = {}        # bytes -> mappings at rest
 _rest = 0                          # bytes at rest
 MIN_BYTES = 64 << 20               # smaller frames are not worth keeping

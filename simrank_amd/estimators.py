@@ -110,12 +110,27 @@ def _make_solver(ops_factory, device, world, specs, mode):
     return Solver(factory, world, specs, mode)
 
 
+_engines = threading.local()        # the default engine of a (thread, device): its stream, counters and slots made once
+
+
 def _default_ops_factory(device):
     from .engine import HipOps          # raises if the library or the GPU is missing
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
-    ops = HipOps(device)
+    cache = _engines.__dict__.setdefault("by_device", {})
+    ops = cache.get(device)
+    if ops is None:
+        # (4 ms per fit otherwise — stream, counter set, pinned slots; one per thread, so that two threads fitting at once never
+        # share a stream or a convergence counter)
+        ops = cache[device] = HipOps(device)
     return lambda rank: ops
+
+
+def _square_frame(S, labels):
+    """``pd.DataFrame(S, index=labels, columns=labels)`` (SimRank.py:141) with the labels converted once instead of twice
+    (7 ms for 32768 of them); the two axes are separate Index objects, as the reference's."""
+    idx = pd.Index(labels)
+    return pd.DataFrame(S, index=idx, columns=idx.copy())
 
 
 def _solve(specs, iterations, eps, verbose, mode, device, world, ops_factory=None):
@@ -209,7 +224,7 @@ class SimRank(object):
         solver.release()
         if S is None:                     # multi-process world, root-only hand-back: not the root
             return None
-        return pd.DataFrame(S, index=self._order, columns=self._order)
+        return _square_frame(S, self._order)
 
     def fit(self, data, C=0.8, weighted=False, from_node_column="from", to_node_column="to",
             weight_column="weight", iterations=100, eps=1e-4, verbose=True, *,
@@ -339,7 +354,7 @@ class BipartiteSimRank(object):
         solver.release()
         if S1 is None:                    # multi-process world, root-only hand-back: not the root
             return None
-        return (pd.DataFrame(S1, index=l1, columns=l1), pd.DataFrame(S2, index=l2, columns=l2))
+        return (_square_frame(S1, l1), _square_frame(S2, l2))
 
     def fit(self, data, C1=0.8, C2=0.8, weighted=False, node_group1_column="user",
             node_group2_column="item", weight_column="weight", iterations=100, eps=1e-4,

@@ -132,6 +132,7 @@ inline hipError_t pool_hip_alloc(void** p, size_t bytes) {       // (for call si
 
 // spmm.hip: (W . I)^T = W^T into a panel-blocked matrix of n_cols(g) rows x n_rows(g) columns — leg 1 of a fit's first update
 int identity_leg1_blocked(const simrank_graph* g, float* Tt, int64_t t_rows_pad, void* stream);
+int identity_leg1_blocked_h16(const simrank_graph* g, uint16_t* Tt, int64_t t_rows_pad, float scale, void* stream);
 
 // planprep.hip: the host-only half of the plans (validation, solver node order, renamed patterns)
 struct PlanPrep {

@@ -70,11 +70,12 @@ static int leg_pair(simrank_plan* p, double eps, int32_t exact_count, int slot) 
     const bool timed = p->timing && p->ev_pool.size() >= 3;
     if (timed) { const int rs = stamp(p); if (rs) return rs; }
     // (the first update of a fit multiplies by the identity: W^T is written directly — the same bits without a gather)
-    const bool from_identity = p->at_identity && p->identity_leg1 && !p->half;
+    const bool from_identity = p->at_identity && p->identity_leg1;
     p->at_identity = 0;
-    int rc = p->half ? simrank_spmm_blocked_h16(p->g, p->S[p->cur], p->rows_pad, p->n, p->Tt, p->rows_pad, 1, nullptr,
-                                                0, kHalfScale, p->stream)
-             : from_identity ? identity_leg1_blocked(p->g, p->Tt, p->rows_pad, p->stream)
+    int rc = from_identity ? (p->half ? identity_leg1_blocked_h16(p->g, reinterpret_cast<uint16_t*>(p->Tt), p->rows_pad, kHalfScale, p->stream)
+                                      : identity_leg1_blocked(p->g, p->Tt, p->rows_pad, p->stream))
+             : p->half ? simrank_spmm_blocked_h16(p->g, p->S[p->cur], p->rows_pad, p->n, p->Tt, p->rows_pad, 1, nullptr,
+                                                  0, kHalfScale, p->stream)
                      : simrank_spmm_blocked(p->g, p->S[p->cur], p->rows_pad, p->n, p->Tt, p->rows_pad, 1, nullptr,
                                             p->stream);
     if (rc) return rc;

@@ -2300,7 +2300,33 @@ __global__ __launch_bounds__(256) void identity_leg1_kernel(const int32_t* __res
     }
 }
 
+// the same for fp16-held matrices (half.hip: value x scale on 64-column panels): what its leg 1 stores for S_0 = I is the fp16
+// nearest to scale * rowscale[a] (f32 sum of one stored 1.0 x scale, times the row scale, one rounding)
+__global__ __launch_bounds__(256) void identity_leg1_h16_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                const float* __restrict__ rowscale, int64_t n_rows,
+                                                                uint16_t* __restrict__ Tt, int64_t t_rows_pad, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * int64_t(blockDim.x) + threadIdx.x) >> 6;
+    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    for (int64_t a = wave; a < n_rows; a += nwaves) {
+        const uint16_t v = __builtin_bit_cast(uint16_t, _Float16(scale * rowscale[a]));
+        uint16_t* base = Tt + ((a >> 6) * t_rows_pad) * 64 + (a & 63);       // column a of Tt: element (i, a) at base + 64 i
+        for (int j = rowptr[a] + lane; j < rowptr[a + 1]; j += 64) base[int64_t(col[j]) * 64] = v;
+    }
+}
+
 namespace simrank {
+int identity_leg1_blocked_h16(const simrank_graph* g, uint16_t* Tt, int64_t t_rows_pad, float scale, void* stream) {
+    SR_REQUIRE(g && Tt && t_rows_pad >= g->n_cols, "bad identity product");
+    const size_t bytes = size_t((g->n_rows + 63) / 64) * size_t(t_rows_pad) * 64 * sizeof(uint16_t);
+    SR_HIP(hipMemsetAsync(Tt, 0, bytes, as_stream(stream)));
+    const int grid = (int)std::min<int64_t>((g->n_rows + 3) / 4, 256 * 8);
+    hipLaunchKernelGGL(identity_leg1_h16_kernel, dim3(grid), dim3(256), 0, as_stream(stream), g->rowptr, g->col, g->rowscale,
+                       g->n_rows, Tt, t_rows_pad, scale);
+    SR_HIP(hipGetLastError());
+    return SIMRANK_OK;
+}
+
 int identity_leg1_blocked(const simrank_graph* g, float* Tt, int64_t t_rows_pad, void* stream) {
     SR_REQUIRE(g && Tt && t_rows_pad >= g->n_cols, "bad identity product");
     const size_t bytes = size_t((g->n_rows + 31) / 32) * size_t(t_rows_pad) * 32 * sizeof(float);

@@ -413,7 +413,8 @@ def test_first_update_from_the_identity_without_gathers(ops, monkeypatch):
         p.free()
         return outs
     cases = [lambda: directed(), lambda: directed(evidence=True), lambda: directed(evidence=True, apriori=sym, lbd=0.3),
-             lambda: directed(evidence=True, apriori=asym, lbd=0.3), two_matrix]
+             lambda: directed(evidence=True, apriori=asym, lbd=0.3), two_matrix,
+             lambda: directed(storage="fp16"), lambda: directed(evidence=True, storage="fp16")]      # fp16-held: the same rounding
     for case in cases:
         monkeypatch.setenv("SIMRANK_IDENTITY_LEG1", "0")
         want = case()

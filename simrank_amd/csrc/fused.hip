@@ -960,6 +960,20 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
         }
     }
 
+    if (const char* dump = std::getenv("SIMRANK_DUMP_FUSED_PLAN")) {
+        // Measurement aid (tools/micro/gather_depth.hip): the unit records and the id streams of the gather phase as the
+        // launch reads them, so that a stand-alone kernel can replay the REAL access pattern.  Header of eight int64, then
+        // units[n_units][32], sids[n_rounds][64] (int32, -1 = empty slot), dcols[n_quads][64].
+        if (FILE* f = std::fopen(dump, "wb")) {
+            const int64_t hdr[8] = {0x53524450, M, K, (int64_t)(units.size() / 32), (int64_t)(sids.size() / 64),
+                                    (int64_t)(dcols.size() / 64), r_nnz, covered};
+            std::fwrite(hdr, sizeof(int64_t), 8, f);
+            std::fwrite(units.data(), sizeof(int32_t), units.size(), f);
+            std::fwrite(sids.data(), sizeof(int32_t), sids.size(), f);
+            std::fwrite(dcols.data(), sizeof(int32_t), dcols.size(), f);
+            std::fclose(f);
+        }
+    }
     simrank_fused_plan* pl = new simrank_fused_plan;
     pl->n_units = (int32_t)(units.size() / 32);
     pl->n_blocks = (int32_t)nblk;

@@ -90,6 +90,124 @@ def config_roofline(key, legs, note=None):
     return top
 
 
+
+# ---- the printed line (round 6): numbers first, <= 8 KB.  The driver keeps the TAIL of what bench.py prints; a 30 KB line
+# of prose left it with the middle of `config5`.  So: the contract keys, then `summary` (every BASELINE config's it/s, ms,
+# roofline fraction and traffic ratio), `fit_wall_s`, `converge`, then the per-variant detail with every prose string
+# removed (what each key means is in profiles/bench_notes.md) and floats cut to five significant digits; sections are
+# dropped from the end of a priority list while the line is still longer than LINE_LIMIT (named under "dropped").
+# The complete record — prose included — goes to --full-json (default gpurun_out/bench_full.json when that can be written).
+LINE_LIMIT = 8000
+KEEP_STRINGS = {"metric", "unit", "scaling", "dtype", "data", "bound", "kind", "leg2_form", "form", "error", "headline_loop",
+                "python_world_error", "skipped", "workload", "sample", "kernel"}
+DROP_ORDER = ["mfma_dense_leg", "roofline_other", "continuity_pl32768", "shards_emulated_p8", "convergence_test",
+              "sharded_c_loop", "config5", "bipartite_pp", "secondary", "roofline_mfma", "fit_wall"]
+
+
+def _num(x):
+    return float(f"{x:.5g}") if isinstance(x, float) else x
+
+
+def _strip(o, key=None):
+    if isinstance(o, dict):
+        out = {}
+        for k, v in o.items():
+            if isinstance(v, str) and (k not in KEEP_STRINGS or len(v) > 160):
+                continue
+            out[k] = _strip(v, k)
+        return out
+    if isinstance(o, (list, tuple)):
+        return [_strip(x, key) for x in o]
+    return _num(o)
+
+
+def _roof(r):
+    """(leg-1 frac, leg-2 frac, leg-1 traffic / algorithmic) of a `roofline` object whose slower launch comes first."""
+    if not isinstance(r, dict):
+        return None, None, None
+    legs = [r] + list(r.get("other") or [])
+    f1 = f2 = t1 = None
+    for o in legs:
+        name = str(o.get("kernel", ""))
+        if "leg 2" in name or "leg2" in name:
+            f2 = o.get("frac")
+        else:
+            f1, t1 = o.get("frac"), o.get("traffic_over_algorithmic")
+    return f1, f2, t1
+
+
+def summary_of(out):
+    """Every BASELINE config on one screen: it/s, ms per update, HBM roofline fraction of both legs, leg-1 traffic ratio."""
+    def row(value, ms, roof, **extra):
+        f1, f2, t1 = _roof(roof)
+        r = {"it_s": value, "ms": ms, "leg1_frac": f1, "leg2_frac": f2, "leg1_traffic_x": t1}
+        r.update(extra)
+        return {k: v for k, v in r.items() if v is not None}
+    s = {}
+    sec, bp, c5 = out.get("secondary") or {}, out.get("bipartite_pp") or {}, out.get("config5") or {}
+    if sec:
+        fl = sec.get("fit_loop") or {}
+        s["cfg2_er8192"] = row(fl.get("value", sec.get("value")), fl.get("ms_per_step", sec.get("ms_per_step")), sec.get("roofline"),
+                               it_s_step_by_step=sec.get("value"))
+    if bp:
+        fl = bp.get("fit_loop") or {}
+        s["cfg3_ml1m_bipartite_pp"] = row(fl.get("value", bp.get("value")), fl.get("ms_per_step", bp.get("ms_per_step")),
+                                          bp.get("roofline"), it_s_step_by_step=bp.get("value"))
+    hr = dict(out.get("roofline") or {})
+    if hr:
+        hr = dict(hr, kernel="leg 1", other=[dict(out.get("roofline_other") or {}, kernel="leg 2")] if out.get("roofline_other") else [])
+        if hr.get("traffic") and hr.get("algorithmic_bytes"):
+            hr["traffic_over_algorithmic"] = hr["traffic"] / hr["algorithmic_bytes"]
+    s["cfg4_" + str((out.get("config") or {}).get("name", "headline"))] = row(out.get("value"), out.get("ms_per_step"), hr or None)
+    for key, name in (("f32_exact_dense_blocks", "cfg5_pl65536_pp_f32"), ("fp16_storage", "cfg5_pl65536_pp_fp16_held")):
+        v = c5.get(key) or {}
+        if v:
+            s[name] = row(v.get("value"), v.get("ms_per_step"), v.get("roofline"))
+    return s
+
+
+def compact_line(out, limit=LINE_LIMIT):
+    head_keys = ["metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "gpu_over_cpu"]
+    line = {k: _strip(out[k], k) for k in head_keys if k in out}
+    for k, v in out.items():
+        if k not in line and k != "converge":
+            line[k] = _strip(v, k)
+    tail = {"summary": _strip(summary_of(out))}
+    fw = out.get("fit_wall") or {}
+    if fw:
+        tail["fit_wall_s"] = {k: _num(v.get("fit_wall_s")) for k, v in fw.items() if isinstance(v, dict) and "fit_wall_s" in v}
+    if "converge" in out:
+        tail["converge"] = _strip(out["converge"])
+    dropped = []
+
+    def text_of():
+        d = dict(line)
+        if dropped:
+            d["dropped"] = dropped
+        d.update(tail)                       # (last: the driver's record keeps the TAIL of what is printed)
+        return json.dumps(d, default=str, separators=(",", ":"))
+    text = text_of()
+    for k in DROP_ORDER:
+        if len(text) <= limit:
+            break
+        if k in line:
+            del line[k]
+            dropped.append(k)
+            text = text_of()
+    return text
+
+
+def write_full(out, path):
+    if not path:
+        return
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(out, f, default=str)
+    except OSError:
+        pass
+
 def cpu_share():
     """CPUs this process may actually use: the affinity mask, cut by the cgroup's quota (the GPU boxes show 256 hardware
     threads and grant 16 CPUs of time: cpu.max = "1600000 100000")."""
@@ -149,11 +267,8 @@ def cpu_baseline(csr, S_host, coef, budget_s=45.0):
     per_iter = (t_update + t_rest) * n / rows
     return {"value": 1.0 / per_iter, "unit": "iterations/s", "cores": int(threads),
             "kind": "port",
-            "sample": f"oracle dense f64 update (2 dgemm + copy + convergence test) of rows "
-                      f"0..{rows - 1} of one N={n} iteration: {t_update + t_rest:.2f} s, "
-                      f"scaled x{n / rows:.1f} to a full iteration ({per_iter:.1f} s); "
-                      f"host cpu_count={os.cpu_count()}, CPUs granted to this process (affinity + cgroup quota) "
-                      f"{share}, BLAS threads {threads}"}
+            "sample": f"oracle dense f64 update, rows 0..{rows - 1} of N={n}: {t_update + t_rest:.2f} s x{n / rows:.1f} = "
+                      f"{per_iter:.1f} s/iteration; {share} CPUs granted of {os.cpu_count()}, BLAS threads {threads}"}
 
 
 def c_loop_section(args, ops, world, dist, torch, synth, ingest, csr, coef, gpu, barrier, rank, out=None):
@@ -338,7 +453,7 @@ def c_loop_only(err):
     def give_up():
         out["sharded_c_loop"]["error"] = f"watchdog: not finished after {deadline:.0f} s"
         if rank == 0:
-            st["emit"](json.dumps(out, default=str))
+            st["emit"](compact_line(out))
         os._exit(3)
     dog = threading.Timer(deadline, give_up)
     dog.daemon = True
@@ -361,7 +476,8 @@ def c_loop_only(err):
         out["value"], out["ms_per_step"] = best[1]["value"], best[1]["ms_per_step"]
         out["headline_loop"] = f"simrank_shardplan_step behind the C ABI, {best[0]} (the Python world failed: python_world_error)"
     if rank == 0:
-        st["emit"](json.dumps(out, default=str))
+        write_full(out, getattr(args, "full_json", None))
+        st["emit"](compact_line(out))
     try:
         st["dist"].destroy_process_group()
     except Exception:
@@ -379,6 +495,8 @@ def main():
     ap.add_argument("--panel", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--full-json", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"),
+                    help="where the complete record (prose notes included) is written; the printed line is its compact form")
     ap.add_argument("--exact-only", action="store_true",
                     help="skip the extra steps with the short-circuit convergence test (profiling runs: every leg-2 "
                          "dispatch is then of the timed, exact-count form)")
@@ -583,11 +701,12 @@ def main():
                                 "the variants above it are what had been measured; value = the Python world's loop")
             if rank == 0:
                 try:
-                    line = json.dumps(out, default=str)
+                    line = compact_line(out)
                 except Exception:
-                    line = json.dumps({k: v for k, v in out.items() if k != "sharded_c_loop"}, default=str)
+                    line = compact_line({k: v for k, v in out.items() if k != "sharded_c_loop"})
                 emit(line)
-            os._exit(0)
+            # (a hung run must not read as a pass: torchrun, launch_ranks() and tools/gpu_final.sh look at the exit code)
+            os._exit(3)
         dog = threading.Timer(deadline, give_up)
         dog.daemon = True
         dog.start()
@@ -1160,9 +1279,13 @@ def main():
             try:
                 # the same fit through the C-level plan: create (graph + plans + matrices), run to eps, f64 hand-back
                 from simrank_amd.engine import Plan
-                _, csr4 = ingest.directed(df4, False, "from", "to", "weight")
+                # (round 6: the split now holds everything fit() does — edge list -> CSR before, the labelled DataFrame after —
+                # so its parts add up to the wall clock of the class surface, the line above)
+                import pandas as pd
                 best, calls = None, []
                 for rep in range(4):                 # (a warm call, then the fastest of three, as timed_fit)
+                    ti = time.perf_counter()
+                    labels4, csr4 = ingest.directed(df4, False, "from", "to", "weight")
                     t0 = time.perf_counter()
                     plan = Plan(ops, csr4, coef=0.8)
                     t1 = time.perf_counter()
@@ -1170,14 +1293,18 @@ def main():
                     t2 = time.perf_counter()
                     res4 = plan.result()
                     t3 = time.perf_counter()
+                    frame4 = pd.DataFrame(res4, index=list(labels4), columns=list(labels4), copy=False)
+                    t4 = time.perf_counter()
                     plan.free()
                     if rep:
-                        calls.append(t3 - t0)
-                        if best is None or t3 - t0 < best["fit_wall_s"]:
-                            best = dict(fit_wall_s=t3 - t0, create_s=t1 - t0, run_s=t2 - t1, result_f64_s=t3 - t2, converged_at=conv)
-                    del res4
+                        calls.append(t4 - ti)
+                        if best is None or t4 - ti < best["fit_wall_s"]:
+                            best = dict(fit_wall_s=t4 - ti, ingest_s=t0 - ti, create_s=t1 - t0, run_s=t2 - t1,
+                                        result_f64_s=t3 - t2, frame_s=t4 - t3, converged_at=conv)
+                    frame4 = None
+                    del res4, frame4
                 best["calls_s"] = calls
-                walls["cfg4_SimRank_pl32768d32_full_handback_c_plan"] = best
+                walls["cfg4_SimRank_pl32768d32_c_plan_split"] = best
                 csr5p = ingest.directed(synth.WORKLOADS["pl65536"][0](), False, "from", "to", "weight")[1]
                 tc = []
                 for _ in range(2):
@@ -1189,7 +1316,7 @@ def main():
                                                        "note": "N = 65536 SimRank++: graph + plans + evidence counts + three 17 GiB "
                                                                "matrices; the second call takes them from the library's block pool"}
             except Exception as e:
-                walls["cfg4_SimRank_pl32768d32_full_handback_c_plan"] = {"error": f"{type(e).__name__}: {e}"}
+                walls["cfg4_SimRank_pl32768d32_c_plan_split"] = {"error": f"{type(e).__name__}: {e}"}
             df3 = synth.WORKLOADS["ml1m"][0]()
             timed_fit("cfg3_BipartiteSimRankPP_ml1m_full_handback", SRA.BipartiteSimRankPP, df3, strict_reference=False)
             df5 = synth.WORKLOADS["pl65536"][0]()
@@ -1314,7 +1441,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(csr, S_host, coef)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
-        emit(json.dumps(out))
+        write_full(out, args.full_json)
+        emit(compact_line(out))
     STATE["emitted"] = True
     if use_dist:
         dist.destroy_process_group()

@@ -604,8 +604,9 @@ SIMRANK_API int simrank_shardplan_destroy(simrank_shardplan* p);
  *      body in strict order (the group-2 update consumes the NEW S1, :300-302), the loop ends when neither matrix moved
  *      (:289).  `options` as for simrank_biplan_create (evidence in its corrected form unless strict_reference: quirk Q2,
  *      incl. NumPy's broadcast error at the first group-2 update); leg2_form / stages / wire_fp16 as in
- *      simrank_shardplan_options, the half form taken group by group where that group's size allows it.  Symmetric
- *      priors only.  simrank_shardbiplan_side hands out group 1 | 2's plan for the hand-back entry points of the
+ *      simrank_shardplan_options, the half form taken group by group where that group's size allows it.  A prior that
+ *      is not symmetric (either group) makes both iterates asymmetric: f32, leg 2 in its full form, its product sent
+ *      round a second all-to-all (as simrank_shardplan_create).  simrank_shardbiplan_side hands out group 1 | 2's plan for the hand-back entry points of the
  *      single-matrix plan (simrank_shardplan_result_f64 / _block_f64 / _columns / _topk / _info / _set_timing) — it
  *      stays owned by the pair. */
 typedef struct simrank_shardbiplan simrank_shardbiplan;

@@ -4,8 +4,8 @@
 (``simrank_biplan_*``: :288-303, :410-425, :478-493) the few methods ``estimators.py`` asks of a solver — ``run`` with
 the reference's console hooks, ``result``, ``topk``, ``evidence``, ``release`` — so that what a user imports runs the
 fastest loop the library has: both legs and the count of an update queued by one C call, update k + 1 queued before the
-count of update k is read on small graphs, and a hand-back that moves only the upper triangle of the (bitwise
-symmetric) result over PCIe (csrc/handback.hip).
+count of update k is read on small graphs, and a banded hand-back (csrc/handback.hip: full form by default; the
+upper-triangle form is opt-in, ``SIMRANK_SYM_HANDBACK=1``, and checks on the device that the result is symmetric).
 
 An asymmetric prior (``SimRank.py:453``: asymmetric iterates) runs in the same plans with leg 2 stored transposed and the
 epilogue as a pass of its own.  ``driver.Solver`` (the same choreography in Python) stays for what a plan does not run: the

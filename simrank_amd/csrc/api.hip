@@ -337,6 +337,9 @@ int simrank_free(void* dptr) {
 
 int simrank_pool_trim(int device) {
     pool_trim(device);
+#ifndef SIMRANK_HOST_ONLY
+    handback_release_slabs(device);
+#endif
     return SIMRANK_OK;
 }
 
@@ -762,6 +765,9 @@ int simrank_graph_destroy(simrank_graph* g) {
     plan_free(g->t_pos);
     plan_free(g->ev_hubidx);
     plan_free(g->ev_hub_image);
+#ifndef SIMRANK_HOST_ONLY
+    if (g->ev_hub_ready) (void)hipEventDestroy((hipEvent_t)g->ev_hub_ready);
+#endif
     plan_free(g->tile_row0);
     plan_free(g->sym_map);
     free_dense_plan(g->dense);

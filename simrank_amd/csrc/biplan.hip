@@ -368,7 +368,7 @@ int simrank_biplan_result_f64(simrank_biplan* p, int32_t group, double* dst, int
     side_t& a = p->s[group - 1];
     SR_REQUIRE(ld >= a.n, "ld %lld < n", (long long)ld);
     SR_REQUIRE(a.S[0], "the plan's matrices were released (simrank_biplan_trim)");
-    // dst[i][j] = S[inv[i]][inv[j]]; the iterates are bitwise symmetric: upper triangle over PCIe, mirrored on the host
+    // dst[i][j] = S[inv[i]][inv[j]], full form (mode 0: every element crosses PCIe; asymmetric priors give asymmetric iterates)
     const int rc = simrank_handback_f64(dst, ld, a.S[a.cur], 32, a.rows_pad, a.n, a.inv, 0, p->stream);
     (void)hipStreamSynchronize(p->stream);
     return rc;

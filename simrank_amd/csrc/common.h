@@ -125,6 +125,7 @@ int pool_alloc(void** dptr, size_t bytes);
 int pool_free(void* ptr);
 void pool_trim(int device);          // -1: every device
 void pool_stats(int device, int64_t* cached_bytes, int64_t* cached_blocks, int64_t* limit_bytes);
+void handback_release_slabs(int device);   // handback.hip: the pinned slabs of the f64 hand-back (-1: every device)
 inline hipError_t pool_hip_alloc(void** p, size_t bytes) {       // (for call sites that speak hipError_t)
     const int rc = pool_alloc(p, bytes);
     return rc == SIMRANK_OK ? hipSuccess : (rc == SIMRANK_ERR_ALLOC ? hipErrorOutOfMemory : hipErrorUnknown);
@@ -323,6 +324,7 @@ struct simrank_graph {
     int32_t* ev_hubidx = nullptr; // [n_cols]    index of a HUB column in the 0/1 image of the evidence counts, -1: none
     int32_t ev_hubs = 0;          // columns of that image (a multiple of 32; 0: no hub columns)
     uint8_t* ev_hub_image = nullptr;  // [rows padded to 128][ev_hubs] the image itself, built at the first evidence call
+    void* ev_hub_ready = nullptr;     // hipEvent_t recorded behind that build: an evidence call on ANOTHER stream waits for it
     int32_t max_row_nnz = 0;
     // balanced tiling of the rows (api.hip: build_tiles): tile t = rows [tile_row0[t],
     // tile_row0[t+1]) — 32-row blocks, the heavy ones cut into aligned halves — and, for the

@@ -212,6 +212,25 @@ int64_t cpu_share() {
 }
 
 }  // namespace
+
+// The pinned slabs (3 x 128 MiB and more per device) are kept for the life of the process because pinning is slow;
+// simrank_pool_trim() — "give back what the library holds at rest" — releases them too (advisor, round 5).
+void handback_release_slabs(int device) {
+#ifndef SIMRANK_HOST_ONLY
+    std::lock_guard<std::mutex> lock(g_slab_mutex);      // (never while a hand-back is using them)
+    for (int d = 0; d < 16; ++d) {
+        if (device >= 0 && d != (device & 15)) continue;
+        Slabs& sl = g_slabs[d];
+        for (int i = 0; i < kSlabs; ++i) {
+            if (sl.pin[i]) (void)hipHostFree(sl.pin[i]);
+            sl.pin[i] = nullptr;
+        }
+        sl.cap = 0;
+    }
+#else
+    (void)device;
+#endif
+}
 }  // namespace simrank
 
 using namespace simrank;
@@ -456,8 +475,15 @@ int simrank_handback_f64(double* dst, int64_t ld_dst, const float* src, int64_t 
         if (pt == 1) {
             patch(0, n);
         } else {
+            // (a thread that cannot be started must not take the process down — no exception may cross the C ABI: the shares
+            // that got no thread are patched here; advisor, round 5)
             std::vector<std::thread> ts;
-            for (int64_t t = 0; t < pt; ++t) ts.emplace_back(patch, n * t / pt, n * (t + 1) / pt);
+            int64_t started = 0;
+            try {
+                for (; started < pt; ++started) ts.emplace_back(patch, n * started / pt, n * (started + 1) / pt);
+            } catch (...) {
+            }
+            if (started < pt) patch(n * started / pt, n);
             for (std::thread& th : ts) th.join();
         }
     }

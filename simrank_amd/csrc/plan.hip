@@ -398,9 +398,10 @@ int simrank_plan_result(simrank_plan* p, float* dst, int64_t ld) {
 int simrank_plan_result_f64(simrank_plan* p, double* dst, int64_t ld) {
     SR_REQUIRE(p && dst && ld >= p->n, "bad result arguments");
     SR_REQUIRE(p->S[0], "the plan's matrices were released (simrank_plan_trim)");
-    // A plan's iterates are bitwise symmetric (symmetric priors only; leg 2 stores the mirror image of every tile it
-    // computes): only the elements on or above the diagonal of the result cross PCIe, the host mirrors them while it
-    // widens to float64 (handback.hip).  Out of the panel-blocked layout and the solver's node order band by band.
+    // Out of the panel-blocked layout and the solver's node order band by band (handback.hip), FULL form (mode 0): every
+    // element crosses PCIe.  The symmetric form (upper triangle over PCIe, mirrored by the host threads) is opt-in
+    // (SIMRANK_SYM_HANDBACK=1) and checks its premise on the device first — a plan with an asymmetric prior has asymmetric
+    // iterates (SimRank.py:453), and even symmetric ones are bitwise symmetric only outside the diagonal tiles.
     const float* src = p->S[p->cur];
     float* wide = nullptr;
     if (p->half) {

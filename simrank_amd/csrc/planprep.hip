@@ -32,7 +32,10 @@ static int check_prior(const float* a, int64_t ld, int64_t n, int which, bool ha
     for (int64_t i = 0; i < n; ++i)
         for (int64_t j = i; j < n; ++j) {
             const float v = a[i * ld + j];
-            if (!(v == a[j * ld + i])) {
+            // (off the diagonal only, as prior_symmetric below: the reference overwrites the diagonal — fill_diagonal,
+            // SimRank.py:454 — so a NaN there is neither an asymmetry nor anything the update reads; one rule for both scans,
+            // or a plan could be built in its half form AND as asymmetric)
+            if (j > i && !(v == a[j * ld + i])) {
                 SR_REQUIRE(asym && !half, "this plan needs symmetric priors (prior %d, element %lld, %lld)", which, (long long)i,
                            (long long)j);
                 *asym = true;

@@ -700,6 +700,7 @@ struct SideIn {
 };
 
 static int create_side(const SideIn& in, simrank_comm* comm, void* stream, simrank_shardplan** out) {
+    SR_REQUIRE(!(in.half_form && in.asym), "a plan cannot be both in the half form of leg 2 and asymmetric");
     *out = nullptr;
     const int32_t P = comm->world;
     const int64_t n = in.n, k = in.k;
@@ -1264,7 +1265,7 @@ int simrank_shardplan_info(const simrank_shardplan* p, int64_t* n, int64_t* col_
 // — two exchanges per loop body in strict order, the loop ends when NEITHER matrix moved (:289).  Same kernels, chunk
 // layouts, node orders (ascending row length per group, dealt to the shards where that group runs its half form) and
 // evidence rules (options.strict_reference: Evidence_N1 on both updates, quirk Q2) as the Python driver's Sides and as
-// simrank_biplan_* on one GPU.  Symmetric priors only (an asymmetric one needs the un-fused epilogue: the Python driver).
+// simrank_biplan_* on one GPU.  Asymmetric priors too (round 5): both iterates asymmetric, leg 2 = leg 1's operation again with a second exchange.
 // ---------------------------------------------------------------------------------------------------------------------
 struct simrank_shardbiplan {
     simrank_shardplan* side[2] = {nullptr, nullptr};

@@ -26,6 +26,8 @@
 #include <algorithm>
 #include <type_traits>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace simrank {
@@ -2615,13 +2617,36 @@ static int evidence_counts_impl(const simrank_graph* g, int64_t col0, int64_t n_
         const int Hp = g->ev_hubs;
         const int64_t Mp = (g->n_rows + 127) / 128 * 128;
         hipStream_t st = as_stream(stream);
-        if (!gm->ev_hub_image) {
-            // (+ 128 rows: the last column tile of a block that does not start at a multiple of 128 reads past row Mp)
-            SR_HIP(plan_alloc((void**)&gm->ev_hub_image, size_t(Mp + 128) * size_t(Hp)));
-            SR_HIP(hipMemsetAsync(gm->ev_hub_image, 0, size_t(Mp + 128) * size_t(Hp), st));
-            hipLaunchKernelGGL(hub_image_kernel, dim3((unsigned)std::min<int64_t>((g->n_rows + 3) / 4, 4096)), dim3(256), 0, st,
-                               g->rowptr, g->col, g->rowscale, g->ev_hubidx, g->n_rows, Hp, gm->ev_hub_image);
-            SR_HIP(hipGetLastError());
+        {
+            // (the image belongs to the graph and is built by whoever asks first: under a lock, with an event behind the build
+            // that every later call makes ITS stream wait for — two evidence calls on one graph from different streams or
+            // threads used to race on the pointer, or read an image still being written; advisor, round 5)
+            static std::mutex image_mutex;
+            std::lock_guard<std::mutex> image_lock(image_mutex);
+            if (!gm->ev_hub_image) {
+                uint8_t* image = nullptr;
+                hipEvent_t ready = nullptr;
+                // (+ 128 rows: the last column tile of a block that does not start at a multiple of 128 reads past row Mp)
+                SR_HIP(plan_alloc((void**)&image, size_t(Mp + 128) * size_t(Hp)));
+                hipError_t e = hipMemsetAsync(image, 0, size_t(Mp + 128) * size_t(Hp), st);
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(hub_image_kernel, dim3((unsigned)std::min<int64_t>((g->n_rows + 3) / 4, 4096)), dim3(256), 0,
+                                       st, g->rowptr, g->col, g->rowscale, g->ev_hubidx, g->n_rows, Hp, image);
+                    e = hipGetLastError();
+                }
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&ready, hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventRecord(ready, st);
+                if (e != hipSuccess) {
+                    (void)hipStreamSynchronize(st);
+                    plan_free(image);
+                    if (ready) (void)hipEventDestroy(ready);
+                    SR_HIP(e);
+                }
+                gm->ev_hub_ready = ready;
+                gm->ev_hub_image = image;
+            } else if (gm->ev_hub_ready) {
+                SR_HIP(hipStreamWaitEvent(st, (hipEvent_t)gm->ev_hub_ready, 0));
+            }
         }
         const int tiles_i = int(Mp / 128), tiles_j = int((n_cols + 127) / 128);
         const int vec16 = (reinterpret_cast<uintptr_t>(counts) % 16 == 0) && (rows_pad ? true : ld % 16 == 0);

@@ -259,18 +259,116 @@ __global__ __launch_bounds__(256, WPS) void gather_kernel(const Args p) {
     }
 }
 
+// The product's form (visible loads, two register sets) with the ids requested THREE rounds ahead instead of one
+// (four id registers), or staged in LDS a chunk at a time (LDSIDS): does the gather loop wait for its id loads?
+template <int IDK, bool LDSIDS>
+__global__ __launch_bounds__(256, 4) void gather_builtin_kernel(const Args p) {
+    __shared__ __attribute__((aligned(16))) uint16_t ids_lds[4][kIdRows][64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char pad_all[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t bid = blockIdx.x, local = bid >> 3;
+    const int panel = int(local / uint32_t(p.n_units)) * 8 + int(bid & 7);
+    if (panel >= p.n_panels) return;
+    const uint32_t unit = local % uint32_t(p.n_units);
+    const int32_t* un = p.units + size_t(unit) * 32;
+    const int n_sub = un[8];
+    const int round0 = un[9 + wave * 5];
+    const int n_all = un[9 + wave * 5 + n_sub];
+    const int q = lane & 7, gbase = lane & ~7;
+    const uint32_t qoff = uint32_t(q) * 16u;
+    const float* xbase = p.X + int64_t(panel) * p.rows_pad * 32;
+    const int sent = int(p.rows_pad);
+    const __amdgpu_buffer_rsrc_t srd =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xbase), 0, int32_t(p.rows_pad * 128), 0x00020000);
+    float4 cur = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fix = [&](int v) -> int { return v == 0xFFFF ? sent : (v & p.mask); };
+    float4 v[2][8];
+    auto issue8 = [&](int iv, float4 (&d)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const v4u w = __builtin_amdgcn_raw_buffer_load_b128(srd, int(__umul24(uint32_t(__shfl(iv, gbase + j)), 128u) + qoff), 0, 0);
+            d[j] = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+        }
+    };
+    auto consume = [&](const float4 (&d)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { cur.x += d[j].x; cur.y += d[j].y; cur.z += d[j].z; cur.w += d[j].w; }
+    };
+    // (written out by hand in the product loop's own style — named variables, plain while loops: the generic version of this
+    // loop came back from the compiler with a drained wait at the loop head)
+    for (int c0 = 0; c0 < n_all; c0 += (LDSIDS ? kChunk : (1 << 30))) {
+        const int n = LDSIDS ? min(kChunk, n_all - c0) : n_all;
+        if constexpr (LDSIDS) {
+            for (int r = 0; r < n; ++r) ids_lds[wave][r][lane] = p.sids[(size_t(round0) + size_t(c0 + r)) * 64 + lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        auto ld = [&](int r) -> int {                        // (past the stream: the last round again; never used)
+            const int rc = min(r, max(n - 1, 0));
+            if constexpr (LDSIDS) return int(ids_lds[wave][rc][lane]);
+            else return int(p.sids[(size_t(round0) + size_t(rc)) * 64 + lane]);
+        };
+        float4 (&vA)[8] = v[0];
+        float4 (&vB)[8] = v[1];
+        int raw0 = ld(0), raw1 = ld(1), raw2 = ld(2), raw3 = ld(3);
+        __builtin_amdgcn_sched_barrier(0);
+        issue8(fix(raw0), vA);
+        int r = 0;
+#define SB __builtin_amdgcn_sched_barrier(0)   /* (the scheduler otherwise sums a set BEFORE it issues the next one) */
+        while (r + 4 < n) {
+            issue8(fix(raw1), vB); raw0 = ld(r + 4); SB; consume(vA); SB;
+            issue8(fix(raw2), vA); raw1 = ld(r + 5); SB; consume(vB); SB;
+            issue8(fix(raw3), vB); raw2 = ld(r + 6); SB; consume(vA); SB;
+            issue8(fix(raw0), vA); raw3 = ld(r + 7); SB; consume(vB); SB;
+            r += 4;
+        }
+#undef SB
+        if (r + 1 < n) {
+            issue8(fix(raw1), vB); consume(vA);
+            if (r + 2 < n) {
+                issue8(fix(raw2), vA); consume(vB);
+                if (r + 3 < n) {
+                    issue8(fix(raw3), vB); consume(vA); consume(vB);
+                } else {
+                    consume(vA);
+                }
+            } else {
+                consume(vB);
+            }
+        } else {
+            consume(vA);
+        }
+    }
+    if (p.check) {
+        if (q == 0) atomicAdd(p.total, (unsigned long long)(cur.x + 0.5f));
+    }
+    if (p.store) {
+        const int b0 = un[0];
+        for (int sb = 0; sb < n_sub; ++sb) {
+            float* base = p.Y + ((int64_t((b0 + sb) * 4) + wave) * p.rows_pad + int64_t(panel) * 32) * 32;
+            const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(base, 0, 4096, 0x00020000);
+            v4u o;
+            o.x = __float_as_uint(cur.x); o.y = __float_as_uint(cur.y); o.z = __float_as_uint(cur.z); o.w = __float_as_uint(cur.w);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) __builtin_amdgcn_raw_buffer_store_b128(o, ysrd, (lane + it * 64) * 16, 0, 2);
+        }
+    } else if (cur.x + cur.y + cur.z + cur.w == 12345.678f) {
+        p.sink[0] = cur.x;
+    }
+}
+
 __global__ void fill_ones(float4* x, size_t n4) {
     for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n4; i += size_t(gridDim.x) * blockDim.x)
         x[i] = make_float4(1.f, 1.f, 1.f, 1.f);
 }
 
-template <int D, int LAND, int WPS>
-static void report(const char* name, Args a, double ids_per_panel, int wgs_per_cu) {
-    auto kern = gather_kernel<D, LAND, WPS>;
+typedef void (*kern_t)(const Args);
+static void report_kernel(const char* name, kern_t kern, Args a, double ids_per_panel, int wgs_per_cu, size_t ring, int depth) {
     hipFuncAttributes fa;
     CHECK(hipFuncGetAttributes(&fa, (const void*)kern));
     // dynamic LDS: the ring (LDS landing) plus padding so that exactly wgs_per_cu workgroups fit a CU's 160 KiB
-    const size_t ring = LAND == kLds ? size_t(4) * D * 8192 : 0;
     const size_t per_wg = (size_t(160) * 1024 / wgs_per_cu) & ~size_t(255);
     if (per_wg < fa.sharedSizeBytes + ring) { printf("%-24s: does not fit %d workgroups per CU\n", name, wgs_per_cu); return; }
     const size_t dyn = per_wg - fa.sharedSizeBytes;
@@ -284,7 +382,10 @@ static void report(const char* name, Args a, double ids_per_panel, int wgs_per_c
     CHECK(hipDeviceSynchronize());
     unsigned long long total = 0;
     CHECK(hipMemcpy(&total, a.total, 8, hipMemcpyDeviceToHost));
-    const bool ok = total == (unsigned long long)(ids_per_panel * a.n_panels + 0.5);
+    const unsigned long long want = (unsigned long long)(ids_per_panel * a.n_panels + 0.5);
+    char verdict[96];
+    if (total == want) snprintf(verdict, sizeof verdict, "ok");
+    else snprintf(verdict, sizeof verdict, "MISMATCH (%llu of %llu)", total, want);
     a.check = 0;
     for (int store = 0; store < 2; ++store) {
         a.store = store;
@@ -301,10 +402,15 @@ static void report(const char* name, Args a, double ids_per_panel, int wgs_per_c
         CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
         const double bytes = ids_per_panel * 128.0 * a.n_panels;
         printf("%-24s mask %5d store %d: %7.3f ms %6.2f TB/s gathered | %3d VGPRs %2d waves/CU %3d KiB in flight/CU (%d rounds/wave) check %s\n",
-               name, a.mask, store, ms, bytes / (ms * 1e-3) / 1e12, fa.numRegs, waves_per_cu, waves_per_cu * (D - 1) * 8, D - 1,
-               ok ? "ok" : "MISMATCH");
+               name, a.mask, store, ms, bytes / (ms * 1e-3) / 1e12, fa.numRegs, waves_per_cu, waves_per_cu * (depth - 1) * 8, depth - 1,
+               verdict);
         fflush(stdout);
     }
+}
+
+template <int D, int LAND, int WPS>
+static void report(const char* name, Args a, double ids_per_panel, int wgs_per_cu) {
+    report_kernel(name, gather_kernel<D, LAND, WPS>, a, ids_per_panel, wgs_per_cu, LAND == kLds ? size_t(4) * D * 8192 : 0, D);
 }
 
 int main(int argc, char** argv) {
@@ -353,6 +459,9 @@ int main(int argc, char** argv) {
     for (int mask : {0xFFFF, 8191, 255}) {
         a.mask = mask;
         report<2, kBuiltin, 4>("builtin depth 2 (today)", a, ipp, 4);
+        // the same loop with its ids requested further ahead / staged in LDS
+        report_kernel("builtin, ids 3 ahead", gather_builtin_kernel<4, false>, a, ipp, 4, 0, 2);
+        report_kernel("builtin, ids via LDS", gather_builtin_kernel<4, true>, a, ipp, 4, 0, 2);
         if (mask != 0xFFFF) continue;
         // the same code at other occupancies (its 70 VGPRs allow 7 waves per SIMD): bytes in flight per CU by WAVES
         report<2, kBuiltin, 4>("builtin depth 2", a, ipp, 2);
@@ -360,15 +469,15 @@ int main(int argc, char** argv) {
         report<2, kBuiltin, 4>("builtin depth 2", a, ipp, 5);
         report<2, kBuiltin, 4>("builtin depth 2", a, ipp, 6);
         report<2, kBuiltin, 4>("builtin depth 2", a, ipp, 7);
+        report_kernel("builtin, ids 3 ahead", gather_builtin_kernel<4, false>, a, ipp, 6, 0, 2);
         // deeper per wave, by hand
         report<2, kVgpr, 4>("vgpr depth 2", a, ipp, 4);
         report<3, kVgpr, 3>("vgpr depth 3", a, ipp, 3);
         report<3, kVgpr, 3>("vgpr depth 3", a, ipp, 2);
         report<4, kVgpr, 2>("vgpr depth 4", a, ipp, 2);
-        // landing in LDS
-        report<2, kLds, 4>("lds depth 2", a, ipp, 2);        // 64 KiB of ring per workgroup: two per CU
-        report<3, kLds, 4>("lds depth 3", a, ipp, 1);        // 96 KiB: one per CU
-        report<4, kLds, 4>("lds depth 4", a, ipp, 1);        // 128 KiB: one per CU
+        // landing in LDS (the ring limits a CU to one workgroup)
+        report<3, kLds, 4>("lds depth 3", a, ipp, 1);        // 96 KiB of ring
+        report<4, kLds, 4>("lds depth 4", a, ipp, 1);        // 128 KiB
     }
     return 0;
 }

@@ -546,6 +546,13 @@ SIMRANK_API int simrank_comm_create(const void* id_bytes, int32_t rank, int32_t 
 SIMRANK_API int simrank_comm_adopt(void* rccl_comm, int32_t rank, int32_t world, simrank_comm** out);
 /* `world` virtual ranks inside this process, on the current device: out[0 .. world) */
 SIMRANK_API int simrank_comm_local_group(int32_t world, simrank_comm** out);
+/* `world` ranks inside this process, on the current device, for `world` HOST THREADS — one rank each, every thread with one
+ * plan, exactly as the processes of an RCCL world (a plan per call, collectives entered by every rank): the loops take the
+ * code path of an RCCL rank (exchange stream, stage events, grouped sends and receives, all-reduced count) over an in-process
+ * transport with RCCL's interface whose sends and receives rendezvous between the threads and copy behind the sender's
+ * event.  For tests of that code path with ranks that run at the same time where one GPU is all there is; a peer that never
+ * arrives is an error after SIMRANK_THREAD_COMM_TIMEOUT seconds (default 120) on every rank, not a hang.  out[0 .. world). */
+SIMRANK_API int simrank_comm_thread_group(int32_t world, simrank_comm** out);
 SIMRANK_API int simrank_comm_destroy(simrank_comm* c);
 
 typedef struct simrank_shardplan simrank_shardplan;

@@ -140,6 +140,7 @@ PROTOTYPES = {
     "simrank_comm_create": [_vp, C.c_int32, C.c_int32, C.POINTER(_vp)],
     "simrank_comm_adopt": [_vp, C.c_int32, C.c_int32, C.POINTER(_vp)],
     "simrank_comm_local_group": [C.c_int32, C.POINTER(_vp)],
+    "simrank_comm_thread_group": [C.c_int32, C.POINTER(_vp)],
     "simrank_comm_destroy": [_vp],
     "simrank_shardplan_create": [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)],
     "simrank_shardplan_reset": [C.POINTER(_vp), C.c_int32],

@@ -213,9 +213,6 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
     // compiler had put the use of the first id load in front of the second load (two trips to memory one after the other
     // in every workgroup's prologue) and read the row records through a flat load selected against a stack slot
     int iv0 = sent, iv1 = sent;
-#ifdef SIMRANK_FUSED_IDS_AHEAD
-    int raw2 = 0, raw3 = 0;      // (experiment, round 6: the ids of rounds r + 2, r + 3 as loaded — requested three rounds ahead)
-#endif
     {   // lane (g, q): row q & 3 of lane group g, blocks q >> 2 and 2 + (q >> 2) of the unit
         const int sbA = q >> 2, sbB = 2 + (q >> 2);
         const int2* src = p.gmeta + ((size_t(un[29]) * 4 + wave) * 8 + g) * 4 + (q & 3);
@@ -226,10 +223,6 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
         if (n_rounds > 0) {
             raw0 = ld_sid_raw(0);
             raw1 = ld_sid_raw(1);
-#ifdef SIMRANK_FUSED_IDS_AHEAD
-            raw2 = ld_sid_raw(2);
-            raw3 = ld_sid_raw(3);
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);                   // (every load of the prologue is on its way before the first use)
         if (sbA >= n_sub) a = make_int2(int(0xFFFFFFFFu), 0);
@@ -576,20 +569,9 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
             float4 vA[8], vB[8];
             issue8(iv0, vA);                                  // round 0
             int r = 0;
-#ifdef SIMRANK_FUSED_IDS_AHEAD
-            while (r + 2 < n_rounds) {                        // at least two more rounds after r
-                const int n4 = ld_sid_raw(r + 4);
-                issue8(iv1, vB);
-                consume(vA, r);
-                const int n5 = ld_sid_raw(r + 5);
-                issue8(fix_sid(raw2), vA);
-                consume(vB, r + 1);
-                iv1 = fix_sid(raw3);
-                raw2 = n4;
-                raw3 = n5;
-                r += 2;
-            }
-#else
+            // (round 6: the ids requested three rounds ahead instead of one — four id registers, ten spills around the loops —
+            // made the leg SLOWER, 5.07 against 4.82 ms at pl32768d32, 18.8 against 17.9 at N = 65536: the loop does not wait
+            // for its ids; profiles/r06_ids_ahead_ab.log, and the stand-alone replay tools/micro/gather_depth.hip agrees)
             while (r + 2 < n_rounds) {                        // at least two more rounds after r
                 const int iv2 = ld_sid(r + 2);
                 issue8(iv1, vB);
@@ -599,7 +581,6 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
                 consume(vB, r + 1);
                 r += 2;
             }
-#endif
             if (r + 1 < n_rounds) {                           // vA = round r in flight, one more after it
                 issue8(iv1, vB);
                 consume(vA, r);

@@ -16,15 +16,22 @@
 //   count       the striped counters summed over the ranks on the device (ncclAllReduce), copied to pinned memory;
 //               simrank_shardplan_run queues update k + 1 before it reads the count of update k, like the single plan
 //
-// A communicator is RCCL (dlopen, so the library does not depend on it) or an in-process group of virtual ranks on
-// one device whose exchanges are device copies — how every line of this file but the RCCL calls themselves is tested
-// on the one GPU available (tests/test_gpu_shardplan.py: bit-equal to one rank in the full form).
+// A communicator is RCCL (dlopen, so the library does not depend on it), or an in-process group of virtual ranks on
+// one device whose exchanges are device copies queued by ONE host thread (simrank_comm_local_group: the ranks advance
+// in turn), or — round 6 — a THREAD group (simrank_comm_thread_group): one host thread per rank, each running the very
+// code path of an RCCL rank (one plan, a stream of its own for the exchanges, stage events, hops, the grouped sends and
+// receives, the all-reduced count) over a transport with RCCL's interface whose sends and receives rendezvous between
+// the threads and move the bytes with peer copies behind the sender's event.  That is how the loop an 8-GPU run executes
+// meets ranks that run AT THE SAME TIME on the one GPU available (tests/test_gpu_shardplan.py).
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <vector>
 
@@ -75,14 +82,225 @@ static Rccl* rccl() {
     return &r;
 }
 
+static const char* comm_error_string(ncclResult_t r) {
+    if (r == ncclSystemError) return "a peer rank did not arrive in time or failed (in-process transport), or RCCL's system error";
+    Rccl* R = rccl();
+    return R->ok ? R->GetErrorString(r) : "transport error";
+}
+
 #define SR_RCCL(call)                                                                          \
     do {                                                                                       \
         ncclResult_t r_ = (call);                                                              \
         if (r_ != ncclSuccess) {                                                               \
-            ::simrank::set_error("%s failed: %s (%s:%d)", #call, rccl()->GetErrorString(r_), __FILE__, __LINE__); \
+            ::simrank::set_error("%s failed: %s (%s:%d)", #call, comm_error_string(r_), __FILE__, __LINE__); \
             return SIMRANK_ERR_HIP;                                                            \
         }                                                                                      \
     } while (0)
+
+// ---- the thread group's transport: RCCL's interface (the entries of `Rccl` the loops call) between the host threads of one
+// process.  A send is POSTED (source pointer, byte count, an event recorded on the sender's stream at that point); the matching
+// receive — the next one from that peer, in order, as RCCL matches them — makes ITS stream wait for that event, copies, and
+// records a second event; the sender's stream then waits for that one (the buffer is the sender's again when the call has
+// completed in stream order, RCCL's rule).  ncclGroupEnd posts every send of the group before it waits for anything, so
+// ranks that issue the same groups in the same order cannot deadlock; a peer that never arrives turns into an error after
+// SIMRANK_THREAD_COMM_TIMEOUT seconds (default 120) on every rank of the group instead of a hang.
+struct TMsg {
+    const void* src;
+    size_t bytes;
+    hipEvent_t ready, done;
+    bool finished = false;
+};
+struct TGroup {
+    int32_t world = 0, alive = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::deque<TMsg*>> box;      // [src * world + dst]: posted, not yet received
+    bool failed = false;
+    double timeout_s = 120.0;
+};
+struct TComm {
+    TGroup* g = nullptr;
+    int32_t rank = 0;
+    struct Op { bool send; void* buf; size_t bytes; int peer; hipStream_t st; };
+    std::vector<Op> ops;                     // of the open group
+    std::deque<hipEvent_t> used;             // events handed out, oldest first (recycled once they have completed)
+    unsigned long long* tmp = nullptr;       // all-reduce: what the peers sent, [world][tmp_count]
+    size_t tmp_count = 0;
+};
+static thread_local int t_depth = 0;
+static thread_local std::vector<TComm*> t_open;
+
+static size_t dt_bytes(ncclDataType_t dt) {
+    switch (dt) {
+        case ncclHalf: return 2;
+        case ncclUint64: case ncclInt64: case ncclFloat64: return 8;
+        case ncclInt8: case ncclUint8: return 1;
+        default: return 4;
+    }
+}
+static hipEvent_t t_event(TComm* c) {
+    if (c->used.size() > 64 && hipEventQuery(c->used.front()) == hipSuccess) {
+        hipEvent_t e = c->used.front();
+        c->used.pop_front();
+        c->used.push_back(e);
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    c->used.push_back(e);
+    return e;
+}
+static ncclResult_t t_fail(TGroup* g) {
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->failed = true;
+    }
+    g->cv.notify_all();
+    return ncclSystemError;
+}
+static ncclResult_t t_flush(TComm* c) {
+    TGroup* g = c->g;
+    const int32_t P = g->world;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(g->timeout_s);
+    std::vector<std::pair<TMsg*, hipStream_t>> mine;
+    std::vector<TComm::Op> ops;
+    ops.swap(c->ops);
+    // 1. every send of the group is posted before anything waits
+    for (const TComm::Op& op : ops) {
+        if (!op.send) continue;
+        TMsg* m = new TMsg{op.buf, op.bytes, t_event(c), t_event(c)};
+        if (!m->ready || !m->done || hipEventRecord(m->ready, op.st) != hipSuccess) { delete m; return t_fail(g); }
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            g->box[size_t(c->rank) * P + op.peer].push_back(m);
+        }
+        mine.push_back({m, op.st});
+    }
+    g->cv.notify_all();
+    // 2. the receives, in order: the next message that peer posted for this rank
+    for (const TComm::Op& op : ops) {
+        if (op.send) continue;
+        TMsg* m = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(g->mu);
+            std::deque<TMsg*>& q = g->box[size_t(op.peer) * P + c->rank];
+            if (!g->cv.wait_until(lk, deadline, [&] { return g->failed || !q.empty(); }) || g->failed) {
+                g->failed = true;
+                lk.unlock();
+                g->cv.notify_all();
+                return ncclSystemError;
+            }
+            m = q.front();
+            q.pop_front();
+        }
+        if (m->bytes != op.bytes || hipStreamWaitEvent(op.st, m->ready, 0) != hipSuccess ||
+            hipMemcpyAsync(op.buf, m->src, op.bytes, hipMemcpyDeviceToDevice, op.st) != hipSuccess ||
+            hipEventRecord(m->done, op.st) != hipSuccess)
+            return t_fail(g);
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            m->finished = true;
+        }
+        g->cv.notify_all();
+    }
+    // 3. a send has completed (in stream order) when its receiver has copied
+    for (auto& ms : mine) {
+        TMsg* m = ms.first;
+        {
+            std::unique_lock<std::mutex> lk(g->mu);
+            if (!g->cv.wait_until(lk, deadline, [&] { return g->failed || m->finished; }) || g->failed) {
+                g->failed = true;
+                lk.unlock();
+                g->cv.notify_all();
+                return ncclSystemError;          // (the message stays with the group: its receiver may still hold it)
+            }
+        }
+        if (hipStreamWaitEvent(ms.second, m->done, 0) != hipSuccess) return t_fail(g);
+        delete m;
+    }
+    return ncclSuccess;
+}
+static ncclResult_t t_group_start() {
+    ++t_depth;
+    return ncclSuccess;
+}
+static ncclResult_t t_group_end() {
+    if (t_depth > 0 && --t_depth > 0) return ncclSuccess;
+    std::vector<TComm*> open;
+    open.swap(t_open);
+    ncclResult_t r = ncclSuccess;
+    for (TComm* c : open) {
+        const ncclResult_t rc = t_flush(c);
+        if (rc != ncclSuccess) r = rc;
+    }
+    return r;
+}
+static ncclResult_t t_queue(TComm* c, bool send, void* buf, size_t bytes, int peer, hipStream_t st) {
+    if (peer < 0 || peer >= c->g->world || peer == c->rank) return ncclInvalidArgument;
+    if (c->ops.empty() && std::find(t_open.begin(), t_open.end(), c) == t_open.end()) t_open.push_back(c);
+    c->ops.push_back({send, buf, bytes, peer, st});
+    if (t_depth == 0) return t_group_end();              // an ungrouped call is a group of one
+    return ncclSuccess;
+}
+static ncclResult_t t_send(const void* buf, size_t count, ncclDataType_t dt, int peer, ncclComm_t comm, hipStream_t st) {
+    return t_queue(reinterpret_cast<TComm*>(comm), true, const_cast<void*>(buf), count * dt_bytes(dt), peer, st);
+}
+static ncclResult_t t_recv(void* buf, size_t count, ncclDataType_t dt, int peer, ncclComm_t comm, hipStream_t st) {
+    return t_queue(reinterpret_cast<TComm*>(comm), false, buf, count * dt_bytes(dt), peer, st);
+}
+#ifndef SIMRANK_HOST_ONLY
+__global__ void t_sum_u64_kernel(unsigned long long* out, const unsigned long long* mine, const unsigned long long* others,
+                                 int world, int me, int count, int stride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    unsigned long long t = mine[i];
+    for (int h = 0; h < world; ++h)
+        if (h != me) t += others[size_t(h) * stride + i];
+    out[i] = t;
+}
+#endif
+// the sum over the ranks of `count` 64-bit counters, in place or not: everybody sends to everybody, then adds in rank order
+static ncclResult_t t_all_reduce(const void* send, void* recv, size_t count, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t comm,
+                                 hipStream_t st) {
+    TComm* c = reinterpret_cast<TComm*>(comm);
+    if (dt != ncclUint64 || op != ncclSum || t_depth != 0) return ncclInvalidArgument;
+    const int32_t P = c->g->world;
+    if (c->tmp_count < count) {
+        if (c->tmp) (void)hipFree(c->tmp);
+        c->tmp = nullptr;
+        if (hipMalloc((void**)&c->tmp, size_t(P) * count * 8) != hipSuccess) return ncclSystemError;
+        c->tmp_count = count;
+    }
+    t_group_start();
+    for (int32_t h = 0; h < P; ++h) {
+        if (h == c->rank) continue;
+        t_send(send, count, dt, h, comm, st);
+        t_recv(c->tmp + size_t(h) * c->tmp_count, count, dt, h, comm, st);
+    }
+    const ncclResult_t r = t_group_end();
+    if (r != ncclSuccess) return r;
+#ifndef SIMRANK_HOST_ONLY
+    hipLaunchKernelGGL(t_sum_u64_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st, (unsigned long long*)recv,
+                       (const unsigned long long*)send, c->tmp, P, c->rank, (int)count, (int)c->tmp_count);
+    if (hipGetLastError() != hipSuccess) return ncclSystemError;
+#endif
+    return ncclSuccess;
+}
+static const char* t_error_string(ncclResult_t r) { return comm_error_string(r); }
+static Rccl* thread_api() {
+    static Rccl t;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        t.GroupStart = t_group_start;
+        t.GroupEnd = t_group_end;
+        t.Send = t_send;
+        t.Recv = t_recv;
+        t.AllReduce = t_all_reduce;
+        t.GetErrorString = t_error_string;
+        t.ok = true;
+    });
+    return &t;
+}
 
 struct LocalGroup {
     int32_t world = 0;
@@ -141,8 +359,10 @@ static int64_t stage_col0(int64_t n_cols, int32_t n_stages, int32_t s, int32_t a
 
 struct simrank_comm {
     int32_t rank = 0, world = 1;
-    simrank::LocalGroup* group = nullptr;    // in-process group, or
-    ncclComm_t nccl = nullptr;               // RCCL
+    simrank::LocalGroup* group = nullptr;    // in-process group whose ranks ONE thread advances in turn, or
+    ncclComm_t nccl = nullptr;               // RCCL (or the thread group's handle of this rank, a TComm)
+    simrank::Rccl* api = nullptr;            // ... and the calls that go with `nccl`: RCCL's own, or the thread transport's
+    simrank::TComm* thread = nullptr;        // set for a rank of a thread group (owned)
     bool owned = false;
 };
 
@@ -280,7 +500,7 @@ static int all_to_all(simrank_shardplan* const* plans, int32_t n_local, std::vec
                 }
             }
     } else {
-        Rccl* R = rccl();
+        Rccl* R = p0->comm->api;
         Route& r = routes[0];
         const int32_t me = p0->rank;
         // the chunk a rank addresses to itself never touches the fabric
@@ -526,8 +746,8 @@ static int update(simrank_shardplan* const* plans, int32_t n_local, double eps, 
         if (rc) return rc;
         SR_MARK(p0, xs, kMarkY0);
         if (P > 1)                                       // the count of the whole update, on every rank
-            SR_RCCL(rccl()->AllReduce(p0->counters, p0->counters, SIMRANK_CHANGED_SLOTS, ncclUint64, ncclSum,
-                                      p0->comm->nccl, xs));
+            SR_RCCL(p0->comm->api->AllReduce(p0->counters, p0->counters, SIMRANK_CHANGED_SLOTS, ncclUint64, ncclSum,
+                                             p0->comm->nccl, xs));
     }
     if (p0->half_form && !staged2) {
         // exchange 2 after the whole leg: the packed mirrored tiles
@@ -624,7 +844,7 @@ int simrank_comm_create(const void* id_bytes, int32_t rank, int32_t world, simra
     ncclComm_t c = nullptr;
     SR_RCCL(R->CommInitRank(&c, world, id, rank));
     simrank_comm* k = new simrank_comm;
-    k->rank = rank; k->world = world; k->nccl = c; k->owned = true;
+    k->rank = rank; k->world = world; k->nccl = c; k->owned = true; k->api = R;
     *out = k;
     return SIMRANK_OK;
 }
@@ -633,7 +853,7 @@ int simrank_comm_adopt(void* rccl_comm, int32_t rank, int32_t world, simrank_com
     SR_REQUIRE(rccl_comm && out && world >= 1 && rank >= 0 && rank < world, "bad communicator arguments");
     SR_REQUIRE(rccl()->ok, "RCCL could not be loaded (librccl.so.1; set SIMRANK_RCCL_LIB)");
     simrank_comm* k = new simrank_comm;
-    k->rank = rank; k->world = world; k->nccl = (ncclComm_t)rccl_comm; k->owned = false;
+    k->rank = rank; k->world = world; k->nccl = (ncclComm_t)rccl_comm; k->owned = false; k->api = rccl();
     *out = k;
     return SIMRANK_OK;
 }
@@ -651,10 +871,46 @@ int simrank_comm_local_group(int32_t world, simrank_comm** out) {
     return SIMRANK_OK;
 }
 
+int simrank_comm_thread_group(int32_t world, simrank_comm** out) {
+    SR_REQUIRE(out && world >= 1 && world <= 64, "a thread group has 1 .. 64 ranks");
+    TGroup* g = new TGroup;
+    g->world = world;
+    g->alive = world;
+    g->box.resize(size_t(world) * size_t(world));
+    if (const char* e = std::getenv("SIMRANK_THREAD_COMM_TIMEOUT")) g->timeout_s = std::max(1.0, std::atof(e));
+    for (int32_t r = 0; r < world; ++r) {
+        simrank_comm* k = new simrank_comm;
+        TComm* t = new TComm;
+        t->g = g;
+        t->rank = r;
+        k->rank = r; k->world = world; k->thread = t; k->nccl = reinterpret_cast<ncclComm_t>(t); k->api = thread_api();
+        out[r] = k;
+    }
+    return SIMRANK_OK;
+}
+
 int simrank_comm_destroy(simrank_comm* c) {
     if (!c) return SIMRANK_OK;
     if (c->group && --c->group->alive == 0) delete c->group;
-    if (c->nccl && c->owned) (void)rccl()->CommDestroy(c->nccl);
+    if (c->thread) {
+        TComm* t = c->thread;
+        for (hipEvent_t e : t->used) (void)hipEventDestroy(e);
+        if (t->tmp) (void)hipFree(t->tmp);
+        TGroup* g = t->g;
+        bool last;
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            last = --g->alive == 0;
+        }
+        if (last) {
+            for (auto& q : g->box)
+                for (TMsg* m : q) delete m;
+            delete g;
+        }
+        delete t;
+    } else if (c->nccl && c->owned) {
+        (void)rccl()->CommDestroy(c->nccl);
+    }
     delete c;
     return SIMRANK_OK;
 }
@@ -1082,7 +1338,7 @@ int simrank_shardplan_result_f64(simrank_shardplan* const* plans, int32_t n_loca
         }
         return SIMRANK_OK;
     }
-    Rccl* R = rccl();
+    Rccl* R = p0->comm->api;
     float* mine = nullptr;
     rc = block_rows_in_callers_order(p0, &mine);
     if (rc) return rc;
@@ -1140,7 +1396,7 @@ int simrank_shardplan_topk(simrank_shardplan* const* plans, int32_t n_local, int
     auto kk_of = [&](int32_t h) { return (int32_t)std::min<int64_t>(k, span(n, P, h)); };
     std::vector<std::vector<int32_t>> cand_idx(P);
     std::vector<std::vector<float>> cand_val(P);
-    Rccl* R = local ? nullptr : rccl();
+    Rccl* R = local ? nullptr : p0->comm->api;
     for (int32_t i = 0; i < n_local; ++i) {
         simrank_shardplan* p = plans[i];
         const int32_t kk = kk_of(p->rank);

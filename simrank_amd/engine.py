@@ -364,6 +364,49 @@ class ShardPlans:
             pass
 
 
+
+class ThreadRanks:
+    """``world`` ranks of a THREAD group (simrank_comm_thread_group) on one device: ``run(fn)`` calls ``fn(rank, ops, comm)``
+    on ``world`` host threads at once, each with its own engine (its own streams) — the ranks of an RCCL world as threads of
+    this process, over the library's in-process transport.  What ``fn`` builds with ``comm`` (``ShardPlans(..., comm=comm)``,
+    ``ShardBiPlans(..., comm=comm)``) takes the code path of an RCCL rank; its calls are collectives between the threads."""
+
+    def __init__(self, world: int, device: int = 0):
+        self.world, self.device = int(world), int(device)
+        self.lib = _lib.load()
+        arr = (C.c_void_p * self.world)()
+        check(self.lib.simrank_comm_thread_group(self.world, arr), "simrank_comm_thread_group")
+        self.comms = [C.c_void_p(arr[r]) for r in range(self.world)]
+
+    def run(self, fn, timeout: float = 300.0):
+        """-> [fn(rank, ops, comm) for every rank].  The first exception of any rank is raised; ranks still running after
+        ``timeout`` seconds raise TimeoutError (the transport's own watchdog, SIMRANK_THREAD_COMM_TIMEOUT, turns a rank that
+        waits for a peer into an error on every rank well before that)."""
+        import threading
+        out, err = [None] * self.world, [None] * self.world
+
+        def body(r):
+            try:
+                out[r] = fn(r, HipOps(self.device), self.comms[r])
+            except BaseException as e:          # noqa: BLE001 — handed to the caller
+                err[r] = e
+        ts = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(self.world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout)
+        if any(t.is_alive() for t in ts):
+            raise TimeoutError(f"thread ranks still running after {timeout} s: {[r for r, t in enumerate(ts) if t.is_alive()]}")
+        for e in err:
+            if e is not None:
+                raise e
+        return out
+
+    def close(self):
+        for c in self.comms:
+            self.lib.simrank_comm_destroy(c)
+        self.comms = []
+
 class ShardBiPlans:
     """This process's share of a SHARDED two-matrix fit behind the C ABI (simrank_shardbiplan_*: the loops of
     SimRank.py:288-302, :410-424, :478-492 with S1 and S2 split by column block over ``world`` ranks): one pair of plans

@@ -430,3 +430,195 @@ def test_sharded_bipartite_plan_step_by_step_and_top_k(ops):
     assert bp.run(0, 1e-4) == (0, None) and bp.run(5, 1.0) == (0, 0)
     np.testing.assert_array_equal(bp.result(2), np.eye(45))
     bp.free()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# concurrent ranks (round 6): one HOST THREAD per rank over the library's in-process transport (simrank_comm_thread_group) —
+# each thread runs the code path of an RCCL rank (one plan, its own kernel and exchange streams, stage events, hops, grouped
+# sends / receives that rendezvous with the peer's, the all-reduced count, speculative queueing of update k + 1) while the
+# others run theirs.  What only a real RCCL world can add: RCCL's own progress engine and memory on several devices.
+# ---------------------------------------------------------------------------------------------------------------------
+def _thread_ranks(world, fn, timeout=420.0):
+    from simrank_amd.engine import ThreadRanks
+    tr = ThreadRanks(world)
+    try:
+        return tr.run(fn, timeout=timeout)
+    finally:
+        tr.close()
+
+
+def _threads_vs_group(ops, csr, world, iterations, eps, scale=None, **kw):
+    """One fit on `world` concurrent thread ranks and the same on the in-process group (ranks in turn): -> per-rank
+    (done, conv, block, ids), root's full matrix, the group's (done, conv, full)."""
+    from simrank_amd.engine import ShardPlans
+
+    def rank(r, rops, comm):
+        sp = ShardPlans(rops, csr, rowscale=scale, world=world, comm=comm, **kw)
+        done, conv = sp.run(iterations, eps)
+        full = sp.result(root=0, i_am_root=(r == 0))
+        blk, ids = sp.block(0)
+        inf = sp.info()
+        sp.free()
+        return done, conv, full, blk, ids, inf
+    outs = _thread_ranks(world, rank)
+    sp = ShardPlans(ops, csr, rowscale=scale, world=world, **kw)
+    ref = sp.run(iterations, eps) + (sp.result(), sp.info())
+    sp.free()
+    return outs, ref
+
+
+@pytest.mark.parametrize("world,form,stages", [(2, 0, 1), (2, 1, 3), (4, 0, 2), (4, 1, 1), (8, 0, 1), (8, 1, 2), (3, 0, 2), (5, 0, 1)])
+@pytest.mark.parametrize("name", ["SimRank_er128", "SimRankPP_er128", "SimRank_toy5", "SimRankPP_bts300"])
+def test_thread_ranks_reproduce_the_golden_vectors(ops, name, world, form, stages):
+    """The golden cases of `test_shardplan_reproduces_the_golden_vectors` on 2 - 8 CONCURRENT ranks: S to 1e-5, the convergence
+    index on every rank, root's gather == the blocks put together == bit for bit what the in-process group (ranks in turn,
+    device copies) computes; uneven and empty blocks (toy5), both forms of leg 2, staged exchanges."""
+    g = Golden(name)
+    csr = golden_csr(g)
+    if form == 1 and csr.n_rows % (32 * world):
+        pytest.skip("the half form needs n % (32 x ranks) == 0")
+    kw = dict(coef=g.kwargs.get("C", 0.8), evidence=name.startswith("SimRankPP"), leg2_form=form, stages=stages)
+    outs, (rdone, rconv, rfull, rinf) = _threads_vs_group(ops, csr, world, g.kwargs.get("iterations", 100), g.kwargs.get("eps", 1e-4), **kw)
+    put = np.full((csr.n_rows, csr.n_rows), np.nan)
+    for r, (done, conv, full, blk, ids, inf) in enumerate(outs):
+        assert (done, conv) == (rdone, rconv), (r, done, conv)
+        assert (conv if conv is not None else -1) == (g.k if g.k is not None else -1)
+        assert inf["half_form"] == bool(form) and inf["stages"] == stages
+        put[:, ids] = blk
+    assert_close(outs[0][2], g.out["S"])
+    assert np.array_equal(outs[0][2], put)
+    assert np.array_equal(outs[0][2], rfull)
+    assert all(o[2] is None for o in outs[1:])
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_thread_ranks_with_priors_wires_and_half_storage(ops, world):
+    """Concurrent ranks through the variants of the loop: a symmetric prior with evidence, a prior that is NOT symmetric (the
+    second all-to-all, the epilogue as its own pass), the fp16 wire, fp16-held matrices — each bit-equal to the in-process
+    group and within its bound of the float64 oracle."""
+    df = synth.powerlaw_directed(64 * 2 * 3, 9, seed=5)            # n = 384: whole 64-column panels on 2 and 3 ranks
+    _, csr = ingest.directed(df, False, "from", "to", "weight")
+    n = csr.n_rows
+    rng = np.random.default_rng(world)
+    A = rng.random((n, n))
+    sym = (A + A.T) / 2
+    G = csr.dense()
+    f32 = lambda x: x.astype(np.float32).astype(np.float64)       # noqa: E731
+    want_sym, _ = O.iterate_directed(G, C=0.7, iterations=6, eps=0, E=O.evidence(G), apriori=f32(sym), lbd=0.3)
+    want_asym, _ = O.iterate_directed(G, C=0.7, iterations=6, eps=0, E=O.evidence(G), apriori=f32(A), lbd=0.3)
+    want_plain, _ = O.iterate_directed(G, C=0.7, iterations=6, eps=0)
+    cases = [("prior+evidence", dict(evidence=True, apriori=sym, lbd=0.3, leg2_form=0, stages=2), want_sym, RTOL),
+             ("asymmetric prior", dict(evidence=True, apriori=A, lbd=0.3, leg2_form=0, stages=1), want_asym, RTOL),
+             ("fp16 wire", dict(leg2_form=0, stages=2, wire_fp16=True), want_plain, 5e-3)]
+    if n % (64 * world) == 0:
+        cases.append(("fp16-held", dict(leg2_form=0, stages=1, storage="fp16"), want_plain, 5e-3))
+    for label, kw, want, tol in cases:
+        outs, (rdone, rconv, rfull, _) = _threads_vs_group(ops, csr, world, 6, 0.0, coef=0.7, **kw)
+        assert all(o[:2] == (6, None) for o in outs) and (rdone, rconv) == (6, None), label
+        assert np.array_equal(outs[0][2], rfull), label
+        if tol == RTOL:
+            assert_close(outs[0][2], want)
+        else:
+            big = want > 1e-4
+            assert (np.abs(outs[0][2] - want)[big] / want[big]).max() < tol and np.abs(outs[0][2] - want).max() < 1e-3, label
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_thread_ranks_on_the_two_matrix_loop(ops, world):
+    """simrank_shardbiplan_* on concurrent ranks: two exchanges per loop body in Gauss-Seidel order (the group-2 update reads
+    the NEW S1 of every peer), both counts all-reduced together — plain, SimRank++ (corrected evidence), strict quirk Q2 on
+    equal group sizes, symmetric and asymmetric priors, full and half form: bit-equal to the in-process group; values and
+    the convergence index against the float64 oracle."""
+    from simrank_amd.engine import ShardBiPlans
+    from tests.graphs import bipartite_random
+    n1, n2 = 32 * world * 2, 32 * world
+    df = bipartite_random(n1, n2, 0.08, seed=10 + world)
+    _, _, _, _, g12, g21 = ingest.bipartite(df, False, "user", "item", "weight")
+    rng = np.random.default_rng(world)
+    p1, p2 = rng.random((n1, n1)), rng.random((n2, n2))
+    s1, s2 = (p1 + p1.T) / 2, (p2 + p2.T) / 2
+    pp1, pp2 = ingest.spread(g12) * g12.rowscale, ingest.spread(g21) * g21.rowscale
+    cases = [("plain", (g12.rowscale, g21.rowscale), dict(leg2_form=0, stages=2), O.fit_bipartite(df, verbose=False)),
+             ("plain, half form", (g12.rowscale, g21.rowscale), dict(leg2_form=1, stages=1), O.fit_bipartite(df, verbose=False)),
+             ("pp", (pp1, pp2), dict(evidence=True, leg2_form=1, stages=2), O.fit_bipartite_pp(df, verbose=False, strict_reference=False)),
+             ("priors", (pp1, pp2), dict(evidence=True, apriori1=s1, apriori2=s2, lbd1=0.3, lbd2=0.2, leg2_form=0, stages=1), None),
+             ("asymmetric priors", (pp1, pp2), dict(evidence=True, apriori1=p1, apriori2=p2, lbd1=0.3, lbd2=0.2, leg2_form=0, stages=2), None)]
+    for label, (rs1, rs2), opts, want in cases:
+        def rank(r, rops, comm):
+            bp = ShardBiPlans(rops, g12, rs1, rs2, world=world, comm=comm, **opts)
+            res = bp.run(100, 1e-4)
+            out = res, bp.result(1, root=0, i_am_root=(r == 0)), bp.result(2, root=0, i_am_root=(r == 0))
+            bp.free()
+            return out
+        outs = _thread_ranks(world, rank)
+        bp = ShardBiPlans(ops, g12, rs1, rs2, world=world, **opts)
+        ref = bp.run(100, 1e-4)
+        r1, r2 = bp.result(1), bp.result(2)
+        bp.free()
+        assert all(o[0] == ref for o in outs), (label, [o[0] for o in outs], ref)
+        assert np.array_equal(outs[0][1], r1) and np.array_equal(outs[0][2], r2), label
+        if want is not None:
+            assert ref[1] == want["k"], label
+            assert_close(outs[0][1], want["S1"])
+            assert_close(outs[0][2], want["S2"])
+
+
+def test_thread_ranks_at_config_4_to_eps(ops):
+    """BASELINE config 4 (pl32768d32) to eps = 1e-4 on EIGHT concurrent ranks, half form, staged, with every device block
+    poisoned before it is handed out: the loop ends at the single rank's iteration (16), every rank agrees, and the last
+    rank's block is bit for bit the in-process group's (whose ranks run one after another)."""
+    from simrank_amd.engine import Plan, ShardPlans
+    df = synth.WORKLOADS["pl32768d32"][0]()
+    _, csr = ingest.directed(df, False, "from", "to", "weight")
+    P = 8
+    os.environ["SIMRANK_POOL_POISON"] = "1"
+    try:
+        def rank(r, rops, comm):
+            sp = ShardPlans(rops, csr, world=P, comm=comm, leg2_form=1, stages=2)
+            res = sp.run(100, 1e-4)
+            blk = sp.block(0) if r in (0, P - 1) else None
+            sp.free()
+            return res, blk
+        outs = _thread_ranks(P, rank, timeout=600.0)
+        sp = ShardPlans(ops, csr, world=P, leg2_form=1, stages=2)
+        ref = sp.run(100, 1e-4)
+        first, last = sp.block(0), sp.block(P - 1)
+        sp.free()
+        plan = Plan(ops, csr, coef=0.8)
+        single = plan.run(100, 1e-4)
+        plan.free()
+    finally:
+        os.environ.pop("SIMRANK_POOL_POISON", None)
+    assert all(o[0] == ref for o in outs), [o[0] for o in outs]
+    assert ref == single == (16, 16)
+    assert np.array_equal(outs[0][1][0], first[0]) and np.array_equal(outs[0][1][1], first[1])
+    assert np.array_equal(outs[P - 1][1][0], last[0]) and np.array_equal(outs[P - 1][1][1], last[1])
+
+
+def test_a_thread_rank_that_never_arrives_is_an_error_not_a_hang(ops):
+    """The transport's watchdog: three of four ranks enter the loop, the fourth never does — every waiting rank gets
+    SimRankHipError after SIMRANK_THREAD_COMM_TIMEOUT seconds instead of waiting for ever."""
+    from simrank_amd._lib import SimRankHipError
+    from simrank_amd.engine import ShardPlans, ThreadRanks
+    g = Golden("SimRank_er128")
+    csr = golden_csr(g)
+    os.environ["SIMRANK_THREAD_COMM_TIMEOUT"] = "3"
+    try:
+        tr = ThreadRanks(4)
+    finally:
+        os.environ.pop("SIMRANK_THREAD_COMM_TIMEOUT", None)
+
+    def rank(r, rops, comm):
+        sp = ShardPlans(rops, csr, world=4, comm=comm, leg2_form=0, stages=1)
+        try:
+            if r == 3:
+                return "absent"
+            with pytest.raises(SimRankHipError):
+                sp.run(5, 0.0)
+            return "error"
+        finally:
+            sp.free()
+    try:
+        assert tr.run(rank, timeout=120.0) == ["error", "error", "error", "absent"]
+    finally:
+        tr.close()

@@ -456,6 +456,10 @@ SIMRANK_API int simrank_plan_trim(simrank_plan* p);
  * PCIe instead of n^2 */
 SIMRANK_API int simrank_plan_topk(simrank_plan* p, int32_t k, int32_t exclude_diag, int32_t* idx_host,
                                   float* val_host);
+/* some ROWS of the current similarity matrix (rows of the DataFrame of SimRank.py:141): dst[i][j] = S[rows[i]][j] in the
+ * caller's node order, float32 as stored (fp16-held plans: widened), host memory, ld >= n floats per row — n_rows x n
+ * values across PCIe instead of n^2 (a query for a few nodes; what the full-size parity tests sample) */
+SIMRANK_API int simrank_plan_rows_f32(simrank_plan* p, const int32_t* rows, int32_t n_rows, float* dst, int64_t ld);
 /* measurement: HIP events on the plan's own stream around both legs of the next `updates` updates (created at this call,
  * outside the timed region; 0 = off); simrank_plan_leg_times drains the stream and returns the mean duration of leg 1
  * (first .dot of SimRank.py:139) and of leg 2 (second .dot + :140 + :74) over the updates stamped since — what bench.py's
@@ -507,6 +511,8 @@ SIMRANK_API int simrank_biplan_result_f64(simrank_biplan* p, int32_t group, doub
  * GATE the group's update: with strict_reference the group-2 counts are Evidence_N1's, position by position */
 SIMRANK_API int simrank_biplan_topk(simrank_biplan* p, int32_t group, int32_t k, int32_t exclude_diag, int32_t* idx_host,
                                     float* val_host);
+SIMRANK_API int simrank_biplan_rows_f32(simrank_biplan* p, int32_t group, const int32_t* rows, int32_t n_rows, float* dst,
+                                        int64_t ld);
 SIMRANK_API int simrank_biplan_evidence_u8(simrank_biplan* p, int32_t group, uint8_t* dst, int64_t ld);
 SIMRANK_API int simrank_biplan_trim(simrank_biplan* p);
 SIMRANK_API int simrank_biplan_destroy(simrank_biplan* p);

@@ -96,6 +96,7 @@ PROTOTYPES = {
     "simrank_fill_identity_blocked": [_vp, _i64, _i64, _i64, _i64, _vp],
     "simrank_spmm_blocked": [_vp, _vp, _i64, _i64, _vp, _i64, _i32, C.POINTER(Epilogue), _vp],
     "simrank_plan_topk": [_vp, _i32, _i32, _vp, _vp],
+    "simrank_plan_rows_f32": [_vp, _vp, _i32, _vp, _i64],
     "simrank_plan_run_cb": [_vp, C.c_int32, C.c_double, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "simrank_plan_evidence_u8": [_vp, _vp, _i64],
     "simrank_plan_set_timing": [_vp, C.c_int32],
@@ -103,6 +104,7 @@ PROTOTYPES = {
     "simrank_plan_trim": [_vp],
     "simrank_biplan_run_cb": [_vp, C.c_int32, C.c_double, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "simrank_biplan_topk": [_vp, _i32, _i32, _i32, _vp, _vp],
+    "simrank_biplan_rows_f32": [_vp, _i32, _vp, _i32, _vp, _i64],
     "simrank_biplan_evidence_u8": [_vp, _i32, _vp, _i64],
     "simrank_biplan_trim": [_vp],
     "simrank_biplan_create": [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

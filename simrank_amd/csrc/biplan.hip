@@ -374,6 +374,14 @@ int simrank_biplan_result_f64(simrank_biplan* p, int32_t group, double* dst, int
     return rc;
 }
 
+int simrank_biplan_rows_f32(simrank_biplan* p, int32_t group, const int32_t* rows, int32_t n_rows, float* dst, int64_t ld) {
+    SR_REQUIRE(p && rows && dst && (group == 1 || group == 2) && n_rows > 0, "bad row arguments");
+    side_t& a = p->s[group - 1];
+    SR_REQUIRE(ld >= a.n, "ld %lld < n", (long long)ld);
+    SR_REQUIRE(a.S[0], "the plan's matrices were released (simrank_biplan_trim)");
+    return rows_to_host(a.S[a.cur], a.rows_pad, a.n, a.inv, rows, n_rows, dst, ld, 4, 1.0f, p->stream);
+}
+
 int simrank_biplan_topk(simrank_biplan* p, int32_t group, int32_t k, int32_t exclude_diag, int32_t* idx_host, float* val_host) {
     SR_REQUIRE(p && idx_host && val_host && (group == 1 || group == 2) && k > 0 && k <= 1024, "bad top-k arguments");
     side_t& a = p->s[group - 1];

@@ -126,6 +126,11 @@ int pool_free(void* ptr);
 void pool_trim(int device);          // -1: every device
 void pool_stats(int device, int64_t* cached_bytes, int64_t* cached_blocks, int64_t* limit_bytes);
 void handback_release_slabs(int device);   // handback.hip: the pinned slabs of the f64 hand-back (-1: every device)
+// handback.hip: rows `rows` (caller's ids, host) of a panel-blocked n x n matrix held in the solver's order, in the caller's
+// column order, into host memory: dst[i][j] = S[inv[rows[i]]][inv[j]].  elem 4: f32, 32-column panels; elem 2: binary16 x
+// `scale`, 64-column panels (widened on the device).  What simrank_plan_rows_f32 / simrank_biplan_rows_f32 do.
+int rows_to_host(const void* S, int64_t rows_pad, int64_t n, const int32_t* inv_dev, const int32_t* rows, int32_t n_rows,
+                 float* dst, int64_t ld, int elem, float scale, hipStream_t stream);
 inline hipError_t pool_hip_alloc(void** p, size_t bytes) {       // (for call sites that speak hipError_t)
     const int rc = pool_alloc(p, bytes);
     return rc == SIMRANK_OK ? hipSuccess : (rc == SIMRANK_ERR_ALLOC ? hipErrorOutOfMemory : hipErrorUnknown);

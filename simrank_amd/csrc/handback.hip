@@ -40,6 +40,8 @@
 #include <thread>
 #include <vector>
 
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 
 namespace simrank {
@@ -212,6 +214,64 @@ int64_t cpu_share() {
 }
 
 }  // namespace
+
+#ifndef SIMRANK_HOST_ONLY
+// dst[i][j] = src[idx[i]][col_idx[j]] out of fp16-held 64-column panels, widened
+__global__ __launch_bounds__(256) void rows_h16_kernel(const uint16_t* __restrict__ src, int64_t rows_pad, float* __restrict__ dst,
+                                                       int64_t ld, int64_t n_rows, int64_t n_cols, const int32_t* __restrict__ row_idx,
+                                                       const int32_t* __restrict__ col_idx, float inv_scale) {
+    for (int64_t i = blockIdx.x; i < n_rows; i += gridDim.x) {
+        const int64_t r = row_idx[i];
+        for (int64_t j = threadIdx.x; j < n_cols; j += blockDim.x) {
+            const int64_t c = col_idx[j];
+            const uint16_t h = src[((c >> 6) * rows_pad + r) * 64 + (c & 63)];
+            dst[i * ld + j] = __half2float(__ushort_as_half(h)) * inv_scale;
+        }
+    }
+}
+#endif
+
+int rows_to_host(const void* S, int64_t rows_pad, int64_t n, const int32_t* inv_dev, const int32_t* rows, int32_t n_rows,
+                 float* dst, int64_t ld, int elem, float scale, hipStream_t stream) {
+#ifdef SIMRANK_HOST_ONLY
+    (void)S; (void)rows_pad; (void)n; (void)inv_dev; (void)rows; (void)n_rows; (void)dst; (void)ld; (void)elem; (void)scale; (void)stream;
+    SR_REQUIRE(false, "host-only build: no device");
+#else
+    SR_REQUIRE(S && inv_dev && rows && dst && n_rows > 0 && ld >= n, "bad row arguments");
+    for (int32_t i = 0; i < n_rows; ++i) SR_REQUIRE(rows[i] >= 0 && rows[i] < n, "row %d out of range", rows[i]);
+    std::vector<int32_t> inv((size_t)n), pos((size_t)n_rows);
+    SR_HIP(hipMemcpyAsync(inv.data(), inv_dev, size_t(n) * 4, hipMemcpyDeviceToHost, stream));
+    SR_HIP(hipStreamSynchronize(stream));
+    for (int32_t i = 0; i < n_rows; ++i) pos[(size_t)i] = inv[(size_t)rows[i]];
+    const int64_t lds = (n + 3) / 4 * 4;
+    int32_t* pos_dev = nullptr;
+    float* out_dev = nullptr;
+    hipError_t e = pool_hip_alloc((void**)&pos_dev, size_t(n_rows) * 4);
+    if (e == hipSuccess) e = pool_hip_alloc((void**)&out_dev, size_t(n_rows) * size_t(lds) * 4);
+    int rc = SIMRANK_OK;
+    if (e == hipSuccess) e = hipMemcpyAsync(pos_dev, pos.data(), size_t(n_rows) * 4, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) {
+        if (elem == 4) {
+            rc = simrank_permute_layout(S, 32, rows_pad, out_dev, lds, 0, n_rows, n, pos_dev, inv_dev, 4, stream);
+        } else {
+            hipLaunchKernelGGL(rows_h16_kernel, dim3((unsigned)std::min<int64_t>(n_rows, 4096)), dim3(256), 0, stream,
+                               (const uint16_t*)S, rows_pad, out_dev, lds, (int64_t)n_rows, n, pos_dev, inv_dev, 1.0f / scale);
+            e = hipGetLastError();
+        }
+    }
+    if (e == hipSuccess && !rc)
+        e = hipMemcpy2DAsync(dst, size_t(ld) * 4, out_dev, size_t(lds) * 4, size_t(n) * 4, size_t(n_rows), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    else (void)hipStreamSynchronize(stream);
+    (void)pool_free(pos_dev); (void)pool_free(out_dev);
+    if (e != hipSuccess) {
+        set_error("rows hand-back: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return SIMRANK_ERR_HIP;
+    }
+    return rc;
+#endif
+}
 
 // The pinned slabs (3 x 128 MiB and more per device) are kept for the life of the process because pinning is slow;
 // simrank_pool_trim() — "give back what the library holds at rest" — releases them too (advisor, round 5).

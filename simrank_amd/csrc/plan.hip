@@ -449,6 +449,12 @@ int simrank_plan_trim(simrank_plan* p) {
     return SIMRANK_OK;
 }
 
+int simrank_plan_rows_f32(simrank_plan* p, const int32_t* rows, int32_t n_rows, float* dst, int64_t ld) {
+    SR_REQUIRE(p && rows && dst && n_rows > 0 && ld >= p->n, "bad row arguments");
+    SR_REQUIRE(p->S[0], "the plan's matrices were released (simrank_plan_trim)");
+    return rows_to_host(p->S[p->cur], p->rows_pad, p->n, p->inv, rows, n_rows, dst, ld, p->half ? 2 : 4, kHalfScale, p->stream);
+}
+
 int simrank_plan_topk(simrank_plan* p, int32_t k, int32_t exclude_diag, int32_t* idx_host, float* val_host) {
     SR_REQUIRE(p && idx_host && val_host && k > 0 && k <= 1024, "bad top-k arguments");
     SR_REQUIRE(p->S[0], "the plan's matrices were released (simrank_plan_trim)");

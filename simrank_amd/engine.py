@@ -205,6 +205,14 @@ class Plan:
         check(self.ops.lib.simrank_plan_result_f64(self.handle, out.ctypes.data, self.n), "simrank_plan_result_f64")
         return out
 
+    def rows(self, rows) -> np.ndarray:
+        """float32 [len(rows), n]: those rows of the current similarity matrix, caller's node order on both axes."""
+        ids = np.ascontiguousarray(rows, dtype=np.int32)
+        out = np.empty((ids.size, self.n), dtype=np.float32)
+        check(self.ops.lib.simrank_plan_rows_f32(self.handle, ids.ctypes.data, int(ids.size), out.ctypes.data, self.n),
+              "simrank_plan_rows_f32")
+        return out
+
     def topk(self, k: int, exclude_diag: bool = True):
         """(ids int32 [n, k], values float32 [n, k]): the k most similar nodes of every node, caller's ids."""
         idx = np.empty((self.n, k), dtype=np.int32)
@@ -565,6 +573,15 @@ class BiPlan:
         m = hostpool.empty_f64(n, n)
         check(self.ops.lib.simrank_biplan_result_f64(self.handle, group, m.ctypes.data, n), "simrank_biplan_result_f64")
         return m
+
+    def rows(self, group: int, rows) -> np.ndarray:
+        """float32 [len(rows), n_group]: those rows of group 1 | 2's current similarity matrix, caller's order on both axes."""
+        n = self.n1 if group == 1 else self.n2
+        ids = np.ascontiguousarray(rows, dtype=np.int32)
+        out = np.empty((ids.size, n), dtype=np.float32)
+        check(self.ops.lib.simrank_biplan_rows_f32(self.handle, int(group), ids.ctypes.data, int(ids.size), out.ctypes.data, n),
+              "simrank_biplan_rows_f32")
+        return out
 
     def topk(self, group: int, k: int, exclude_diag: bool = True):
         """(ids int32 [n, k], values float32 [n, k]) of group 1 | 2, caller's ids."""

@@ -544,7 +544,7 @@ def main():
     import torch
     import torch.distributed as dist
     from simrank_amd import ingest, synth
-    from simrank_amd.driver import LocalWorld, SideSpec, Solver, TorchWorld
+    from tests.pydriver import LocalWorld, SideSpec, Solver, TorchWorld
 
     gpu = args.backend == "nccl"
     use_dist = world_size > 1 or args.force_dist
@@ -670,7 +670,7 @@ def main():
                                f"eps test every iteration (every element compared, exact count)",
                    "N": n, "nnz": nnz, "mode": solver.mode,
                    "loop": ("simrank_plan_step behind the C ABI (csrc/plan.hip): what fit() runs on one GPU" if hplan is not None
-                            else "driver.Solver.step (Python choreography over the C ABI's kernels)"),
+                            else "tests/pydriver.Solver.step (the tests' Python choreography over the C ABI's kernels)"),
                    "layout": "panel-blocked (32-column panels)" if getattr(solver, "blocked", False) else "row-major",
                    "sharding": f"S column-sharded over {world_size} rank(s), all-to-all per update"
                                + (f" in {side_stages} overlapped stage(s)" if use_dist else "")
@@ -682,7 +682,7 @@ def main():
     if use_dist and getattr(world, "form_measured", None):
         out["shard_form_measured"] = world.form_measured      # both forms of leg 2 timed on this node's links
     if use_dist:
-        out["headline_loop"] = "driver.Solver over torch.distributed (TorchWorld)"
+        out["headline_loop"] = "tests/pydriver.Solver over torch.distributed (the tests' Python choreography; replaced below by the C loop)"
         out["python_driver"] = {"value": out["value"], "unit": "iterations/s", "ms_per_step": out["ms_per_step"]}
         # The one shot at a multi-GPU node: the SAME ranks also time the sharded loop behind the C ABI
         # (simrank_shardplan_*: ncclSend / ncclRecv groups on a stream of their own) in its forms — f32 full / half, the fp16
@@ -720,7 +720,9 @@ def main():
         for name, rec in out["sharded_c_loop"].get("variants", {}).items():
             if rec.get("parity_grade") and "value" in rec and (best is None or rec["value"] > best[1]["value"]):
                 best = (name, rec)
-        if best is not None and best[1]["value"] > out["value"]:
+        if best is not None:
+            # (round 6: the sharded loop behind the C ABI is the ONLY loop fit() runs on several ranks — it is the headline
+            # whatever the Python choreography of tests/pydriver.py, timed above for comparison, reached)
             out["value"], out["ms_per_step"] = best[1]["value"], best[1]["ms_per_step"]
             out["headline_loop"] = f"simrank_shardplan_step behind the C ABI, {best[0]}"
     if short_ms is not None:

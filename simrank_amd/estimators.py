@@ -4,13 +4,14 @@ Same class names, ``fit`` signatures (positional order and defaults), return typ
 post-fit attributes and console text as ysong1231/SimRank (SimRank/SimRank.py:8, :143,
 :305, :365, :427, :457), so ``from simrank_amd import SimRank`` is a drop-in for
 ``from SimRank import SimRank``.  What differs is *how*: the edge list becomes a CSR graph
-(``ingest.py``), the loop runs as HIP kernels (``driver.py`` / ``csrc/``), the similarity
+(``ingest.py``), the loop runs as HIP kernels behind the C ABI (``cplan.py`` / ``cshard.py`` / ``csrc/``), the similarity
 matrix never exists densely on the host until the result is handed back, and the dense
 attributes the reference keeps (``Graph``, ``Weight``, ``Evidence`` …) are materialised only
 when read.
 
 Extra keyword-only arguments (defaults keep the reference's behaviour):
-    mode              "auto" | "sparse" | "dense" | "hybrid" — which kernels run the two legs
+    mode              "auto" | "sparse": the gather legs ("dense" | "hybrid", BASELINE's literal dense-GEMM leg, left fit()
+                      in round 6: they run through the tests' Python choreography and ``bench.py`` only)
     device            HIP device ordinal (default: LOCAL_RANK or 0)
     world             ``driver.LocalWorld`` / ``driver.TorchWorld`` (sharded runs; in a multi-process
                       world the dense result goes to rank 0 only unless TorchWorld(handback="all"))
@@ -35,7 +36,7 @@ import numpy as np
 import pandas as pd
 
 from . import ingest
-from .driver import LocalWorld, SideSpec, Solver
+from .driver import LocalWorld, SideSpec
 from .progress import announce_converged, update_progress
 
 
@@ -70,44 +71,53 @@ def _precision(dense_precision, storage_precision="f32"):
         stack.pop()
 
 
+PYTHON_SOLVER = None      # tests/pydriver.py installs its kernel-by-kernel Python choreography here (a test double; never set by the product)
+
+
 def _make_solver(ops_factory, device, world, specs, mode):
     """The solver with the graphs created at the precision asked for: it travels in the specs and is set
     per graph object (simrank_graph_set_dense_terms), not through the process-wide tuning defaults.
 
-    One rank, gather legs (every class the reference has; a prior that is not symmetric in f32 only): the loop behind the
-    C ABI (``cplan.PlanSolver`` over simrank_plan_* / simrank_biplan_*).  Several RCCL ranks (or virtual ranks with
-    ``loop="c"``): the sharded loops behind the C ABI (``cshard.CShardSolver``), fp16-held matrices included.
-    Everything else — dense / hybrid modes, gloo worlds, ``LocalWorld(P)`` in its default form, the CPU tests' NumPy
-    double — ``driver.Solver``."""
-    from . import cplan
+    TWO choreographies, both behind the C ABI: one rank -> ``cplan.PlanSolver`` (simrank_plan_* / simrank_biplan_*: every
+    class the reference has, fp16-held matrices, asymmetric priors in f32); several ranks — virtual (``LocalWorld(P)``) or
+    RCCL (``TorchWorld``) -> ``cshard.CShardSolver`` (simrank_shardplan_* / simrank_shardbiplan_*).  What neither runs is
+    refused with the reason.  (``PYTHON_SOLVER``: the tests' double — an injected engine (``_ops_factory``), the GEMM modes
+    "dense" / "hybrid", a world with ``loop="python"``, a gloo world — runs ``tests/pydriver.Solver`` when that module is
+    loaded, and only then.)"""
+    from . import cplan, cshard
+    from .driver import TorchWorld
     dense, storage = _precision_now.__dict__.get("stack", [("f32", "f32")])[-1]
     terms = _DENSE_TERMS[dense]
     if terms != 3 or storage != "f32":
         specs = [dataclasses.replace(s, dense_terms=terms, storage=storage) for s in specs]
-    if world.size == 1 and not isinstance(world, LocalWorld) and storage == "fp16":
-        world = LocalWorld(1)            # (a one-rank process group: this process holds everything)
-    if cplan.applies(ops_factory, world, specs, mode):
-        ops = _default_ops_factory(device)(0)
-        if cplan.lean_knobs(ops):
-            return cplan.PlanSolver(ops, world, specs)
-        ops_factory = lambda rank: ops
+    if mode not in ("auto", "sparse", "dense", "hybrid"):
+        raise ValueError(f"mode must be 'auto' or 'sparse', not {mode!r}")
+    loop = getattr(world, "loop", "c")
+    gloo = isinstance(world, TorchWorld) and world.dist.get_backend(world.group) != "nccl"
+    shards_fp16 = storage == "fp16" and world.size > 1      # (fp16-held shards exist behind the C ABI only: cshard says why not)
+    if (ops_factory is not None or mode in ("dense", "hybrid") or loop == "python" or (gloo and loop != "c")) and not shards_fp16:
+        if PYTHON_SOLVER is None:
+            what = ("an injected engine" if ops_factory is not None else f"mode={mode!r}" if mode in ("dense", "hybrid")
+                    else "loop='python'" if loop == "python" else "a gloo world")
+            raise ValueError(f"{what} needs the Python choreography of tests/pydriver.py (a test double: import it first); "
+                             "fit() itself runs the gather legs behind the C ABI (mode 'auto' / 'sparse') on one GPU, on "
+                             "LocalWorld(P) or on an RCCL TorchWorld")
+        if world.size == 1 and not isinstance(world, LocalWorld) and storage == "fp16":
+            world = LocalWorld(1, loop="python")
+        return PYTHON_SOLVER(ops_factory, device, world, specs, mode)
     factory = ops_factory or _default_ops_factory(device)
-    if world.size > 1 or getattr(world, "loop", "auto") == "c":
-        # several ranks: the sharded loop behind the C ABI (csrc/shardplan.hip) wherever it applies — the ranks of an RCCL
-        # world, or virtual ranks that ask for it (LocalWorld(P, loop="c")); fp16-held matrices exist on shards only there
-        from . import cshard
-        from .driver import TorchWorld
-        wants_c = ops_factory is None and (
-            (isinstance(world, TorchWorld) and world.dist.get_backend(world.group) == "nccl" and
-             getattr(world, "loop", "auto") != "python") or
-            (isinstance(world, LocalWorld) and getattr(world, "loop", "python") == "c"))
-        if wants_c or storage == "fp16":
-            why = cshard.applies(world, specs, mode)
-            if why is None:
-                return cshard.CShardSolver(factory, world, specs)
-            if storage == "fp16":
-                raise ValueError("storage_precision='fp16' on several ranks: " + why)
-    return Solver(factory, world, specs, mode)
+    if world.size == 1 and (isinstance(world, LocalWorld) or loop != "c"):
+        # (a one-rank process group holds everything: the single-GPU plan, unless the caller asks for the sharded loop's
+        # RCCL path on one rank — TorchWorld(loop="c"), how that path is exercised on one GPU)
+        ops = factory(0)
+        one = world if isinstance(world, LocalWorld) else LocalWorld(1)
+        if not cplan.applies(None, one, specs, "sparse") or not cplan.lean_knobs(ops):
+            raise ValueError("this fit has no C-level plan (non-default kernel knobs, or evidence / priors of a foreign shape)")
+        return cplan.PlanSolver(ops, one, specs)
+    why = cshard.applies(world, specs, "sparse")
+    if why is not None:
+        raise ValueError(("storage_precision='fp16' on several ranks: " if storage == "fp16" else "fit on several ranks: ") + why)
+    return cshard.CShardSolver(factory, world, specs)
 
 
 _engines = threading.local()        # the default engine of a (thread, device): its stream, counters and slots made once

@@ -6,6 +6,8 @@ import numpy as np
 import pandas as pd
 import pytest
 
+import tests.pydriver  # noqa: F401,E402  (installs the Python choreography — the tests' double — as estimators.PYTHON_SOLVER)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -21,7 +21,7 @@ def main():
     dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
     import simrank_amd.SimRank as SRA
     from simrank_amd import synth
-    from simrank_amd.driver import LocalWorld, TorchWorld
+    from tests.pydriver import LocalWorld, TorchWorld
     from tests.conftest import Golden
     from tests.helpers import check_against_golden, run_estimator
     rank = dist.get_rank()
@@ -63,7 +63,7 @@ def main():
         np.testing.assert_allclose(got.values, want.values, rtol=2e-6, atol=1e-30)
     # leg 2 in its half form (simrank_spmm_shard, the second all_to_all_single on the engine's stream,
     # simrank_shard_unpack); N must be a multiple of 32 x ranks.  "force" takes it in a one-rank world too
-    import simrank_amd.driver as drv
+    import tests.pydriver as drv
     made = []
     orig = drv.Solver.__init__
 

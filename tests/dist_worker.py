@@ -15,9 +15,9 @@ def main(argv):
     stages, names = int(argv[0]), argv[1:]
     dist.init_process_group("gloo")
     rank = dist.get_rank()
-    import simrank_amd.driver as drv
+    import tests.pydriver as drv
     drv.STAGE_ALIGN = 4              # small fixtures: let the stages really split the columns
-    from simrank_amd.driver import TorchWorld
+    from tests.pydriver import TorchWorld
     from tests.conftest import Golden
     from tests.cpu_ops import NumpyOps
     from tests.helpers import check_against_golden, run_estimator
@@ -25,7 +25,7 @@ def main(argv):
         # half-form leg 2 (driver.Side.shard_sym): N divisible by 32 x world, second all-to-all real
         import simrank_amd.SimRank as SRA
         from simrank_amd import synth
-        from simrank_amd.driver import LocalWorld
+        from tests.pydriver import LocalWorld
         cls = name.split(":")[1]
         # (256 nodes per rank = 8 column tiles when the exchange is staged: leg 2 and its second all-to-all
         # are then cut into stages too, Side.sh_stages)
@@ -47,7 +47,7 @@ def main(argv):
         # of the same wire gives (same roundings of the same values)
         import simrank_amd.SimRank as SRA
         from simrank_amd import synth
-        from simrank_amd.driver import LocalWorld
+        from tests.pydriver import LocalWorld
         cls = name.split(":")[1]
         P = dist.get_world_size()
         frame = synth.powerlaw_directed((256 if stages > 1 else 64) * P, 5, 3)
@@ -76,7 +76,7 @@ def main(argv):
         # timed, every rank adopts the same one, the result is the one-rank result either way
         import simrank_amd.SimRank as SRA
         from simrank_amd import synth
-        from simrank_amd.driver import LocalWorld
+        from tests.pydriver import LocalWorld
         drv.MEASURE_FORM_FROM_N = 0
         frame = synth.powerlaw_directed(64 * dist.get_world_size(), 5, 3)
         one = NumpyOps()

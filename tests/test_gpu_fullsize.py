@@ -93,12 +93,9 @@ def test_config2_er8192_whole_fit_against_the_oracle(ops):
     assert np.array_equal(plan.rows(rows).astype(np.float64), direct[rows])
     plan.free()
     assert np.array_equal(direct, got.values)          # fit() IS this loop: the same bits
-    # SimRank++ of the same graph, the whole fit as well (evidence counts on the device, spread weights)
-    wantp = O.fit_simrank_pp(df, verbose=False)
-    estp = SRA.SimRankPP()
-    gotp = estp.fit(df, verbose=False)
-    assert estp.converged_at == wantp["k"]
-    assert_close(gotp.values, wantp["S"])
+    # (SimRank++ of this size is not repeated here: the oracle's evidence is an int64 dense matmul, SimRank.py:315 — four
+    # minutes at N = 8192 on the box's 16 CPUs; its whole fits are compared at N <= 4096 in test_gpu_parity.py, and config 5
+    # below checks the evidence factor at N = 65536 on sampled rows)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -247,7 +244,7 @@ def test_sharded_c_loop_at_full_size_on_eight_ranks(ops, workload, pp, form, sta
     if storage == "f32" and not wire and workload == "pl32768d32":
         # the Python choreography (kernel by kernel through the ABI) makes the same launches on the same node orders: the
         # last rank's block carries the same BITS (three of its own nodes' rows x all its columns), in both forms
-        from simrank_amd.driver import LocalWorld, SideSpec, Solver
+        from tests.pydriver import LocalWorld, SideSpec, Solver
         blk, bids = sp8.block(P - 1)
         s = Solver(lambda r: ops, LocalWorld(P, symmetric_shards=bool(form)),
                    [SideSpec(csr, scale, 0.8, evidence_from=csr if pp else None)], "sparse")

@@ -285,7 +285,7 @@ def test_fit_with_half_storage_on_virtual_ranks(cls):
     import simrank_amd.SimRank as SRA
     from oracle import simrank_oracle as O
     from simrank_amd import synth
-    from simrank_amd.driver import LocalWorld
+    from tests.pydriver import LocalWorld
     df = synth.powerlaw_directed(2048, 24, seed=12)
     oracle = O.fit_simrank if cls == "SimRank" else O.fit_simrank_pp
     want = oracle(df, verbose=False, iterations=10, eps=1e-30)
@@ -338,7 +338,7 @@ def test_plan_api_with_half_storage(ops):
     couple of fp16 spacings), prior and evidence included; hand-back through the f32 layout in the
     caller's order."""
     from simrank_amd import ingest, synth
-    from simrank_amd.driver import LocalWorld, SideSpec, Solver
+    from tests.pydriver import LocalWorld, SideSpec, Solver
     from simrank_amd.engine import Plan
     df = synth.powerlaw_directed(1500, 12, seed=7)
     _, csr = ingest.directed(df, False, "from", "to", "weight")
@@ -488,7 +488,7 @@ def test_fp16_wire_on_virtual_ranks(cls, half):
     result moves by a few fp16 roundings per update and no more."""
     import simrank_amd.SimRank as SRA
     from simrank_amd import synth
-    from simrank_amd.driver import LocalWorld
+    from tests.pydriver import LocalWorld
     df = synth.powerlaw_directed(1024, 8, seed=4)
     kw = dict(weighted=True) if cls.endswith("PP") else {}
     exact = getattr(SRA, cls)().fit(df, iterations=6, eps=0, verbose=False, mode="sparse",

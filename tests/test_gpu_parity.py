@@ -10,7 +10,7 @@ import scipy.sparse as sp
 import simrank_amd.SimRank as SRA
 from oracle import simrank_oracle as O
 from simrank_amd import ingest, synth
-from simrank_amd.driver import LocalWorld, SideSpec, Solver
+from tests.pydriver import LocalWorld, SideSpec, Solver
 from tests.conftest import Golden, free_port, golden_names
 from tests.graphs import bipartite_random
 from tests.helpers import RTOL, assert_close, check_against_golden, run_estimator
@@ -660,7 +660,7 @@ def test_randomized_half_form_against_oracle(seed, monkeypatch):
     size, density and class — bipartite, evidence (also support-restricted), symmetric prior —
     against the oracle; the convergence iteration must match too (the counter counts mirrored
     elements twice)."""
-    import simrank_amd.driver as drv
+    import tests.pydriver as drv
     rng = np.random.default_rng(7000 + seed)
     P = int(rng.choice([2, 3, 4, 8]))
     n = 32 * P * int(rng.integers(1, 7 if P < 8 else 4))
@@ -710,7 +710,7 @@ def test_randomized_half_form_against_oracle(seed, monkeypatch):
 def test_logical_shards_with_padded_chunks(world, monkeypatch):
     """The padded chunk layout (t_pad) through the real kernels, forced on at small size and
     natural at N = 4096 (blocks of 2048 / 1024 rows)."""
-    import simrank_amd.driver as drv
+    import tests.pydriver as drv
     g = Golden("SimRankPP_er128")
     monkeypatch.setattr(drv, "PAD_MIN_ROWS", 1)
     monkeypatch.setattr(drv, "PAD_MULTIPLE", 1)
@@ -748,7 +748,7 @@ def test_top_k_hand_back_on_gpu():
 # ---------------------------------------------------------------------------------------
 def _dense_corner_graph():
     from simrank_amd import ingest
-    from simrank_amd.driver import SideSpec, reorder_specs
+    from tests.pydriver import SideSpec, reorder_specs
     from simrank_amd.engine import HipOps
     df = synth.powerlaw_directed(4096, 32, seed=21)
     _, csr = ingest.directed(df, False, "from", "to", "weight")
@@ -776,7 +776,7 @@ def test_support_restricted_simrank_pp_is_bit_equal(world, monkeypatch):
     of leg 2 skips the gathers of 32-column segments whose evidence counts are all zero; it must
     give the bits of the unrestricted one (single rank: upper-triangle form; sharded: plain form),
     on a sparse-evidence graph (where the driver picks it by itself) and on one with dense sets."""
-    import simrank_amd.driver as drv
+    import tests.pydriver as drv
     from simrank_amd.engine import HipOps
     for df in (synth.er_directed(4096, 0.001, seed=11), _dense_corner_graph()):
         out = {}

@@ -133,19 +133,24 @@ def test_half_and_full_hand_back_of_config_4_are_the_same_bits(ops, monkeypatch)
 # which loop fit() runs, and its console hooks
 # ---------------------------------------------------------------------------------------------------------------
 def test_fit_runs_the_c_level_loops(monkeypatch):
-    """Every class on one GPU goes through cplan.PlanSolver (simrank_plan_run_cb / simrank_biplan_run_cb) — asymmetric
-    priors included (un-fused epilogue inside the plan) unless the matrices are fp16-held; the GEMM modes and virtual
-    ranks keep driver.Solver."""
+    """The product has TWO choreographies, both behind the C ABI: every class on one GPU goes through cplan.PlanSolver
+    (simrank_plan_run_cb / simrank_biplan_run_cb) — asymmetric priors included unless the matrices are fp16-held —, several
+    ranks through cshard.CShardSolver (simrank_shardplan_* / simrank_shardbiplan_*).  With the tests' double unplugged
+    (estimators.PYTHON_SOLVER = None: the state of a user's process) nothing else exists: the GEMM modes and an injected
+    engine are refused with the reason; with it plugged in they — and only they — run tests/pydriver.Solver."""
     import simrank_amd.cplan as cplan
-    import simrank_amd.driver as drv
+    import simrank_amd.cshard as cshard
+    import simrank_amd.estimators as est
+    import tests.pydriver as drv
     made = []
-    for cls, tag in ((cplan.PlanSolver, "plan"), (drv.Solver, "python")):
+    for cls, tag in ((cplan.PlanSolver, "plan"), (cshard.CShardSolver, "shards"), (drv.Solver, "double")):
         orig = cls.__init__
 
         def spy(self, *a, _orig=orig, _tag=tag, **k):
             _orig(self, *a, **k)
             made.append(_tag)
         monkeypatch.setattr(cls, "__init__", spy)
+    from simrank_amd.driver import LocalWorld as ProductWorld
     df = synth.er_directed(96, 0.08, seed=2)
     dfb = bipartite_random(40, 40, 0.15, seed=5)
     rng = np.random.default_rng(1)
@@ -156,6 +161,7 @@ def test_fit_runs_the_c_level_loops(monkeypatch):
     b1 = (b1 + b1.T) / 2
     cases = [
         (lambda: SRA.SimRank().fit(df, verbose=False), "plan"),
+        (lambda: SRA.SimRank().fit(df, verbose=False, mode="sparse"), "plan"),
         (lambda: SRA.SimRankPP().fit(df, verbose=False), "plan"),
         (lambda: SRA.SimRankPP().fit(df, verbose=False, storage_precision="fp16"), "plan"),
         (lambda: SRA.SimRankPP().fit(df, verbose=False, dense_precision="fp16"), "plan"),
@@ -166,18 +172,31 @@ def test_fit_runs_the_c_level_loops(monkeypatch):
         (lambda: SRA.BipartiteSimRankPP().fit(dfb, verbose=False), "plan"),
         (lambda: SRA.BipartiteSimRankPP().fit(dfb, verbose=False, strict_reference=False, top_k=3), "plan"),
         (lambda: SRA.BipartitleAprioriSimRank().fit(dfb, b1, b1.copy(), verbose=False), "plan"),
-        (lambda: SRA.SimRank().fit(df, verbose=False, mode="dense"), "python"),
-        (lambda: SRA.SimRank().fit(df, verbose=False, world=SRA_local(2)), "python"),
+        (lambda: SRA.SimRank().fit(df, verbose=False, world=ProductWorld(1)), "plan"),
+        (lambda: SRA.SimRank().fit(df, verbose=False, world=ProductWorld(2)), "shards"),
+        (lambda: SRA.SimRankPP().fit(df, verbose=False, world=ProductWorld(3, symmetric_shards=False)), "shards"),
+        (lambda: SRA.AprioriSimRank().fit(df, asym, verbose=False, world=ProductWorld(2)), "shards"),
+        (lambda: SRA.BipartiteSimRankPP().fit(dfb, verbose=False, world=ProductWorld(4)), "shards"),
     ]
+    monkeypatch.setattr(est, "PYTHON_SOLVER", None)
     for run, want in cases:
         made.clear()
         run()
         assert made == [want], (made, want)
-
-
-def SRA_local(p):
-    from simrank_amd.driver import LocalWorld
-    return LocalWorld(p)
+    for kw, why in ((dict(mode="dense"), "mode='dense'"), (dict(mode="hybrid"), "mode='hybrid'"),
+                    (dict(_ops_factory=lambda r: None), "an injected engine"), (dict(world=drv.LocalWorld(2)), "loop='python'")):
+        with pytest.raises(ValueError, match=why):
+            SRA.SimRank().fit(df, verbose=False, **kw)
+    with pytest.raises(ValueError, match="mode must be"):
+        SRA.SimRank().fit(df, verbose=False, mode="gemm")
+    monkeypatch.setattr(est, "PYTHON_SOLVER", drv.make_solver)
+    for kw in (dict(mode="dense"), dict(mode="hybrid"), dict(world=drv.LocalWorld(2))):
+        made.clear()
+        SRA.SimRank().fit(df, verbose=False, **kw)
+        assert made == ["double"], (kw, made)
+    made.clear()
+    SRA.SimRank().fit(df, verbose=False)                       # (the double plugged in changes nothing for an ordinary fit)
+    assert made == ["plan"]
 
 
 def test_progress_hooks_of_the_c_loop(ops):
@@ -275,7 +294,7 @@ def test_plan_evidence_counts_trim_and_biplan_topk(ops):
 # two fits side by side on one device (advisor, round 4: the pinned counter slots were a per-device table)
 # ---------------------------------------------------------------------------------------------------------------
 def test_two_threads_fit_side_by_side():
-    from simrank_amd.driver import LocalWorld, SideSpec, Solver
+    from tests.pydriver import LocalWorld, SideSpec, Solver
     from simrank_amd.engine import HipOps
     dfs = [synth.er_directed(500, 0.02, seed=21), synth.powerlaw_directed(700, 5, seed=22)]
     wants = [O.fit_simrank(d, verbose=False) for d in dfs]
@@ -328,7 +347,7 @@ import numpy as np
 import simrank_amd.SimRank as SRA
 from oracle import simrank_oracle as O
 from simrank_amd import synth
-from simrank_amd.driver import LocalWorld
+from tests.pydriver import LocalWorld
 for n, deg in ((77, 4), (333, 6), (1000, 5), (2113, 7)):          # not multiples of 32 / 64
     df = synth.powerlaw_directed(n, deg, seed=n)
     for cls, ref in ((SRA.SimRank, O.fit_simrank), (SRA.SimRankPP, O.fit_simrank_pp)):

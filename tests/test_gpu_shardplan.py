@@ -14,7 +14,7 @@ import pytest
 import simrank_amd.SimRank as SRA
 from oracle import simrank_oracle as O
 from simrank_amd import ingest, synth
-from simrank_amd.driver import LocalWorld
+from tests.pydriver import LocalWorld
 from tests.conftest import Golden
 from tests.helpers import RTOL, assert_close
 

@@ -7,7 +7,7 @@ import pytest
 
 from oracle import simrank_oracle as O
 from simrank_amd import ingest
-from simrank_amd.driver import LocalWorld
+from tests.pydriver import LocalWorld
 from tests.conftest import Golden, golden_names
 from tests.cpu_ops import NumpyOps
 from tests.helpers import check_against_golden, run_estimator
@@ -151,7 +151,7 @@ def test_reference_class_names_and_signatures():
 @pytest.mark.parametrize("name", ["SimRank_er64", "AprioriSimRank_er64_asym", "BipartiteSimRank_b5030"])
 def test_virtual_ranks_with_padded_chunks(name, world, monkeypatch):
     """Exchanged chunk rows padded by 32 floats (what large power-of-two blocks get)."""
-    import simrank_amd.driver as drv
+    import tests.pydriver as drv
     monkeypatch.setattr(drv, "PAD_MIN_ROWS", 1)
     monkeypatch.setattr(drv, "PAD_MULTIPLE", 1)
     g = Golden(name)
@@ -184,7 +184,7 @@ def test_top_k_hand_back(world):
 
 
 def test_stage_plan_is_a_permutation():
-    from simrank_amd.driver import stage_widths, staged_row_order, permute_columns
+    from tests.pydriver import stage_widths, staged_row_order, permute_columns
     for k, world, stages in [(64, 2, 3), (1000, 3, 4), (32768, 8, 4), (5, 2, 4)]:
         perm = staged_row_order(k, world, stages)
         assert sorted(perm.tolist()) == list(range(k))
@@ -225,7 +225,7 @@ def test_solver_node_order_is_invisible(name, world):
     """The solver iterates with every node set sorted by row length (driver.reorder_specs);
     results, evidence and top-k come back in the caller's order and match a solver that
     keeps the caller's order throughout."""
-    from simrank_amd import driver
+    from tests import pydriver as driver
     g = Golden(name)
     made = []
     orig = driver.Solver.__init__
@@ -345,8 +345,8 @@ def test_half_form_sharded_leg2(cls_name, world):
 
 
 def test_dealt_order():
-    from simrank_amd import driver
-    from simrank_amd.driver import dealt_order
+    from tests import pydriver as driver
+    from tests.pydriver import dealt_order
     o = np.arange(1024)
     d = dealt_order(o, 4)                 # runs of 128: 0..127 -> shard 0, 128..255 -> shard 1, ...
     assert sorted(d) == list(o) and list(d[:128]) == list(range(128))

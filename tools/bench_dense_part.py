@@ -4,7 +4,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simrank_amd import ingest, synth
-from simrank_amd.driver import SideSpec, reorder_specs
+from tests.pydriver import SideSpec, reorder_specs
 from simrank_amd.engine import HipOps
 
 ops = HipOps(0)

@@ -8,9 +8,9 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import simrank_amd.driver as drv                                    # noqa: E402
+import tests.pydriver as drv                                    # noqa: E402
 from simrank_amd import ingest, synth                              # noqa: E402
-from simrank_amd.driver import LocalWorld, SideSpec, Solver        # noqa: E402
+from tests.pydriver import LocalWorld, SideSpec, Solver        # noqa: E402
 from simrank_amd.engine import HipOps                              # noqa: E402
 
 ops = HipOps(0)

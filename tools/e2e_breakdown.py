@@ -2,7 +2,7 @@ import sys, time
 sys.path.insert(0, ".")
 import numpy as np, pandas as pd
 from simrank_amd import ingest, synth
-from simrank_amd.driver import LocalWorld, SideSpec, Solver
+from tests.pydriver import LocalWorld, SideSpec, Solver
 from simrank_amd.engine import HipOps
 for w in (sys.argv[1:] or ["bts300", "er8192", "pl32768"]):
     df = synth.WORKLOADS[w][0]()

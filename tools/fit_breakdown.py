@@ -6,7 +6,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simrank_amd import ingest, synth
-from simrank_amd.driver import LocalWorld, SideSpec, Solver
+from tests.pydriver import LocalWorld, SideSpec, Solver
 from simrank_amd.engine import HipOps
 
 storage = sys.argv[1] if len(sys.argv) > 1 else "f32"

@@ -21,7 +21,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simrank_amd import ingest, synth                       # noqa: E402
-from simrank_amd.driver import SideSpec, reorder_specs      # noqa: E402
+from tests.pydriver import SideSpec, reorder_specs      # noqa: E402
 
 
 def plan(rowptr, col, n, block, thr, min_steps=8):

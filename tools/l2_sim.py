@@ -20,7 +20,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simrank_amd import ingest, synth                       # noqa: E402
-from simrank_amd.driver import SideSpec, reorder_specs      # noqa: E402
+from tests.pydriver import SideSpec, reorder_specs      # noqa: E402
 
 
 def dense_remainder(rowptr, col, n, dmin=4, dcols=128):

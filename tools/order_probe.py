@@ -15,7 +15,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simrank_amd import ingest, synth                              # noqa: E402
-from simrank_amd.driver import LocalWorld, SideSpec, Solver        # noqa: E402
+from tests.pydriver import LocalWorld, SideSpec, Solver        # noqa: E402
 from simrank_amd.engine import HipOps                              # noqa: E402
 
 

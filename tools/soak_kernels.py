@@ -115,7 +115,7 @@ for case in range(cases):
 # ten times over — one stale partial sum anywhere changes a bit
 if os.environ.get("SOAK_BIG", "1") != "0":
     from simrank_amd import ingest, synth
-    from simrank_amd.driver import SideSpec, reorder_specs
+    from tests.pydriver import SideSpec, reorder_specs
     df = synth.WORKLOADS["pl32768d32"][0]()
     _, csr = ingest.directed(df, False, "from", "to", "weight")
     specs, _ = reorder_specs([SideSpec(csr, csr.rowscale, 0.8)])

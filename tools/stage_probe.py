@@ -4,7 +4,7 @@ columns against 2 / 4 / 8 launches over slices (what TorchWorld(stages=k) queues
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simrank_amd import ingest, synth
-from simrank_amd.driver import SideSpec, reorder_specs
+from tests.pydriver import SideSpec, reorder_specs
 from simrank_amd.engine import HipOps
 
 ops = HipOps(0)

@@ -4,7 +4,7 @@ read-back of the convergence count."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simrank_amd import ingest, synth
-from simrank_amd.driver import LocalWorld, SideSpec, Solver
+from tests.pydriver import LocalWorld, SideSpec, Solver
 from simrank_amd.engine import HipOps
 
 ops = HipOps(0)

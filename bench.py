@@ -271,6 +271,52 @@ def cpu_baseline(csr, S_host, coef, budget_s=45.0):
                       f"{per_iter:.1f} s/iteration; {share} CPUs granted of {os.cpu_count()}, BLAS threads {threads}"}
 
 
+def link_probe(world, dist, torch, rank, mib=64, reps=5):
+    """What the links of THIS node move: every rank sends `mib` MiB of f32 to every peer and receives as much from each, all
+    peers at once (ncclSend / ncclRecv pairs in one group: the traffic shape of the update's all-to-all), `reps` times behind
+    a warm-up; -> GB/s per rank and direction (sum over its peers), and per peer link.  DESIGN.md §5's projection of the
+    8-GPU update (448 MiB per rank over 7 links in ~0.9 ms = 75 GB/s per link) rests on this number; no multi-GPU node has
+    been available to take it (one rank: nothing to time, the keys say so)."""
+    P = world.size
+    rec = {"ranks": P, "MiB_per_peer": mib, "peers": P - 1}
+    if P < 2:
+        rec["skipped"] = "one rank: no peer to exchange with"
+        return rec
+    try:
+        n = mib * (1 << 20) // 4
+        send = [torch.full((n,), float(rank), dtype=torch.float32, device="cuda") for _ in range(P)]
+        recv = [torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(P)]
+
+        def once():
+            ops_ = []
+            for h in range(P):
+                if h != rank:
+                    ops_.append(dist.P2POp(dist.isend, send[h], h, group=world.group))
+                    ops_.append(dist.P2POp(dist.irecv, recv[h], h, group=world.group))
+            for w in dist.batch_isend_irecv(ops_):
+                w.wait()
+        once()
+        torch.cuda.synchronize()
+        dist.barrier(group=world.group)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            once()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        t = torch.tensor([ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=world.group)
+        ms = float(t.item())
+        ok = all(float(recv[h][0].item()) == float(h) for h in range(P) if h != rank)
+        sent = (P - 1) * mib * (1 << 20)
+        rec.update({"ms": ms, "GBps_per_rank_each_way": sent / (ms * 1e-3) / 1e9,
+                    "GBps_per_peer_link_each_way": sent / (P - 1) / (ms * 1e-3) / 1e9, "payload_ok": ok})
+    except Exception as e:                           # (a probe must never sink the line)
+        rec["error"] = f"{type(e).__name__}: {e}"
+    return rec
+
+
 def c_loop_section(args, ops, world, dist, torch, synth, ingest, csr, coef, gpu, barrier, rank, out=None):
     """The sharded loop behind the C ABI on this world's ranks: every variant `steps` updates with the exact count, the
     MAX over the ranks of the wall time, per-piece HIP-event times of rank 0.  Over gloo (the CPU rehearsal of the launch
@@ -290,10 +336,12 @@ def c_loop_section(args, ops, world, dist, torch, synth, ingest, csr, coef, gpu,
         out["config5"] = {"skipped": why}
         out["config3"] = {"skipped": why}
         out["form_measured"] = {"skipped": why}
+        out["link_probe"] = {"skipped": "gloo rehearsal: no xGMI links to time"}
         return out
     from simrank_amd import cshard
     from simrank_amd.engine import ShardPlans
     comm = cshard._rccl_comm(world, ops)
+    out["link_probe"] = link_probe(world, dist, torch, rank)
 
     def max_over_ranks(v):
         t = torch.tensor([v], dtype=torch.float64, device="cuda")

@@ -112,7 +112,9 @@ def _make_solver(ops_factory, device, world, specs, mode):
         ops = factory(0)
         one = world if isinstance(world, LocalWorld) else LocalWorld(1)
         if not cplan.applies(None, one, specs, "sparse") or not cplan.lean_knobs(ops):
-            raise ValueError("this fit has no C-level plan (non-default kernel knobs, or evidence / priors of a foreign shape)")
+            raise ValueError("this fit has no C-level plan: the plans behind the C ABI run the default kernel knobs, one storage "
+                             "precision, fp16-held matrices for the one-matrix classes with symmetric priors only, exact "
+                             "products in the two-matrix classes")
         return cplan.PlanSolver(ops, one, specs)
     why = cshard.applies(world, specs, "sparse")
     if why is not None:

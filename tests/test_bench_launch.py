@@ -29,13 +29,15 @@ def test_bench_launches_its_own_ranks_over_gloo():
     assert out["metric"] == "simrank_iterations_per_sec" and out["value"] > 0
     assert out["scaling"] == "strong" and "NOT a measurement" in out["data"]
     # the one command for an 8-GPU node carries every key of the sharded runs (here: named, and marked as not run)
-    assert out["headline_loop"].startswith("driver.Solver") and out["python_driver"]["value"] == out["value"]
+    assert out["headline_loop"].startswith("tests/pydriver.Solver") and out["python_driver"]["value"] == out["value"]
     c = out["sharded_c_loop"]
     assert c["ranks"] == 2 and set(c["variants"]) == {"f32_full_form", "f32_half_form", "f32_half_form_fp16_wire",
                                                       "fp16_held_full_form"}
     assert all("skipped" in v and "value" not in v for v in c["variants"].values())
     assert [v["parity_grade"] for v in c["variants"].values()] == [True, True, False, False]
     assert "skipped" in c["config5"] and "skipped" in c["config3"] and "skipped" in c["form_measured"]
+    assert "skipped" in c["link_probe"]          # (the xGMI link-rate probe of a real multi-GPU run)
+    assert len(lines[0]) <= 8000                 # the driver's record keeps the tail of the line: it must be all of it
     assert "exchange_ms" in out
 
 

@@ -375,15 +375,20 @@ def test_bipartite_fit_with_half_storage():
     from tests.graphs import bipartite_random
     df = bipartite_random(900, 500, 0.03, seed=14)
     want = O.fit_bipartite_pp(df, verbose=False, strict_reference=False, iterations=10, eps=1e-30)
+    # (round 6: the two-matrix plan behind the C ABI is f32; fp16-held rectangular legs run through the tests' Python
+    # choreography — a world of tests/pydriver.py — and fit() on its own refuses the combination with the reason)
+    from tests.pydriver import LocalWorld
+    with pytest.raises(ValueError, match="no C-level plan"):
+        SRA.BipartiteSimRankPP().fit(df, verbose=False, strict_reference=False, iterations=1, storage_precision="fp16")
     s1, s2 = SRA.BipartiteSimRankPP().fit(df, verbose=False, strict_reference=False, iterations=10, eps=1e-30,
-                                          storage_precision="fp16")
+                                          storage_precision="fp16", world=LocalWorld(1))
     for got, ref in ((s1.values, want["S1"]), (s2.values, want["S2"])):
         assert np.array_equal(got, got.T) and np.all(np.diag(got) == 1.0)
         err = np.abs(got - ref)
         rel = err[ref > 0] / ref[ref > 0]
         assert err.max() < 6e-4 and rel.max() < 3e-3 and np.median(rel) < 4e-4, (err.max(), rel.max(), np.median(rel))
     small = bipartite_random(40, 30, 0.2, seed=2)
-    a, b = SRA.BipartiteSimRank().fit(small, verbose=False, storage_precision="fp16")
+    a, b = SRA.BipartiteSimRank().fit(small, verbose=False, storage_precision="fp16", world=LocalWorld(1))
     wa = O.fit_bipartite(small, verbose=False)
     assert np.abs(a.values - wa["S1"]).max() < 1e-3 and np.abs(b.values - wa["S2"]).max() < 1e-3
 

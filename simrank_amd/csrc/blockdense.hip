@@ -64,17 +64,6 @@ __device__ __forceinline__ void split3(float x0, float x1, uint32_t& hi, uint32_
     lo = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
 }
 
-#ifdef SIMRANK_TERMS2
-__device__ __forceinline__ void split2h(float x0, float x1, uint32_t& hi, uint32_t& lo) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const float s0 = x0 * 16384.0f, s1 = x1 * 16384.0f;
-    const h2 h = {(_Float16)s0, (_Float16)s1};
-    const h2 l = {(_Float16)((s0 - (float)h.x) * 2048.0f), (_Float16)((s1 - (float)h.y) * 2048.0f)};
-    hi = __builtin_bit_cast(uint32_t, h);
-    lo = __builtin_bit_cast(uint32_t, l);
-}
-#endif
-
 __device__ __forceinline__ bf16x8 as_bf16x8(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
     const uint4 v = make_uint4(a, b, c, d);
     return __builtin_bit_cast(bf16x8, v);
@@ -156,37 +145,8 @@ __global__ __launch_bounds__(256, 2) void dense_tiles_kernel(const DenseArgs p) 
             issue(k + 16);
             if (k + 32 < k1) fetch_ids(k + 32);
         }
-#ifdef SIMRANK_TERMS2
-        if constexpr (TERMS == 3) {
-            // (experiment, round 6) two fp16 terms, x 2^14 = hi + lo 2^-11; the accumulators carry the factor 2^14
-            uint32_t hi[2][4], lo[2][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                split2h(cur[2 * j].x, cur[2 * j + 1].x, hi[0][j], lo[0][j]);
-                split2h(cur[2 * j].y, cur[2 * j + 1].y, hi[1][j], lo[1][j]);
-            }
-            f16x8 ah[4], al[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                ah[m] = __builtin_bit_cast(f16x8, make_uint4(ac[m].x & 0x3C003C00u, ac[m].y & 0x3C003C00u, ac[m].z & 0x3C003C00u, ac[m].w & 0x3C003C00u));
-                al[m] = __builtin_bit_cast(f16x8, make_uint4(ac[m].x & 0x10001000u, ac[m].y & 0x10001000u, ac[m].z & 0x10001000u, ac[m].w & 0x10001000u));
-            }
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const f16x8 bh = __builtin_bit_cast(f16x8, make_uint4(hi[n][0], hi[n][1], hi[n][2], hi[n][3]));
-                const f16x8 bl = __builtin_bit_cast(f16x8, make_uint4(lo[n][0], lo[n][1], lo[n][2], lo[n][3]));
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bl, acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh, acc[m][n], 0, 0, 0);
-                }
-            }
-        } else if constexpr (TERMS == 33) {
-            uint32_t hi[2][4], mid[2][4], lo[2][4];
-#else
         if constexpr (TERMS == 3) {
             uint32_t hi[2][4], mid[2][4], lo[2][4];
-#endif
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 split3(cur[2 * j].x, cur[2 * j + 1].x, hi[0][j], mid[0][j], lo[0][j]);
@@ -240,12 +200,7 @@ __global__ __launch_bounds__(256, 2) void dense_tiles_kernel(const DenseArgs p) 
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = 32 * m + (i & 3) + 8 * (i >> 2) + 4 * h;
-#ifdef SIMRANK_TERMS2
-            const float un = TERMS == 3 ? 1.0f / 16384.0f : 1.0f;
-            *reinterpret_cast<float2*>(Pw + int64_t(row) * p.ldp) = make_float2(acc[m][0][i] * un, acc[m][1][i] * un);
-#else
             *reinterpret_cast<float2*>(Pw + int64_t(row) * p.ldp) = make_float2(acc[m][0][i], acc[m][1][i]);
-#endif
         }
 }
 

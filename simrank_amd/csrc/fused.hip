@@ -274,11 +274,11 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
             // steps that pad a set to whole quads multiply zero pattern bits.
             float* bbuf = bbuf_all + wave * (16 * 32);
             const int n = lane & 31, h = lane >> 5;
-#ifdef SIMRANK_TERMS2
-            struct Terms { uint32_t lo[4], hi[4]; };
-#else
+            // (round 6, measured and dropped: TWO fp16 terms, x 2^14 = hi + lo 2^-11 — 22 significant bits, two MFMAs per tile
+            // and step instead of three; pl32768d32 4.78 -> 4.75 ms, N = 65536 17.80 -> 17.58, MovieLens-shaped 1.39 -> 1.32 ms per
+            // loop body: the phase is not bound by its MFMAs, and the operand would need a proven range;
+            // profiles/r06_terms2_ab.log)
             struct Terms { uint32_t lo[4], mid[4], hi[4]; };
-#endif
             // B fragment through the wave's LDS buffer: [k][n] -> lane (n, h) holds k = 8h .. 8h + 7
             auto stage = [&](const float4& x0, const float4& x1, float (&x)[8]) {
                 wave_lds_order();
@@ -288,29 +288,6 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
 #pragma unroll
                 for (int j = 0; j < 8; ++j) x[j] = bbuf[(8 * h + j) * 32 + n];
             };
-#ifdef SIMRANK_TERMS2
-            auto split = [&](const float (&x)[8], Terms& t) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) split2h(x[2 * j], x[2 * j + 1], t.hi[j], t.lo[j]);
-            };
-            auto mma = [&](const Terms& t, uint32_t aw) {
-                const f16x8 bl = frag_h(t.lo[0], t.lo[1], t.lo[2], t.lo[3]);
-                const f16x8 bh = frag_h(t.hi[0], t.hi[1], t.hi[2], t.hi[3]);
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt) {
-                    // the table holds bf16 1.0 (0x3F80): fp16 1.0 = 0x3C00 and fp16 2^-11 = 0x1000 are subsets of its bits
-                    const uint4 a = lut[(aw >> (8 * tt)) & 255u];
-                    const f16x8 ah = frag_h(a.x & 0x3C003C00u, a.y & 0x3C003C00u, a.z & 0x3C003C00u, a.w & 0x3C003C00u);
-                    const f16x8 al = frag_h(a.x & 0x10001000u, a.y & 0x10001000u, a.z & 0x10001000u, a.w & 0x10001000u);
-                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bl, acc[tt], 0, 0, 0);
-                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[tt], 0, 0, 0);
-                }
-            };
-            auto mma_unused = [&](const Terms& t, uint32_t aw) {
-                (void)t; (void)aw;
-            };
-            (void)mma_unused;
-#else
             auto split = [&](const float (&x)[8], Terms& t) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) split3f(x[2 * j], x[2 * j + 1], t.hi[j], t.mid[j], t.lo[j]);
@@ -328,7 +305,6 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
                     acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bh, acc[tt], 0, 0, 0);
                 }
             };
-#endif
             Terms tA, tB;
             float x[8];
             stage(rA0, rA1, x);
@@ -371,12 +347,7 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
 #pragma unroll
                         for (int i4 = 0; i4 < 4; ++i4) {
                             float4* dst = reinterpret_cast<float4*>(tile + n * kTS + 32 * t + 8 * i4 + 4 * h);
-#ifdef SIMRANK_TERMS2
-                            constexpr float kUn = 1.0f / 16384.0f;
-                            float4 v = make_float4(acc[t][4 * i4] * kUn, acc[t][4 * i4 + 1] * kUn, acc[t][4 * i4 + 2] * kUn, acc[t][4 * i4 + 3] * kUn);
-#else
                             float4 v = make_float4(acc[t][4 * i4], acc[t][4 * i4 + 1], acc[t][4 * i4 + 2], acc[t][4 * i4 + 3]);
-#endif
                             if (w > 0) {
                                 const float4 o = *dst;
                                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;

@@ -20,22 +20,6 @@ __device__ __forceinline__ void split3f(float x0, float x1, uint32_t& hi, uint32
     lo = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
 }
 
-// (experiment, round 6: -DSIMRANK_TERMS2) an operand in [0, 4) as TWO fp16 terms, x 2^14 = hi + lo 2^-11 — 22 significant
-// bits against the 24 of the three bf16 terms, two MFMAs per tile and step instead of three
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void split2h(float x0, float x1, uint32_t& hi, uint32_t& lo) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const float s0 = x0 * 16384.0f, s1 = x1 * 16384.0f;
-    const h2 h = {(_Float16)s0, (_Float16)s1};
-    const h2 l = {(_Float16)((s0 - (float)h.x) * 2048.0f), (_Float16)((s1 - (float)h.y) * 2048.0f)};
-    hi = __builtin_bit_cast(uint32_t, h);
-    lo = __builtin_bit_cast(uint32_t, l);
-}
-__device__ __forceinline__ f16x8 frag_h(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-    const uint4 v = make_uint4(a, b, c, d);
-    return __builtin_bit_cast(f16x8, v);
-}
-
 __device__ __forceinline__ bf16x8 frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
     const uint4 v = make_uint4(a, b, c, d);
     return __builtin_bit_cast(bf16x8, v);

@@ -220,7 +220,7 @@ class TorchWorld(_product.TorchWorld):
 
     def __init__(self, group=None, stages: int = 0, stage_single_rank: bool = False,
                  handback: str = "root", symmetric_shards="auto", measure_single_rank: bool = False,
-                 exchange_precision: str = "f32", loop: str = "auto"):
+                 exchange_precision: str = "f32", loop: str = "python"):
         """``stages``: leg 1 is cut into that many column slices, each exchanged by its own
         all_to_all_single as soon as its kernel has finished, so the transfers over xGMI overlap
         the remaining leg-1 kernels (1 = one exchange after the whole leg; 0 = by the width of a

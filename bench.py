@@ -98,7 +98,7 @@ def config_roofline(key, legs, note=None):
 # dropped from the end of a priority list while the line is still longer than LINE_LIMIT (named under "dropped").
 # The complete record — prose included — goes to --full-json (default gpurun_out/bench_full.json when that can be written).
 LINE_LIMIT = 8000
-KEEP_STRINGS = {"metric", "unit", "scaling", "dtype", "data", "bound", "kind", "leg2_form", "form", "error", "headline_loop",
+KEEP_STRINGS = {"metric", "unit", "scaling", "dtype", "data", "bound", "kind", "leg2_form", "form", "error", "headline_loop", "name",
                 "python_world_error", "skipped", "workload", "sample", "kernel"}
 DROP_ORDER = ["mfma_dense_leg", "roofline_other", "continuity_pl32768", "shards_emulated_p8", "convergence_test",
               "sharded_c_loop", "config5", "bipartite_pp", "secondary", "roofline_mfma", "fit_wall"]
@@ -493,7 +493,7 @@ def c_loop_only(err):
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"{args.workload}: synthetic directed graph N={st['csr'].n_rows} nnz={st['csr'].nnz} SimRank C=0.8 "
                                   "fp32, eps test every iteration (every element compared, exact count)",
-                      "N": st["csr"].n_rows, "nnz": st["csr"].nnz, "mode": "sparse",
+                      "name": args.workload, "N": st["csr"].n_rows, "nnz": st["csr"].nnz, "mode": "sparse",
                       "sharding": f"S column-sharded over {st['world_size']} rank(s), all-to-all per update"},
            "python_world_error": err, "sharded_c_loop": {}}
     deadline = float(os.environ.get("SIMRANK_BENCH_CLOOP_DEADLINE", "300"))
@@ -716,7 +716,7 @@ def main():
                                f"{'SimRank++ (evidence + spread)' if args.pp else 'SimRank'} C=0.8 fp32"
                                f"{' with fp16 dense blocks' if args.dense_precision == 'fp16' else ''}, "
                                f"eps test every iteration (every element compared, exact count)",
-                   "N": n, "nnz": nnz, "mode": solver.mode,
+                   "name": args.workload, "N": n, "nnz": nnz, "mode": solver.mode,
                    "loop": ("simrank_plan_step behind the C ABI (csrc/plan.hip): what fit() runs on one GPU" if hplan is not None
                             else "tests/pydriver.Solver.step (the tests' Python choreography over the C ABI's kernels)"),
                    "layout": "panel-blocked (32-column panels)" if getattr(solver, "blocked", False) else "row-major",

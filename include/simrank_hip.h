@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define SIMRANK_ABI_VERSION 6
+#define SIMRANK_ABI_VERSION 7
 #define SIMRANK_CHANGED_SLOTS 1024
 
 #if defined(__GNUC__)

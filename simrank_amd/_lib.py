@@ -39,7 +39,7 @@ class Epilogue(C.Structure):
     ]
 
 
-ABI_VERSION = 6          # SIMRANK_ABI_VERSION of include/simrank_hip.h
+ABI_VERSION = 7          # SIMRANK_ABI_VERSION of include/simrank_hip.h
 # the console hooks of the C-level loops (simrank_progress_fn)
 PROGRESS_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_int32)
 

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_string():
     lib = _lib.load()
-    assert lib.simrank_abi_version() == 6
+    assert lib.simrank_abi_version() == 7
     rc = lib.simrank_set_tuning(b"no_such_knob", 1)
     assert rc == -1 and b"no_such_knob" in lib.simrank_last_error()
     assert lib.simrank_set_tuning(b"panel", 48) == -1
@@ -118,4 +118,4 @@ int main(void) {
                         capture_output=True, text=True)
     assert cc.returncode == 0, cc.stderr
     run = subprocess.run([str(exe)], capture_output=True, text=True)
-    assert run.returncode == 0 and "abi 6 ok" in run.stdout, (run.returncode, run.stdout, run.stderr)
+    assert run.returncode == 0 and "abi 7 ok" in run.stdout, (run.returncode, run.stdout, run.stderr)

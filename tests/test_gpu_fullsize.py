@@ -206,8 +206,8 @@ def test_sharded_c_loop_at_full_size_on_eight_ranks(ops, workload, pp, form, sta
     within the counts' own tolerance; in f32 the full form is BIT-EQUAL to the Python choreography (driver.Solver) that makes
     the same launches."""
     from simrank_amd.engine import Plan, ShardPlans
-    if workload == "pl65536" and (wire or (storage == "fp16" and form)):
-        pytest.skip("config 5 on shards: f32 full / half form and fp16-held")
+    if storage == "fp16" and form:
+        pytest.skip("fp16-held shards run leg 2 in its full form")
     df = synth.WORKLOADS[workload][0]()
     nodes, csr = ingest.directed(df, False, "from", "to", "weight")
     n = csr.n_rows

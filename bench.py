@@ -612,6 +612,7 @@ def main():
                            exchange_precision=args.exchange_precision)
     else:
         world = LocalWorld(1)
+    one_rank = LocalWorld(1)          # (the single-GPU sections below run on this process alone whatever the headline's world)
 
     if gpu:
         from simrank_amd.engine import HipOps
@@ -969,7 +970,7 @@ def main():
         try:
             dfd = synth.WORKLOADS["pl32768"][0]()
             _, csrd = ingest.directed(dfd, False, "from", "to", "weight")
-            sd = Solver(lambda r: ops, world, [make_spec(csrd, False)], args.mode)
+            sd = Solver(lambda r: ops, one_rank, [make_spec(csrd, False)], args.mode)
             sd.exact_count = True
             sd.reset()
             for _ in range(3):
@@ -1002,7 +1003,7 @@ def main():
         try:
             df2 = synth.WORKLOADS["er8192"][0]()
             _, csr2 = ingest.directed(df2, False, "from", "to", "weight")
-            s2 = Solver(lambda r: ops, world, [SideSpec(csr2, csr2.rowscale, coef)], args.mode)
+            s2 = Solver(lambda r: ops, one_rank, [SideSpec(csr2, csr2.rowscale, coef)], args.mode)
             s2.exact_count = True
             s2.reset()
             for _ in range(3):
@@ -1101,7 +1102,7 @@ def main():
         try:
             df3 = synth.WORKLOADS["ml1m"][0]()
             _, _, _, _, g12, g21 = ingest.bipartite(df3, False, "user", "item", "weight")
-            s3 = Solver(lambda r: ops, world,
+            s3 = Solver(lambda r: ops, one_rank,
                         [SideSpec(g12, g12.rowscale, coef, evidence_from=g12),
                          SideSpec(g21, g21.rowscale, coef, evidence_from=g21)], args.mode)
             s3.exact_count = True
@@ -1196,7 +1197,7 @@ def main():
                     # (the first creation of matrices of this size in the process pays the allocator — hipMalloc maps a
                     # 17 GiB block in 0.0 .. 0.5 s depending on the box —; the second takes them from the block pool)
                     t0 = time.perf_counter()
-                    s5 = Solver(lambda r: ops, world, [make_spec(csr5, True, terms, storage)], args.mode)
+                    s5 = Solver(lambda r: ops, one_rank, [make_spec(csr5, True, terms, storage)], args.mode)
                     ops.synchronize()
                     setup_s = time.perf_counter() - t0
                     if prec == "f32" and attempt == 0:
@@ -1444,7 +1445,7 @@ def main():
         # BASELINE.json's literal recipe — sparse leg 1, dense f32 MFMA GEMM for leg 2 —
         # measured on the same workload so the dispatch decision is a number, not a claim
         try:
-            hy = Solver(lambda r: ops, world, [SideSpec(csr, csr.rowscale, coef)], "hybrid")
+            hy = Solver(lambda r: ops, one_rank, [SideSpec(csr, csr.rowscale, coef)], "hybrid")
             hy.reset()
             hy.step(0.0)
             hy.enable_timing()

@@ -121,4 +121,7 @@ WORKLOADS = {
     "pl32768d32": (lambda: powerlaw_directed(32768, 32, 32768, exact=True), "directed"),
     # not a BASELINE.json configuration: same size and average degree as pl32768 without the skew
     "er32768": (lambda: er_directed(32768, 32 / 32768, 32768), "directed"),
+    # not a BASELINE.json configuration either: config 4's recipe at half the nodes — a panel's operand slice is 2 MiB, half an
+    # XCD's L2 (what leg 1 does when the slice fits with room to spare)
+    "pl16384d32": (lambda: powerlaw_directed(16384, 32, 16384, exact=True), "directed"),
 }

@@ -27,6 +27,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -456,9 +457,11 @@ int main(int argc, char** argv) {
     a.X = X; a.Y = Y; a.units = d_units; a.sids = d_sids; a.rows_pad = rows_pad;
     a.n_panels = n_panels; a.n_units = int(n_units); a.sink = sink;
     const double ipp = double(real);
+    const bool brief = argc > 2 && std::string(argv[2]) == "--brief";      // (for a counter pass: the product's loop at the three masks)
     for (int mask : {0xFFFF, 8191, 255}) {
         a.mask = mask;
         report<2, kBuiltin, 4>("builtin depth 2 (today)", a, ipp, 4);
+        if (brief) continue;
         // the same loop with its ids requested further ahead / staged in LDS
         report_kernel("builtin, ids 3 ahead", gather_builtin_kernel<4, false>, a, ipp, 4, 0, 2);
         report_kernel("builtin, ids via LDS", gather_builtin_kernel<4, true>, a, ipp, 4, 0, 2);

@@ -13,6 +13,8 @@ import simrank_amd.SimRank as SRA                      # noqa: E402
 from oracle import simrank_oracle as O                 # noqa: E402
 from simrank_amd import synth                          # noqa: E402
 from tests.graphs import bipartite_random              # noqa: E402
+from tests.pydriver import LocalWorld                  # noqa: E402  (the two-matrix classes on fp16-held matrices run through
+                                                       # the tests' Python choreography: the C-level two-matrix plan is f32)
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
@@ -42,7 +44,7 @@ for seed in range(first, first + count):
         pp = bool(rng.integers(0, 2))
         extra = dict(strict_reference=False) if pp else {}
         s1, s2 = (SRA.BipartiteSimRankPP if pp else SRA.BipartiteSimRank)().fit(
-            df, storage_precision="fp16", C1=0.7, C2=0.85, **it, **extra)
+            df, storage_precision="fp16", C1=0.7, C2=0.85, world=LocalWorld(1), **it, **extra)
         want = (O.fit_bipartite_pp if pp else O.fit_bipartite)(df, C1=0.7, C2=0.85, **it, **extra)
         check(s1.values, want["S1"])
         check(s2.values, want["S2"])

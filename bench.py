@@ -482,9 +482,9 @@ STATE = {}        # what main() has built so far: the fallback of a multi-rank r
 
 
 def c_loop_only(err):
-    """A run on several RCCL ranks whose Python world (driver.Solver over torch.distributed) raised: time the sharded loop
-    behind the C ABI alone and report THAT as the line — the same metric, on the same graph, through the library's own
-    communicator.  Best effort: if the ranks did not all get here the watchdog ends them."""
+    """A run on several RCCL ranks: time the sharded loop behind the C ABI — the loop fit() runs there — and report THAT as the
+    line, through the library's own communicator (``err``: why the tests' Python world, asked for with --python-world, did not
+    finish; None by default).  If the ranks do not all get through, the watchdog prints what there is and exits non-zero."""
     import threading
     st = STATE
     args, rank = st["args"], st["rank"]
@@ -522,7 +522,20 @@ def c_loop_only(err):
             best = (name, rec)
     if best is not None:
         out["value"], out["ms_per_step"] = best[1]["value"], best[1]["ms_per_step"]
-        out["headline_loop"] = f"simrank_shardplan_step behind the C ABI, {best[0]} (the Python world failed: python_world_error)"
+        out["headline_loop"] = f"simrank_shardplan_step behind the C ABI, {best[0]}" + (
+            " (the tests' Python world failed: python_world_error)" if err else "")
+        # dominant launch of a rank: leg 1 on its column block (X block read once, the transposed product written once, the CSR)
+        ev = best[1].get("rank0_events_ms") or {}
+        if ev.get("leg1_ms"):
+            n_, P_, z_ = st["csr"].n_rows, st["world_size"], st["csr"].nnz
+            b1 = leg_bytes(n_, n_, -(-n_ // P_), z_, leg2=False)
+            gbs = b1 / (ev["leg1_ms"] * 1e-3) / 1e9
+            out["roofline"] = {"kernel": "leg 1 of rank 0 (fused_trans_kernel on its column block, chunked transposed store)",
+                               "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                               "traffic": None, "ms": ev["leg1_ms"], "algorithmic_bytes": b1,
+                               "other_ms": {k: v for k, v in ev.items() if k != "leg1_ms"}}
+    if not err:
+        out.pop("python_world_error", None)
     if rank == 0:
         write_full(out, getattr(args, "full_json", None))
         st["emit"](compact_line(out))
@@ -566,6 +579,11 @@ def main():
                     help="wire format of the all-to-alls of a sharded run: f32 = exact (default, the parity path); "
                          "fp16 = value x 2^14 in fp16 on the links, f32 kernels (half the link bytes, one fp16 "
                          "rounding per update: outside the 1e-5 bar, reported as such)")
+    ap.add_argument("--python-world", action="store_true",
+                    help="several ranks: also time the tests' Python choreography (tests/pydriver.py over torch.distributed) "
+                         "before the C loop; default: the C loop alone")
+    ap.add_argument("--c-loop-only", action="store_true",
+                    help="with --force-dist: take the several-rank path (the C loop alone) in a one-rank RCCL world")
     ap.add_argument("--force-dist", action="store_true",
                     help="use the torch.distributed world even with one rank (exercises RCCL)")
     args = ap.parse_args()
@@ -635,6 +653,12 @@ def main():
                  c_fallback=bool(gpu and use_dist and (world_size > 1 or rehearse_failure) and args.mode in ("auto", "sparse")))
     if rehearse_failure and use_dist:
         raise RuntimeError("SIMRANK_BENCH_FAIL_PYTHON_WORLD=1: rehearsal of a failing Python world")
+    if gpu and use_dist and (world_size > 1 or args.c_loop_only) and not args.python_world and args.mode in ("auto", "sparse"):
+        # Several RCCL ranks: the sharded loop behind the C ABI is the ONLY loop fit() runs there (round 6), so it is the
+        # only thing timed by default — under a watchdog that turns a rank stuck in a collective into a partial line and a
+        # non-zero exit.  The tests' Python choreography over torch's own collectives (never run on more than one GPU either)
+        # is a comparison on request: --python-world.
+        sys.exit(c_loop_only(None))
 
     def make_spec(c, pp, terms=3, storage="f32"):
         if not pp:

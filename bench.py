@@ -341,7 +341,6 @@ def c_loop_section(args, ops, world, dist, torch, synth, ingest, csr, coef, gpu,
     from simrank_amd import cshard
     from simrank_amd.engine import ShardPlans
     comm = cshard._rccl_comm(world, ops)
-    out["link_probe"] = link_probe(world, dist, torch, rank)
 
     def max_over_ranks(v):
         t = torch.tensor([v], dtype=torch.float64, device="cuda")
@@ -437,6 +436,9 @@ def c_loop_section(args, ops, world, dist, torch, synth, ingest, csr, coef, gpu,
                 bp.free()
         except Exception as e:
             out["config3"] = {"error": f"{type(e).__name__}: {e}"}
+    # LAST (a probe that hangs must not cost the measurements above: the watchdog prints what is there): what the links move
+    barrier()
+    out["link_probe"] = link_probe(world, dist, torch, rank)
     return out
 
 

@@ -6,9 +6,10 @@ all-to-all per update.
 
 Every rank passes the same edge list.  `top_k=10` hands the ten most similar nodes of every node to every
 rank without moving N x N values over PCIe; without it the dense similarity DataFrame goes to rank 0 only
-(the other ranks' fit() returns None; TorchWorld(handback="all") gives it to every rank).  The world picks
-the pipeline depth of the exchange from the width of a rank's column block (stages=0) and, from 4096 nodes
-on, the form of leg 2 by timing one update in each form on the node's links."""
+(the other ranks' fit() returns None; TorchWorld(handback="all") gives it to every rank).  What runs is the
+sharded loop behind the C ABI (simrank_shardplan_*, csrc/shardplan.hip) over the library's own RCCL communicator; the
+library picks the pipeline depth of the exchange (stages=0) and runs leg 2 in its half form from eight ranks on
+(TorchWorld(symmetric_shards=True / False) fixes the form; `bench.py --gpus N` times both on the node's links)."""
 import os
 import sys
 import time

@@ -889,6 +889,9 @@ int simrank_set_tuning(const char* key, int64_t value) {
     } else if (!strcmp(key, "fuse_group")) {
         SR_REQUIRE(value >= 1 && value <= 4, "fuse_group must be 1 .. 4");
         t.fuse_group = value;
+    } else if (!strcmp(key, "fuse_sym")) {
+        SR_REQUIRE(value >= -1 && value <= 1, "fuse_sym must be -1 (automatic), 0 or 1");
+        t.fuse_sym = value;
     } else if (!strcmp(key, "fuse_steps")) {
         SR_REQUIRE(value >= -1 && value <= (1 << 20), "fuse_steps must be >= 0, or -1 (by the operand's size)");
         t.fuse_steps = value;
@@ -924,6 +927,7 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     else if (!strcmp(key, "fuse_dens")) *value = t.fuse_dens;
     else if (!strcmp(key, "fuse_unit")) *value = t.fuse_unit;
     else if (!strcmp(key, "fuse_group")) *value = t.fuse_group;
+    else if (!strcmp(key, "fuse_sym")) *value = t.fuse_sym;
     else if (!strcmp(key, "fuse_cap")) *value = t.fuse_cap;
     else if (!strcmp(key, "fuse_shards")) *value = t.fuse_shards;
     else if (!strcmp(key, "ev_tri")) *value = t.ev_tri;

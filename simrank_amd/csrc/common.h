@@ -84,6 +84,9 @@ struct Tuning {
     int64_t fuse_wgs = 4;    // (experiment build only) its resident workgroups per CU
     int64_t fuse_shards = 1; // ... also for the row-major column block of a sharded rank (result in the all-to-all's chunks)
     int64_t fuse_group = 3;  // ... and up to this many consecutive blocks without a set share a workgroup (1..4)
+    int64_t fuse_sym = -1;   // (round 6) leg 2 of a symmetric update as ONE launch too (fused.hip, SYM: matrix cores + gathers +
+                             // epilogue + both stores of a tile): 1 wherever it applies, 0 never, -1 where the dense sets hold at
+                             // least half of the pattern's entries (MovieLens-shaped graphs: the two-launch leg's second pass)
     int64_t dense_lazy = 0;  // (set by simrank_plan_create, not a knob) the graph's only launch that could use the dense-block
                              // plan is the upper-triangle leg 2: build it only if that leg would take it (dense_sym), i.e. skip
                              // the 256-byte-per-column fragment image and its upload on power-law graphs (8 ms at N = 65536)
@@ -287,6 +290,10 @@ void free_fused_plan(simrank_fused_plan* p);
 int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col, const float* rowscale);
 int launch_fused_trans(const simrank_graph* g, const float* X, int64_t x_rows_pad, int64_t L, float* Y,
                        int64_t y_rows_pad, hipStream_t st);
+bool fused_sym_applies(const simrank_graph* g, int64_t x_rows_pad, int64_t L, int64_t y_rows_pad);
+int launch_fused_sym(const simrank_graph* g, const float* X, int64_t x_rows_pad, int64_t L, float* Y, int64_t y_rows_pad,
+                     float coef, float lbd, double eps, const uint8_t* ev, const float* ap, const float* prev,
+                     unsigned long long* n_changed, int32_t set_diag, int32_t count_any, hipStream_t st);
 bool fused_rowmajor_fits(const simrank_graph* g, const float* X, int64_t ldx, int64_t L, const float* Y, int64_t t_block,
                          int64_t t_pad);
 int launch_fused_trans_rowmajor(const simrank_graph* g, const float* X, int64_t ldx, int64_t L, float* Y, int64_t t_block,

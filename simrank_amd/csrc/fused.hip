@@ -95,6 +95,16 @@ struct FusedArgs {
                               // of the block; row 255: none, end 0xFFFFFF: no remainder), rowscale bits
     const uint16_t* sids16;   // id stream of the gather phase, 64 per round (0xFFFF: no neighbour), or
     const int32_t* sids32;    // the same in 32 bits (-1: no neighbour)
+    // ---- leg 2 of a symmetric update (SYM, round 6): Y = epilogue(diag(rowscale) . A . X), X = Tt (K rows), Y = S' (M x M, M = L):
+    // the 32 x 32 tiles on or above the diagonal are computed, put through the epilogue (SimRank.py:139-140, :316, :362,
+    // :453 and the count of :74), stored, and their mirror image stored too.  The epilogue's operands share Y's layout.
+    float coef, lbd;
+    double eps;
+    const uint8_t* ev;        // common-neighbour counts (u8), panel-blocked like Y (32 bytes per row and panel), or NULL
+    const float* ap;          // prior, or NULL
+    const float* prev;        // previous iterate (the count), or NULL
+    unsigned long long* n_changed;
+    int32_t set_diag, count_any;
 };
 
 #ifndef SIMRANK_HOST_ONLY          // (the sanitizer build of the host logic has no device code: common.h)
@@ -132,8 +142,12 @@ __device__ __forceinline__ unsigned long long fst_now() {
 #define SIMRANK_FUSED_LB 4     // waves per SIMD the register allocation aims at
 #endif
 // IDS16: 16-bit ids (fewer than 65535 operand rows; 0xFFFF marks an empty slot of the gather stream)
-template <bool IDS16>
-__global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(const FusedArgs p) {
+// SYM: leg 2 (epilogue, upper triangle + mirror) instead of leg 1 (transposed store)
+#ifndef SIMRANK_FUSED_LB_SYM
+#define SIMRANK_FUSED_LB_SYM 3     // ... of leg 2 (its epilogue's operands on top of the gather pipeline's two register sets: at 4
+#endif                             // the compiler kept the accumulators of the matrix-core phase in scratch)
+template <bool IDS16, bool SYM = false>
+__global__ __launch_bounds__(256, SYM ? SIMRANK_FUSED_LB_SYM : SIMRANK_FUSED_LB) void fused_trans_kernel(const FusedArgs p) {
     __shared__ __attribute__((aligned(16))) float tile[32 * kTS];          // [column][row] of the block's result
     __shared__ __attribute__((aligned(16))) float bbuf_all[4 * 16 * 32];    // per wave: 16 operand segments
     __shared__ __attribute__((aligned(16))) uint4 lut[256];                 // pattern byte -> 8 bf16 (0 / 1.0)
@@ -158,6 +172,11 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
 #endif
     const int b0 = un[0];                                   // first (usually only) block of the unit
     const int64_t c0 = int64_t(panel) * 32;
+    // (SYM) a block wholly left of the diagonal — its first row beyond the panel's last column — does nothing; the blocks of
+    // a unit are consecutive, so the leading ones stay (every unit of a split block decides alike: no ticket is ever short)
+    const int n_sub_all = un[8];
+    const int n_sub_sym = SYM ? min(n_sub_all, int((c0 + 31) >> 7) - b0 + 1) : n_sub_all;
+    if (SYM && n_sub_sym <= 0) return;
     const int g = lane >> 3, q = lane & 7, gbase = lane & ~7;
     const uint32_t qoff = uint32_t(q) * 16u;
 
@@ -171,7 +190,7 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
     const int nq = (p.probe & 4) ? 0 : un[2];
     const int unit_k = un[3], unit_nb = un[4], pslot = un[5], cslot = un[6];
     const bool has_set = !(p.probe & 4) && un[7] != 0;      // the block has a dense set (this unit may be one of several)
-    const int n_sub = un[8];                                // blocks of the unit
+    const int n_sub = n_sub_sym;                            // blocks of the unit (SYM: those that reach the diagonal)
     const int per = (nq + 3) >> 2;                          // quads per wave
     const int n_active = per ? (nq + per - 1) / per : 0;    // waves that have MFMA work
 
@@ -369,6 +388,16 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
         __syncthreads();
     }
     const bool has_d = has_set || split_unit;                 // the tile holds something before the rows are emitted
+    // (SYM) the convergence count of this wave's elements; count_any: once this wave's striped counter is known to be non-zero
+    // the previous iterate is not read any more (`_converged` uses the sum as a truth value only, SimRank.py:74-77)
+    unsigned changed = 0;
+    const unsigned slot = ((blockIdx.x * 4u + unsigned(wave)) * 7u) % SIMRANK_CHANGED_SLOTS;
+    bool check_prev = false;
+    if constexpr (SYM) {
+        check_prev = p.prev != nullptr;
+        if (check_prev && p.count_any) check_prev = __hip_atomic_load(p.n_changed + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+        check_prev = __builtin_amdgcn_readfirstlane(int(check_prev)) != 0;
+    }
 
     FST(2);
     // ---------------------------------------------------------------- 3. gather phase (the remainder)
@@ -384,13 +413,13 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
         // gathers of the next block's first round are in flight while this block's tile is stored)
         int sb = 0;                                           // block of the unit the stream is in
         int r_base = 0;                                       // first round of that block
-        auto end_of = [&](int k) -> int { return k == 0 ? e1 : k == 1 ? e2 : k == 2 ? e3 : e4; };
+        auto end_of = [&](int k) __attribute__((always_inline)) -> int { return k == 0 ? e1 : k == 1 ? e2 : k == 2 ? e3 : e4; };
         int r_end = (p.probe & 1) ? 0 : e1;                   // rounds up to the end of block sb
         const int2* gmp = gm_lds + (wave * 8 + g) * 4;        // + sb * 128: the lane group's rows in block sb
         wave_lds_order();
         // (row, scale, end) of the row the lane group is in: .x = row of the block or -1, .y = scale bits,
         // .z = end of the row in the group's stream or -1
-        auto unpack = [](const int2& m) -> int3 {
+        auto unpack = [](const int2& m) __attribute__((always_inline)) -> int3 {
             const unsigned u = unsigned(m.x);
             const int row = int(u & 255u), end = int(u >> 8);
             return make_int3(row == 255 ? -1 : row, m.y, end == 0xFFFFFF ? -1 : end);
@@ -398,7 +427,7 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
         int3 m_cur = unpack(gmp[0]);
         float4 cur = make_float4(0.f, 0.f, 0.f, 0.f);
         int krow = 0;                                         // rows of the lane group finished in this block
-        auto emit = [&](const int3& m, const float4& sv) {
+        auto emit = [&](const int3& m, const float4& sv) __attribute__((always_inline)) {
             if (m.x >= 0) {
                 const float sc = split_unit ? 1.0f : __int_as_float(m.y);     // (a split block is scaled by its last arriver)
                 float* tp = tile + (4 * q) * kTS + m.x;
@@ -411,7 +440,7 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
             }
         };
         // slot f of the lane group's stream (of this block) has been added: was it the last of the current row?
-        auto row_end = [&](int f) {
+        auto row_end = [&](int f) __attribute__((always_inline)) {
             if (f + 1 == m_cur.z) {
                 emit(m_cur, cur);
                 cur = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -421,7 +450,7 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
             }
         };
         // every round of block sb has been summed: its rows without a remainder, then the tile goes out
-        auto finish = [&]() {
+        auto finish = [&]() __attribute__((always_inline)) {
             for (int k = krow; k < 4; ++k) emit(unpack(gmp[sb * 128 + k]), make_float4(0.f, 0.f, 0.f, 0.f));
             FST(3);
             __syncthreads();
@@ -497,11 +526,108 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
                 }
                 __syncthreads();
             }
-            // ------------------------------------------------------------ 4. transposed store
             const int nrows = int(min(int64_t(kFB), p.M - row0));
             const int rows_out = max(0, min(32, nrows - 32 * wave));
             const int cols_here = int(min(int64_t(32), p.L - c0));
-            if (rows_out > 0 && !(p.probe & 2)) {
+            bool mirror = true;                               // (leg 1: every tile goes out transposed)
+            if constexpr (SYM) {
+                // ------------------------------------------------------------ 3b. leg 2: the epilogue, in the tile
+                // The wave owns rows 32 wave .. + 31 of the block: one 32 x 32 tile of the result.  Left of the diagonal: nothing
+                // (the tile above it supplies it); on it: every element computed and stored once; right of it: stored, and its
+                // mirror image (step 4, what leg 1 calls the transposed store).  Lane group g takes rows g, g + 8, g + 16,
+                // g + 24 of the tile, lane q of it columns 4 q .. 4 q + 3: one 16-byte piece of a row of Y / the previous
+                // iterate / the prior, one 4-byte word of the counts.  Order of operations as the gather kernel's epilogue
+                // (spmm.hip emit_row3): x coef, x (1 - 2^-count), blend with the prior, diagonal, count, store.
+                const int64_t rt_row0 = int64_t(row0) + 32 * wave;
+                const bool on_diag = c0 == rt_row0;
+                mirror = c0 > rt_row0;                         // (both are multiples of 32)
+                if (rows_out > 0 && (mirror || on_diag)) {
+                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                    const int64_t pbase = int64_t(panel) * p.y_rows_pad;      // rows of this panel in Y, prev, prior, counts
+                    const int bytes_f = int(p.y_rows_pad * 128);              // (below 2^31: launch_fused_sym)
+                    const __amdgpu_buffer_rsrc_t ysrd2 = __builtin_amdgcn_make_buffer_rsrc(p.Y + pbase * 32, 0, bytes_f, 0x00020000);
+                    const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<float*>(p.prev ? p.prev + pbase * 32 : p.Y), 0, p.prev ? bytes_f : 0, 0x00020000);
+                    const __amdgpu_buffer_rsrc_t asrd = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<float*>(p.ap ? p.ap + pbase * 32 : p.Y), 0, p.ap ? bytes_f : 0, 0x00020000);
+                    const __amdgpu_buffer_rsrc_t esrd = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<uint8_t*>(p.ev ? p.ev + pbase * 32 : reinterpret_cast<const uint8_t*>(p.Y)), 0,
+                        p.ev ? int(p.y_rows_pad * 32) : 0, 0x00020000);
+                    const int nvalid = max(0, min(4, cols_here - 4 * q));
+                    const float keep = 1.0f - p.lbd;
+                    // (two rows of a lane group per batch of epilogue loads: with all four the two register sets of the gather
+                    // pipeline, which are live across this code, spilled)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                    unsigned w_ev[2];
+                    v4u w_ap[2], w_old[2];
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {          // both rows' loads are requested before the first use
+                        const int rr = 8 * (2 * half + it) + g;
+                        const uint32_t a = uint32_t(rt_row0 + rr);
+                        const bool on = rr < rows_out;
+                        const uint32_t row = on ? a : 0x7FFFFF0u;             // (off: past the descriptor's end: zeros)
+                        w_ev[it] = __builtin_amdgcn_raw_buffer_load_b32(esrd, int(row * 32u + 4u * q), 0, 2);
+                        w_ap[it] = __builtin_amdgcn_raw_buffer_load_b128(asrd, int(row * 128u + qoff), 0, 2);
+                        w_old[it] = check_prev ? __builtin_amdgcn_raw_buffer_load_b128(osrd, int(row * 128u + qoff), 0, 2)
+                                               : v4u{0u, 0u, 0u, 0u};
+                    }
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int rr = 8 * (2 * half + it) + g;
+                        if (rr < rows_out) {
+                            const int64_t a = rt_row0 + rr;
+                            float* tp = tile + (4 * q) * kTS + 32 * wave + rr;
+                            float o[4] = {tp[0] * p.coef, tp[kTS] * p.coef, tp[2 * kTS] * p.coef, tp[3 * kTS] * p.coef};
+                            if (p.ev) {
+                                const unsigned w = w_ev[it];
+                                o[0] *= 1.0f - __builtin_ldexpf(1.0f, -int(w & 255u));
+                                o[1] *= 1.0f - __builtin_ldexpf(1.0f, -int((w >> 8) & 255u));
+                                o[2] *= 1.0f - __builtin_ldexpf(1.0f, -int((w >> 16) & 255u));
+                                o[3] *= 1.0f - __builtin_ldexpf(1.0f, -int(w >> 24));
+                            }
+                            if (p.ap) {
+                                const float pr[4] = {__uint_as_float(w_ap[it].x), __uint_as_float(w_ap[it].y),
+                                                     __uint_as_float(w_ap[it].z), __uint_as_float(w_ap[it].w)};
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) o[i] = keep * o[i] + p.lbd * pr[i];
+                            }
+                            if (p.set_diag) {
+                                const int64_t d = a - (c0 + 4 * q);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    if (d == i) o[i] = 1.0f;
+                            }
+                            if (check_prev) {
+                                const float old[4] = {__uint_as_float(w_old[it].x), __uint_as_float(w_old[it].y),
+                                                      __uint_as_float(w_old[it].z), __uint_as_float(w_old[it].w)};
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    changed += (i < nvalid && fabs(double(o[i]) - double(old[i])) > p.eps) ? (mirror ? 2u : 1u) : 0u;
+                            }
+                            tp[0] = o[0]; tp[kTS] = o[1]; tp[2 * kTS] = o[2]; tp[3 * kTS] = o[3];     // (what the mirror image gets)
+                            if (!(p.probe & 2)) {
+                                const int yoff = int(uint32_t(a) * 128u + qoff);
+                                if (nvalid == 4) {
+                                    v4u out;
+                                    out.x = __float_as_uint(o[0]); out.y = __float_as_uint(o[1]);
+                                    out.z = __float_as_uint(o[2]); out.w = __float_as_uint(o[3]);
+                                    if (p.nt) __builtin_amdgcn_raw_buffer_store_b128(out, ysrd2, yoff, 0, 2);
+                                    else __builtin_amdgcn_raw_buffer_store_b128(out, ysrd2, yoff, 0, 0);
+                                } else {
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i)
+                                        if (i < nvalid) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[i]), ysrd2, yoff + 4 * i, 0, 0);
+                                }
+                            }
+                        }
+                    }
+                    }
+                    wave_lds_order();                          // the mirror image reads what the wave's other lanes wrote
+                }
+            }
+            // ------------------------------------------------------------ 4. transposed store (SYM: the mirror image)
+            if (rows_out > 0 && mirror && !(p.probe & 2)) {
                 // panel-blocked Tt: the wave's 32 x 32 tile is 4 KiB contiguous, element (c, r) at c * 32 + r;
                 // chunked Tt (a sharded rank): 32 segments of 128 bytes, one per output column, in the chunk of the
                 // row block the rows belong to (a 128-row block never straddles two chunks: t_block % 128 == 0)
@@ -594,6 +720,13 @@ __global__ __launch_bounds__(256, SIMRANK_FUSED_LB) void fused_trans_kernel(cons
             }
         }
         while (sb < n_sub) finish();
+    }
+    if constexpr (SYM) {
+        if (p.prev) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) changed += __shfl_down(changed, off);
+            if (lane == 0 && changed) atomicAdd(p.n_changed + slot, (unsigned long long)changed);
+        }
     }
     FST(4);
 }
@@ -1040,7 +1173,7 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
     return SIMRANK_OK;
 }
 
-static int launch_fused(const simrank_graph* g, FusedArgs& a, hipStream_t st) {
+static int launch_fused(const simrank_graph* g, FusedArgs& a, hipStream_t st, bool sym = false) {
     simrank_fused_plan* pl = g->fused;
     // (the partial sums and tickets of the split blocks belong to the GRAPH: launches on one graph must be stream-ordered —
     // one solver per graph object, include/simrank_hip.h — and two host threads must not launch on it at once: this lock
@@ -1087,10 +1220,16 @@ static int launch_fused(const simrank_graph* g, FusedArgs& a, hipStream_t st) {
     (void)lds_pad;
     SR_REQUIRE(false, "host-only build: no kernels");
 #else
-    if (pl->ids16)
-        hipLaunchKernelGGL(fused_trans_kernel<true>, dim3((unsigned)grid), dim3(256), lds_pad, st, a);
-    else
-        hipLaunchKernelGGL(fused_trans_kernel<false>, dim3((unsigned)grid), dim3(256), lds_pad, st, a);
+    if (sym) {
+        if (pl->ids16)
+            hipLaunchKernelGGL((fused_trans_kernel<true, true>), dim3((unsigned)grid), dim3(256), lds_pad, st, a);
+        else
+            hipLaunchKernelGGL((fused_trans_kernel<false, true>), dim3((unsigned)grid), dim3(256), lds_pad, st, a);
+    } else if (pl->ids16) {
+        hipLaunchKernelGGL((fused_trans_kernel<true, false>), dim3((unsigned)grid), dim3(256), lds_pad, st, a);
+    } else {
+        hipLaunchKernelGGL((fused_trans_kernel<false, false>), dim3((unsigned)grid), dim3(256), lds_pad, st, a);
+    }
 #endif
     SR_HIP(hipGetLastError());
     return SIMRANK_OK;
@@ -1112,6 +1251,43 @@ int launch_fused_trans(const simrank_graph* g, const float* X, int64_t x_rows_pa
     a.x_bytes = int32_t(x_rows_pad * 128);
     a.x_sentinel = (int32_t)x_rows_pad;
     return launch_fused(g, a, st);
+}
+
+// Leg 2 of a symmetric panel-blocked update in one launch (SYM): Y (M x M, M = n_rows(g) = L) = epilogue(diag(rowscale) . A . X),
+// X panel-blocked with K = n_cols(g) rows; the epilogue's operands (counts, prior, previous iterate) share Y's layout.
+// false from fused_sym_applies: the two-launch leg (dense_tiles + gather3<kSym>) stays.
+bool fused_sym_applies(const simrank_graph* g, int64_t x_rows_pad, int64_t L, int64_t y_rows_pad) {
+    const simrank_fused_plan* pl = g->fused;
+    if (!pl || !g->tun.fuse || g->tun.fuse_sym == 0 || g->tun.dense_terms != 3) return false;
+    if (L != g->n_rows || g->n_cols > g->tun.fuse_max_rows) return false;
+    if ((x_rows_pad + 1) * 128 >= (int64_t(1) << 31) || (y_rows_pad + 1) * 128 >= (int64_t(1) << 31) ||
+        x_rows_pad >= (int64_t(1) << 24) - 1 || y_rows_pad >= (int64_t(1) << 24) - 1)
+        return false;
+    if (g->tun.fuse_sym < 0) return 2 * pl->nnz_covered >= g->nnz;      // (the dense sets hold at least half of the entries)
+    return true;
+}
+
+int launch_fused_sym(const simrank_graph* g, const float* X, int64_t x_rows_pad, int64_t L, float* Y, int64_t y_rows_pad,
+                     float coef, float lbd, double eps, const uint8_t* ev, const float* ap, const float* prev,
+                     unsigned long long* n_changed, int32_t set_diag, int32_t count_any, hipStream_t st) {
+    SR_REQUIRE(fused_sym_applies(g, x_rows_pad, L, y_rows_pad), "fused leg 2 does not apply");
+    SR_REQUIRE(aligned16(X) && aligned16(Y) && (!ap || aligned16(ap)) && (!prev || aligned16(prev)) &&
+                   (!ev || reinterpret_cast<uintptr_t>(ev) % 4 == 0),
+               "fused leg 2 needs 16-byte aligned operands");
+    SR_REQUIRE(x_rows_pad >= g->n_cols && y_rows_pad >= g->n_rows && (!prev || n_changed), "fused leg 2: bad operands");
+    FusedArgs a{};
+    a.X = X; a.Y = Y;
+    a.x_rows_pad = x_rows_pad; a.y_rows_pad = y_rows_pad;
+    a.L = L;
+    a.x_panel_stride = x_rows_pad * 32;
+    a.x_pitch = 128;
+    a.x_bytes = int32_t(x_rows_pad * 128);
+    a.x_sentinel = (int32_t)x_rows_pad;
+    a.coef = coef; a.lbd = lbd; a.eps = eps;
+    a.ev = ev; a.ap = ap; a.prev = prev;
+    a.n_changed = n_changed;
+    a.set_diag = set_diag; a.count_any = count_any;
+    return launch_fused(g, a, st, true);
 }
 
 // The same leg on a ROW-MAJOR operand (K x L, leading dimension ldx) with the transposed result in the chunked

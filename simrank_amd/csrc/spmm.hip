@@ -2171,6 +2171,13 @@ static int spmm_impl(const simrank_graph* g, const float* X, int64_t ldx, int64_
         if (fused_rowmajor_fits(g, X, ldx, n_cols_x, Y, tb, tp))
             return launch_fused_trans_rowmajor(g, X, ldx, n_cols_x, Y, tb, tp, st);
     }
+    // leg 2 of a symmetric panel-blocked update in ONE launch where the dense sets carry it (round 6; tuning "fuse_sym"): the
+    // matrix-core phase, the gathered remainder, the epilogue and both stores of a tile by the same workgroup — the two-launch
+    // leg below hands the dense part's partial sums over through memory
+    if (blocked && want_sym && !transpose_out && ep && (!ep->restrict_support || T.fuse_sym > 0) &&
+        fused_sym_applies(g, x_rows_pad, n_cols_x, y_rows_pad))
+        return launch_fused_sym(g, X, x_rows_pad, n_cols_x, Y, y_rows_pad, a.coef, a.lbd, a.eps, a.ev, a.ap, a.prev, a.n_changed,
+                                a.set_diag, a.count_any, st);
     // the block-dense part goes to the matrix cores first; the gather then runs on the remainder
     // In the upper-triangle form only when the pattern is dense throughout (MovieLens-like: 87 % of
     // the entries in dense sets, leg 2 0.9 -> 0.4 ms): on a power-law pattern the long rows, which

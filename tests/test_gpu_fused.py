@@ -22,7 +22,8 @@ def ops():
     o = HipOps(0)
     o.set_tuning(fuse_steps=1, fuse_min=2)   # small test graphs: a dense set however few steps it makes
     yield o
-    o.set_tuning(fuse=1, fuse_min=3, fuse_steps=-1, fuse_unit=48, fuse_group=3, fuse_shards=1, fuse_rows=8192, fuse_order=0)
+    o.set_tuning(fuse=1, fuse_min=3, fuse_steps=-1, fuse_unit=48, fuse_group=3, fuse_shards=1, fuse_rows=8192, fuse_order=0,
+                 fuse_sym=-1)
 
 
 @contextlib.contextmanager
@@ -31,7 +32,8 @@ def knobs(ops, **kw):
     try:
         yield
     finally:
-        ops.set_tuning(fuse=1, fuse_min=2, fuse_steps=1, fuse_unit=48, fuse_group=3, fuse_shards=1, fuse_rows=8192, fuse_order=0)
+        ops.set_tuning(fuse=1, fuse_min=2, fuse_steps=1, fuse_unit=48, fuse_group=3, fuse_shards=1, fuse_rows=8192, fuse_order=0,
+                       fuse_sym=-1)
 
 
 def put_blocked(ops, a, dtype=np.float32):
@@ -293,3 +295,104 @@ def test_fused_leg1_on_a_sharded_ranks_operand(ops, shape, tb, pad):
     if tb == 0 or tb % 128 == 0:
         g = ops.graph(csr)
         assert np.array_equal(got, leg1(ops, g, X, M))               # the same plan on a panel-blocked copy: same bits
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# leg 2 as one launch (round 6: fused_trans_kernel<…, SYM>): matrix cores + gathered remainder + epilogue + both stores of a
+# tile; second `.dot` of SimRank.py:139 / :298 / :361 / :420, the element-wise lines :140, :316, :362, :453, the count of :74
+# ---------------------------------------------------------------------------------------------------------------------
+def _leg2_case(ops, n, variant, seed, **graph_knobs):
+    """-> (result, exact count, count_any count, float64 reference, previous iterate): a symmetric product (Tt = (W S)^T of a
+    symmetric S), symmetric counts / prior, through the epilogue with `symmetric=True` on panel-blocked matrices."""
+    csr = corner_csr(n, n, seed=seed, hubs=min(n, 150))
+    rng = np.random.default_rng(seed)
+    W = dense64(csr)
+    S = rng.random((n, n)) ** 3
+    S = ((S + S.T) / 2).astype(np.float32)
+    np.fill_diagonal(S, 1)
+    Tt = (W @ S.astype(np.float64)).T.astype(np.float32)           # as leg 1 stores it (rounded to f32)
+    cnt = prior = None
+    lbd = 0.0
+    if variant in ("evidence", "all"):
+        c = rng.integers(0, 6, size=(n, n))
+        cnt = (np.triu(c) + np.triu(c, 1).T).astype(np.uint8)
+        cnt[0, :4] = cnt[:4, 0] = [0, 1, 30, 255]
+    if variant in ("prior", "all"):
+        pr = rng.random((n, n)).astype(np.float32)
+        prior = ((pr + pr.T) / 2).astype(np.float32)
+        lbd = 0.3
+    want = 0.8 * (W @ Tt.astype(np.float64))
+    if cnt is not None:
+        want = want * (1 - 0.5 ** cnt.astype(np.float64))
+    if prior is not None:
+        want = (1 - np.float32(lbd)) * want + np.float32(lbd) * prior.astype(np.float64)
+    np.fill_diagonal(want, 1.0)
+    prev = S
+    with knobs(ops, **graph_knobs):
+        g = ops.graph(csr)
+        steps, cov, rem = ops.fused_stats(g)
+        y = ops.matrix(n, n, blocked=True)
+        ep = dict(coef=0.8, previous=put_blocked(ops, prev), eps=0.05, diag_col0=0, symmetric=True, lbd=lbd,
+                  evidence=None if cnt is None else put_blocked(ops, cnt, np.uint8),
+                  apriori=None if prior is None else put_blocked(ops, prior))
+        ops.spmm(g, put_blocked(ops, Tt), y, epilogue=ep)
+        got, exact = ops.download(y), ops.read_changed()
+        y2 = ops.matrix(n, n, blocked=True)
+        ops.spmm(g, put_blocked(ops, Tt), y2, epilogue=dict(ep, count_any=True))
+        assert np.array_equal(ops.download(y2), got)
+        some = ops.read_changed()
+    return got, exact, some, want, prev, (steps, cov, rem)
+
+
+@pytest.mark.parametrize("n", [64, 129, 200, 520, 1000, 1031, 2100])
+@pytest.mark.parametrize("variant", ["plain", "evidence", "prior", "all"])
+def test_fused_leg2_epilogue_triangle_and_mirror(ops, n, variant):
+    """The one-launch leg 2 (`fuse_sym=1`) against float64 and against the two-launch leg (`fuse_sym=0`: dense_tiles +
+    gather3<kSym>): values within 1e-5 / to rounding, the result exactly symmetric outside the diagonal tiles and with a unit
+    diagonal, the exact count = the count over the stored matrix, count_any non-zero exactly when the count is."""
+    got, exact, some, want, prev, stats = _leg2_case(ops, n, variant, seed=n, fuse_sym=1)
+    assert stats[1] > 0                                            # (the graph has dense sets: the matrix-core phase runs)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-30)
+    assert np.array_equal(np.diag(got), np.ones(n, dtype=np.float32))
+    if n > 64:
+        assert np.array_equal(got[:32, 32:], got[32:, :32].T)       # mirrored tiles: same bits
+    np.testing.assert_allclose(got, got.T, rtol=2e-6, atol=1e-30)
+    assert exact == int((np.abs(got.astype(np.float64) - prev.astype(np.float64)) > 0.05).sum())
+    assert (some > 0) == (exact > 0) and 0 < some <= exact
+    old, exact0, some0, _, _, _ = _leg2_case(ops, n, variant, seed=n, fuse_sym=0)
+    np.testing.assert_allclose(got, old, rtol=2e-6, atol=1e-30)
+    assert n < 500 or not np.array_equal(got, old)                  # (another order of the sums: it WAS the other launch)
+    assert abs(exact - exact0) <= 4                                 # (elements within rounding of eps may fall either way)
+
+
+@pytest.mark.parametrize("split", [dict(fuse_unit=4, fuse_rows=400), dict(fuse_group=1), dict(fuse_group=4, fuse_min=4)])
+def test_fused_leg2_with_split_blocks_and_grouped_units(ops, split):
+    """Blocks cut into matrix-core units and gather units (the last arriver combines, scales, runs the epilogue and stores),
+    and units of several blocks without a set: the same values, the exact count."""
+    got, exact, some, want, prev, stats = _leg2_case(ops, 2600, "all", seed=77, **{**dict(fuse_sym=1, fuse_min=3, fuse_steps=2), **split})
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-30)
+    assert np.array_equal(got[:128, 128:], got[128:, :128].T)
+    assert exact == int((np.abs(got.astype(np.float64) - prev.astype(np.float64)) > 0.05).sum()) and 0 < some <= exact
+
+
+def test_fused_leg2_runs_the_bipartite_plan_where_the_dense_sets_dominate(ops):
+    """`fuse_sym = -1` (the default): the two-matrix plan of a MovieLens-shaped graph takes the one-launch leg 2 (its dense sets
+    hold > half of the entries), a sparse one keeps gather3<kSym>; both against the oracle."""
+    from oracle import simrank_oracle as O
+    from simrank_amd import ingest
+    from simrank_amd.engine import BiPlan, HipOps
+    from tests.graphs import bipartite_random
+    fresh = HipOps(0)                                                # (the library's default knobs)
+    fresh.set_tuning(fuse=1, fuse_min=3, fuse_steps=-1, fuse_unit=48, fuse_group=3, fuse_shards=1, fuse_rows=8192, fuse_order=0,
+                     fuse_sym=-1)
+    for n1, n2, dens in ((1400, 900, 0.12), (900, 700, 0.004)):
+        df = bipartite_random(n1, n2, dens, seed=n1)
+        _, _, _, _, g12, g21 = ingest.bipartite(df, False, "user", "item", "weight")
+        want = O.fit_bipartite_pp(df, verbose=False, strict_reference=False)
+        bp = BiPlan(fresh, g12, ingest.spread(g12) * g12.rowscale, ingest.spread(g21) * g21.rowscale, evidence=True)
+        done, conv = bp.run(100, 1e-4)
+        assert conv == want["k"]
+        s1, s2 = bp.result()
+        np.testing.assert_allclose(s1, want["S1"], rtol=RTOL, atol=1e-30)
+        np.testing.assert_allclose(s2, want["S2"], rtol=RTOL, atol=1e-30)
+        bp.free()

@@ -778,16 +778,22 @@ def test_support_restricted_simrank_pp_is_bit_equal(world, monkeypatch):
     on a sparse-evidence graph (where the driver picks it by itself) and on one with dense sets."""
     import tests.pydriver as drv
     from simrank_amd.engine import HipOps
-    for df in (synth.er_directed(4096, 0.001, seed=11), _dense_corner_graph()):
-        out = {}
-        for name, below in (("never", 0.0), ("always", 2.0), ("auto", drv.RESTRICT_BELOW)):
-            monkeypatch.setattr(drv, "RESTRICT_BELOW", below)
-            est = SRA.SimRankPP()
-            S = est.fit(df, verbose=False, world=LocalWorld(world), mode="sparse")
-            out[name] = (S.values, est.converged_at)
-        assert np.array_equal(out["never"][0], out["always"][0])
-        assert np.array_equal(out["never"][0], out["auto"][0])
-        assert out["never"][1] == out["always"][1] == out["auto"][1]
+    # (fuse_sym = 0: the subject is gather3's restricted instantiation; where the dense sets dominate, the unrestricted leg 2 of
+    # a single rank is otherwise the one-launch form of fused.hip — another order of the sums)
+    HipOps(0).set_tuning(fuse_sym=0)
+    try:
+        for df in (synth.er_directed(4096, 0.001, seed=11), _dense_corner_graph()):
+            out = {}
+            for name, below in (("never", 0.0), ("always", 2.0), ("auto", drv.RESTRICT_BELOW)):
+                monkeypatch.setattr(drv, "RESTRICT_BELOW", below)
+                est = SRA.SimRankPP()
+                S = est.fit(df, verbose=False, world=LocalWorld(world), mode="sparse")
+                out[name] = (S.values, est.converged_at)
+            assert np.array_equal(out["never"][0], out["always"][0])
+            assert np.array_equal(out["never"][0], out["auto"][0])
+            assert out["never"][1] == out["always"][1] == out["auto"][1]
+    finally:
+        HipOps(0).set_tuning(fuse_sym=-1)
     # the sparse-evidence graph is the case the driver restricts by itself
     _, csr = ingest.directed(synth.er_directed(4096, 0.001, seed=11), False, "from", "to", "weight")
     ops = HipOps(0)

@@ -1161,7 +1161,8 @@ def main():
                     ("leg 1 (fused_trans_kernel / gather3_kernel<1>), mean of both groups", "leg1",
                      0.5 * (lm["leg1.0"] + lm["leg1.1"]),
                      0.5 * (leg_bytes(m1, m2, m2, z3, False) + leg_bytes(m2, m1, m1, z3, False))),
-                    ("leg 2 = gather3_kernel (upper triangle, evidence epilogue, exact count), mean of both groups", "leg2",
+                    ("leg 2 = fused_trans_kernel<SYM> (one launch: matrix cores + gathers + evidence epilogue + exact count, upper "
+                     "triangle + mirror), mean of both groups", "leg2",
                      0.5 * (lm["leg2.0"] + lm["leg2.1"]),
                      0.5 * (leg_bytes(m1, m2, m1, z3, True, has_evidence=True, triangle=True)
                             + leg_bytes(m2, m1, m2, z3, True, has_evidence=True, triangle=True)))],

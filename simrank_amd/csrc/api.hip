@@ -857,8 +857,11 @@ int simrank_set_tuning(const char* key, int64_t value) {
         SR_REQUIRE(value >= 0 && value <= 1000, "ev_hub must be 0 (off) .. 1000 (thousandths of the row count)");
         t.ev_hub = value;
     } else if (!strcmp(key, "fuse_min")) {
-        SR_REQUIRE(value >= 2 && value <= 128, "fuse_min must be 2 .. 128");
+        SR_REQUIRE(value == 0 || (value >= 2 && value <= 128), "fuse_min must be 2 .. 128, or 0 (quads that pay)");
         t.fuse_min = value;
+    } else if (!strcmp(key, "fuse_pays")) {
+        SR_REQUIRE(value >= -1 && value <= 8192, "fuse_pays must be -1 (automatic) .. 8192");
+        t.fuse_pays = value;
     } else if (!strcmp(key, "fuse_unit")) {
         SR_REQUIRE(value >= 4 && value <= (1 << 20), "fuse_unit must be >= 4");
         t.fuse_unit = value;
@@ -923,6 +926,7 @@ int simrank_get_tuning(const char* key, int64_t* value) {
     else if (!strcmp(key, "fuse")) *value = t.fuse;
     else if (!strcmp(key, "ev_hub")) *value = t.ev_hub;
     else if (!strcmp(key, "fuse_min")) *value = t.fuse_min;
+    else if (!strcmp(key, "fuse_pays")) *value = t.fuse_pays;
     else if (!strcmp(key, "fuse_steps")) *value = t.fuse_steps;
     else if (!strcmp(key, "fuse_dens")) *value = t.fuse_dens;
     else if (!strcmp(key, "fuse_unit")) *value = t.fuse_unit;

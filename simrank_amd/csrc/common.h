@@ -63,8 +63,11 @@ struct Tuning {
     int64_t fuse = 1;        // leg 1 of a panel-blocked update as ONE launch (fused.hip): the columns shared by
                              // >= fuse_min rows of a 128-row block on the matrix cores, the rest gathered, by the
                              // same workgroup on the same L2-resident panel slice; 0 = dense_tiles + gather3 launches
-    int64_t fuse_min = 3;    // ... a column joins a block's dense set when this many of its rows reference it (2 and 4:
-                             // +8 % and +1 % on the leg at pl32768d32)
+    int64_t fuse_min = 0;    // ... a column joins a block's dense set when this many of its rows reference it (3 was the default
+                             // of rounds 3-5; 2 and 4: +8 % and +1 % on the leg at pl32768d32); 0 (round 6): by quads that pay
+    int64_t fuse_pays = -1;  // ... fuse_min = 0: a block's columns by descending count, 64 (one quad = four matrix-core steps) at a
+                             // time, while the quad covers at least this many entries; -1: 192, or 256 where the matrix-core
+                             // steps outweigh the gathered remainder (build_fused_plan; profiles/r06_fuse_pays_sweep.log)
     int64_t fuse_steps = -1; // ... and a block keeps its set only when it makes this many 16-column steps; -1: by the size
                              // of a panel's operand slice (fuse_min_steps below)
     int64_t fuse_dens = 0;   // ... or (> 0) when it makes at least 4 and covers this many entries per step

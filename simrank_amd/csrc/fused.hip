@@ -61,6 +61,8 @@ constexpr int kTS = 132;          // floats per column of the LDS tile (32 colum
 #endif
 constexpr int kMinUnits = SIMRANK_KMINUNITS;       // units per panel below which blocks are grouped less
 constexpr int kGroupEntries = SIMRANK_KGROUPENTRIES; // gathered entries a unit of several set-less blocks may hold
+// fuse_min = 0 (build_fused_plan): what a quad of 64 columns must cover, and one 16-column step priced in gathered entries
+constexpr int64_t kPaysGatherBound = 192, kPaysMfmaBound = 256, kStepInEntries = 77;
 constexpr int kMaxRem = SIMRANK_KMAXREM;      // a row whose remainder would be longer sends all its columns to the dense set
 
 struct FusedArgs {
@@ -765,9 +767,53 @@ void free_fused_plan(simrank_fused_plan* p) {
 //    (past its end: a marker).
 int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col, const float* rowscale) {
     const int64_t M = g->n_rows, K = g->n_cols;
+    // fuse_min = 0: no fixed threshold — a block's columns by descending count, 64 at a time, while such a quad covers at
+    // least `pays` entries (what its four matrix-core steps cost in gathered entries: fuse_quad_pays in common.h)
+    const bool by_quads = g->tun.fuse_min == 0;
     const int64_t thr = std::max<int64_t>(2, g->tun.fuse_min);
     const int64_t min_steps = fuse_min_steps(g->tun, g->n_cols);
     const int64_t nblk = (M + kFB - 1) / kFB;
+    // What a quad must cover (fuse_pays = -1): the two phases of the launch overlap across the workgroups of a CU, so work is
+    // cheap to move TO the phase that is not the critical one.  A sample of the blocks (16 of them, evenly spaced) at the lower price says which that
+    // is: where the matrix-core steps outweigh the gathered remainder (a MovieLens-shaped pattern: 90 % of the entries in
+    // sets) a quad has to cover 256 entries, elsewhere (power-law graphs: the gathers are what the launch waits for) 192.
+    // profiles/r06_fuse_pays_sweep.log: 256 is -9 % on the MovieLens-shaped update and +5 % on leg 1 at pl32768d32.
+    int64_t pays = g->tun.fuse_pays;
+    if (by_quads && pays < 0) {
+        pays = kPaysGatherBound;
+        std::vector<uint16_t> cnt(size_t(K), 0);
+        std::vector<int32_t> touched;
+        std::vector<int32_t> hist(size_t(kFB) + 1);
+        int64_t s_steps = 0, s_rem = 0;
+        const int64_t stride = std::max<int64_t>(1, nblk / 16);
+        for (int64_t b = 0; b < nblk; b += stride) {
+            const int64_t lo = b * kFB, hi = std::min<int64_t>(M, lo + kFB);
+            touched.clear();
+            std::fill(hist.begin(), hist.end(), 0);
+            for (int32_t j = rowptr[lo]; j < rowptr[hi]; ++j)
+                if (cnt[col[j]]++ == 0) touched.push_back(col[j]);
+            for (int32_t c : touched) { ++hist[cnt[c]]; cnt[c] = 0; }
+            // quads of the columns in descending count, from the histogram
+            int64_t nq = 0, cov = 0, in_quad = 0, gain = 0;
+            bool open = true;
+            for (int c = kFB; c >= 1 && open; --c) {
+                int64_t left = hist[size_t(c)];
+                while (left > 0) {
+                    const int64_t take = std::min<int64_t>(left, 64 - in_quad);
+                    in_quad += take; gain += take * c; left -= take;
+                    if (in_quad == 64) {
+                        if (gain < pays) { open = false; in_quad = 0; gain = 0; break; }
+                        ++nq; cov += gain; in_quad = 0; gain = 0;
+                    }
+                }
+            }
+            if (open && in_quad > 0 && gain >= pays) { ++nq; cov += gain; }
+            if (4 * nq < min_steps) { nq = 0; cov = 0; }
+            s_steps += 4 * nq;
+            s_rem += int64_t(rowptr[hi] - rowptr[lo]) - cov;
+        }
+        if (kStepInEntries * s_steps > s_rem) pays = kPaysMfmaBound;
+    }
     // 16-bit ids while 0xFFFF, the marker of an empty slot of a gather stream, is no column's id.  (Exactly 65536 operand rows
     // — BASELINE config 5 — would need that one column kept out of the streams: forcing it into the dense set of every
     // block that references it was tried and made config 5 slower, the column being a hub that nearly every block
@@ -812,8 +858,21 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
         set.clear();
         for (int32_t j = rowptr[lo]; j < rowptr[hi]; ++j)
             if (cnt[col[j]]++ == 0) touched.push_back(col[j]);
-        for (int32_t c : touched)
-            if (cnt[c] >= thr) { set.push_back(c); kpos[c] = 0; }
+        if (by_quads) {
+            std::stable_sort(touched.begin(), touched.end(), [&](int32_t x, int32_t y) { return cnt[x] > cnt[y]; });
+            size_t n = 0;
+            while (n < touched.size()) {
+                const size_t e = std::min(touched.size(), n + 64);
+                int64_t gain = 0;
+                for (size_t i = n; i < e; ++i) gain += cnt[touched[i]];
+                if (gain < pays) break;
+                n = e;
+            }
+            for (size_t i = 0; i < n; ++i) { set.push_back(touched[i]); kpos[touched[i]] = 0; }
+        } else {
+            for (int32_t c : touched)
+                if (cnt[c] >= thr) { set.push_back(c); kpos[c] = 0; }
+        }
         {
             const int64_t steps = (int64_t)(set.size() + 15) / 16;
             bool keep = steps >= min_steps;

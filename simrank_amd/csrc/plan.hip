@@ -187,8 +187,12 @@ int simrank_plan_create(int64_t n, int64_t nnz, const int32_t* rowptr, const int
             // one fp16 MFMA term instead of three bf16 ones, but an operand segment serves 64 columns, so the gathers got
             // cheaper still: the break-even moves up by one (4 is 3 % faster than 3, 2 is 12 % slower), and groups of four
             // blocks without a set beat three (7 % at config 5) — while the knobs are at their defaults (as driver.Side did)
+            // (round 6, fuse_min = 0 — quads that pay: the same step up, 256 entries per quad instead of 192)
             if (t.fuse_min == 3) {
                 t.fuse_min = 4;
+                if (t.fuse_group == 3) t.fuse_group = 4;
+            } else if (t.fuse_min == 0 && t.fuse_pays < 0) {
+                t.fuse_pays = 256;
                 if (t.fuse_group == 3) t.fuse_group = 4;
             }
         }

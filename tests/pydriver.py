@@ -532,6 +532,11 @@ class Side:
             knobs["fuse_min"] = 4
             if ops.get_tuning("fuse_group") == 3:      # (and groups of four: 7 % faster than three at config 5 here,
                 knobs["fuse_group"] = 4                #  where three is 5 % faster than four in f32)
+        elif (spec.storage == "fp16" and hasattr(ops, "get_tuning") and ops.get_tuning("fuse_min") == 0
+              and ops.get_tuning("fuse_pays") < 0):
+            knobs["fuse_pays"] = 256                   # (round 6: dense sets by quads that pay — the same step up, as plan.hip)
+            if ops.get_tuning("fuse_group") == 3:
+                knobs["fuse_group"] = 4
         # SimRank++ on the graph's own pattern (the directed classes): the evidence counts are queued while the graph's
         # plans are still being built on the host (engine.Graph(counting=)); counted below otherwise
         self.ev = None

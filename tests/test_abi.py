@@ -43,7 +43,7 @@ def test_abi_version_and_error_string():
         assert lib.simrank_set_tuning(b"probe_mask", 255) == -1
     assert lib.simrank_set_tuning(b"probe_flags", 0) == 0 and lib.simrank_set_tuning(b"probe_mask", -1) == 0
     v = ctypes.c_int64(-7)
-    assert lib.simrank_get_tuning(b"fuse_min", ctypes.byref(v)) == 0 and v.value == 3
+    assert lib.simrank_get_tuning(b"fuse_min", ctypes.byref(v)) == 0 and v.value == 0
     assert lib.simrank_graph_set_dense_terms(None, 3) == -1
 
 

@@ -22,7 +22,7 @@ def ops():
     o = HipOps(0)
     o.set_tuning(fuse_steps=1, fuse_min=2)   # small test graphs: a dense set however few steps it makes
     yield o
-    o.set_tuning(fuse=1, fuse_min=3, fuse_steps=-1, fuse_unit=48, fuse_group=3, fuse_shards=1, fuse_rows=8192, fuse_order=0,
+    o.set_tuning(fuse=1, fuse_min=0, fuse_steps=-1, fuse_unit=48, fuse_group=3, fuse_shards=1, fuse_rows=8192, fuse_order=0,
                  fuse_sym=-1)
 
 
@@ -383,7 +383,7 @@ def test_fused_leg2_runs_the_bipartite_plan_where_the_dense_sets_dominate(ops):
     from simrank_amd.engine import BiPlan, HipOps
     from tests.graphs import bipartite_random
     fresh = HipOps(0)                                                # (the library's default knobs)
-    fresh.set_tuning(fuse=1, fuse_min=3, fuse_steps=-1, fuse_unit=48, fuse_group=3, fuse_shards=1, fuse_rows=8192, fuse_order=0,
+    fresh.set_tuning(fuse=1, fuse_min=0, fuse_pays=-1, fuse_steps=-1, fuse_unit=48, fuse_group=3, fuse_shards=1, fuse_rows=8192, fuse_order=0,
                      fuse_sym=-1)
     for n1, n2, dens in ((1400, 900, 0.12), (900, 700, 0.004)):
         df = bipartite_random(n1, n2, dens, seed=n1)

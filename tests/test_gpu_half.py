@@ -21,7 +21,7 @@ def ops():
     # meet in memory: fits on fp16-held matrices create their graphs that way themselves, driver.Side)
     o.set_tuning(fuse_steps=1, fuse_min=2, fuse_unit=1 << 20)
     yield o
-    o.set_tuning(fuse=1, fuse_min=3, fuse_steps=-1, fuse_unit=48, fuse_group=3)
+    o.set_tuning(fuse=1, fuse_min=0, fuse_steps=-1, fuse_unit=48, fuse_group=3)
 
 
 def put_half(ops, a, scale=1.0):

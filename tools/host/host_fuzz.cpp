@@ -440,7 +440,8 @@ int main(int argc, char** argv) {
         simrank_set_tuning("balance", it % 5 == 0 ? 0 : 1 + it % 4);
         simrank_set_tuning("dense_min", 2 + it % 4);
         simrank_set_tuning("dense_cols", it % 2 ? 16 : 64);
-        simrank_set_tuning("fuse_min", 2 + it % 3);
+        simrank_set_tuning("fuse_min", it % 4 == 3 ? 0 : 2 + it % 3);          // (0: the set by quads that pay)
+        simrank_set_tuning("fuse_pays", it % 8 == 3 ? -1 : 64 + 64 * (it % 5));
         simrank_set_tuning("fuse_steps", (it % 4) * 3);
         simrank_set_tuning("fuse_unit", it % 3 == 0 ? 4 : (it % 3 == 1 ? 64 : 1 << 20));
         simrank_set_tuning("fuse_rows", it % 4 == 0 ? 64 : (it % 4 == 1 ? 700 : 8192));

@@ -20,8 +20,8 @@ out_dir, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEYS = {"cfg2_er8192": "er8192:1", "cfg3_ml1m": "ml1m:1:pp", "cfg4_pl32768d32": "pl32768d32:1",
         "cfg5_pl65536_pp": "pl65536:1:pp", "cfg5_pl65536_pp_fp16": "pl65536:1:pp:fp16storage"}
-LEG1 = ("fused_trans_kernel", "gather3_kernel<1", "half_leg_kernel<true, false", "half_leg_kernel<false, false")
-LEG2 = ("gather3_kernel<2", "gather3_kernel<0", "half_leg_kernel<true, true", "half_leg_kernel<false, true")
+LEG1 = ("fused_trans_kernel<true, false", "fused_trans_kernel<false, false", "gather3_kernel<1", "half_leg_kernel<true, false", "half_leg_kernel<false, false")
+LEG2 = ("fused_trans_kernel<true, true", "fused_trans_kernel<false, true", "gather3_kernel<2", "gather3_kernel<0", "half_leg_kernel<true, true", "half_leg_kernel<false, true")
 try:
     commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 except Exception:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised soak of the one-launch leg 1 (fused.hip) and of both legs on fp16-held matrices (half.hip) on a
+"""Randomised soak of the one-launch legs (fused.hip: leg 1, and leg 2 of a symmetric update) and of both legs on fp16-held matrices (half.hip) on a
 real GPU: random shapes, densities, hub corners, knobs; every case against float64 NumPy.  Not part of the
 test suite (minutes, not seconds): `python3 tools/soak_kernels.py [cases] [seed]`, log in profiles/.
 """
@@ -38,7 +38,8 @@ for case in range(cases):
     from simrank_amd.ingest import CSR
     csr = CSR(csr.n_rows, csr.n_cols, csr.rowptr, csr.col,
               csr.rowscale / np.maximum(1, np.diff(csr.rowptr)))
-    knobs = dict(fuse_min=int(rng.choice([2, 3, 4, 8])), fuse_steps=int(rng.choice([1, 2, 8])),
+    knobs = dict(fuse_min=int(rng.choice([0, 0, 2, 3, 4, 8])), fuse_pays=int(rng.choice([-1, 64, 192, 320])),
+                 fuse_steps=int(rng.choice([1, 2, 8])),
                  fuse_group=int(rng.choice([1, 2, 4])), fuse_unit=int(rng.choice([4, 8, 48, 1 << 20])),
                  fuse_rows=int(rng.choice([64, 500, 8192])), fuse_order=int(rng.choice([0, 0, 1, 2, 3])))
     g = ops.graph(csr, knobs=knobs)
@@ -59,6 +60,51 @@ for case in range(cases):
     bad = err.max() if want.size else 0.0
     assert bad < 1e-5, ("f32 leg 1", case, M, K, L, knobs, bad)
     worst32 = max(worst32, float(bad))
+    # f32, leg 2 of a symmetric update as ONE launch (fused.hip, SYM; square patterns): every variant of the epilogue against
+    # float64, the mirrored tiles bit for bit, the exact count = the count over the stored matrix
+    if square and M >= 64:
+        gs = ops.graph(csr, knobs=dict(knobs, fuse_sym=1))
+        S = rng.random((M, M)) ** 3
+        S = ((S + S.T) / 2).astype(np.float32)
+        Tt = (W @ S.astype(np.float64)).T.astype(np.float32)
+        c = rng.integers(0, 5, size=(M, M))
+        counts = (np.triu(c) + np.triu(c, 1).T).astype(np.uint8) if rng.random() < 0.5 else None
+        prior = None
+        if rng.random() < 0.5:
+            prior = rng.random((M, M)).astype(np.float32)
+            prior = ((prior + prior.T) / 2).astype(np.float32)
+        lbd = 0.3 if prior is not None else 0.0
+        v = 0.8 * (W @ Tt.astype(np.float64))
+        if counts is not None:
+            v = v * (1.0 - 0.5 ** counts.astype(np.float64))
+        if prior is not None:
+            v = (1 - np.float32(lbd)) * v + np.float32(lbd) * prior.astype(np.float64)
+        np.fill_diagonal(v, 1.0)
+        mats = [ops.matrix(M, M, blocked=True) for _ in range(3)]
+        ops.upload(mats[0], Tt)
+        ops.upload(mats[1], S)
+        ev = ap = None
+        if counts is not None:
+            ev = ops.matrix(M, M, np.uint8, blocked=True)
+            ops.upload(ev, counts)
+            mats.append(ev)
+        if prior is not None:
+            ap = ops.matrix(M, M, blocked=True)
+            ops.upload(ap, prior)
+            mats.append(ap)
+        ops.spmm(gs, mats[0], mats[2], epilogue=dict(coef=0.8, previous=mats[1], eps=0.02, diag_col0=0, symmetric=True,
+                                                     evidence=ev, apriori=ap, lbd=lbd))
+        got2, moved = ops.download(mats[2]), ops.read_changed()
+        e2 = np.abs(got2 - v) / np.maximum(np.abs(v), 1e-30)
+        assert e2.max() < 1e-5, ("f32 one-launch leg 2", case, M, knobs, float(e2.max()))
+        iu = np.triu_indices(M, 32)                              # (tiles off the diagonal: the same bits both sides)
+        tl = (iu[0] // 32) != (iu[1] // 32)
+        assert np.array_equal(got2[iu][tl], got2.T[iu][tl]), ("f32 one-launch leg 2: mirrored tiles", case, M, knobs)
+        assert moved == int((np.abs(got2.astype(np.float64) - S) > 0.02).sum()), ("f32 one-launch leg 2: count", case, M, knobs)
+        worst32 = max(worst32, float(e2.max()))
+        for m in mats:
+            m.free()
+        gs.free()
     # fp16-held, leg 1
     Xh = X.astype(np.float16)
     want_h = (W @ Xh.astype(np.float64)).T

@@ -122,25 +122,25 @@ def _strip(o, key=None):
 
 
 def _roof(r):
-    """(leg-1 frac, leg-2 frac, leg-1 traffic / algorithmic) of a `roofline` object whose slower launch comes first."""
+    """(leg-1 frac, leg-2 frac, leg-1 and leg-2 traffic / algorithmic) of a `roofline` object whose slower launch comes first."""
     if not isinstance(r, dict):
-        return None, None, None
+        return None, None, None, None
     legs = [r] + list(r.get("other") or [])
-    f1 = f2 = t1 = None
+    f1 = f2 = t1 = t2 = None
     for o in legs:
         name = str(o.get("kernel", ""))
         if "leg 2" in name or "leg2" in name:
-            f2 = o.get("frac")
+            f2, t2 = o.get("frac"), o.get("traffic_over_algorithmic")
         else:
             f1, t1 = o.get("frac"), o.get("traffic_over_algorithmic")
-    return f1, f2, t1
+    return f1, f2, t1, t2
 
 
 def summary_of(out):
     """Every BASELINE config on one screen: it/s, ms per update, HBM roofline fraction of both legs, leg-1 traffic ratio."""
     def row(value, ms, roof, **extra):
-        f1, f2, t1 = _roof(roof)
-        r = {"it_s": value, "ms": ms, "leg1_frac": f1, "leg2_frac": f2, "leg1_traffic_x": t1}
+        f1, f2, t1, t2 = _roof(roof)
+        r = {"it_s": value, "ms": ms, "leg1_frac": f1, "leg2_frac": f2, "leg1_traffic_x": t1, "leg2_traffic_x": t2}
         r.update(extra)
         return {k: v for k, v in r.items() if v is not None}
     s = {}
@@ -152,12 +152,14 @@ def summary_of(out):
     if bp:
         fl = bp.get("fit_loop") or {}
         s["cfg3_ml1m_bipartite_pp"] = row(fl.get("value", bp.get("value")), fl.get("ms_per_step", bp.get("ms_per_step")),
-                                          bp.get("roofline"), it_s_step_by_step=bp.get("value"))
+                                          bp.get("roofline"), it_s_step_by_step=bp.get("value"),
+                                          leg1_mfma_frac=(bp.get("roofline_mfma") or {}).get("frac"))
     hr = dict(out.get("roofline") or {})
     if hr:
         hr = dict(hr, kernel="leg 1", other=[dict(out.get("roofline_other") or {}, kernel="leg 2")] if out.get("roofline_other") else [])
-        if hr.get("traffic") and hr.get("algorithmic_bytes"):
-            hr["traffic_over_algorithmic"] = hr["traffic"] / hr["algorithmic_bytes"]
+        for o in [hr] + hr["other"]:
+            if o.get("traffic") and o.get("algorithmic_bytes"):
+                o["traffic_over_algorithmic"] = o["traffic"] / o["algorithmic_bytes"]
     s["cfg4_" + str((out.get("config") or {}).get("name", "headline"))] = row(out.get("value"), out.get("ms_per_step"), hr or None)
     for key, name in (("f32_exact_dense_blocks", "cfg5_pl65536_pp_f32"), ("fp16_storage", "cfg5_pl65536_pp_fp16_held")):
         v = c5.get(key) or {}
@@ -1142,7 +1144,7 @@ def main():
                 s3.step(0.0)
             ops.synchronize()
             dt = (time.perf_counter() - t0) / 10
-            st3 = [ops.dense_stats(next(iter(sd.values())).graph) for sd in s3.sides]
+            st3 = [ops.fused_stats(next(iter(sd.values())).graph) for sd in s3.sides]     # (steps, covered, gathered) per panel
             out["bipartite_pp"] = {
                 "workload": f"ml1m: synthetic MovieLens-1M-shaped bipartite graph {g12.n_rows} x "
                             f"{g12.n_cols}, nnz={g12.nnz}, BipartiteSimRankPP C1=C2=0.8 fp32",
@@ -1150,7 +1152,7 @@ def main():
                 "legs_ms": {k: v[0] for k, v in s3.leg_times().items()},
                 "legs_ms_note": "HIP events of the Python driver's launches of the same kernels (the C loop queues them "
                                 "back to back)",
-                "entries_in_dense_sets": [c / max(1, g12.nnz) for _, _, c in st3]}
+                "entries_in_dense_sets": [c / max(1, g12.nnz) for _, c, _ in st3]}
             try:
                 # the mean launch of each leg over both groups (what the per-kernel rocprofv3 figures average too):
                 # group 1: S1' = C1 W12 S2 W12^T (leg 1 reads S2, n2 x n2, writes n1 x n2; leg 2 reads that, writes S1,
@@ -1168,6 +1170,17 @@ def main():
                             + leg_bytes(m2, m1, m2, z3, True, has_evidence=True, triangle=True)))],
                     note="6040 x 3706: the matrices are 146 MB, 55 MB and 90 MB - Infinity-Cache resident; the HBM figure is "
                          "the contract's, the gathers' vector-memory path is what binds")
+                # the launches of this configuration are paced by their matrix-core phase (90 % of the entries in dense sets;
+                # DESIGN 4.10b): leg 1 priced against the dense bf16 MFMA peak — 12 v_mfma_f32_32x32x16_bf16 (three bf16 terms
+                # x four 32-row tiles) per 16-column step and 32-column panel
+                fl = [st3[i][0] * 12 * 32768.0 * ((k + 31) // 32) for i, k in ((0, m2), (1, m1))]
+                ms1 = [lm["leg1.0"], lm["leg1.1"]]
+                tf = sum(fl) / (sum(ms1) * 1e-3) / 1e12
+                out["bipartite_pp"]["roofline_mfma"] = {
+                    "kernel": "matrix-core phase of leg 1 (both groups), exact f32 products as three bf16 terms", "bound": "mfma",
+                    "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TF,
+                    "flop_per_launch": fl, "ms": ms1, "steps_per_panel": [st3[0][0], st3[1][0]],
+                    "f32_equivalent_TFLOPs": tf / 3.0}
             except Exception as e:
                 out["bipartite_pp"]["roofline"] = {"error": f"{type(e).__name__}: {e}"}
             s3.release()

@@ -10,17 +10,18 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*extra):
+def _run(*extra, full_json):
     env = {k: v for k, v in os.environ.items()
            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["OMP_NUM_THREADS"] = "1"
-    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *extra],
+    # (the complete record goes to the test's own directory: the default path is where a real run's record lives)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *extra, "--full-json", str(full_json)],
                           capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
 
 
-def test_bench_launches_its_own_ranks_over_gloo():
+def test_bench_launches_its_own_ranks_over_gloo(tmp_path):
     p = _run("--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
-             "--workload", "er:96:0.06")
+             "--workload", "er:96:0.06", full_json=tmp_path / "full.json")
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1                       # rank 0's line, relayed once
@@ -39,8 +40,9 @@ def test_bench_launches_its_own_ranks_over_gloo():
     assert "skipped" in c["link_probe"]          # (the xGMI link-rate probe of a real multi-GPU run)
     assert len(lines[0]) <= 8000                 # the driver's record keeps the tail of the line: it must be all of it
     assert "exchange_ms" in out
+    assert abs(json.load(open(tmp_path / "full.json"))["value"] - out["value"]) < 1e-3 * out["value"]   # the complete record
 
 
-def test_bench_child_failure_is_reported():
-    p = _run("--gpus", "2", "--backend", "gloo", "--workload", "no-such-workload")
+def test_bench_child_failure_is_reported(tmp_path):
+    p = _run("--gpus", "2", "--backend", "gloo", "--workload", "no-such-workload", full_json=tmp_path / "full.json")
     assert p.returncode != 0

@@ -650,15 +650,20 @@ SIMRANK_API int simrank_shardbiplan_destroy(simrank_shardbiplan* bp);
  *      "balance"  32-row tiles heavier than this many times the mean tile are cut in halves
  *                 (0 = uniform tiles; default 2)
  *      "dense_min" / "dense_cols"  selection of the block-dense part (see above); dense_min 0 = off
- *      "fuse" / "fuse_min" / "fuse_steps"  leg 1 of a panel-blocked update as one launch (see above): a
- *                 column joins a 128-row block's dense set when fuse_min (3) of its rows reference it, a
- *                 block keeps its set when it makes fuse_steps 16-column steps (default -1: 20 while a panel's
- *                 operand slice fits the XCD's L2, i.e. up to 32768 operand rows, 8 beyond); fuse 0 = the
- *                 dense_tiles + gather launches of round 2
+ *      "fuse" / "fuse_min" / "fuse_pays" / "fuse_steps"  leg 1 of a panel-blocked update as one launch (see above):
+ *                 fuse_min 0 (default): a 128-row block's columns in descending count join its dense set 64 at a
+ *                 time (one quad = four 16-column steps) while the quad covers fuse_pays entries (default -1: 192,
+ *                 or 256 where the plan's matrix-core steps outweigh its gathered remainder); fuse_min >= 2: every
+ *                 column that many of the block's rows reference; a block keeps its set when it makes fuse_steps
+ *                 16-column steps (default -1: 20 while a panel's operand slice fits the XCD's L2, i.e. up to
+ *                 32768 operand rows, 8 beyond); fuse 0 = the dense_tiles + gather launches of round 2
+ *      "fuse_sym"  leg 2 of a symmetric panel-blocked update in the same launch (epilogue on the tile, upper
+ *                 triangle + mirror): 1 wherever it applies, 0 never, -1 (default) where the dense sets hold at
+ *                 least half of the pattern's entries
  *      "fuse_max_rows" operands with more rows than this (default 2^20: never) keep the two-launch leg 1
  *      "fuse_group" up to this many (1..4, default 3) consecutive blocks without a set share a workgroup
- *      "fuse_unit"  sets of more 64-column groups than this are cut into several workgroups whose
- *                 partial sums meet in memory (off by default: 1 << 20)
+ *      "fuse_unit"  sets of more 64-column groups than this (default 48) are cut into several workgroups whose
+ *                 partial sums meet in memory (1 << 20: never)
  *      "fuse_order" launch order of a panel's workgroups: 0 heaviest first, k: matrix-core units spread
  *                 over the first 1/k of the order
  *      "fuse_store" cache policy of the tile stores (0 plain, 1 nt, 2 sc1, 3 sc0 sc1); "fuse_meta_nt"

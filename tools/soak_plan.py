@@ -16,6 +16,11 @@ from simrank_amd.engine import HipOps, Plan            # noqa: E402
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 ops = HipOps(0)
+# SOAK_KNOBS="fuse_sym=1,fuse_steps=1": library knobs for the whole run (e.g. the one-launch leg 2 on every graph that has a set)
+if os.environ.get("SOAK_KNOBS"):
+    from simrank_amd.engine import HipOps as _H
+    _H(0).set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in os.environ["SOAK_KNOBS"].split(","))})
+    print("knobs:", os.environ["SOAK_KNOBS"], flush=True)
 t0 = time.time()
 for seed in range(first, first + count):
     rng = np.random.default_rng(9000 + seed)

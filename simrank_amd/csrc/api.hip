@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -123,21 +124,41 @@ int64_t build_tiles(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int64_t 
 // interface empties the pool and tries once more, so cached blocks never cause an out-of-memory error the
 // process would not have had without them.  Cached memory is invisible to other allocators of the process
 // (torch's caching allocator, the caller's own hipMalloc): simrank_pool_trim() hands it back.
+// (round 6) SMALL blocks — the few dozen arrays of a graph object and its plans, the counters, the tickets — are kept too, in
+// size classes (2^k x {1, 1.25, 1.5, 1.75}, from 512 bytes): a fit made ~60 hipMalloc / hipFree pairs of them, 5 ms of the
+// 60 ms of a MovieLens-shaped fit in the frees alone.  At most kSmallLimit bytes at rest per device; simrank_pool_trim
+// returns them with the rest.
 namespace {
 constexpr size_t kPoolMin = size_t(64) << 20;
+constexpr size_t kSmallLimit = size_t(1) << 30;
+constexpr int kSmallClasses = 4 * 40;
+inline size_t small_class_bytes(int c) { return (size_t(4 + (c & 3)) << (c >> 2)) * 128; }      // class 0 = 512 bytes
+inline int small_class_of(size_t bytes) {
+    int c = 0;
+    while (small_class_bytes(c) < bytes) ++c;
+    return c;
+}
 struct PoolBlock { void* ptr; size_t bytes; uint64_t age; };
 struct PoolState {
     std::mutex m;
     std::vector<std::vector<PoolBlock>> cached;      // per device
     std::vector<size_t> cached_bytes;
-    std::vector<std::pair<void*, std::pair<size_t, int>>> live;   // blocks handed out: ptr -> (bytes, device)
+    std::vector<std::vector<std::vector<void*>>> small;   // per device and size class
+    std::vector<size_t> small_bytes;
+    std::unordered_map<void*, std::pair<size_t, int>> live;   // blocks handed out: ptr -> (bytes, device)
     uint64_t clock = 0;
     size_t limit = size_t(56) << 30;      // what one config-5 plan holds: three 17 GiB matrices + its counts
     PoolState() {
         if (const char* e = getenv("SIMRANK_POOL_GIB")) limit = size_t(std::max(0ll, atoll(e))) << 30;
     }
     void grow(int dev) {
-        if ((int)cached.size() <= dev) { cached.resize(size_t(dev) + 1); cached_bytes.resize(size_t(dev) + 1, 0); }
+        if ((int)cached.size() <= dev) {
+            cached.resize(size_t(dev) + 1);
+            cached_bytes.resize(size_t(dev) + 1, 0);
+            small.resize(size_t(dev) + 1);
+            small_bytes.resize(size_t(dev) + 1, 0);
+        }
+        if (small[size_t(dev)].empty()) small[size_t(dev)].resize(kSmallClasses);
     }
 };
 PoolState& pool() {
@@ -154,6 +175,15 @@ void pool_trim_locked(PoolState& P, int device) {
         for (PoolBlock& b : P.cached[size_t(d)]) (void)hipFree(b.ptr);
         P.cached[size_t(d)].clear();
         P.cached_bytes[size_t(d)] = 0;
+    }
+    for (int d = 0; d < (int)P.small.size(); ++d) {
+        if ((device >= 0 && d != device) || P.small_bytes[size_t(d)] == 0) continue;
+        (void)hipSetDevice(d);
+        for (std::vector<void*>& l : P.small[size_t(d)]) {
+            for (void* q : l) (void)hipFree(q);
+            l.clear();
+        }
+        P.small_bytes[size_t(d)] = 0;
     }
     if (restore >= 0) (void)hipSetDevice(restore);
 }
@@ -177,8 +207,21 @@ static int pool_alloc_raw(void** dptr, size_t bytes) {
             const PoolBlock b = c[size_t(best)];
             c.erase(c.begin() + best);
             P.cached_bytes[size_t(dev)] -= b.bytes;
-            P.live.push_back({b.ptr, {b.bytes, dev}});
+            P.live[b.ptr] = {b.bytes, dev};
             *dptr = b.ptr;
+            return SIMRANK_OK;
+        }
+    } else if (P.limit > 0) {
+        const int cls = small_class_of(std::max<size_t>(bytes, 1));
+        bytes = small_class_bytes(cls);
+        std::lock_guard<std::mutex> lock(P.m);
+        P.grow(dev);
+        std::vector<void*>& l = P.small[size_t(dev)][size_t(cls)];
+        if (!l.empty()) {
+            *dptr = l.back();
+            l.pop_back();
+            P.small_bytes[size_t(dev)] -= bytes;
+            P.live[*dptr] = {bytes, dev};
             return SIMRANK_OK;
         }
     }
@@ -197,9 +240,9 @@ static int pool_alloc_raw(void** dptr, size_t bytes) {
         (void)hipGetLastError();
         return e == hipErrorOutOfMemory ? SIMRANK_ERR_ALLOC : SIMRANK_ERR_HIP;
     }
-    if (bytes >= kPoolMin) {
+    if (P.limit > 0 || bytes >= kPoolMin) {
         std::lock_guard<std::mutex> lock(P.m);
-        P.live.push_back({*dptr, {bytes, dev}});
+        P.live[*dptr] = {bytes, dev};
     }
     return SIMRANK_OK;
 }
@@ -228,14 +271,33 @@ int pool_free(void* ptr) {
     int dev = -1;
     {
         std::lock_guard<std::mutex> lock(P.m);
-        for (size_t i = 0; i < P.live.size(); ++i)
-            if (P.live[i].first == ptr) {
-                bytes = P.live[i].second.first;
-                dev = P.live[i].second.second;
-                P.live[i] = P.live.back();
-                P.live.pop_back();
-                break;
+        auto it = P.live.find(ptr);
+        if (it != P.live.end()) {
+            bytes = it->second.first;
+            dev = it->second.second;
+            P.live.erase(it);
+        }
+    }
+    if (bytes && bytes < kPoolMin && P.limit > 0) {
+        // a small block: back to its size class (as below: nothing queued on the device may still use it)
+        int cur = 0;
+        SR_HIP(hipGetDevice(&cur));
+        if (cur != dev) SR_HIP(hipSetDevice(dev));
+        const hipError_t e = hipDeviceSynchronize();
+        if (cur != dev) (void)hipSetDevice(cur);
+        if (e == hipSuccess) {
+            std::lock_guard<std::mutex> lock(P.m);
+            P.grow(dev);
+            if (P.small_bytes[size_t(dev)] + bytes <= kSmallLimit) {
+                P.small[size_t(dev)][size_t(small_class_of(bytes))].push_back(ptr);
+                P.small_bytes[size_t(dev)] += bytes;
+                return SIMRANK_OK;
             }
+        } else {
+            (void)hipGetLastError();
+        }
+        SR_HIP(hipFree(ptr));
+        return SIMRANK_OK;
     }
     if (bytes && bytes <= P.limit) {
         // like hipFree: nothing queued anywhere on the device may still use the block when the next owner gets it
@@ -279,7 +341,11 @@ void pool_stats(int device, int64_t* cached_bytes, int64_t* cached_blocks, int64
     std::lock_guard<std::mutex> lock(P.m);
     int64_t b = 0, n = 0;
     for (int d = 0; d < (int)P.cached.size(); ++d)
-        if (device < 0 || d == device) { b += (int64_t)P.cached_bytes[size_t(d)]; n += (int64_t)P.cached[size_t(d)].size(); }
+        if (device < 0 || d == device) {
+            b += (int64_t)P.cached_bytes[size_t(d)] + (int64_t)P.small_bytes[size_t(d)];
+            n += (int64_t)P.cached[size_t(d)].size();
+            for (const std::vector<void*>& l : P.small[size_t(d)]) n += (int64_t)l.size();
+        }
     if (cached_bytes) *cached_bytes = b;
     if (cached_blocks) *cached_blocks = n;
     if (limit_bytes) *limit_bytes = (int64_t)P.limit;
@@ -647,11 +713,19 @@ int graph_create_with(const Tuning& tun, int64_t n_rows, int64_t n_cols, int64_t
     auto dense_job = [](simrank_graph* gg, const int32_t* rp, const int32_t* cl, const float*) { return build_dense_plan(gg, rp, cl); };
     int n_jobs = 0;
     if (big) {
+        if (g->tun.fuse) g->fused_build.store(1, std::memory_order_release);      // (before the dense builder can look)
         if (g->tun.dense_min > 0 && nnz > 0) spawn(jobs[n_jobs++], dense_job);
 #ifdef SIMRANK_EXPERIMENT_FUSED2
         if (g->tun.fuse == 2 && nnz > 0) spawn(jobs[n_jobs++], build_fused2_plan);
 #endif
-        if (g->tun.fuse) spawn(jobs[n_jobs++], build_fused_plan);
+        if (g->tun.fuse) {
+            auto fused_job = [](simrank_graph* gg, const int32_t* rp, const int32_t* cl, const float* rs) {
+                const int rc2 = build_fused_plan(gg, rp, cl, rs);
+                gg->fused_build.store(2, std::memory_order_release);
+                return rc2;
+            };
+            spawn(jobs[n_jobs++], fused_job);
+        }
     }
     // (the plan builders above read the validated CSR only: the transposed pattern, the hub list and the tiles are worked out
     // here, beside them)
@@ -734,11 +808,12 @@ int graph_create_with(const Tuning& tun, int64_t n_rows, int64_t n_cols, int64_t
         }
     }
     if (!big) {
+        if (!rc && g->tun.fuse) rc = build_fused_plan(g, rowptr, col, rowscale);    // (also without entries: fp16-held updates have no other path)
+        if (g->tun.fuse) g->fused_build.store(2, std::memory_order_release);
         if (!rc && g->tun.dense_min > 0 && nnz > 0) rc = build_dense_plan(g, rowptr, col);
 #ifdef SIMRANK_EXPERIMENT_FUSED2
         if (!rc && g->tun.fuse == 2 && g->nnz > 0) rc = build_fused2_plan(g, rowptr, col, rowscale);
 #endif
-        if (!rc && g->tun.fuse) rc = build_fused_plan(g, rowptr, col, rowscale);    // (also without entries: fp16-held updates have no other path)
     }
     if (timed)
         std::fprintf(stderr, "simrank_graph_create: n %lld nnz %lld: transposed pattern + tiles + base uploads %.1f ms, all %.1f ms\n",

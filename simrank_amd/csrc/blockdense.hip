@@ -25,6 +25,8 @@
 #include <numeric>
 #include <vector>
 
+#include <thread>
+
 #include "common.h"
 
 namespace simrank {
@@ -260,6 +262,15 @@ int build_dense_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
     // (a single-GPU plan whose leg 1 is the one-launch kernel: the only taker would be the upper-triangle leg 2, and it takes
     // the plan only under this rule — spmm.hip, `dp && want_sym`)
     if (g->tun.dense_lazy && !(g->tun.dense_sym > 0 || (g->tun.dense_sym < 0 && 2 * covered >= g->nnz))) return SIMRANK_OK;
+    // ... and (round 6) not where that leg is the one-launch kernel's (fused.hip, SYM): the one-launch plan, built on a thread
+    // beside this one, says so once it is there (spmm.hip dispatches on the same rule; a launch the rule's shapes exclude
+    // falls back to the plain gather, which needs no plan)
+    if (g->tun.dense_lazy && g->tun.fuse && g->tun.fuse_sym != 0 && g->tun.dense_terms == 3 && g->n_rows >= 64) {
+        while (g->fused_build.load(std::memory_order_acquire) == 1) std::this_thread::yield();
+        if (g->fused_build.load(std::memory_order_acquire) == 2 && g->fused &&
+            (g->tun.fuse_sym > 0 || 2 * g->fused->nnz_covered >= g->nnz))
+            return SIMRANK_OK;
+    }
     // Units: a workgroup per (unit, 256 output columns); an XCD works through a column block with
     // 64 resident workgroups, so no unit should be longer than 1/64 of the column block's work —
     // and none shorter than kUnitCols, because every unit costs a slab of partial sums.

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -113,10 +114,16 @@ inline hipError_t plan_upload(void* d, const void* h, size_t bytes) { memcpy(d, 
 inline hipError_t plan_download(void* h, const void* d, size_t bytes) { memcpy(h, d, bytes); return hipSuccess; }
 inline void plan_free(void* p) { free(p); }
 #else
-inline hipError_t plan_alloc(void** p, size_t bytes) { return hipMalloc(p, bytes); }
+// (through the device pool since round 6: the small blocks of a graph object are kept in size classes between fits)
+int pool_alloc(void** dptr, size_t bytes);
+int pool_free(void* ptr);
+inline hipError_t plan_alloc(void** p, size_t bytes) {
+    const int rc = pool_alloc(p, bytes);
+    return rc == SIMRANK_OK ? hipSuccess : (rc == SIMRANK_ERR_ALLOC ? hipErrorOutOfMemory : hipErrorUnknown);
+}
 inline hipError_t plan_upload(void* d, const void* h, size_t bytes) { return hipMemcpy(d, h, bytes, hipMemcpyHostToDevice); }
 inline hipError_t plan_download(void* h, const void* d, size_t bytes) { return hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost); }
-inline void plan_free(void* p) { (void)hipFree(p); }
+inline void plan_free(void* p) { (void)pool_free(p); }
 #endif
 
 // simrank_graph_create with the knobs given (the plans set some per graph: fp16-held fits take no split blocks)
@@ -350,6 +357,8 @@ struct simrank_graph {
     int32_t sym_blocks = 0;
     simrank_dense_plan* dense = nullptr;   // NULL: no block of the pattern is dense enough
     simrank_fused_plan* fused = nullptr;   // leg 1 as one launch (fused.hip); NULL: tuning "fuse" = 0
+    std::atomic<int> fused_build{0};       // its builder thread during simrank_graph_create: 0 none, 1 running, 2 finished (the
+                                           // dense-block builder of a lazy graph waits for it: the one-launch leg 2 may take its place)
 #ifdef SIMRANK_EXPERIMENT_FUSED2
     simrank_fused2_plan* fused2 = nullptr; // leg 1 as one persistent launch (experiment build); tuning "fuse" = 2
 #endif

@@ -747,7 +747,7 @@ void free_fused_plan(simrank_fused_plan* p) {
     if (!p) return;
     plan_free(p->units);
 #ifndef SIMRANK_HOST_ONLY
-    (void)pool_free(p->partials); (void)hipFree(p->tickets);
+    (void)pool_free(p->partials); (void)pool_free(p->tickets);
 #endif
     plan_free(p->dcols16); plan_free(p->dcols32); plan_free(p->abits);
     plan_free(p->gmeta); plan_free(p->sids16); plan_free(p->sids32);
@@ -1004,7 +1004,10 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
         // and compares the arrays)
         const char* forced = std::getenv("SIMRANK_BUILD_THREADS");
         const int n_thr = forced ? std::max(1, std::atoi(forced))
-                                 : (int)std::min<int64_t>(8, (rowptr[M] >= 100000 && nblk >= 16) ? nblk / 8 : 1);
+                                 : (int)std::min<int64_t>(8, (rowptr[M] >= 100000 && nblk >= 8)
+                                                                 ? std::min<int64_t>(nblk / 2, std::max<int64_t>(nblk / 8, rowptr[M] / 120000)) : 1);
+        // (by blocks on sparse patterns, by entries on dense ones: 29 blocks of 34 000 entries each — the MovieLens-shaped
+        // item side — are worth eight threads, not three)
         if (n_thr <= 1) {
             Scratch sc(K);
             for (int64_t b = 0; b < nblk; ++b) process_block(b, sc, outs[(size_t)b]);
@@ -1213,7 +1216,7 @@ int build_fused_plan(simrank_graph* g, const int32_t* rowptr, const int32_t* col
         // node set: max(M, K) columns); a wider one grows them at its first launch
         const int32_t panels = (int32_t)((std::max<int64_t>(M, K) + 31) / 32);
         hipError_t e = pool_hip_alloc((void**)&pl->partials, size_t(n_pslots) * panels * 32 * kFB * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void**)&pl->tickets, size_t(n_cslots) * panels * sizeof(int32_t));
+        if (e == hipSuccess) e = pool_hip_alloc((void**)&pl->tickets, size_t(n_cslots) * panels * sizeof(int32_t));
         if (e == hipSuccess) e = hipMemset(pl->tickets, 0, size_t(n_cslots) * panels * sizeof(int32_t));
         if (e != hipSuccess) {
             set_error("one-launch plan: partial sums of %d split blocks: %s", n_cslots, hipGetErrorString(e));
@@ -1251,10 +1254,10 @@ static int launch_fused(const simrank_graph* g, FusedArgs& a, hipStream_t st, bo
     if (pl->n_pslots > 0 && a.n_panels > pl->cap_panels) {
         // (an operand wider than the plan was built for — not what a solver does: grow once)
         SR_HIP(hipStreamSynchronize(st));                  // an earlier launch may still use the old ones
-        (void)pool_free(pl->partials); (void)hipFree(pl->tickets);
+        (void)pool_free(pl->partials); (void)pool_free(pl->tickets);
         pl->partials = nullptr; pl->tickets = nullptr; pl->cap_panels = 0;
         SR_HIP(pool_hip_alloc((void**)&pl->partials, size_t(pl->n_pslots) * a.n_panels * 32 * kFB * sizeof(float)));
-        SR_HIP(hipMalloc((void**)&pl->tickets, size_t(pl->n_cslots) * a.n_panels * sizeof(int32_t)));
+        SR_HIP(pool_hip_alloc((void**)&pl->tickets, size_t(pl->n_cslots) * a.n_panels * sizeof(int32_t)));
         SR_HIP(hipMemsetAsync(pl->tickets, 0, size_t(pl->n_cslots) * a.n_panels * sizeof(int32_t), st));
         pl->cap_panels = a.n_panels;
     }

@@ -13,13 +13,20 @@ from simrank_amd import synth              # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "pl32768d32"
 df = synth.WORKLOADS[wl][0]()
+bip = synth.WORKLOADS[wl][1] == "bipartite"       # (config 3: BipartiteSimRankPP, as bench.py's fit_wall)
+
+
+def fit():
+    return SRA.BipartiteSimRankPP().fit(df, verbose=False, strict_reference=False) if bip else SRA.SimRank().fit(df, verbose=False)
+
+
 for rep in range(2):
     t0 = time.perf_counter()
-    res = SRA.SimRank().fit(df, verbose=False)
+    res = fit()
     print(f"call {rep}: {time.perf_counter() - t0:.3f} s", flush=True)
     del res
 pr = cProfile.Profile()
 pr.enable()
-res = SRA.SimRank().fit(df, verbose=False)
+res = fit()
 pr.disable()
 pstats.Stats(pr).sort_stats("cumtime").print_stats(28)

@@ -17,4 +17,5 @@ for i in range(3):
     idx, val = plan.topk(10)
     t3 = time.perf_counter()
     plan.free()
-    print(f"call {i}: create {t1 - t0:.3f} s, run {t2 - t1:.3f} s ({done} updates), top-10 {t3 - t2:.3f} s", flush=True)
+    t4 = time.perf_counter()
+    print(f"call {i}: create {t1 - t0:.4f} s, run {t2 - t1:.4f} s ({done} updates), top-10 {t3 - t2:.4f} s, free {t4 - t3:.4f} s", flush=True)

@@ -70,7 +70,9 @@ SIMRANK_API int simrank_device_info(int device, char* name, int name_len, int64_
  * np.zeros at SimRank.py:124-125): a request takes the smallest cached block of its size up to 1/8 more,
  * simrank_free synchronises the device (as hipFree does) and keeps the block, least recently freed blocks
  * leave when more than SIMRANK_POOL_GIB (environment, default 56: what one N = 65536 plan holds) GiB are at rest, and an allocation that
- * fails empties the pool and is tried once more.  The plans (simrank_plan_*, simrank_biplan_*) allocate
+ * fails empties the pool and is tried once more.  Smaller blocks (the arrays of a graph object and its plans) are kept in size
+ * classes (2^k x {1, 1.25, 1.5, 1.75} bytes from 512; at most 1 GiB at rest per device; SIMRANK_POOL_GIB=0 turns every kind
+ * of pooling off).  The plans (simrank_plan_*, simrank_biplan_*) allocate
  * their matrices and scratch through the same pool.  Cached blocks are invisible to other allocators of
  * the process: simrank_pool_trim(device) (-1 = every device) returns them to the driver. */
 SIMRANK_API int simrank_malloc(void** dptr, size_t bytes);

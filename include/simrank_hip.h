@@ -308,7 +308,11 @@ SIMRANK_API int simrank_fill_identity_blocked(float* S, int64_t n_rows, int64_t 
                                               int64_t rows_pad, int64_t col0, void* stream);
 /* X: n_cols(g) rows (x_rows_pad per panel) x n_cols_x columns.  transpose_out = 0: Y is n_rows(g)
  * rows x n_cols_x columns and the epilogue operands share its layout (their ld_* are ignored);
- * transpose_out = 1: Y is n_cols_x rows x n_rows(g) columns.  y_rows_pad = padded rows of Y. */
+ * transpose_out = 1: Y is n_cols_x rows x n_rows(g) columns.  y_rows_pad = padded rows of Y.
+ * Which launches serve a call (tuning, below): transpose_out = 1 (leg 1, first `.dot` of SimRank.py:139) is ONE launch,
+ * matrix cores + gathers ("fuse"); transpose_out = 0 with epilogue.symmetric (leg 2, the second `.dot` and the element-wise
+ * lines) is the upper-triangle gather + mirror ("triangle"), or the same ONE launch as leg 1 with the epilogue applied to
+ * the tile where the graph's dense sets hold most of its entries ("fuse_sym"). */
 SIMRANK_API int simrank_spmm_blocked(const simrank_graph* g, const float* X, int64_t x_rows_pad,
                                      int64_t n_cols_x, float* Y, int64_t y_rows_pad,
                                      int32_t transpose_out, const simrank_epilogue* epilogue,

@@ -44,4 +44,4 @@ for name in names:
         print(f"{name} {mode} {t}: (steps, covered, remainder) {stats} legs {legs} sum {sum(legs.values()):.3f} ms", flush=True)
         s.release()
         del s
-        ops.set_tuning(fuse_min=3, fuse_pays=-1)
+        ops.set_tuning(fuse_min=0, fuse_pays=-1, fuse_unit=48, fuse_rows=8192, fuse_group=3)

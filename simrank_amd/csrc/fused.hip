@@ -34,6 +34,13 @@
 //   4. Each wave stores one transposed 32 x 32 tile = 4 KiB contiguous of the panel-blocked Tt.
 // Panels are bound to XCDs as in spmm.hip (blocks equal mod 8 share an L2; speed only); within a
 // panel the heaviest blocks are launched first.  Bitwise reproducible: fixed order everywhere.
+//
+// Round 6.  (a) Which columns make a block's dense set is decided by what a QUAD of 64 columns saves in gathered entries
+// (build_fused_plan, tuning fuse_min = 0 / fuse_pays) instead of a fixed count per column.  (b) The SYM instantiation is
+// LEG 2 of a symmetric update in the same launch: the same product with Tt as the operand, then — instead of step 4 alone —
+// the epilogue of SimRank.py:139-140 / :316 / :362 / :453 and the count of :74 on the wave's 32 x 32 tile in LDS, its store,
+// and (right of the diagonal) step 4 as the store of the mirror image; tiles left of the diagonal are not computed
+// (launch_fused_sym; taken where the dense sets hold most of the pattern, tuning fuse_sym).
 #include <algorithm>
 #include <cstring>
 #include <numeric>

@@ -167,7 +167,8 @@ def test_two_different_graphs_back_to_back_on_pooled_blocks():
         assert_close(got, want)
 
     fit(*cases[0])
-    assert ops.pool_stats()[1] > 0                         # the first fit's matrices are at rest in the pool
+    # the first fit's matrices are at rest in the pool (SIMRANK_POOL_GIB=0 turns the pool off: then the rest still holds)
+    assert ops.pool_stats()[1] > 0 or ops.pool_stats()[2] == 0
     fit(*cases[1])
     plan(*cases[0])
     plan(*cases[1])
